@@ -1,0 +1,143 @@
+/*
+ * pffdtd_hip.h -- C ABI of the MI355X-native FDTD time-step engine (libpffdtd_hip.so).
+ *
+ * This is the drop-in boundary for the reference's in-process engine seam
+ *
+ *     double run_sim(struct SimData *sd);          c_cuda/cpu_engine.h:52, c_cuda/gpu_engine.h:665
+ *
+ * called from c_cuda/fdtd_main.c:44-53 (load_sim_data -> scale_input -> run_sim ->
+ * rescale_output -> write_outputs).  `pf_simdata` is a field-for-field POD mirror of
+ * `struct SimData` (c_cuda/fdtd_data.h:38-76); the only additions are `real_bytes`
+ * (the reference selects `Real` at compile time with -DPRECISION, c_cuda/fdtd_common.h:44-71;
+ * this library carries both precisions and selects at run time) and the widened copies of the
+ * `Real` scalars.  Everything is plain pointers and sizes: no C++ or torch types cross this line.
+ *
+ * All array pointers in pf_simdata are HOST pointers owned by the caller (as in the reference,
+ * where load_sim_data mallocs and free_sim_data frees, fdtd_data.h:99,721).  The engine owns
+ * only its device state.  Linear indices are in the file layout  ii = ix*Ny*Nz + iy*Nz + iz
+ * (cpu_engine.h:180); the engine re-bases them onto its own padded HBM layout internally.
+ *
+ * Error behaviour: the reference asserts/exits (helper_funcs.h:86-94, gpu_engine.h:192-200);
+ * this ABI returns a non-zero pf_status and keeps a message retrievable with pf_last_error().
+ */
+#ifndef PFFDTD_HIP_H
+#define PFFDTD_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PF_MMB 12 /* max RLC branches per material: MMb, fdtd_data.h:33 */
+#define PF_MNM 64 /* max number of materials:      MNm, fdtd_data.h:35 */
+
+/* struct MatQuad (fdtd_data.h:79-84) for Real=float / Real=double */
+typedef struct pf_matquad_f32 { float  b, bd, bDh, bFh; } pf_matquad_f32;
+typedef struct pf_matquad_f64 { double b, bd, bDh, bFh; } pf_matquad_f64;
+
+/* Mirror of struct SimData (fdtd_data.h:38-76), same field order. */
+typedef struct pf_simdata {
+   int64_t  *bn_ixyz;     /* [Nb]  boundary node indices */
+   int64_t  *bnl_ixyz;    /* [Nbl] lossy boundary node indices */
+   int64_t  *bna_ixyz;    /* [Nba] absorbing (ABC) node indices */
+   int8_t   *Q_bna;       /* [Nba] 1 face, 2 edge, 3 corner */
+   int64_t  *in_ixyz;     /* [Ns]  source nodes */
+   int64_t  *out_ixyz;    /* [Nr]  receiver nodes (duplicates allowed) */
+   int64_t  *out_reorder; /* [Nr]  row permutation used by write_outputs (fdtd_data.h:941-945) */
+   uint16_t *adj_bn;      /* [Nb]  adjacency bits, bit j = neighbour j (fdtd_data.h:532-538) */
+   void     *ssaf_bnl;    /* [Nbl] Real: scaled surface-area factors (fdtd_data.h:283-289,608) */
+   uint8_t  *bn_mask;     /* [(Npts-1)/8+1] bit ii%8 of byte ii>>3 (fdtd_data.h:567-572); may be NULL:
+                             the engine rebuilds its own mask from bn_ixyz (as gpu_engine.h:791 does) */
+   int8_t   *mat_bnl;     /* [Nbl] material index of lossy nodes */
+   int8_t   *K_bn;        /* [Nb]  popcount(adj_bn); may be NULL (cpu_engine.h:238-240 recomputes it) */
+   double   *in_sigs;     /* [Ns*Nt] input signals, row-major (already scaled by scale_input) */
+   double   *u_out;       /* [Nr*Nt] receiver outputs, engine row order, written by the engine */
+   int64_t   Ns, Nr, Nt, Npts, Nx, Ny, Nz, Nb, Nbl, Nba;
+   double    l, l2;
+   int8_t    fcc_flag;    /* 0 Cartesian, 1 FCC checkerboard, 2 FCC folded */
+   int8_t    NN;          /* 6 | 12 */
+   int8_t    Nm;          /* number of materials */
+   int8_t   *Mb;          /* [Nm] branches per material */
+   void     *mat_quads;   /* [Nm*PF_MMB] pf_matquad_f32 | pf_matquad_f64 */
+   void     *mat_beta;    /* [Nm] Real */
+   double    infac;       /* input rescaling (scale_input, fdtd_data.h:879-909); not used by the engine */
+   double    sl2, lo2, a2, a1; /* the Real-rounded coefficients of fdtd_data.h:186-194, widened exactly */
+   int32_t   real_bytes;  /* 4 = float (PRECISION=1), 8 = double (PRECISION=2) */
+} pf_simdata;
+
+typedef enum pf_status {
+   PF_OK = 0,
+   PF_ERR_ARG = 1,      /* bad argument / unsupported configuration */
+   PF_ERR_HIP = 2,      /* a HIP runtime call failed */
+   PF_ERR_NODEV = 3,    /* no HIP device visible */
+   PF_ERR_STATE = 4     /* call sequence violated */
+} pf_status;
+
+/* numerics modes */
+#define PF_NUM_CPU_EXACT 0 /* operation order and rounding of cpu_engine.h:174-301,363-405; no FMA contraction:
+                              results are bit-identical to the reference C CPU engine */
+#define PF_NUM_FMA       1 /* same association, FMA contraction allowed (faster VALU, not bit-identical) */
+
+typedef struct pf_opts {
+   int32_t device;        /* HIP device ordinal */
+   int32_t numerics;      /* PF_NUM_* */
+   int32_t slab_first;    /* 1 if this grid holds the global ix=0 ghost plane (gpu_engine.h:1030-1032) */
+   int32_t slab_last;     /* 1 if this grid holds the global ix=Nx-1 ghost plane (gpu_engine.h:1033-1035) */
+   int32_t readout_chunk; /* receiver ring depth in steps before a D2H flush (0 = default) */
+   int32_t air_variant;   /* 0 = default air kernel; others are tuning variants */
+   int32_t air_chunk;     /* planes marched per workgroup (0 = auto) */
+   int32_t timing;        /* 1 = bracket the air kernel with HIP events every step (pf_engine_timing) */
+   void   *ext_u0;        /* optional caller-owned DEVICE buffers for the two state grids, each of */
+   void   *ext_u1;        /*   pf_grid_bytes() bytes, zero-filled by the caller; NULL = engine allocates */
+   int32_t reserved[8];
+} pf_opts;
+
+typedef struct pf_timing {
+   double  air_ms_total;    /* sum of HIP-event durations of the air kernel launches */
+   int64_t air_launches;
+   double  step_ms_total;   /* sum of HIP-event durations of whole steps (pre .. readout) */
+   int64_t steps;
+} pf_timing;
+
+typedef struct pf_engine pf_engine;
+
+/* ---- library-level ---- */
+const char *pf_last_error(void);
+const char *pf_version(void);
+int         pf_device_count(void);
+/* bytes of one state grid in the engine's padded HBM layout, and its z pitch in elements */
+size_t      pf_grid_bytes(int64_t Nx, int64_t Ny, int64_t Nz, int32_t real_bytes);
+int64_t     pf_grid_pitch(int64_t Nz, int32_t real_bytes);
+void        pf_opts_default(pf_opts *o);
+
+/* ---- the reference seam: double run_sim(struct SimData*) ---- */
+/* Runs all sd->Nt steps on device 0, fills sd->u_out, returns elapsed seconds (<0 on error). */
+double      pf_run_sim(pf_simdata *sd);
+
+/* ---- engine object (what run_sim does inside, exposed for the Python host, slabs and tests) ---- */
+int  pf_engine_create(const pf_simdata *sd, const pf_opts *opts, pf_engine **out);
+void pf_engine_destroy(pf_engine *e);
+/* steps n0 .. n0+nsteps-1 with no halo exchange (single slab); receivers land in sd->u_out[r*Nt+n] */
+int  pf_engine_run(pf_engine *e, int64_t n0, int64_t nsteps);
+/* split-phase step for Z-slab runs (gpu_engine.h:993-1145 re-thought): begin enqueues the edge planes +
+ * all boundary-node work on the edge stream and the interior planes on the main stream; the caller then
+ * exchanges the planes returned by pf_engine_halo_ptrs() (ordered after the edge stream), and end joins
+ * the streams and rotates the state pointers. */
+int  pf_engine_step_begin(pf_engine *e, int64_t n);
+int  pf_engine_halo_ptrs(pf_engine *e, void **send_lo, void **send_hi, void **recv_lo, void **recv_hi,
+                         size_t *plane_bytes);
+int  pf_engine_step_end(pf_engine *e, int64_t n);
+void *pf_engine_stream(pf_engine *e, int32_t which); /* 0 main, 1 edge: hipStream_t */
+int  pf_engine_sync(pf_engine *e);
+int  pf_engine_flush_outputs(pf_engine *e);          /* ring -> sd->u_out */
+/* copy a state grid to/from a host array in FILE layout [Nx*Ny*Nz] Real; which: 0 = u0, 1 = u1 */
+int  pf_engine_get_grid(pf_engine *e, int32_t which, void *host);
+int  pf_engine_set_grid(pf_engine *e, int32_t which, const void *host);
+int  pf_engine_timing(pf_engine *e, pf_timing *t, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFFDTD_HIP_H */
