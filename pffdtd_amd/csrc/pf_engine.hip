@@ -1,0 +1,666 @@
+// pf_engine.hip -- host side of libpffdtd_hip.so: the C ABI of include/pffdtd_hip.h over the kernels of
+// pf_kernels.h.  Replaces the reference's `double run_sim(struct SimData*)` (c_cuda/gpu_engine.h:665-1255,
+// c_cuda/cpu_engine.h:52-360) for MI355X.  Not derived from gpu_engine.h: different memory layout (padded
+// pitch, engine-built skip-mask), different kernels (2.5D register marching), device-resident source signals
+// and receiver ring instead of per-step host traffic, and a split-phase step for overlapped slab exchange.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "pffdtd_hip.h"
+#include "pf_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int set_err(int code, const char *fmt, ...) {
+   char buf[1024];
+   va_list ap;
+   va_start(ap, fmt);
+   vsnprintf(buf, sizeof buf, fmt, ap);
+   va_end(ap);
+   g_err = buf;
+   return code;
+}
+
+#define HIPCHK(expr)                                                                                          \
+   do {                                                                                                       \
+      hipError_t _e = (expr);                                                                                 \
+      if (_e != hipSuccess)                                                                                   \
+         return set_err(PF_ERR_HIP, "HIP error %s at %s:%d: %s", hipGetErrorName(_e), __FILE__, __LINE__,     \
+                        hipGetErrorString(_e));                                                               \
+   } while (0)
+
+inline int64_t round_up(int64_t a, int64_t m) { return (a + m - 1) / m * m; }
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+int64_t grid_pitch(int64_t Nz, int32_t real_bytes) { return round_up(Nz, 128 / real_bytes); }
+
+// DPP wave-shift semantics verified once per process on the device
+int dpp_ok_cached = -1;
+int check_dpp(hipStream_t s) {
+   if (dpp_ok_cached >= 0) return dpp_ok_cached;
+   int *d = nullptr, h = 0;
+   if (hipMalloc(&d, sizeof(int)) != hipSuccess) return 0;
+   hipLaunchKernelGGL(pf::k_dpp_selftest, dim3(1), dim3(64), 0, s, d);
+   hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, s);
+   hipStreamSynchronize(s);
+   hipFree(d);
+   dpp_ok_cached = h;
+   return h;
+}
+
+struct Range { int64_t b, e; };
+
+struct EngineBase {
+   virtual ~EngineBase() {}
+   virtual int run(int64_t n0, int64_t nsteps) = 0;
+   virtual int step_begin(int64_t n) = 0;
+   virtual int step_end(int64_t n) = 0;
+   virtual int halo_ptrs(void **slo, void **shi, void **rlo, void **rhi, size_t *bytes) = 0;
+   virtual int sync() = 0;
+   virtual int flush() = 0;
+   virtual int get_grid(int which, void *host) = 0;
+   virtual int set_grid(int which, const void *host) = 0;
+   virtual int timing(pf_timing *t, int reset) = 0;
+   virtual void *stream(int which) = 0;
+};
+
+template <typename Real> struct Engine : EngineBase {
+   pf_simdata sd{};
+   pf_opts op{};
+   int64_t Nx = 0, Ny = 0, Nz = 0, P = 0, plane = 0, npad = 0;
+   int64_t Nb = 0, Nbl = 0, Nba = 0, Ns = 0, Nr = 0, Nt = 0;
+   bool fcc = false, fold = false;
+   bool use_dpp = true;
+   Real a1, a2, sl2, lo2, l;
+   // device state
+   Real *u0 = nullptr, *u1 = nullptr;
+   bool own_grids = true;
+   uint8_t *mask = nullptr;
+   int64_t *d_bn = nullptr, *d_bnl = nullptr, *d_bna = nullptr, *d_in = nullptr, *d_out = nullptr;
+   uint16_t *d_adj = nullptr;
+   int8_t *d_Q = nullptr, *d_mat = nullptr, *d_Mb = nullptr;
+   Real *d_ssaf = nullptr, *d_beta = nullptr, *d_insig = nullptr;
+   pf::MatQuadT<Real> *d_mq = nullptr;
+   Real *ub[3] = {nullptr, nullptr, nullptr}; // u0b, u1b, u2b (cpu_engine.h:94-96), rotated each step
+   Real *u2ba = nullptr, *vh1 = nullptr, *gh1 = nullptr;
+   Real *ring = nullptr;
+   Real *h_ring = nullptr; // pinned
+   int64_t ring_depth = 0, ring_fill = 0, ring_n0 = 0;
+   std::vector<int64_t> out_row; // sorted receiver slot -> caller row
+   // plane ranges of the sorted lists: lo = first owned plane (ix==1), hi = last owned plane (ix==Nx-2)
+   Range bn_lo, bn_mid, bn_hi, bnl_lo, bnl_mid, bnl_hi, bna_lo, bna_mid, bna_hi, in_lo, in_mid, in_hi;
+   hipStream_t s_main = nullptr, s_edge = nullptr;
+   hipEvent_t ev_pre = nullptr, ev_edge = nullptr, ev_main = nullptr;
+   bool in_step = false;
+   int64_t steps_done = 0;
+   // timing
+   std::vector<std::pair<hipEvent_t, hipEvent_t>> air_ev, step_ev, ev_pool;
+   pf_timing tm{};
+
+   ~Engine() override { destroy(); }
+
+   void destroy() {
+      if (s_main) hipStreamSynchronize(s_main);
+      if (s_edge) hipStreamSynchronize(s_edge);
+      auto F = [](void *p) { if (p) hipFree(p); };
+      if (own_grids) { F(u0); F(u1); }
+      F(mask); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
+      F(d_beta); F(d_insig); F(d_mq); F(ub[0]); F(ub[1]); F(ub[2]); F(u2ba); F(vh1); F(gh1); F(ring);
+      if (h_ring) hipHostFree(h_ring);
+      for (auto &p : air_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+      for (auto &p : step_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+      for (auto &p : ev_pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+      if (ev_pre) hipEventDestroy(ev_pre);
+      if (ev_edge) hipEventDestroy(ev_edge);
+      if (ev_main) hipEventDestroy(ev_main);
+      if (s_main) hipStreamDestroy(s_main);
+      if (s_edge) hipStreamDestroy(s_edge);
+      u0 = u1 = nullptr; s_main = s_edge = nullptr;
+   }
+
+   // file-layout linear index -> padded index
+   inline int64_t pad_idx(int64_t ii) const { return (ii / Nz) * P + (ii % Nz); }
+
+   template <typename T> int upload(T **dst, const T *src, int64_t n) {
+      *dst = nullptr;
+      HIPCHK(hipMalloc((void **)dst, std::max<int64_t>(n, 1) * sizeof(T)));
+      if (n > 0) HIPCHK(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+      return PF_OK;
+   }
+   template <typename T> int dzalloc(T **dst, int64_t n) {
+      *dst = nullptr;
+      size_t bytes = std::max<int64_t>(n, 1) * sizeof(T);
+      HIPCHK(hipMalloc((void **)dst, bytes));
+      HIPCHK(hipMemset(*dst, 0, bytes));
+      return PF_OK;
+   }
+
+   // split a sorted padded-index list into the ranges of plane 1 / planes 2..Nx-3 / plane Nx-2
+   void plane_ranges(const std::vector<int64_t> &idx, Range &lo, Range &mid, Range &hi) const {
+      const int64_t n = (int64_t)idx.size();
+      auto first_ge = [&](int64_t px) { return (int64_t)(std::lower_bound(idx.begin(), idx.end(), px * plane) - idx.begin()); };
+      const int64_t b1 = first_ge(1), b2 = first_ge(2), b3 = first_ge(Nx - 2), b4 = first_ge(Nx - 1);
+      lo = {b1, std::min(b2, b4)};
+      if (Nx - 2 > 1) { mid = {b2, std::max(b2, b3)}; hi = {std::max(b2, b3), b4}; }
+      else { mid = {b2, b2}; hi = {b2, b2}; }
+      (void)n;
+   }
+
+   int init(const pf_simdata *s, const pf_opts *o) {
+      sd = *s;
+      op = *o;
+      Nx = sd.Nx; Ny = sd.Ny; Nz = sd.Nz;
+      Nb = sd.Nb; Nbl = sd.Nbl; Nba = sd.Nba; Ns = sd.Ns; Nr = sd.Nr; Nt = sd.Nt;
+      if (Nx < 3 || Ny < 3 || Nz < 3) return set_err(PF_ERR_ARG, "grid must be at least 3x3x3 (got %ld %ld %ld)", (long)Nx, (long)Ny, (long)Nz);
+      if (sd.Npts != Nx * Ny * Nz) return set_err(PF_ERR_ARG, "Npts != Nx*Ny*Nz");
+      if (sd.fcc_flag < 0 || sd.fcc_flag > 2) return set_err(PF_ERR_ARG, "fcc_flag must be 0, 1 or 2");
+      if (sd.NN != (sd.fcc_flag ? 12 : 6)) return set_err(PF_ERR_ARG, "NN does not match fcc_flag");
+      if (sd.Nm > PF_MNM) return set_err(PF_ERR_ARG, "too many materials (MNm=%d)", PF_MNM);
+      if (Nt < 0 || Ns < 0 || Nr < 0 || Nb < 0 || Nbl < 0 || Nba < 0) return set_err(PF_ERR_ARG, "negative count");
+      for (int k = 0; k < sd.Nm; k++)
+         if (sd.Mb[k] < 0 || sd.Mb[k] > PF_MMB) return set_err(PF_ERR_ARG, "Mb[%d] out of range (MMb=%d)", k, PF_MMB);
+      fcc = sd.fcc_flag > 0;
+      fold = sd.fcc_flag == 2;
+      a1 = (Real)sd.a1; a2 = (Real)sd.a2; sl2 = (Real)sd.sl2; lo2 = (Real)sd.lo2; l = (Real)sd.l;
+      P = grid_pitch(Nz, sizeof(Real));
+      plane = Ny * P;
+      npad = Nx * plane;
+
+      int ndev = 0;
+      if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_err(PF_ERR_NODEV, "no HIP device visible");
+      if (op.device < 0 || op.device >= ndev) return set_err(PF_ERR_ARG, "device %d out of range (%d visible)", op.device, ndev);
+      HIPCHK(hipSetDevice(op.device));
+      int lo_prio = 0, hi_prio = 0;
+      hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
+      HIPCHK(hipStreamCreateWithPriority(&s_main, hipStreamNonBlocking, lo_prio));
+      HIPCHK(hipStreamCreateWithPriority(&s_edge, hipStreamNonBlocking, hi_prio));
+      HIPCHK(hipEventCreateWithFlags(&ev_pre, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&ev_edge, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
+      use_dpp = check_dpp(s_main) == 1;
+
+      // ---- state grids ----
+      if (op.ext_u0 && op.ext_u1) {
+         u0 = (Real *)op.ext_u0; u1 = (Real *)op.ext_u1; own_grids = false;
+      } else {
+         int rc;
+         if ((rc = dzalloc(&u0, npad))) return rc;
+         if ((rc = dzalloc(&u1, npad))) return rc;
+      }
+
+      // ---- sorted, re-based node lists ----
+      auto sorted_perm = [&](const int64_t *src, int64_t n, std::vector<int64_t> &idx) {
+         std::vector<int64_t> perm(n);
+         std::iota(perm.begin(), perm.end(), 0);
+         bool is_sorted = true;
+         for (int64_t i = 1; i < n && is_sorted; i++) is_sorted = src[i - 1] <= src[i];
+         if (!is_sorted) std::stable_sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) { return src[a] < src[b]; });
+         idx.resize(n);
+         for (int64_t i = 0; i < n; i++) idx[i] = pad_idx(src[perm[i]]);
+         return perm;
+      };
+      auto in_interior = [&](const int64_t *src, int64_t n, const char *what) -> int {
+         for (int64_t i = 0; i < n; i++) {
+            const int64_t ii = src[i];
+            if (ii < 0 || ii >= sd.Npts) return set_err(PF_ERR_ARG, "%s[%ld]=%ld outside the grid", what, (long)i, (long)ii);
+            const int64_t iz = ii % Nz, iy = (ii / Nz) % Ny, ix = ii / (Nz * Ny);
+            if (ix < 1 || iy < 1 || iz < 1 || ix > Nx - 2 || iy > Ny - 2 || iz > Nz - 2)
+               return set_err(PF_ERR_ARG, "%s[%ld]=%ld is not an interior node", what, (long)i, (long)ii); // fdtd_common.h:83-101
+         }
+         return PF_OK;
+      };
+      int rc;
+      if ((rc = in_interior(sd.bn_ixyz, Nb, "bn_ixyz"))) return rc;
+      if ((rc = in_interior(sd.bnl_ixyz, Nbl, "bnl_ixyz"))) return rc;
+      if ((rc = in_interior(sd.bna_ixyz, Nba, "bna_ixyz"))) return rc;
+      if ((rc = in_interior(sd.in_ixyz, Ns, "in_ixyz"))) return rc;
+      for (int64_t i = 0; i < Nr; i++)
+         if (sd.out_ixyz[i] < 0 || sd.out_ixyz[i] >= sd.Npts) return set_err(PF_ERR_ARG, "out_ixyz[%ld] outside the grid", (long)i);
+
+      std::vector<int64_t> idx;
+      { // boundary nodes + adjacency
+         auto perm = sorted_perm(sd.bn_ixyz, Nb, idx);
+         std::vector<uint16_t> adj(Nb);
+         for (int64_t i = 0; i < Nb; i++) adj[i] = sd.adj_bn[perm[i]];
+         if ((rc = upload(&d_bn, idx.data(), Nb))) return rc;
+         if ((rc = upload(&d_adj, adj.data(), Nb))) return rc;
+         plane_ranges(idx, bn_lo, bn_mid, bn_hi);
+         // skip-mask: ghost z / pad / parity, then the boundary nodes
+         if ((rc = dzalloc(&mask, npad / 8))) return rc;
+         HIPCHK(hipDeviceSynchronize()); // memsets above ran on the null stream; our streams are non-blocking
+         hipLaunchKernelGGL(pf::k_mask_init, dim3((unsigned)cdiv(npad / 8, 256)), dim3(256), 0, s_main, mask, Nx, Ny, P, Nz,
+                            sd.fcc_flag == 1 ? 1 : 0);
+         if (Nb) hipLaunchKernelGGL(pf::k_mask_set, dim3((unsigned)cdiv(Nb, 256)), dim3(256), 0, s_main, mask, d_bn, Nb);
+         HIPCHK(hipGetLastError());
+      }
+      { // lossy nodes
+         auto perm = sorted_perm(sd.bnl_ixyz, Nbl, idx);
+         std::vector<Real> ssaf(Nbl);
+         std::vector<int8_t> mat(Nbl);
+         for (int64_t i = 0; i < Nbl; i++) {
+            ssaf[i] = ((const Real *)sd.ssaf_bnl)[perm[i]];
+            mat[i] = sd.mat_bnl[perm[i]];
+            if (mat[i] < 0 || mat[i] >= sd.Nm) return set_err(PF_ERR_ARG, "mat_bnl[%ld]=%d out of range", (long)perm[i], mat[i]);
+         }
+         if ((rc = upload(&d_bnl, idx.data(), Nbl))) return rc;
+         if ((rc = upload(&d_ssaf, ssaf.data(), Nbl))) return rc;
+         if ((rc = upload(&d_mat, mat.data(), Nbl))) return rc;
+         plane_ranges(idx, bnl_lo, bnl_mid, bnl_hi);
+         for (int i = 0; i < 3; i++) if ((rc = dzalloc(&ub[i], Nbl))) return rc;
+         if ((rc = dzalloc(&vh1, Nbl * PF_MMB))) return rc;
+         if ((rc = dzalloc(&gh1, Nbl * PF_MMB))) return rc;
+         const int64_t nm = std::max<int64_t>(sd.Nm, 1);
+         if ((rc = upload(&d_mq, (const pf::MatQuadT<Real> *)sd.mat_quads, sd.Nm ? nm * PF_MMB : 0))) return rc;
+         if ((rc = upload(&d_beta, (const Real *)sd.mat_beta, sd.Nm))) return rc;
+         if ((rc = upload(&d_Mb, sd.Mb, sd.Nm))) return rc;
+      }
+      { // ABC nodes
+         auto perm = sorted_perm(sd.bna_ixyz, Nba, idx);
+         std::vector<int8_t> Q(Nba);
+         for (int64_t i = 0; i < Nba; i++) Q[i] = sd.Q_bna[perm[i]];
+         if ((rc = upload(&d_bna, idx.data(), Nba))) return rc;
+         if ((rc = upload(&d_Q, Q.data(), Nba))) return rc;
+         if ((rc = dzalloc(&u2ba, Nba))) return rc;
+         plane_ranges(idx, bna_lo, bna_mid, bna_hi);
+      }
+      { // sources: rows permuted with the nodes, samples cast to Real once (cpu_engine.h:312 casts per step)
+         auto perm = sorted_perm(sd.in_ixyz, Ns, idx);
+         std::vector<Real> sig((size_t)std::max<int64_t>(Ns * Nt, 1));
+         for (int64_t i = 0; i < Ns; i++)
+            for (int64_t n = 0; n < Nt; n++) sig[i * Nt + n] = (Real)sd.in_sigs[perm[i] * Nt + n];
+         if ((rc = upload(&d_in, idx.data(), Ns))) return rc;
+         if ((rc = upload(&d_insig, sig.data(), Ns * Nt))) return rc;
+         plane_ranges(idx, in_lo, in_mid, in_hi);
+      }
+      { // receivers
+         auto perm = sorted_perm(sd.out_ixyz, Nr, idx);
+         out_row = perm;
+         if ((rc = upload(&d_out, idx.data(), Nr))) return rc;
+         ring_depth = op.readout_chunk > 0 ? op.readout_chunk : 1024;
+         if (Nt > 0) ring_depth = std::min<int64_t>(ring_depth, Nt);
+         ring_depth = std::max<int64_t>(ring_depth, 1);
+         if ((rc = dzalloc(&ring, Nr * ring_depth))) return rc;
+         HIPCHK(hipHostMalloc((void **)&h_ring, std::max<int64_t>(Nr * ring_depth, 1) * sizeof(Real), hipHostMallocDefault));
+      }
+      HIPCHK(hipDeviceSynchronize());
+      return PF_OK;
+   }
+
+   // ------------------------------------------------------------------------------------------------------------
+   void launch_air(hipStream_t s, int xb, int xe) {
+      if (xe <= xb) return;
+      std::pair<hipEvent_t, hipEvent_t> ev{};
+      if (op.timing) {
+         if (!ev_pool.empty()) { ev = ev_pool.back(); ev_pool.pop_back(); }
+         else { hipEventCreate(&ev.first); hipEventCreate(&ev.second); }
+         hipEventRecord(ev.first, s);
+      }
+      if (op.air_variant == 9) {
+         dim3 g((unsigned)cdiv(Nz, 256), (unsigned)(Ny - 2), (unsigned)(xe - xb));
+         if (fcc) {
+            if (op.numerics == PF_NUM_FMA) hipLaunchKernelGGL((pf::k_air_naive<Real, true, true>), g, dim3(256), 0, s, u1, u0, mask, a1, a2, Ny, Nz, P, plane, xb, xe);
+            else hipLaunchKernelGGL((pf::k_air_naive<Real, true, false>), g, dim3(256), 0, s, u1, u0, mask, a1, a2, Ny, Nz, P, plane, xb, xe);
+         } else {
+            if (op.numerics == PF_NUM_FMA) hipLaunchKernelGGL((pf::k_air_naive<Real, false, true>), g, dim3(256), 0, s, u1, u0, mask, a1, a2, Ny, Nz, P, plane, xb, xe);
+            else hipLaunchKernelGGL((pf::k_air_naive<Real, false, false>), g, dim3(256), 0, s, u1, u0, mask, a1, a2, Ny, Nz, P, plane, xb, xe);
+         }
+      } else {
+         launch_air_march(s, xb, xe);
+      }
+      if (op.timing) { hipEventRecord(ev.second, s); air_ev.push_back(ev); }
+   }
+
+   template <int R, int WY, int WZ> void launch_air_cfg(hipStream_t s, int xb, int xe) {
+      constexpr int V = pf::VecOf<Real>::V;
+      pf::AirParams ap;
+      ap.Ny = Ny; ap.P = P; ap.plane = plane;
+      ap.x_begin = xb; ap.x_end = xe;
+      ap.nzt = (int)cdiv(P, (int64_t)WZ * 64 * V);
+      ap.nyt = (int)cdiv(Ny - 2, (int64_t)WY * R);
+      int chunk = op.air_chunk;
+      const int nplanes = xe - xb;
+      if (chunk <= 0) {
+         // enough workgroups to fill 256 CUs several times over, but keep the 2-plane chunk prologue small
+         const int64_t tiles = (int64_t)ap.nzt * ap.nyt;
+         int64_t want = cdiv(256 * 24, std::max<int64_t>(tiles, 1));
+         chunk = (int)std::max<int64_t>(cdiv(nplanes, std::max<int64_t>(want, 1)), 16);
+      }
+      chunk = std::min(chunk, nplanes);
+      ap.chunk = chunk;
+      ap.nxc = (int)cdiv(nplanes, chunk);
+      ap.swizzle = (op.air_variant & 16) ? 0 : 1;
+      const uint32_t total = (uint32_t)ap.nzt * ap.nyt * ap.nxc;
+      dim3 g(total), b(64 * WY * WZ);
+      const bool fma = op.numerics == PF_NUM_FMA;
+#define PF_LAUNCH(K, FMA, DPP) hipLaunchKernelGGL((K<Real, R, WY, WZ, FMA, DPP>), g, b, 0, s, u1, u0, mask, a1, a2, ap)
+      if (fcc) {
+         if (fma) { if (use_dpp) PF_LAUNCH(pf::k_air_fcc, true, true); else PF_LAUNCH(pf::k_air_fcc, true, false); }
+         else { if (use_dpp) PF_LAUNCH(pf::k_air_fcc, false, true); else PF_LAUNCH(pf::k_air_fcc, false, false); }
+      } else {
+         if (fma) { if (use_dpp) PF_LAUNCH(pf::k_air_cart, true, true); else PF_LAUNCH(pf::k_air_cart, true, false); }
+         else { if (use_dpp) PF_LAUNCH(pf::k_air_cart, false, true); else PF_LAUNCH(pf::k_air_cart, false, false); }
+      }
+#undef PF_LAUNCH
+   }
+
+   void launch_air_march(hipStream_t s, int xb, int xe) {
+      switch (op.air_variant & 15) {
+         case 1: launch_air_cfg<2, 4, 1>(s, xb, xe); break;
+         case 2: launch_air_cfg<4, 1, 4>(s, xb, xe); break;
+         case 3: launch_air_cfg<2, 2, 2>(s, xb, xe); break;
+         case 4: launch_air_cfg<4, 2, 2>(s, xb, xe); break;
+         case 5: launch_air_cfg<2, 1, 4>(s, xb, xe); break;
+         case 6: launch_air_cfg<1, 4, 1>(s, xb, xe); break;
+         default: launch_air_cfg<4, 4, 1>(s, xb, xe); break;
+      }
+   }
+
+   void launch_pre(hipStream_t s) {
+      if (Nba) hipLaunchKernelGGL(pf::k_abc_save<Real>, dim3((unsigned)cdiv(Nba, 256)), dim3(256), 0, s, u0, d_bna, u2ba, Nba);
+      dim3 gy((unsigned)cdiv(Nz, 256), (unsigned)Nx);
+      if (fold) hipLaunchKernelGGL(pf::k_flip_y<Real>, gy, dim3(256), 0, s, u1, Nx, Ny, P, Nz, 4);
+      hipLaunchKernelGGL(pf::k_flip_z<Real>, dim3((unsigned)cdiv(Nx * Ny, 256)), dim3(256), 0, s, u1, Nx * Ny, P, Nz);
+      hipLaunchKernelGGL(pf::k_flip_y<Real>, gy, dim3(256), 0, s, u1, Nx, Ny, P, Nz, fold ? 1 : 3);
+      if (op.slab_first || op.slab_last)
+         hipLaunchKernelGGL(pf::k_flip_x<Real>, dim3((unsigned)cdiv(plane, 256)), dim3(256), 0, s, u1, Nx, plane, op.slab_first, op.slab_last);
+   }
+   void launch_abc(hipStream_t s, Range r) {
+      if (r.e > r.b) hipLaunchKernelGGL(pf::k_abc_loss<Real>, dim3((unsigned)cdiv(r.e - r.b, 256)), dim3(256), 0, s, u0, d_bna, d_Q, u2ba, l, r.b, r.e);
+   }
+   void launch_rigid(hipStream_t s, Range r) {
+      if (r.e <= r.b) return;
+      dim3 g((unsigned)cdiv(r.e - r.b, 256)), b(256);
+      const bool fma = op.numerics == PF_NUM_FMA;
+      if (fcc) {
+         if (fma) hipLaunchKernelGGL((pf::k_rigid<Real, true, true>), g, b, 0, s, u1, u0, d_bn, d_adj, a2, sl2, P, plane, r.b, r.e);
+         else hipLaunchKernelGGL((pf::k_rigid<Real, true, false>), g, b, 0, s, u1, u0, d_bn, d_adj, a2, sl2, P, plane, r.b, r.e);
+      } else {
+         if (fma) hipLaunchKernelGGL((pf::k_rigid<Real, false, true>), g, b, 0, s, u1, u0, d_bn, d_adj, a2, sl2, P, plane, r.b, r.e);
+         else hipLaunchKernelGGL((pf::k_rigid<Real, false, false>), g, b, 0, s, u1, u0, d_bn, d_adj, a2, sl2, P, plane, r.b, r.e);
+      }
+   }
+   void launch_fd(hipStream_t s, Range r) {
+      if (r.e > r.b)
+         hipLaunchKernelGGL(pf::k_fd_boundary<Real>, dim3((unsigned)cdiv(r.e - r.b, 128)), dim3(128), 0, s, u0, d_bnl, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq, d_beta, vh1, gh1, lo2, Nbl, r.b, r.e);
+   }
+   // receivers on/off + a range of the (sorted) source list
+   void launch_io(hipStream_t s, int64_t n, bool receivers, Range src) {
+      const int64_t nr = receivers ? Nr : 0;
+      const int64_t ns = src.e - src.b;
+      if (nr == 0 && ns <= 0) return;
+      hipLaunchKernelGGL(pf::k_io<Real>, dim3((unsigned)cdiv(nr + 1, 128)), dim3(128), 0, s, u1, u0, d_out, ring, nr, ring_fill, ring_depth,
+                         d_in + src.b, d_insig + src.b * Nt, std::max<int64_t>(ns, 0), Nt, n);
+   }
+   void rotate() {
+      std::swap(u0, u1);
+      Real *t = ub[2]; ub[2] = ub[1]; ub[1] = ub[0]; ub[0] = t;
+   }
+   int after_step(int64_t n) {
+      if (ring_fill == 0) ring_n0 = n;
+      ring_fill++;
+      steps_done++;
+      if (ring_fill == ring_depth) return flush();
+      return PF_OK;
+   }
+
+   // one whole step on the main stream, in the reference CPU engine's order (cpu_engine.h:127-326)
+   int step_single(int64_t n) {
+      if (n < 0 || n >= Nt) return set_err(PF_ERR_ARG, "step %ld outside [0,Nt=%ld)", (long)n, (long)Nt);
+      std::pair<hipEvent_t, hipEvent_t> ev{};
+      if (op.timing) {
+         if (!ev_pool.empty()) { ev = ev_pool.back(); ev_pool.pop_back(); }
+         else { hipEventCreate(&ev.first); hipEventCreate(&ev.second); }
+         hipEventRecord(ev.first, s_main);
+      }
+      launch_pre(s_main);
+      launch_air(s_main, 1, (int)Nx - 1);
+      launch_abc(s_main, {0, Nba});
+      launch_rigid(s_main, {0, Nb});
+      launch_fd(s_main, {0, Nbl});
+      launch_io(s_main, n, true, {0, Ns});
+      if (op.timing) { hipEventRecord(ev.second, s_main); step_ev.push_back(ev); }
+      HIPCHK(hipGetLastError());
+      rotate();
+      return after_step(n);
+   }
+
+   int run(int64_t n0, int64_t nsteps) override {
+      if (in_step) return set_err(PF_ERR_STATE, "pf_engine_run inside a split-phase step");
+      HIPCHK(hipSetDevice(op.device));
+      for (int64_t n = n0; n < n0 + nsteps; n++) {
+         int rc = step_single(n);
+         if (rc) return rc;
+         if (op.timing && air_ev.size() >= 512) { rc = harvest(); if (rc) return rc; }
+      }
+      int rc = flush();
+      if (rc) return rc;
+      return harvest();
+   }
+
+   // split-phase step for slab chains: edge planes and every boundary list entry that lives in them first
+   // (high-priority stream), interior concurrently on the main stream.
+   int step_begin(int64_t n) override {
+      if (in_step) return set_err(PF_ERR_STATE, "step_begin called twice");
+      if (n < 0 || n >= Nt) return set_err(PF_ERR_ARG, "step %ld outside [0,Nt=%ld)", (long)n, (long)Nt);
+      HIPCHK(hipSetDevice(op.device));
+      const int xl = 1, xh = (int)Nx - 2;
+      launch_pre(s_edge);
+      HIPCHK(hipEventRecord(ev_pre, s_edge));
+      HIPCHK(hipStreamWaitEvent(s_main, ev_pre, 0));
+      // edge stream: first / last owned plane
+      launch_air(s_edge, xl, xl + 1);
+      if (xh > xl) launch_air(s_edge, xh, xh + 1);
+      launch_abc(s_edge, bna_lo); launch_abc(s_edge, bna_hi);
+      launch_rigid(s_edge, bn_lo); launch_rigid(s_edge, bn_hi);
+      launch_fd(s_edge, bnl_lo); launch_fd(s_edge, bnl_hi);
+      launch_io(s_edge, n, false, in_lo); launch_io(s_edge, n, false, in_hi);
+      HIPCHK(hipEventRecord(ev_edge, s_edge));
+      // main stream: interior planes
+      launch_air(s_main, xl + 1, xh);
+      launch_abc(s_main, bna_mid);
+      launch_rigid(s_main, bn_mid);
+      launch_fd(s_main, bnl_mid);
+      launch_io(s_main, n, true, in_mid);
+      HIPCHK(hipGetLastError());
+      in_step = true;
+      return PF_OK;
+   }
+   int halo_ptrs(void **slo, void **shi, void **rlo, void **rhi, size_t *bytes) override {
+      // new state is u0 until step_end rotates (gpu_engine.h:1086-1126 sends the same planes)
+      if (slo) *slo = u0 + plane;
+      if (shi) *shi = u0 + (Nx - 2) * plane;
+      if (rlo) *rlo = u0;
+      if (rhi) *rhi = u0 + (Nx - 1) * plane;
+      if (bytes) *bytes = (size_t)plane * sizeof(Real);
+      return PF_OK;
+   }
+   int step_end(int64_t n) override {
+      if (!in_step) return set_err(PF_ERR_STATE, "step_end without step_begin");
+      HIPCHK(hipSetDevice(op.device));
+      // join: next step's ghost work (edge stream) must see the interior, and the main stream the exchange
+      HIPCHK(hipEventRecord(ev_main, s_main));
+      HIPCHK(hipStreamWaitEvent(s_edge, ev_main, 0));
+      HIPCHK(hipEventRecord(ev_edge, s_edge));
+      HIPCHK(hipStreamWaitEvent(s_main, ev_edge, 0));
+      in_step = false;
+      rotate();
+      return after_step(n);
+   }
+
+   int sync() override {
+      HIPCHK(hipSetDevice(op.device));
+      HIPCHK(hipStreamSynchronize(s_edge));
+      HIPCHK(hipStreamSynchronize(s_main));
+      return PF_OK;
+   }
+
+   // ring -> sd.u_out[row*Nt + n]  ((double) cast as cpu_engine.h:306)
+   int flush() override {
+      if (ring_fill == 0) return PF_OK;
+      HIPCHK(hipSetDevice(op.device));
+      HIPCHK(hipStreamSynchronize(s_edge));
+      if (Nr > 0) {
+         HIPCHK(hipMemcpyAsync(h_ring, ring, (size_t)(Nr * ring_depth) * sizeof(Real), hipMemcpyDeviceToHost, s_main));
+      }
+      HIPCHK(hipStreamSynchronize(s_main));
+      if (sd.u_out)
+         for (int64_t t = 0; t < Nr; t++) {
+            double *dst = sd.u_out + out_row[t] * Nt + ring_n0;
+            const Real *src = h_ring + t * ring_depth;
+            for (int64_t k = 0; k < ring_fill; k++) dst[k] = (double)src[k];
+         }
+      ring_fill = 0;
+      return PF_OK;
+   }
+
+   int harvest() {
+      if (!op.timing) return PF_OK;
+      HIPCHK(hipStreamSynchronize(s_edge));
+      HIPCHK(hipStreamSynchronize(s_main));
+      for (auto &p : air_ev) {
+         float ms = 0;
+         HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));
+         tm.air_ms_total += ms; tm.air_launches++;
+         ev_pool.push_back(p);
+      }
+      air_ev.clear();
+      for (auto &p : step_ev) {
+         float ms = 0;
+         HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));
+         tm.step_ms_total += ms; tm.steps++;
+         ev_pool.push_back(p);
+      }
+      step_ev.clear();
+      return PF_OK;
+   }
+   int timing(pf_timing *t, int reset) override {
+      int rc = harvest();
+      if (rc) return rc;
+      if (t) *t = tm;
+      if (reset) tm = pf_timing{};
+      return PF_OK;
+   }
+
+   int get_grid(int which, void *host) override {
+      HIPCHK(hipSetDevice(op.device));
+      int rc = sync();
+      if (rc) return rc;
+      const Real *src = which == 0 ? u0 : u1;
+      HIPCHK(hipMemcpy2D(host, Nz * sizeof(Real), src, P * sizeof(Real), Nz * sizeof(Real), Nx * Ny, hipMemcpyDeviceToHost));
+      return PF_OK;
+   }
+   int set_grid(int which, const void *host) override {
+      HIPCHK(hipSetDevice(op.device));
+      int rc = sync();
+      if (rc) return rc;
+      Real *dst = which == 0 ? u0 : u1;
+      HIPCHK(hipMemcpy2D(dst, P * sizeof(Real), host, Nz * sizeof(Real), Nz * sizeof(Real), Nx * Ny, hipMemcpyHostToDevice));
+      return PF_OK;
+   }
+   void *stream(int which) override { return which == 1 ? (void *)s_edge : (void *)s_main; }
+};
+
+} // namespace
+
+struct pf_engine {
+   EngineBase *impl;
+};
+
+extern "C" {
+
+const char *pf_last_error(void) { return g_err.c_str(); }
+const char *pf_version(void) { return "pffdtd_hip 0.1 (gfx950)"; }
+
+int pf_device_count(void) {
+   int n = 0;
+   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+   return n;
+}
+
+int64_t pf_grid_pitch(int64_t Nz, int32_t real_bytes) {
+   if (real_bytes != 4 && real_bytes != 8) return -1;
+   return grid_pitch(Nz, real_bytes);
+}
+size_t pf_grid_bytes(int64_t Nx, int64_t Ny, int64_t Nz, int32_t real_bytes) {
+   if (real_bytes != 4 && real_bytes != 8) return 0;
+   return (size_t)(Nx * Ny * grid_pitch(Nz, real_bytes)) * (size_t)real_bytes;
+}
+
+void pf_opts_default(pf_opts *o) {
+   if (!o) return;
+   memset(o, 0, sizeof *o);
+   o->slab_first = 1;
+   o->slab_last = 1;
+}
+
+int pf_engine_create(const pf_simdata *sd, const pf_opts *opts, pf_engine **out) {
+   if (!sd || !out) return set_err(PF_ERR_ARG, "null argument");
+   *out = nullptr;
+   pf_opts o;
+   if (opts) o = *opts; else pf_opts_default(&o);
+   EngineBase *impl = nullptr;
+   int rc;
+   if (sd->real_bytes == 4) {
+      auto *e = new Engine<float>();
+      rc = e->init(sd, &o);
+      impl = e;
+   } else if (sd->real_bytes == 8) {
+      auto *e = new Engine<double>();
+      rc = e->init(sd, &o);
+      impl = e;
+   } else {
+      return set_err(PF_ERR_ARG, "real_bytes must be 4 or 8 (got %d)", sd->real_bytes);
+   }
+   if (rc) { std::string keep = g_err; delete impl; g_err = keep; return rc; }
+   *out = new pf_engine{impl};
+   return PF_OK;
+}
+
+void pf_engine_destroy(pf_engine *e) {
+   if (!e) return;
+   delete e->impl;
+   delete e;
+}
+
+#define PF_NEED(e) if (!(e) || !(e)->impl) return set_err(PF_ERR_ARG, "null engine")
+
+int pf_engine_run(pf_engine *e, int64_t n0, int64_t nsteps) { PF_NEED(e); return e->impl->run(n0, nsteps); }
+int pf_engine_step_begin(pf_engine *e, int64_t n) { PF_NEED(e); return e->impl->step_begin(n); }
+int pf_engine_halo_ptrs(pf_engine *e, void **send_lo, void **send_hi, void **recv_lo, void **recv_hi, size_t *plane_bytes) {
+   PF_NEED(e);
+   return e->impl->halo_ptrs(send_lo, send_hi, recv_lo, recv_hi, plane_bytes);
+}
+int pf_engine_step_end(pf_engine *e, int64_t n) { PF_NEED(e); return e->impl->step_end(n); }
+void *pf_engine_stream(pf_engine *e, int32_t which) { return (e && e->impl) ? e->impl->stream(which) : nullptr; }
+int pf_engine_sync(pf_engine *e) { PF_NEED(e); return e->impl->sync(); }
+int pf_engine_flush_outputs(pf_engine *e) { PF_NEED(e); return e->impl->flush(); }
+int pf_engine_get_grid(pf_engine *e, int32_t which, void *host) { PF_NEED(e); return e->impl->get_grid(which, host); }
+int pf_engine_set_grid(pf_engine *e, int32_t which, const void *host) { PF_NEED(e); return e->impl->set_grid(which, host); }
+int pf_engine_timing(pf_engine *e, pf_timing *t, int32_t reset) { PF_NEED(e); return e->impl->timing(t, reset); }
+
+// double run_sim(struct SimData *sd): cpu_engine.h:52 / gpu_engine.h:665
+double pf_run_sim(pf_simdata *sd) {
+   pf_engine *e = nullptr;
+   pf_opts o;
+   pf_opts_default(&o);
+   if (pf_engine_create(sd, &o, &e) != PF_OK) return -1.0;
+   auto t0 = std::chrono::steady_clock::now();
+   int rc = pf_engine_run(e, 0, sd->Nt);
+   if (rc == PF_OK) rc = pf_engine_sync(e);
+   double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+   std::string keep = g_err;
+   pf_engine_destroy(e);
+   if (rc != PF_OK) { g_err = keep; return -1.0; }
+   return el;
+}
+
+} // extern "C"

@@ -1,0 +1,534 @@
+// pf_kernels.h -- device code of the MI355X FDTD engine (gfx950 only, wave64).
+//
+// HBM layout ("padded file layout"): a state grid is Real[Nx][Ny][P], P = z pitch = Nz rounded up to a
+// multiple of 128 B, so every row starts on a cache line and a lane's 16-byte vector never straddles rows.
+// Linear index jj = (ix*Ny + iy)*P + iz.  The engine's own skip-mask has one bit per padded cell (bit jj&7 of
+// byte jj>>3) and is the union of: boundary nodes (the reference's bn_mask, fdtd_data.h:567-572), the z ghost
+// columns iz=0 / iz=Nz-1, the pad columns iz>=Nz, and -- for the FCC checkerboard form (fcc_flag 1) -- the
+// odd-parity cells that do not exist on the subgrid (cpu_engine.h:200,219).
+//
+// Numerics: every kernel follows the operation order of the reference C CPU engine (file:line cited at each
+// kernel); with FMA=false nothing is contracted (the TU is built with -ffp-contract=off), so results are
+// bit-identical to cpu_engine.h.  FMA=true fuses each `p += a2*x` into one fma.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace pf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+template <typename Real> struct VecOf;
+template <> struct VecOf<float> { typedef f32x4 type; static constexpr int V = 4; };
+template <> struct VecOf<double> { typedef f64x2 type; static constexpr int V = 2; };
+
+// ---- wave64 neighbour exchange along the unit-stride axis -------------------------------------------------
+// DPP wave shifts (gfx9 family): wave_shr:1 moves data to the next-higher lane (lane i reads lane i-1),
+// wave_shl:1 the other way.  Lanes with no source keep `old` (=0).
+__device__ __forceinline__ int dpp_from_lower(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int dpp_from_upper(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
+
+template <bool DPP> __device__ __forceinline__ float lane_from_lower(float v) {
+   if (DPP) return __int_as_float(dpp_from_lower(__float_as_int(v)));
+   return __shfl_up(v, 1, 64);
+}
+template <bool DPP> __device__ __forceinline__ float lane_from_upper(float v) {
+   if (DPP) return __int_as_float(dpp_from_upper(__float_as_int(v)));
+   return __shfl_down(v, 1, 64);
+}
+template <bool DPP> __device__ __forceinline__ double lane_from_lower(double v) {
+   if (DPP) {
+      int lo = dpp_from_lower(__double2loint(v)), hi = dpp_from_lower(__double2hiint(v));
+      return __hiloint2double(hi, lo);
+   }
+   return __shfl_up(v, 1, 64);
+}
+template <bool DPP> __device__ __forceinline__ double lane_from_upper(double v) {
+   if (DPP) {
+      int lo = dpp_from_upper(__double2loint(v)), hi = dpp_from_upper(__double2hiint(v));
+      return __hiloint2double(hi, lo);
+   }
+   return __shfl_down(v, 1, 64);
+}
+
+// self-test kernel for the two DPP controls (run once per process; the engine falls back to ds_bpermute
+// shuffles if the semantics are not the expected ones)
+__global__ void k_dpp_selftest(int *out) {
+   int lane = threadIdx.x & 63;
+   int a = dpp_from_lower(lane + 100);
+   int b = dpp_from_upper(lane + 100);
+   int ok = 1;
+   if (lane > 0 && a != lane - 1 + 100) ok = 0;
+   if (lane < 63 && b != lane + 1 + 100) ok = 0;
+   unsigned long long all = __ballot(ok);
+   if (lane == 0) out[0] = (all == ~0ull) ? 1 : 0;
+}
+
+template <bool FMA, typename Real> __device__ __forceinline__ Real acc(Real p, Real a2, Real x) {
+   if (FMA) return __builtin_fma(a2, x, p);
+   return p + a2 * x;
+}
+
+// ---- XCD-aware workgroup order (guide T1): hardware places block b on XCD b%8; give each XCD one contiguous
+// run of logical tiles so that tiles sharing halo rows share an L2.  Bijective for any total.
+__device__ __forceinline__ uint32_t xcd_swizzle(uint32_t b, uint32_t total) {
+   uint32_t q = total >> 3, r = total & 7u;
+   uint32_t k = b & 7u, i = b >> 3;
+   return k * q + (k < r ? k : r) + i;
+}
+
+struct AirParams {
+   int64_t Ny, P, plane;  // rows, z pitch, plane stride Ny*P (elements)
+   int32_t x_begin, x_end; // planes updated by this launch: [x_begin, x_end)
+   int32_t chunk;          // planes marched per workgroup
+   int32_t nzt, nyt, nxc;  // tile counts along z, y and x-chunks
+   int32_t swizzle;
+};
+
+// =============================================================================================================
+// Air update, 7-point Cartesian (cpu_engine.h:175-194; reference GPU counterpart gpu_engine.h:220-242).
+//   u0 = a1*u1 - u0 + a2*(+x) + a2*(-x) + a2*(+y) + a2*(-y) + a2*(+z) + a2*(-z), accumulated left to right,
+//   skipped where the mask bit is set.
+// 2.5D register marching: a workgroup owns a (WY*R rows) x (WZ*64*V columns) tile and marches along x; each
+// lane owns R rows x V consecutive z of the tile.  Per plane it issues one coalesced 16 B/lane load per row for
+// the next u1 plane (+2 halo rows per wave), one for u0, one store.  x neighbours live in registers (prev /
+// next), y neighbours are adjacent registers of the same lane (halo rows loaded from L2), z neighbours inside
+// a lane's vector are registers and across lanes one DPP wave shift; the two wave-edge columns are loaded by
+// the edge lanes.
+// =============================================================================================================
+template <typename Real, int R, int WY, int WZ, bool FMA, bool DPP>
+__global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restrict__ u1, Real *__restrict__ u0,
+                                                          const uint8_t *__restrict__ mask, Real a1, Real a2,
+                                                          AirParams ap) {
+   typedef typename VecOf<Real>::type vec;
+   constexpr int V = VecOf<Real>::V;
+   const uint32_t total = (uint32_t)ap.nzt * ap.nyt * ap.nxc;
+   uint32_t b = blockIdx.x;
+   if (ap.swizzle) b = xcd_swizzle(b, total);
+   const int zt = b % ap.nzt;
+   const int yt = (b / ap.nzt) % ap.nyt;
+   const int xc = b / (ap.nzt * ap.nyt);
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   const int wz = wave % WZ, wy = wave / WZ;
+   const int64_t z0 = ((int64_t)(zt * WZ + wz) * 64 + lane) * V;
+   const int64_t y0 = 1 + (int64_t)(yt * WY + wy) * R;
+   const int xs = ap.x_begin + xc * ap.chunk;
+   const int xe = min(xs + ap.chunk, ap.x_end);
+   const int64_t Ny = ap.Ny, P = ap.P, plane = ap.plane;
+   const bool active = z0 < P;
+   if (y0 > Ny - 2) return; // whole wave out of rows (uniform per wave)
+   const int64_t zl = active ? z0 : 0; // inactive lanes read column 0 (in range), never store
+   const bool need_l = (lane == 0) && (z0 > 0);
+   const bool need_r = (lane == 63) && (z0 + V < P);
+
+   // row offsets inside a plane, clamped so that halo/invalid rows stay in range
+   int64_t roff[R + 2];
+#pragma unroll
+   for (int j = 0; j < R + 2; j++) {
+      int64_t y = y0 - 1 + j;
+      if (y > Ny - 1) y = Ny - 1;
+      roff[j] = y * P + zl;
+   }
+   vec prev[R], cur[R + 2], nxt[R + 2];
+   Real curL[R], curR[R], nxtL[R], nxtR[R]; // wave-edge columns (meaningful in lanes 0 / 63 only)
+   {
+      const Real *pm = u1 + (int64_t)(xs - 1) * plane;
+      const Real *pc = u1 + (int64_t)xs * plane;
+#pragma unroll
+      for (int r = 0; r < R; r++) prev[r] = *(const vec *)(pm + roff[r + 1]);
+#pragma unroll
+      for (int j = 0; j < R + 2; j++) cur[j] = *(const vec *)(pc + roff[j]);
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+         curL[r] = need_l ? pc[roff[r + 1] - 1] : Real(0);
+         curR[r] = need_r ? pc[roff[r + 1] + V] : Real(0);
+      }
+   }
+   for (int x = xs; x < xe; x++) {
+      const Real *pn = u1 + (int64_t)(x + 1) * plane;
+      Real *po = u0 + (int64_t)x * plane;
+      const uint8_t *pmk = mask + (((int64_t)x * plane) >> 3);
+      vec old[R];
+      uint32_t mb[R];
+#pragma unroll
+      for (int j = 0; j < R + 2; j++) nxt[j] = *(const vec *)(pn + roff[j]);
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+         old[r] = *(const vec *)(po + roff[r + 1]);
+         mb[r] = pmk[roff[r + 1] >> 3];
+         nxtL[r] = need_l ? pn[roff[r + 1] - 1] : Real(0);
+         nxtR[r] = need_r ? pn[roff[r + 1] + V] : Real(0);
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+         const vec c = cur[r + 1];
+         Real zm = lane_from_lower<DPP>(c[V - 1]);
+         Real zp = lane_from_upper<DPP>(c[0]);
+         if (lane == 0) zm = curL[r];
+         if (lane == 63) zp = curR[r];
+         const uint32_t bits = mb[r] >> (uint32_t)(roff[r + 1] & 7);
+         vec o;
+#pragma unroll
+         for (int i = 0; i < V; i++) {
+            const Real left = (i == 0) ? zm : c[i > 0 ? i - 1 : 0];
+            const Real right = (i == V - 1) ? zp : c[i < V - 1 ? i + 1 : V - 1];
+            Real p = a1 * c[i] - old[r][i];
+            p = acc<FMA>(p, a2, nxt[r + 1][i]);  // +NzNy
+            p = acc<FMA>(p, a2, prev[r][i]);     // -NzNy
+            p = acc<FMA>(p, a2, cur[r + 2][i]);  // +Nz
+            p = acc<FMA>(p, a2, cur[r][i]);      // -Nz
+            p = acc<FMA>(p, a2, right);          // +1
+            p = acc<FMA>(p, a2, left);           // -1
+            o[i] = ((bits >> i) & 1u) ? old[r][i] : p;
+         }
+         if (active && (y0 + r <= Ny - 2)) *(vec *)(po + roff[r + 1]) = o;
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+         prev[r] = cur[r + 1];
+         curL[r] = nxtL[r];
+         curR[r] = nxtR[r];
+      }
+#pragma unroll
+      for (int j = 0; j < R + 2; j++) cur[j] = nxt[j];
+   }
+}
+
+// =============================================================================================================
+// Air update, 13-point FCC (cpu_engine.h:195-223; gpu_engine.h:245-274), dense form: serves the folded grid
+// (fcc_flag 2) directly and the checkerboard grid (fcc_flag 1) through the odd-parity bits of the skip-mask.
+// Neighbour order (= accumulation order): (+x+y)(-x-y)(+y+z)(-y-z)(+x+z)(-x-z)(+x-y)(-x+y)(+y-z)(-y+z)(+x-z)(-x+z).
+// Same marching scheme; all three planes keep R+2 rows, and every row used with a z offset gets its wave-edge
+// columns from the edge lanes.
+// =============================================================================================================
+template <typename Real, int R, int WY, int WZ, bool FMA, bool DPP>
+__global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict__ u1, Real *__restrict__ u0,
+                                                         const uint8_t *__restrict__ mask, Real a1, Real a2,
+                                                         AirParams ap) {
+   typedef typename VecOf<Real>::type vec;
+   constexpr int V = VecOf<Real>::V;
+   const uint32_t total = (uint32_t)ap.nzt * ap.nyt * ap.nxc;
+   uint32_t b = blockIdx.x;
+   if (ap.swizzle) b = xcd_swizzle(b, total);
+   const int zt = b % ap.nzt;
+   const int yt = (b / ap.nzt) % ap.nyt;
+   const int xc = b / (ap.nzt * ap.nyt);
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   const int wz = wave % WZ, wy = wave / WZ;
+   const int64_t z0 = ((int64_t)(zt * WZ + wz) * 64 + lane) * V;
+   const int64_t y0 = 1 + (int64_t)(yt * WY + wy) * R;
+   const int xs = ap.x_begin + xc * ap.chunk;
+   const int xe = min(xs + ap.chunk, ap.x_end);
+   const int64_t Ny = ap.Ny, P = ap.P, plane = ap.plane;
+   const bool active = z0 < P;
+   if (y0 > Ny - 2) return;
+   const int64_t zl = active ? z0 : 0;
+   const bool need_l = (lane == 0) && (z0 > 0);
+   const bool need_r = (lane == 63) && (z0 + V < P);
+
+   int64_t roff[R + 2];
+#pragma unroll
+   for (int j = 0; j < R + 2; j++) {
+      int64_t y = y0 - 1 + j;
+      if (y > Ny - 1) y = Ny - 1;
+      roff[j] = y * P + zl;
+   }
+   // three planes x (R+2) rows, each with its two wave-edge columns
+   vec prev[R + 2], cur[R + 2], nxt[R + 2];
+   Real prevL[R + 2], prevR[R + 2], curL[R + 2], curR[R + 2], nxtL[R + 2], nxtR[R + 2];
+   {
+      const Real *pm = u1 + (int64_t)(xs - 1) * plane;
+      const Real *pc = u1 + (int64_t)xs * plane;
+#pragma unroll
+      for (int j = 0; j < R + 2; j++) {
+         prev[j] = *(const vec *)(pm + roff[j]);
+         cur[j] = *(const vec *)(pc + roff[j]);
+         prevL[j] = need_l ? pm[roff[j] - 1] : Real(0);
+         prevR[j] = need_r ? pm[roff[j] + V] : Real(0);
+         curL[j] = need_l ? pc[roff[j] - 1] : Real(0);
+         curR[j] = need_r ? pc[roff[j] + V] : Real(0);
+      }
+   }
+   for (int x = xs; x < xe; x++) {
+      const Real *pn = u1 + (int64_t)(x + 1) * plane;
+      Real *po = u0 + (int64_t)x * plane;
+      const uint8_t *pmk = mask + (((int64_t)x * plane) >> 3);
+      vec old[R];
+      uint32_t mb[R];
+#pragma unroll
+      for (int j = 0; j < R + 2; j++) {
+         nxt[j] = *(const vec *)(pn + roff[j]);
+         nxtL[j] = need_l ? pn[roff[j] - 1] : Real(0);
+         nxtR[j] = need_r ? pn[roff[j] + V] : Real(0);
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+         old[r] = *(const vec *)(po + roff[r + 1]);
+         mb[r] = pmk[roff[r + 1] >> 3];
+      }
+      // z-shifted views: lo(v)[i] = v[z-1], hi(v)[i] = v[z+1]
+      auto shift_lo = [&](const vec &v, Real edge) {
+         Real zm = lane_from_lower<DPP>(v[V - 1]);
+         if (lane == 0) zm = edge;
+         vec s;
+#pragma unroll
+         for (int i = 0; i < V; i++) s[i] = (i == 0) ? zm : v[i > 0 ? i - 1 : 0];
+         return s;
+      };
+      auto shift_hi = [&](const vec &v, Real edge) {
+         Real zp = lane_from_upper<DPP>(v[0]);
+         if (lane == 63) zp = edge;
+         vec s;
+#pragma unroll
+         for (int i = 0; i < V; i++) s[i] = (i == V - 1) ? zp : v[i < V - 1 ? i + 1 : V - 1];
+         return s;
+      };
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+         const int j = r + 1; // own row inside the (R+2)-row windows
+         const vec c = cur[j];
+         const vec cu_lo = shift_lo(cur[j + 1], curL[j + 1]), cu_hi = shift_hi(cur[j + 1], curR[j + 1]);
+         const vec cd_lo = shift_lo(cur[j - 1], curL[j - 1]), cd_hi = shift_hi(cur[j - 1], curR[j - 1]);
+         const vec n_lo = shift_lo(nxt[j], nxtL[j]), n_hi = shift_hi(nxt[j], nxtR[j]);
+         const vec p_lo = shift_lo(prev[j], prevL[j]), p_hi = shift_hi(prev[j], prevR[j]);
+         const uint32_t bits = mb[r] >> (uint32_t)(roff[j] & 7);
+         vec o;
+#pragma unroll
+         for (int i = 0; i < V; i++) {
+            Real p = a1 * c[i] - old[r][i];
+            p = acc<FMA>(p, a2, nxt[j + 1][i]);  // +NzNy+Nz
+            p = acc<FMA>(p, a2, prev[j - 1][i]); // -NzNy-Nz
+            p = acc<FMA>(p, a2, cu_hi[i]);       // +Nz+1
+            p = acc<FMA>(p, a2, cd_lo[i]);       // -Nz-1
+            p = acc<FMA>(p, a2, n_hi[i]);        // +NzNy+1
+            p = acc<FMA>(p, a2, p_lo[i]);        // -NzNy-1
+            p = acc<FMA>(p, a2, nxt[j - 1][i]);  // +NzNy-Nz
+            p = acc<FMA>(p, a2, prev[j + 1][i]); // -NzNy+Nz
+            p = acc<FMA>(p, a2, cu_lo[i]);       // +Nz-1
+            p = acc<FMA>(p, a2, cd_hi[i]);       // -Nz+1
+            p = acc<FMA>(p, a2, n_lo[i]);        // +NzNy-1
+            p = acc<FMA>(p, a2, p_hi[i]);        // -NzNy+1
+            o[i] = ((bits >> i) & 1u) ? old[r][i] : p;
+         }
+         if (active && (y0 + r <= Ny - 2)) *(vec *)(po + roff[j]) = o;
+      }
+#pragma unroll
+      for (int j = 0; j < R + 2; j++) {
+         prev[j] = cur[j]; prevL[j] = curL[j]; prevR[j] = curR[j];
+         cur[j] = nxt[j];  curL[j] = nxtL[j];  curR[j] = nxtR[j];
+      }
+   }
+}
+
+// Naive one-thread-per-cell air kernels: debugging reference variant (air_variant 9), same arithmetic.
+template <typename Real, bool FCC, bool FMA>
+__global__ void k_air_naive(const Real *__restrict__ u1, Real *__restrict__ u0, const uint8_t *__restrict__ mask,
+                            Real a1, Real a2, int64_t Ny, int64_t Nz, int64_t P, int64_t plane, int32_t x_begin,
+                            int32_t x_end) {
+   const int64_t iz = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   const int64_t iy = 1 + blockIdx.y;
+   const int64_t ix = x_begin + blockIdx.z;
+   if (iz < 1 || iz > Nz - 2 || iy > Ny - 2 || ix >= x_end) return;
+   const int64_t jj = ix * plane + iy * P + iz;
+   if ((mask[jj >> 3] >> (jj & 7)) & 1) return;
+   Real p = a1 * u1[jj] - u0[jj];
+   if (!FCC) {
+      p = acc<FMA>(p, a2, u1[jj + plane]);
+      p = acc<FMA>(p, a2, u1[jj - plane]);
+      p = acc<FMA>(p, a2, u1[jj + P]);
+      p = acc<FMA>(p, a2, u1[jj - P]);
+      p = acc<FMA>(p, a2, u1[jj + 1]);
+      p = acc<FMA>(p, a2, u1[jj - 1]);
+   } else {
+      p = acc<FMA>(p, a2, u1[jj + plane + P]);
+      p = acc<FMA>(p, a2, u1[jj - plane - P]);
+      p = acc<FMA>(p, a2, u1[jj + P + 1]);
+      p = acc<FMA>(p, a2, u1[jj - P - 1]);
+      p = acc<FMA>(p, a2, u1[jj + plane + 1]);
+      p = acc<FMA>(p, a2, u1[jj - plane - 1]);
+      p = acc<FMA>(p, a2, u1[jj + plane - P]);
+      p = acc<FMA>(p, a2, u1[jj - plane + P]);
+      p = acc<FMA>(p, a2, u1[jj + P - 1]);
+      p = acc<FMA>(p, a2, u1[jj - P + 1]);
+      p = acc<FMA>(p, a2, u1[jj + plane - 1]);
+      p = acc<FMA>(p, a2, u1[jj - plane + 1]);
+   }
+   u0[jj] = p;
+}
+
+// ---- ghost-shell maintenance (cpu_engine.h:135-172; gpu_engine.h:277-285,435-494) ---------------------------
+// z faces: one thread per (x,y) row
+template <typename Real>
+__global__ void k_flip_z(Real *__restrict__ u1, int64_t nrows, int64_t P, int64_t Nz) {
+   const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (r >= nrows) return;
+   Real *row = u1 + r * P;
+   row[0] = row[2];
+   row[Nz - 1] = row[Nz - 3];
+}
+// y faces (+ the folded-FCC ghost row, which the reference copies before the flips: done by the caller's order)
+// mode bit0: row0 <- row2 ; bit1: row Ny-1 <- row Ny-3 ; bit2: row Ny-1 <- row Ny-2 (fold)
+template <typename Real>
+__global__ void k_flip_y(Real *__restrict__ u1, int64_t Nx, int64_t Ny, int64_t P, int64_t Nz, int mode) {
+   const int64_t iz = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   const int64_t ix = blockIdx.y;
+   if (iz >= Nz || ix >= Nx) return;
+   Real *pl = u1 + ix * Ny * P + iz;
+   if (mode & 4) pl[(Ny - 1) * P] = pl[(Ny - 2) * P];
+   if (mode & 1) pl[0] = pl[2 * P];
+   if (mode & 2) pl[(Ny - 1) * P] = pl[(Ny - 3) * P];
+}
+// x faces: plane 0 <- plane 2 (first slab), plane Nx-1 <- plane Nx-3 (last slab)
+template <typename Real>
+__global__ void k_flip_x(Real *__restrict__ u1, int64_t Nx, int64_t plane, int first, int last) {
+   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (i >= plane) return;
+   if (first) u1[i] = u1[2 * plane + i];
+   if (last) u1[(Nx - 1) * plane + i] = u1[(Nx - 3) * plane + i];
+}
+
+// ---- ABC (first-order Engquist-Majda), cpu_engine.h:131-134 (save) and :225-229 (loss) ----------------------
+template <typename Real>
+__global__ void k_abc_save(const Real *__restrict__ u0, const int64_t *__restrict__ idx, Real *__restrict__ u2ba,
+                           int64_t n) {
+   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (i < n) u2ba[i] = u0[idx[i]];
+}
+template <typename Real>
+__global__ void k_abc_loss(Real *__restrict__ u0, const int64_t *__restrict__ idx, const int8_t *__restrict__ Q,
+                           const Real *__restrict__ u2ba, Real l, int64_t begin, int64_t end) {
+   const int64_t i = begin + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (i >= end) return;
+   const Real lQ = l * (Real)Q[i];
+   const int64_t ib = idx[i];
+   const Real num = u0[ib] + lQ * u2ba[i];
+   // the reference divides by (1.0 + lQ) with a double literal: denominator and division are double even in
+   // the float build (cpu_engine.h:228) -- reproduced
+   u0[ib] = (Real)((double)num / (1.0 + (double)lQ));
+}
+
+// ---- rigid boundary nodes, cpu_engine.h:234-287 (gpu_engine.h:288-348) --------------------------------------
+template <typename Real, bool FCC, bool FMA>
+__global__ void k_rigid(const Real *__restrict__ u1, Real *__restrict__ u0, const int64_t *__restrict__ idx,
+                        const uint16_t *__restrict__ adjv, Real a2, Real sl2, int64_t P, int64_t plane,
+                        int64_t begin, int64_t end) {
+   const int64_t nb = begin + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (nb >= end) return;
+   const int64_t ii = idx[nb];
+   const uint32_t adj = adjv[nb];
+   const Real two = 2.0, K = (Real)__popc(adj), b2 = a2, b1 = (two - sl2 * K);
+   Real p = b1 * u1[ii] - u0[ii];
+   if (!FCC) {
+      const int64_t off[6] = {plane, -plane, P, -P, 1, -1};
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+         const Real w = b2 * (Real)((adj >> j) & 1u);
+         p = FMA ? __builtin_fma(w, u1[ii + off[j]], p) : p + w * u1[ii + off[j]];
+      }
+   } else {
+      const int64_t off[12] = {plane + P, -plane - P, P + 1, -P - 1, plane + 1, -plane - 1,
+                               plane - P, -plane + P, P - 1, -P + 1, plane - 1, -plane + 1};
+#pragma unroll
+      for (int j = 0; j < 12; j++) {
+         const Real w = b2 * (Real)((adj >> j) & 1u);
+         p = FMA ? __builtin_fma(w, u1[ii + off[j]], p) : p + w * u1[ii + off[j]];
+      }
+   }
+   u0[ii] = p;
+}
+
+// ---- frequency-dependent (lossy) boundary nodes, cpu_engine.h:290-301 + 363-405 (gpu_engine.h:368-432) ------
+// gather + ODE update + scatter in one pass; branch states are SoA [m*Nbl + nb] so that lanes coalesce.
+template <typename Real> struct MatQuadT { Real b, bd, bDh, bFh; };
+
+template <typename Real>
+__global__ void k_fd_boundary(Real *__restrict__ u0, const int64_t *__restrict__ idx, Real *__restrict__ u0b,
+                              const Real *__restrict__ u2b, const Real *__restrict__ ssaf,
+                              const int8_t *__restrict__ mat, const int8_t *__restrict__ Mb,
+                              const MatQuadT<Real> *__restrict__ mq, const Real *__restrict__ beta,
+                              Real *__restrict__ vh1, Real *__restrict__ gh1, Real lo2, int64_t Nbl, int64_t begin,
+                              int64_t end) {
+   const int64_t nb = begin + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (nb >= end) return;
+   const Real one = 1.0, two = 2.0;
+   const int32_t k = mat[nb];
+   const int M = Mb[k];
+   const Real sf = ssaf[nb];
+   const Real g = lo2 * sf * beta[k];
+   const Real fac = two * lo2 * sf / (one + g);
+   const int64_t ii = idx[nb];
+   Real u = u0[ii];
+   const Real u2 = u2b[nb];
+   u = (u + g * u2) / (one + g);
+   Real v1[12], g1[12];
+#pragma unroll
+   for (int m = 0; m < 12; m++) {
+      if (m < M) {
+         const MatQuadT<Real> q = mq[k * 12 + m];
+         v1[m] = vh1[(int64_t)m * Nbl + nb];
+         g1[m] = gh1[(int64_t)m * Nbl + nb];
+         u -= fac * (two * q.bDh * v1[m] - q.bFh * g1[m]);
+      }
+   }
+   const Real du = u - u2;
+#pragma unroll
+   for (int m = 0; m < 12; m++) {
+      if (m < M) {
+         const MatQuadT<Real> q = mq[k * 12 + m];
+         const Real v0 = q.b * du + q.bd * v1[m] - two * q.bFh * g1[m];
+         gh1[(int64_t)m * Nbl + nb] = g1[m] + (v0 + v1[m]) / two;
+         vh1[(int64_t)m * Nbl + nb] = v0;
+      }
+   }
+   u0b[nb] = u;
+   u0[ii] = u;
+}
+
+// ---- receivers (read time n from u1) and sources (add to time n+1 in u0), cpu_engine.h:304-313 --------------
+// one launch: threads [0,Nr) gather into the ring column, thread Nr (alone) applies all sources in list order
+// (the reference loop is serial, so duplicate source nodes accumulate in order).
+template <typename Real>
+__global__ void k_io(const Real *__restrict__ u1, Real *__restrict__ u0, const int64_t *__restrict__ out_idx,
+                     Real *__restrict__ ring, int64_t Nr, int64_t ring_col, int64_t ring_depth,
+                     const int64_t *__restrict__ in_idx, const Real *__restrict__ in_sigs, int64_t Ns, int64_t Nt,
+                     int64_t n) {
+   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (t < Nr) {
+      ring[t * ring_depth + ring_col] = u1[out_idx[t]];
+   } else if (t == Nr) {
+      for (int64_t s = 0; s < Ns; s++) u0[in_idx[s]] += in_sigs[s * Nt + n];
+   }
+}
+
+// build the engine's skip-mask rows for ghost z columns / pad / odd parity (boundary-node bits are OR-ed in
+// afterwards by k_mask_set)
+__global__ void k_mask_init(uint8_t *__restrict__ mask, int64_t Nx, int64_t Ny, int64_t P, int64_t Nz, int parity) {
+   const int64_t byte = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   const int64_t nbytes = Nx * Ny * P / 8;
+   if (byte >= nbytes) return;
+   const int64_t j0 = byte * 8;
+   const int64_t iz0 = j0 % P;
+   const int64_t row = j0 / P;
+   const int64_t iy = row % Ny, ix = row / Ny;
+   uint32_t m = 0;
+   for (int i = 0; i < 8; i++) {
+      const int64_t iz = iz0 + i;
+      bool skip = (iz == 0) || (iz >= Nz - 1);
+      if (parity && (((ix + iy + iz) & 1) != 0)) skip = true;
+      if (skip) m |= 1u << i;
+   }
+   mask[byte] = (uint8_t)m;
+}
+__global__ void k_mask_set(uint8_t *__restrict__ mask, const int64_t *__restrict__ idx, int64_t n) {
+   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (i >= n) return;
+   const int64_t jj = idx[i];
+   // byte-granular atomic OR through the containing 32-bit word
+   uint32_t *w = (uint32_t *)(mask + ((jj >> 3) & ~(int64_t)3));
+   atomicOr(w, (1u << (jj & 7)) << (8 * ((jj >> 3) & 3)));
+}
+
+} // namespace pf

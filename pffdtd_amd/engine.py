@@ -1,0 +1,175 @@
+"""ctypes binding of libpffdtd_hip.so (include/pffdtd_hip.h): the only compute path of this package.
+
+There is no CPU fallback: if the HIP library is missing or no GPU is visible, construction raises.
+"""
+import ctypes
+from pathlib import Path
+
+import numpy as np
+
+from .sim_data import PfSimData
+
+_HERE = Path(__file__).resolve().parent
+_LIB = None
+
+PF_NUM_CPU_EXACT = 0
+PF_NUM_FMA = 1
+
+
+class PfOpts(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int32), ("numerics", ctypes.c_int32), ("slab_first", ctypes.c_int32),
+                ("slab_last", ctypes.c_int32), ("readout_chunk", ctypes.c_int32), ("air_variant", ctypes.c_int32),
+                ("air_chunk", ctypes.c_int32), ("timing", ctypes.c_int32), ("ext_u0", ctypes.c_void_p),
+                ("ext_u1", ctypes.c_void_p), ("reserved", ctypes.c_int32 * 8)]
+
+
+class PfTiming(ctypes.Structure):
+    _fields_ = [("air_ms_total", ctypes.c_double), ("air_launches", ctypes.c_int64),
+                ("step_ms_total", ctypes.c_double), ("steps", ctypes.c_int64)]
+
+
+class PfError(RuntimeError):
+    pass
+
+
+EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_grid_bytes", "pf_grid_pitch", "pf_opts_default",
+           "pf_run_sim", "pf_engine_create", "pf_engine_destroy", "pf_engine_run", "pf_engine_step_begin",
+           "pf_engine_halo_ptrs", "pf_engine_step_end", "pf_engine_stream", "pf_engine_sync",
+           "pf_engine_flush_outputs", "pf_engine_get_grid", "pf_engine_set_grid", "pf_engine_timing"]
+
+
+def lib_path():
+    return _HERE / "libpffdtd_hip.so"
+
+
+def lib():
+    """Load libpffdtd_hip.so; raises if it has not been built (no silent fallback)."""
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not p.exists():
+            raise PfError(f"{p} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = ctypes.CDLL(str(p))
+        vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+        L.pf_last_error.restype = ctypes.c_char_p
+        L.pf_version.restype = ctypes.c_char_p
+        L.pf_device_count.restype = ctypes.c_int
+        L.pf_grid_bytes.restype = ctypes.c_size_t
+        L.pf_grid_bytes.argtypes = [i64, i64, i64, i32]
+        L.pf_grid_pitch.restype = i64
+        L.pf_grid_pitch.argtypes = [i64, i32]
+        L.pf_opts_default.argtypes = [ctypes.POINTER(PfOpts)]
+        L.pf_run_sim.restype = ctypes.c_double
+        L.pf_run_sim.argtypes = [ctypes.POINTER(PfSimData)]
+        L.pf_engine_create.argtypes = [ctypes.POINTER(PfSimData), ctypes.POINTER(PfOpts), ctypes.POINTER(vp)]
+        L.pf_engine_destroy.argtypes = [vp]
+        L.pf_engine_destroy.restype = None
+        L.pf_engine_run.argtypes = [vp, i64, i64]
+        L.pf_engine_step_begin.argtypes = [vp, i64]
+        L.pf_engine_step_end.argtypes = [vp, i64]
+        L.pf_engine_halo_ptrs.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                          ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
+        L.pf_engine_stream.restype = vp
+        L.pf_engine_stream.argtypes = [vp, i32]
+        L.pf_engine_sync.argtypes = [vp]
+        L.pf_engine_flush_outputs.argtypes = [vp]
+        L.pf_engine_get_grid.argtypes = [vp, i32, vp]
+        L.pf_engine_set_grid.argtypes = [vp, i32, vp]
+        L.pf_engine_timing.argtypes = [vp, ctypes.POINTER(PfTiming), i32]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise PfError(f"pffdtd_hip error {rc}: {lib().pf_last_error().decode()}")
+
+
+def device_count():
+    return int(lib().pf_device_count())
+
+
+def grid_pitch(Nz, real_bytes):
+    return int(lib().pf_grid_pitch(int(Nz), int(real_bytes)))
+
+
+def run_sim(sd):
+    """`double run_sim(struct SimData*)` (cpu_engine.h:52 / gpu_engine.h:665): fills sd.u_out, returns seconds."""
+    s = sd.as_struct()
+    el = lib().pf_run_sim(ctypes.byref(s))
+    if el < 0:
+        raise PfError(f"pf_run_sim failed: {lib().pf_last_error().decode()}")
+    return el
+
+
+class HipEngine:
+    """One engine instance = one grid (or one Z-slab) resident on one MI355X."""
+
+    def __init__(self, sd, device=0, numerics=PF_NUM_CPU_EXACT, slab_first=True, slab_last=True, air_variant=0,
+                 air_chunk=0, timing=False, readout_chunk=0, ext_u0=None, ext_u1=None):
+        L = lib()
+        self.sd = sd
+        self._s = sd.as_struct()
+        o = PfOpts()
+        L.pf_opts_default(ctypes.byref(o))
+        o.device, o.numerics = int(device), int(numerics)
+        o.slab_first, o.slab_last = int(bool(slab_first)), int(bool(slab_last))
+        o.air_variant, o.air_chunk, o.timing, o.readout_chunk = int(air_variant), int(air_chunk), int(bool(timing)), \
+            int(readout_chunk)
+        if ext_u0 is not None and ext_u1 is not None:
+            o.ext_u0, o.ext_u1 = int(ext_u0), int(ext_u1)
+        self._h = ctypes.c_void_p()
+        _check(L.pf_engine_create(ctypes.byref(self._s), ctypes.byref(o), ctypes.byref(self._h)))
+        self.dtype = np.float32 if sd.real_bytes == 4 else np.float64
+
+    def run(self, n0, nsteps):
+        _check(lib().pf_engine_run(self._h, int(n0), int(nsteps)))
+
+    def step_begin(self, n):
+        _check(lib().pf_engine_step_begin(self._h, int(n)))
+
+    def step_end(self, n):
+        _check(lib().pf_engine_step_end(self._h, int(n)))
+
+    def halo_ptrs(self):
+        vp = ctypes.c_void_p
+        slo, shi, rlo, rhi, nb = vp(), vp(), vp(), vp(), ctypes.c_size_t()
+        _check(lib().pf_engine_halo_ptrs(self._h, ctypes.byref(slo), ctypes.byref(shi), ctypes.byref(rlo),
+                                         ctypes.byref(rhi), ctypes.byref(nb)))
+        return slo.value, shi.value, rlo.value, rhi.value, nb.value
+
+    def stream(self, which):
+        return lib().pf_engine_stream(self._h, int(which))
+
+    def sync(self):
+        _check(lib().pf_engine_sync(self._h))
+
+    def flush_outputs(self):
+        _check(lib().pf_engine_flush_outputs(self._h))
+
+    def get_grid(self, which):
+        a = np.empty((self.sd.Nx, self.sd.Ny, self.sd.Nz), dtype=self.dtype)
+        _check(lib().pf_engine_get_grid(self._h, int(which), a.ctypes.data_as(ctypes.c_void_p)))
+        return a
+
+    def set_grid(self, which, a):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        assert a.size == self.sd.Npts
+        _check(lib().pf_engine_set_grid(self._h, int(which), a.ctypes.data_as(ctypes.c_void_p)))
+
+    def timing(self, reset=False):
+        t = PfTiming()
+        _check(lib().pf_engine_timing(self._h, ctypes.byref(t), int(reset)))
+        return {"air_ms_total": t.air_ms_total, "air_launches": t.air_launches, "step_ms_total": t.step_ms_total,
+                "steps": t.steps}
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().pf_engine_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,100 @@
+"""GPU parity: the HIP engine (through the C ABI) against the CPU oracle on identical inputs.
+
+Bar: BIT-EXACT in the default numerics mode (PF_NUM_CPU_EXACT) for float and double -- receiver outputs
+and the full final state grids.  The FMA mode is held to a relative tolerance instead.
+"""
+import numpy as np
+import pytest
+
+import cases
+import oracle
+from pffdtd_amd import engine
+
+pytestmark = pytest.mark.gpu
+
+PRECS = ["double", "single"]
+
+
+def _oracle_run(sd):
+    e = oracle.Engine(sd)
+    for n in range(sd.Nt):
+        e.step(n)
+    u0, u1 = e.grid(0).copy(), e.grid(1).copy()
+    out = sd.u_out.copy()
+    e.close()
+    sd.u_out[:] = 0
+    return out, u0, u1
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("name", list(cases.CASES))
+@pytest.mark.parametrize("variant", [0, 9])
+def test_bit_exact_vs_oracle(name, prec, variant):
+    sd = cases.make_sd(name, prec)
+    ref_out, ref_u0, ref_u1 = _oracle_run(sd)
+    assert np.abs(ref_out).max() > 0
+    eng = engine.HipEngine(sd, air_variant=variant, readout_chunk=16)
+    eng.run(0, sd.Nt)
+    u0, u1 = eng.get_grid(0), eng.get_grid(1)
+    eng.close()
+    assert np.array_equal(sd.u_out, ref_out), f"u_out max|d|={np.abs(sd.u_out - ref_out).max()}"
+    assert np.array_equal(u1, ref_u1), f"u1 max|d|={np.abs(u1 - ref_u1).max()}"
+    assert np.array_equal(u0, ref_u0), f"u0 max|d|={np.abs(u0 - ref_u0).max()}"
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("name", ["cart_lossy", "cart_oddz", "fcc2_lossy", "fcc1_lossy"])
+def test_tile_variants_bit_exact(name, variant):
+    for prec in PRECS:
+        sd = cases.make_sd(name, prec)
+        ref_out, ref_u0, ref_u1 = _oracle_run(sd)
+        eng = engine.HipEngine(sd, air_variant=variant, air_chunk=5)
+        eng.run(0, sd.Nt)
+        u1 = eng.get_grid(1)
+        eng.close()
+        assert np.array_equal(sd.u_out, ref_out)
+        assert np.array_equal(u1, ref_u1)
+
+
+def test_run_sim_entry_point():
+    """pf_run_sim == `double run_sim(struct SimData*)`."""
+    sd = cases.make_sd("cart_lossy", "single")
+    ref_out, _, _ = _oracle_run(sd)
+    el = engine.run_sim(sd)
+    assert el > 0
+    assert np.array_equal(sd.u_out, ref_out)
+
+
+def test_split_phase_equals_single_stream():
+    """step_begin/step_end (edge planes first on the second stream) must give the same bits as run()."""
+    for name in ("cart_lossy", "fcc2_lossy"):
+        sd = cases.make_sd(name, "single")
+        ref_out, _, ref_u1 = _oracle_run(sd)
+        eng = engine.HipEngine(sd)
+        for n in range(sd.Nt):
+            eng.step_begin(n)
+            eng.step_end(n)
+        eng.flush_outputs()
+        u1 = eng.get_grid(1)
+        eng.close()
+        assert np.array_equal(sd.u_out, ref_out)
+        assert np.array_equal(u1, ref_u1)
+
+
+def test_fma_mode_close():
+    sd = cases.make_sd("cart_lossy", "single")
+    ref_out, _, _ = _oracle_run(sd)
+    eng = engine.HipEngine(sd, numerics=engine.PF_NUM_FMA)
+    eng.run(0, sd.Nt)
+    eng.close()
+    peak = np.abs(ref_out).max()
+    # fp32, 60 steps: contraction changes roundings only; tolerance 1e-5 of peak
+    assert np.abs(sd.u_out - ref_out).max() <= 1e-5 * peak
+
+
+def test_bad_arguments_raise():
+    sd = cases.make_sd("cart_rigid", "double")
+    sd.bn_ixyz = sd.bn_ixyz.copy()
+    sd.bn_ixyz[0] = 0  # ghost corner: not an interior node (fdtd_common.h:83-101)
+    with pytest.raises(engine.PfError):
+        engine.HipEngine(sd)
