@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the FDTD time-step hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[3]): synthetic shoebox 1024^3, 7-point Cartesian, fp32,
+walls 3 cells in, inside wall layer frequency-dependent (Mb=11 branches), outside layer rigid, 1 source,
+2 receivers x 8 nodes; state grids pre-filled with seeded U(-1,1)*1e-3 (no all-zero field: see DVFS note in
+DESIGN.md).  One "step" = one whole time step (ghost flips, air stencil, ABC, rigid + FD boundary nodes,
+source/receiver I/O, slab exchange).  The grid is fixed at 1024^3 for every N (strong scaling: BASELINE.json
+names 1024^3 at 1/2/4/8 GPUs); N>1 = Z-slab chain, one rank per GPU, RCCL plane exchange.
+
+Prints ONE JSON line on rank 0: metric Gvoxel-updates/s = Nx*Ny*Nz*K / t / 1e9 (the reference's own formula,
+cpu_engine.h:357 / gpu_engine.h:1253), plus `roofline` (air kernel, HIP-event timed, algorithmic bytes =
+12.125 B/voxel fp32) and `cpu_baseline` (the CPU oracle on this box's host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+
+
+def build_scene(n, steps_total, prec, fcc, lossy, mb):
+    from pffdtd_amd import sim_data, synth
+    if fcc:
+        # folded FCC with a stored grid of n x n x n: unfolded Ny = 2(n-1)
+        sim = synth.shoebox(n, 2 * (n - 1), n, Nt=steps_total, fcc=True, Nm=1, Mb=mb, lossy=lossy)
+        synth.fold_fcc(sim)
+        synth.sort_sim(sim)
+    else:
+        sim = synth.shoebox(n, n, n, Nt=steps_total, Nm=1, Mb=mb, lossy=lossy)
+    sd = sim_data.SimData.from_sim(sim, prec, build_mask=False)
+    sd.scale_input()
+    return sd
+
+
+def usable_cpus():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:  # cgroup v2 quota
+        q, p = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(prec, fcc, mb, lossy, budget_s=15.0):
+    """The CPU oracle (bit-exact restatement of the reference C CPU engine) on a bounded sample."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import oracle
+    from pffdtd_amd import sim_data, synth
+    n, nt = 256, 12
+    cores = min(usable_cpus(), 64)
+    if fcc:
+        sim = synth.shoebox(n, 2 * (n - 1), n, Nt=nt, fcc=True, Nm=1, Mb=mb, lossy=lossy)
+        synth.fold_fcc(sim)
+        synth.sort_sim(sim)
+    else:
+        sim = synth.shoebox(n, n, n, Nt=nt, Nm=1, Mb=mb, lossy=lossy)
+    sd = sim_data.SimData.from_sim(sim, prec)
+    sd.scale_input()
+    t0 = time.time()
+    el, t_air, t_bn = oracle.run_sim(sd, threads=cores)
+    wall = time.time() - t0
+    if wall > 3 * budget_s:
+        print(f"[bench] cpu baseline took {wall:.1f}s", file=sys.stderr)
+    return {"value": round(sd.Npts * nt / el / 1e9, 4), "unit": "Gvoxel-updates/s", "cores": cores, "kind": "port",
+            "sample": f"{n}^3 {'13-pt folded FCC' if fcc else '7-pt Cartesian'} {prec} shoebox, "
+                      f"{'Mb=%d lossy walls' % mb if lossy else 'rigid walls'}, {nt} steps, OpenMP CPU oracle "
+                      f"(oracle/pf_oracle.c = cpu_engine.h restated, bit-exact vs the compiled reference)",
+            "air_fraction": round(t_air / el, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--precision", default="single", choices=["single", "double"])
+    ap.add_argument("--fcc", action="store_true")
+    ap.add_argument("--rigid", action="store_true", help="rigid walls only (no FD boundary nodes)")
+    ap.add_argument("--mb", type=int, default=11)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--numerics", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split-phase", action="store_true", help="N=1: drive the split-phase step like N>1 does")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+
+    import torch
+    from pffdtd_amd import engine
+    if not torch.cuda.is_available() or engine.device_count() == 0:
+        raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    K, W = args.steps, args.warmup
+    n = args.size
+    lossy = not args.rigid
+    sd = build_scene(n, K + W, args.precision, args.fcc, lossy, args.mb)
+    real_bytes = 4 if args.precision == "single" else 8
+    ekw = dict(numerics=args.numerics, air_variant=args.variant, air_chunk=args.chunk, timing=True)
+
+    from pffdtd_amd import dist as pdist
+    runner, loc, info = pdist.make_hip_runner(sd, rank, world, local_rank, group, **ekw)
+    eng = runner.st.eng
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234 + rank)
+    for g in runner.st.grids:  # device-side fill of the torch-owned state grids (pad/ghost cells are never read back)
+        g.copy_((torch.rand(g.shape, generator=gen, device=g.device, dtype=torch.float32) * 2.0 - 1.0) * 1e-3)
+    torch.cuda.synchronize()
+    if world == 1 and not args.split_phase:
+        run = lambda n0, k: eng.run(n0, k)  # noqa: E731  (whole loop inside the C library, one stream)
+        parallelism = "1 GPU"
+    else:
+        run = lambda n0, k: runner.run(n0, k)  # noqa: E731
+        parallelism = f"z-slab x{world}, 1 rank/GPU, RCCL p2p plane exchange overlapped with interior planes"
+    sync = eng.sync
+    timing = eng.timing
+    interior_planes = loc.Nx - 2
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    run(0, W)
+    sync()
+    timing(reset=True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(W, K)
+    sync()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    el = t1 - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    tm = timing()
+
+    # sanity: the field must still be finite
+    if not bool(torch.isfinite(runner.st.grids[0][loc.Nx // 2]).all()):
+        raise SystemExit("bench: non-finite field")
+
+    if rank == 0:
+        gvox = sd.Npts * K / el / 1e9
+        bpv = 3 * real_bytes + 0.125  # u1 read, u0 read + write, one mask bit
+        # algorithmic bytes of one step's air launches on this rank: the interior voxels they update
+        upd = interior_planes * (sd.Ny - 2) * (sd.Nz - 2)
+        air_ms_per_step = tm["air_ms_total"] / max(tm["steps"] if tm["steps"] else K, 1)
+        achieved = upd * bpv / (air_ms_per_step * 1e-3) / 1e9 if air_ms_per_step > 0 else None
+        res = {
+            "metric": "Gvoxel-updates/s", "value": round(gvox, 3), "unit": "Gvoxel-updates/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(el / K * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if real_bytes == 4 else "f64", "data": "synthetic",
+            "config": {"workload": f"shoebox {n}^3 {'13-pt folded FCC' if args.fcc else '7-pt Cartesian'} "
+                                   f"{'fp32' if real_bytes == 4 else 'fp64'}, "
+                                   f"{'Mb=%d freq-dependent walls' % args.mb if lossy else 'rigid walls'} "
+                                   "(BASELINE.json configs[3])",
+                       "grid": [sd.Nx, sd.Ny, sd.Nz], "Nb": sd.Nb, "Nbl": sd.Nbl, "Nba": sd.Nba,
+                       "numerics": "cpu-exact" if args.numerics == 0 else "fma",
+                       "parallelism": parallelism, "air_variant": args.variant},
+            "achieved_hbm_GBs_whole_step": round(gvox * bpv, 1),
+            "roofline": {"bound": "hbm", "kernel": "k_air_fcc" if args.fcc else "k_air_cart",
+                         "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
+                         "air_ms_per_step": round(air_ms_per_step, 4),
+                         "bytes_per_voxel": bpv, "voxels_per_step": upd},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(args.precision, args.fcc, args.mb, lossy)
+        print(json.dumps(res), flush=True)
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -30,7 +30,25 @@ def lib():
             getattr(L, "orc_grid" + sfx).restype = ctypes.c_void_p
             getattr(L, "orc_grid" + sfx).argtypes = [ctypes.c_void_p, ctypes.c_int]
         _LIB = L
+        # OpenMP's default (one thread per visible CPU) is pathological under a cgroup CPU quota (the GPU box shows
+        # 256 CPUs with a 16-CPU quota): spin-wait barriers of 256 threads on 16 CPUs take seconds per step.
+        L.oracle_set_threads(default_threads())
     return _LIB
+
+
+def default_threads():
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, p = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+    except (OSError, ValueError):
+        q, p = "max", "1"
+    if q != "max":
+        n = max(1, min(n, int(int(q) / int(p))))
+    return max(1, min(n, 64))
 
 
 def _sfx(sd):

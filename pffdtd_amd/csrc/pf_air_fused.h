@@ -1,0 +1,374 @@
+// pf_air_fused.h -- the production interior kernel: one launch per step does
+//   * the ghost-shell "halo flips" (cpu_engine.h:135-172) VIRTUALLY: ghost planes / rows / columns are never
+//     written; every load that would touch one reads the cell two steps inward instead (plane 0 -> 2, row 0 -> 2,
+//     column Nz-1 -> Nz-3, folded-FCC row Ny-1 -> Ny-2, ...), which is exactly what the flips would have stored;
+//   * the air update, 7-point Cartesian or 13-point FCC (cpu_engine.h:175-223), same association;
+//   * the ABC loss on the outermost interior shell (cpu_engine.h:131-134,225-229): the "previous state" u2ba is
+//     the old u0 the stencil has in registers anyway, Q follows from the coordinates (fdtd_data.h:636-647);
+//   * optionally the rigid boundary-node update (cpu_engine.h:234-287): the adjacency word of a boundary node is
+//     found by ranking its mask bit inside the row segment (segment start table + wave prefix count), so all its
+//     neighbours come from the same registers the air stencil uses.
+// 2.5D tiling: a workgroup = WY waves stacked along y, each lane owns R rows x V consecutive z (16 bytes) and
+// marches along x with three plane windows in registers.  Own rows stream from HBM exactly once per plane
+// (coalesced 16 B/lane); the rows shared between neighbouring waves go through LDS (first/last row of every
+// wave + the two workgroup halo rows, double buffered, one barrier per plane); z neighbours across lanes are one
+// DPP wave shift, the two wave-edge columns travel with each row.  Loads for plane x+2 are in flight while plane
+// x is computed.
+//
+// The host enables this kernel only when its preconditions hold (see Engine::fused_ok): no boundary node in
+// the ABC shell, grid >= 5 cells per axis, DPP self-test passed.  Otherwise the step falls back to the separate
+// flip / air / ABC / rigid kernels of pf_kernels.h (same arithmetic, reference kernel order).
+#pragma once
+#include "pf_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace pf {
+
+struct FusedParams {
+   const void *u1;
+   void *u0;
+   const uint8_t *mask;      // padded layout, boundary nodes only (bit jj&7 of byte jj>>3)
+   const uint16_t *adj;      // adjacency words of the sorted boundary-node list
+   const int32_t *segstart;  // [(ix*Ny+iy)*nzt + seg] -> index of the first boundary node of that row segment
+   int64_t plane;            // Ny*P
+   int32_t Nx, Ny, Nz, P;
+   int32_t x_begin, x_end, chunk;
+   int32_t nzt, nyt, nxc, swizzle;
+   int32_t first, last;      // slab holds the global ix=0 / ix=Nx-1 ghost plane
+   int32_t fold, parity;     // fcc_flag==2 / fcc_flag==1
+   int32_t do_abc, do_rigid;
+};
+
+template <typename Real, bool FCC, int R, int WY, bool FMA>
+__global__ __launch_bounds__(64 * WY) void k_air_fused(FusedParams fp, Real a1, Real a2, Real sl2, Real l) {
+   typedef typename VecOf<Real>::type vec;
+   constexpr int V = VecOf<Real>::V;
+   constexpr int W = 64 * V;
+   constexpr int LROW = W + 4;           // W values, L edge, R edge, 2 pad (keeps rows 16-byte aligned)
+   constexpr int NROWS = 2 * WY + 2;     // halo_top, {first,last} of every wave, halo_bot
+   constexpr int NW = FCC ? R + 2 : R;   // rows kept for the previous plane
+   static_assert(WY >= 2, "the top and the bottom wave each carry one workgroup halo row");
+   __shared__ __attribute__((aligned(16))) Real lds[2][NROWS][LROW];
+
+   const Real *__restrict__ u1 = (const Real *)fp.u1;
+   Real *__restrict__ u0 = (Real *)fp.u0;
+   const uint32_t total = (uint32_t)fp.nzt * fp.nyt * fp.nxc;
+   uint32_t b = blockIdx.x;
+   if (fp.swizzle) b = xcd_swizzle(b, total);
+   const int zt = b % fp.nzt;
+   const int yt = (b / fp.nzt) % fp.nyt;
+   const int xc = b / (fp.nzt * fp.nyt);
+   const int lane = threadIdx.x & 63;
+   const int w = threadIdx.x >> 6;
+   const int Nx = fp.Nx, Ny = fp.Ny, Nz = fp.Nz, P = fp.P;
+   const int64_t plane = fp.plane;
+   const int z0 = (zt * 64 + lane) * V;
+   const bool active = z0 < P;
+   const int zl = active ? z0 : 0;
+   const int yb0 = 1 + yt * WY * R;
+   const int y0 = yb0 + w * R;
+   const int xs = fp.x_begin + xc * fp.chunk;
+   const int xe = min(xs + fp.chunk, fp.x_end);
+
+   // ---- virtual ghost shell: source row / plane of a load ----
+   auto rowsrc = [&](int y) {
+      y = min(y, Ny - 1);
+      if (y == 0) return 2;
+      if (y == Ny - 1) return fp.fold ? Ny - 2 : Ny - 3;
+      return y;
+   };
+   auto planesrc = [&](int x) {
+      if (fp.first && x == 0) return 2;
+      if (fp.last && x == Nx - 1) return Nx - 3;
+      return x;
+   };
+   const bool need_l = (lane == 0) && (z0 > 0);
+   const bool need_r = (lane == 63) && (z0 + V < P);
+   const bool r_is_ghost = (z0 + V == Nz - 1);       // right neighbour column is the ghost column: value = column Nz-3
+   const bool has_z0 = active && (z0 == 0);
+   const bool ownsN = active && (z0 <= Nz - 1) && (Nz - 1 < z0 + V);
+   const int zzN = Nz - 1 - z0;
+
+   // one row of a plane: 16 B per lane + wave-edge columns, ghost columns replaced by their mirror cells
+   auto load_row = [&](const Real *pl, uint32_t off, vec &v, Real &L, Real &Rr) {
+      v = *(const vec *)(pl + off);
+      L = need_l ? pl[off - 1] : Real(0);
+      Real rr = need_r ? pl[off + V] : Real(0);
+      const Real gN = ownsN ? pl[off - (uint32_t)zl + (uint32_t)(Nz - 3)] : Real(0);
+      if (V == 4) {
+         if (has_z0) v[0] = v[2];
+      } else {
+         const Real g0 = has_z0 ? pl[off + 2] : Real(0);
+         if (has_z0) v[0] = g0;
+      }
+      if (ownsN) {
+#pragma unroll
+         for (int i = 0; i < V; i++)
+            if (i == zzN) v[i] = gN;
+      }
+      if (need_r && r_is_ghost) rr = v[V - 2];
+      Rr = rr;
+   };
+
+   // in-plane offsets (elements) of the rows this lane touches
+   uint32_t ro[R], so[R];
+   bool valid[R];
+#pragma unroll
+   for (int r = 0; r < R; r++) {
+      ro[r] = (uint32_t)rowsrc(y0 + r) * (uint32_t)P + (uint32_t)zl;
+      so[r] = (uint32_t)min(y0 + r, Ny - 1) * (uint32_t)P + (uint32_t)zl;
+      valid[r] = active && (y0 + r <= Ny - 2);
+   }
+   const uint32_t ro_above = (uint32_t)rowsrc(y0 - 1) * (uint32_t)P + (uint32_t)zl;
+   const uint32_t ro_below = (uint32_t)rowsrc(y0 + R) * (uint32_t)P + (uint32_t)zl;
+   const bool top_wave = (w == 0), bot_wave = (w == WY - 1);
+
+   // per-lane cell classes that do not depend on x: z ghost / pad columns, z shell, y shell
+   bool skipz[V];
+   int qz[V];
+#pragma unroll
+   for (int i = 0; i < V; i++) {
+      const int z = z0 + i;
+      skipz[i] = (z == 0) || (z >= Nz - 1);
+      qz[i] = (z == 1 || z == Nz - 2) ? 1 : 0;
+   }
+   int qy[R];
+#pragma unroll
+   for (int r = 0; r < R; r++) {
+      const int y = y0 + r;
+      qy[r] = (y == 1 || (!fp.fold && y == Ny - 2)) ? 1 : 0;
+   }
+
+   // ---- plane windows ----
+   vec prev[NW], cur[R + 2], nxt[R + 2], nn[R];
+   Real prevL[NW], prevR[NW], curL[R + 2], curR[R + 2], nxtL[R + 2], nxtR[R + 2], nnL[R], nnR[R];
+   vec hv = {};            // workgroup halo row of the plane in flight (top / bottom wave only)
+   Real hL = 0, hR = 0;
+   vec old[R], oldn[R];
+   uint32_t mb[R], mbn[R];
+
+   auto load_own = [&](int x, vec *dst, Real *dL, Real *dR) { // dst[r] <- own rows of plane x
+      const Real *pl = u1 + (int64_t)planesrc(x) * plane;
+#pragma unroll
+      for (int r = 0; r < R; r++) load_row(pl, ro[r], dst[r], dL[r], dR[r]);
+   };
+   auto load_halo = [&](int x) { // workgroup halo row of plane x into hv/hL/hR (top and bottom wave)
+      const Real *pl = u1 + (int64_t)planesrc(x) * plane;
+      if (top_wave) load_row(pl, ro_above, hv, hL, hR);
+      if (bot_wave) load_row(pl, ro_below, hv, hL, hR);
+   };
+   auto load_old = [&](int x, vec *d, uint32_t *m) {
+      const Real *po = u0 + (int64_t)x * plane;
+      const uint8_t *pm = fp.mask + (((int64_t)x * plane) >> 3);
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+         d[r] = *(const vec *)(po + so[r]);
+         m[r] = pm[so[r] >> 3];
+      }
+   };
+   {  // prologue: windows of planes xs-1 and xs straight from global memory, own rows of xs+1 in flight
+      const Real *pm = u1 + (int64_t)planesrc(xs - 1) * plane;
+      const Real *pc = u1 + (int64_t)planesrc(xs) * plane;
+      if (FCC) {
+         load_row(pm, ro_above, prev[0], prevL[0], prevR[0]);
+         load_row(pm, ro_below, prev[NW - 1], prevL[NW - 1], prevR[NW - 1]);
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) load_row(pm, ro[r], prev[FCC ? r + 1 : r], prevL[FCC ? r + 1 : r], prevR[FCC ? r + 1 : r]);
+      load_row(pc, ro_above, cur[0], curL[0], curR[0]);
+      load_row(pc, ro_below, cur[R + 1], curL[R + 1], curR[R + 1]);
+#pragma unroll
+      for (int r = 0; r < R; r++) load_row(pc, ro[r], cur[r + 1], curL[r + 1], curR[r + 1]);
+      load_own(xs + 1, &nxt[1], &nxtL[1], &nxtR[1]);
+      load_halo(xs + 1);
+      load_old(xs, old, mb);
+   }
+
+   for (int x = xs; x < xe; x++) {
+      const bool more = (x + 1 < xe);
+      // (A) publish the edge rows of plane x+1 (loaded one iteration ago) for the neighbouring waves
+      Real(*S)[LROW] = lds[(x + 1) & 1];
+      {
+         *(vec *)&S[1 + 2 * w][lane * V] = nxt[1];
+         *(vec *)&S[2 + 2 * w][lane * V] = nxt[R];
+         if (lane == 0) { S[1 + 2 * w][W] = nxtL[1]; S[2 + 2 * w][W] = nxtL[R]; }
+         if (lane == 63) { S[1 + 2 * w][W + 1] = nxtR[1]; S[2 + 2 * w][W + 1] = nxtR[R]; }
+         if (top_wave || bot_wave) {
+            const int hr = top_wave ? 0 : NROWS - 1;
+            *(vec *)&S[hr][lane * V] = hv;
+            if (lane == 0) S[hr][W] = hL;
+            if (lane == 63) S[hr][W + 1] = hR;
+         }
+      }
+      // (B) next loads: own rows (+ workgroup halo row) of plane x+2, old state and mask of plane x+1
+      if (more) {
+         load_own(x + 2, nn, nnL, nnR);
+         load_halo(x + 2);
+         load_old(x + 1, oldn, mbn);
+      }
+      __syncthreads();
+      // (C) rows above / below my strip in plane x+1
+      nxt[0] = *(const vec *)&S[2 * w][lane * V];
+      nxtL[0] = S[2 * w][W];
+      nxtR[0] = S[2 * w][W + 1];
+      nxt[R + 1] = *(const vec *)&S[2 * w + 3][lane * V];
+      nxtL[R + 1] = S[2 * w + 3][W];
+      nxtR[R + 1] = S[2 * w + 3][W + 1];
+
+      // (D) update plane x
+      Real *po = u0 + (int64_t)x * plane;
+      const int qx = ((fp.first && x == 1) || (fp.last && x == Nx - 2)) ? 1 : 0;
+      auto zlo = [&](const vec &v, Real edge) { // value at z-1 for every element
+         Real zm = lane_from_lower<true>(v[V - 1]);
+         if (lane == 0) zm = edge;
+         vec s;
+#pragma unroll
+         for (int i = 0; i < V; i++) s[i] = (i == 0) ? zm : v[i > 0 ? i - 1 : 0];
+         return s;
+      };
+      auto zhi = [&](const vec &v, Real edge) { // value at z+1 for every element
+         Real zp = lane_from_upper<true>(v[0]);
+         if (lane == 63) zp = edge;
+         vec s;
+#pragma unroll
+         for (int i = 0; i < V; i++) s[i] = (i == V - 1) ? zp : v[i < V - 1 ? i + 1 : V - 1];
+         return s;
+      };
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+         const int j = r + 1;
+         const int y = y0 + r;
+         const vec c = cur[j];
+         // neighbour values in the reference's accumulation order
+         constexpr int NNB = FCC ? 12 : 6;
+         vec nb[NNB];
+         if (!FCC) {
+            nb[0] = nxt[j];                 // +NzNy
+            nb[1] = prev[r];                // -NzNy
+            nb[2] = cur[j + 1];             // +Nz
+            nb[3] = cur[j - 1];             // -Nz
+            nb[4] = zhi(c, curR[j]);        // +1
+            nb[5] = zlo(c, curL[j]);        // -1
+         } else {
+            const int jp = r + 1;           // own row inside prev[] (R+2 rows)
+            nb[0] = nxt[j + 1];                          // +NzNy+Nz
+            nb[1] = prev[jp - 1];                        // -NzNy-Nz
+            nb[2] = zhi(cur[j + 1], curR[j + 1]);        // +Nz+1
+            nb[3] = zlo(cur[j - 1], curL[j - 1]);        // -Nz-1
+            nb[4] = zhi(nxt[j], nxtR[j]);                // +NzNy+1
+            nb[5] = zlo(prev[jp], prevL[jp]);            // -NzNy-1
+            nb[6] = nxt[j - 1];                          // +NzNy-Nz
+            nb[7] = prev[jp + 1];                        // -NzNy+Nz
+            nb[8] = zlo(cur[j + 1], curL[j + 1]);        // +Nz-1
+            nb[9] = zhi(cur[j - 1], curR[j - 1]);        // -Nz+1
+            nb[10] = zlo(nxt[j], nxtL[j]);               // +NzNy-1
+            nb[11] = zhi(prev[jp], prevR[jp]);           // -NzNy+1
+         }
+         const uint32_t bits = valid[r] ? ((mb[r] >> (so[r] & 7u)) & ((1u << V) - 1u)) : 0u;
+         const bool row_has_bn = __ballot(bits != 0) != 0ull;
+         vec o;
+         if (!(fp.do_rigid && row_has_bn)) {
+            // air cells only (boundary cells keep their value for the separate rigid kernel)
+#pragma unroll
+            for (int i = 0; i < V; i++) {
+               Real p = a1 * c[i] - old[r][i];
+#pragma unroll
+               for (int k = 0; k < NNB; k++) p = acc<FMA>(p, a2, nb[k][i]);
+               o[i] = p;
+            }
+         } else {
+            // row segment with boundary nodes: per-cell centre coefficient and neighbour weights.
+            // rank of a boundary cell = #mask bits before it in this row segment (wave prefix count)
+            uint32_t before = 0;
+#pragma unroll
+            for (int i = 0; i < V; i++) {
+               const unsigned long long m = __ballot((bits >> i) & 1u);
+               before += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            }
+            const int32_t seg0 = fp.segstart[((int64_t)x * Ny + y) * fp.nzt + zt];
+            uint32_t inl = 0;
+#pragma unroll
+            for (int i = 0; i < V; i++) {
+               const bool isbn = (bits >> i) & 1u;
+               uint32_t adjw = (1u << NNB) - 1u;
+               if (isbn) adjw = fp.adj[seg0 + (int32_t)(before + inl)];
+               inl += isbn ? 1u : 0u;
+               const Real two = 2.0;
+               const Real cc = isbn ? (two - sl2 * (Real)__popc(adjw)) : a1; // b1 (cpu_engine.h:245) | a1
+               Real p = cc * c[i] - old[r][i];
+#pragma unroll
+               for (int k = 0; k < NNB; k++) {
+                  const Real wk = ((adjw >> k) & 1u) ? a2 : Real(0); // == a2*(Real)bit exactly
+                  p = FMA ? __builtin_fma(wk, nb[k][i], p) : p + wk * nb[k][i];
+               }
+               o[i] = p;
+            }
+         }
+         // ABC loss on the outermost interior shell; u2ba is the old value of this very cell
+         if (fp.do_abc) {
+            bool any = false;
+#pragma unroll
+            for (int i = 0; i < V; i++) any = any || ((qx + qy[r] + qz[i]) > 0);
+            if (__ballot(any) != 0ull) {
+#pragma unroll
+               for (int i = 0; i < V; i++) {
+                  const int Q = qx + qy[r] + qz[i];
+                  if (Q > 0 && !((bits >> i) & 1u)) {
+                     const Real lQ = l * (Real)Q;
+                     const Real num = o[i] + lQ * old[r][i];
+                     o[i] = (Real)((double)num / (1.0 + (double)lQ)); // double literal of cpu_engine.h:228
+                  }
+               }
+            }
+         }
+#pragma unroll
+         for (int i = 0; i < V; i++) {
+            bool keep = skipz[i];
+            if (fp.parity) keep = keep || (((x + y + z0 + i) & 1) != 0);
+            if (!fp.do_rigid) keep = keep || ((bits >> i) & 1u);
+            if (keep) o[i] = old[r][i];
+         }
+         if (valid[r]) *(vec *)(po + so[r]) = o;
+      }
+      // (E) rotate the windows
+      if (FCC) {
+#pragma unroll
+         for (int j = 0; j < R + 2; j++) { prev[j] = cur[j]; prevL[j] = curL[j]; prevR[j] = curR[j]; }
+      } else {
+#pragma unroll
+         for (int r = 0; r < R; r++) { prev[r] = cur[r + 1]; }
+      }
+#pragma unroll
+      for (int j = 0; j < R + 2; j++) { cur[j] = nxt[j]; curL[j] = nxtL[j]; curR[j] = nxtR[j]; }
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+         nxt[r + 1] = nn[r]; nxtL[r + 1] = nnL[r]; nxtR[r + 1] = nnR[r];
+         old[r] = oldn[r]; mb[r] = mbn[r];
+      }
+   }
+}
+
+// first boundary node of every (row, z-segment): lower bound of the segment's first padded index in the sorted list
+__global__ void k_segstart(const int64_t *__restrict__ bn, int64_t Nb, int32_t *__restrict__ segstart, int64_t nrows,
+                           int32_t nzt, int64_t P, int32_t segw) {
+   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (t >= nrows * nzt) return;
+   const int64_t row = t / nzt;
+   const int32_t seg = (int32_t)(t % nzt);
+   const int64_t key = row * P + (int64_t)seg * segw;
+   int64_t lo = 0, hi = Nb;
+   while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (bn[mid] < key) lo = mid + 1; else hi = mid;
+   }
+   segstart[t] = (int32_t)lo;
+}
+
+// boundary-node-only mask in the padded layout
+__global__ void k_mask_zero(uint8_t *__restrict__ mask, int64_t nbytes) {
+   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (i < nbytes) mask[i] = 0;
+}
+
+} // namespace pf

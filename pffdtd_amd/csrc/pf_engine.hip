@@ -15,6 +15,7 @@
 
 #include "pffdtd_hip.h"
 #include "pf_kernels.h"
+#include "pf_air_fused.h"
 
 namespace {
 
@@ -84,7 +85,11 @@ template <typename Real> struct Engine : EngineBase {
    // device state
    Real *u0 = nullptr, *u1 = nullptr;
    bool own_grids = true;
-   uint8_t *mask = nullptr;
+   uint8_t *mask = nullptr;      // skip-mask of the unfused kernels (boundary nodes + ghost z + pad + parity)
+   uint8_t *mask_bn = nullptr;   // boundary nodes only (fused kernel)
+   int32_t *segstart = nullptr;  // first boundary node of every (row, z segment) (fused rigid update)
+   bool fused = false, fused_rigid = false;
+   int fused_nzt = 0;
    int64_t *d_bn = nullptr, *d_bnl = nullptr, *d_bna = nullptr, *d_in = nullptr, *d_out = nullptr;
    uint16_t *d_adj = nullptr;
    int8_t *d_Q = nullptr, *d_mat = nullptr, *d_Mb = nullptr;
@@ -113,7 +118,7 @@ template <typename Real> struct Engine : EngineBase {
       if (s_edge) hipStreamSynchronize(s_edge);
       auto F = [](void *p) { if (p) hipFree(p); };
       if (own_grids) { F(u0); F(u1); }
-      F(mask); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
+      F(mask); F(mask_bn); F(segstart); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
       F(d_beta); F(d_insig); F(d_mq); F(ub[0]); F(ub[1]); F(ub[2]); F(u2ba); F(vh1); F(gh1); F(ring);
       if (h_ring) hipHostFree(h_ring);
       for (auto &p : air_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -153,6 +158,41 @@ template <typename Real> struct Engine : EngineBase {
       if (Nx - 2 > 1) { mid = {b2, std::max(b2, b3)}; hi = {std::max(b2, b3), b4}; }
       else { mid = {b2, b2}; hi = {b2, b2}; }
       (void)n;
+   }
+
+   // Preconditions of the fused interior kernel (pf_air_fused.h).  They hold for every scene the reference's own
+   // voxelizer produces (CartGrid offset 3.5 keeps walls >= 3 cells inside, sim_setup.py:91) but not for arbitrary
+   // hand-made inputs, which then take the unfused kernel sequence.
+   bool fused_ok() const {
+      if (!use_dpp) return false;
+      if (Nx < 5 || Ny < 5 || Nz < 5) return false;
+      if (plane >= ((int64_t)1 << 31)) return false;   // 32-bit in-plane offsets
+      // boundary nodes must not sit in the ABC shell (the reference applies ABC before the rigid update there)
+      for (int64_t i = 0; i < Nb; i++) {
+         const int64_t ii = sd.bn_ixyz[i];
+         const int64_t iz = ii % Nz, iy = (ii / Nz) % Ny, ix = ii / (Nz * Ny);
+         if (ix == 1 || ix == Nx - 2 || iy == 1 || iz == 1 || iz == Nz - 2) return false;
+         if (!fold && iy == Ny - 2) return false;
+      }
+      // receivers must not read ghost cells (their memory copy is not maintained)
+      for (int64_t i = 0; i < Nr; i++) {
+         const int64_t ii = sd.out_ixyz[i];
+         const int64_t iz = ii % Nz, iy = (ii / Nz) % Ny, ix = ii / (Nz * Ny);
+         if (ix < 1 || iy < 1 || iz < 1 || ix > Nx - 2 || iy > Ny - 2 || iz > Nz - 2) return false;
+      }
+      // the ABC list must be the canonical shell (it is generated by the loader; a caller could pass anything)
+      int64_t Nyf = fold ? 2 * (Ny - 1) : Ny;
+      int64_t expect = 2 * (Nx * Nyf + Nx * Nz + Nyf * Nz) - 12 * (Nx + Nyf + Nz) + 56;
+      if (fcc) expect /= 2;
+      if (!(op.slab_first && op.slab_last)) return Nba <= expect; // slabs carry their share of it
+      return Nba == expect;
+   }
+   // with a separate rigid kernel the boundary nodes read ghost MEMORY: only the folded ghost row can be adjacent
+   bool rigid_separable() const {
+      if (!fold) return true;
+      for (int64_t i = 0; i < Nb; i++)
+         if ((sd.bn_ixyz[i] / Nz) % Ny == Ny - 2) return false;
+      return true;
    }
 
    int init(const pf_simdata *s, const pf_opts *o) {
@@ -234,12 +274,36 @@ template <typename Real> struct Engine : EngineBase {
          if ((rc = upload(&d_bn, idx.data(), Nb))) return rc;
          if ((rc = upload(&d_adj, adj.data(), Nb))) return rc;
          plane_ranges(idx, bn_lo, bn_mid, bn_hi);
-         // skip-mask: ghost z / pad / parity, then the boundary nodes
-         if ((rc = dzalloc(&mask, npad / 8))) return rc;
+         // which interior path? (0 = auto)
+         const int v = op.air_variant & 15;
+         const bool want_fused = (op.air_variant == 0) || ((op.air_variant & 15) >= 10);
+         (void)v;
+         fused = want_fused && fused_ok();
+         if (!fused && (op.air_variant & 15) >= 10)
+            return set_err(PF_ERR_ARG, "air_variant %d (fused kernel) requested but its preconditions do not hold", op.air_variant);
+         fused_rigid = fused && !(op.air_variant & 32);
+         if (fused && !fused_rigid && !rigid_separable())
+            return set_err(PF_ERR_ARG, "unfused rigid update needs boundary nodes away from the folded ghost row");
          HIPCHK(hipDeviceSynchronize()); // memsets above ran on the null stream; our streams are non-blocking
-         hipLaunchKernelGGL(pf::k_mask_init, dim3((unsigned)cdiv(npad / 8, 256)), dim3(256), 0, s_main, mask, Nx, Ny, P, Nz,
-                            sd.fcc_flag == 1 ? 1 : 0);
-         if (Nb) hipLaunchKernelGGL(pf::k_mask_set, dim3((unsigned)cdiv(Nb, 256)), dim3(256), 0, s_main, mask, d_bn, Nb);
+         if (fused) {
+            if ((rc = dzalloc(&mask_bn, npad / 8))) return rc;
+            HIPCHK(hipDeviceSynchronize());
+            if (Nb) hipLaunchKernelGGL(pf::k_mask_set, dim3((unsigned)cdiv(Nb, 256)), dim3(256), 0, s_main, mask_bn, d_bn, Nb);
+            constexpr int V = pf::VecOf<Real>::V;
+            fused_nzt = (int)cdiv(P, 64 * V);
+            const int64_t nseg = Nx * Ny * fused_nzt;
+            if (Nb >= (int64_t)1 << 31) return set_err(PF_ERR_ARG, "too many boundary nodes for 32-bit ranks");
+            if ((rc = dzalloc(&segstart, nseg))) return rc;
+            HIPCHK(hipDeviceSynchronize());
+            hipLaunchKernelGGL(pf::k_segstart, dim3((unsigned)cdiv(nseg, 256)), dim3(256), 0, s_main, d_bn, Nb, segstart, Nx * Ny, fused_nzt, P, 64 * V);
+         } else {
+            // skip-mask: ghost z / pad / parity, then the boundary nodes
+            if ((rc = dzalloc(&mask, npad / 8))) return rc;
+            HIPCHK(hipDeviceSynchronize());
+            hipLaunchKernelGGL(pf::k_mask_init, dim3((unsigned)cdiv(npad / 8, 256)), dim3(256), 0, s_main, mask, Nx, Ny, P, Nz,
+                               sd.fcc_flag == 1 ? 1 : 0);
+            if (Nb) hipLaunchKernelGGL(pf::k_mask_set, dim3((unsigned)cdiv(Nb, 256)), dim3(256), 0, s_main, mask, d_bn, Nb);
+         }
          HIPCHK(hipGetLastError());
       }
       { // lossy nodes
@@ -313,6 +377,8 @@ template <typename Real> struct Engine : EngineBase {
             if (op.numerics == PF_NUM_FMA) hipLaunchKernelGGL((pf::k_air_naive<Real, false, true>), g, dim3(256), 0, s, u1, u0, mask, a1, a2, Ny, Nz, P, plane, xb, xe);
             else hipLaunchKernelGGL((pf::k_air_naive<Real, false, false>), g, dim3(256), 0, s, u1, u0, mask, a1, a2, Ny, Nz, P, plane, xb, xe);
          }
+      } else if (fused) {
+         launch_air_fused(s, xb, xe);
       } else {
          launch_air_march(s, xb, xe);
       }
@@ -356,16 +422,58 @@ template <typename Real> struct Engine : EngineBase {
       switch (op.air_variant & 15) {
          case 1: launch_air_cfg<2, 4, 1>(s, xb, xe); break;
          case 2: launch_air_cfg<4, 1, 4>(s, xb, xe); break;
-         case 3: launch_air_cfg<2, 2, 2>(s, xb, xe); break;
-         case 4: launch_air_cfg<4, 2, 2>(s, xb, xe); break;
-         case 5: launch_air_cfg<2, 1, 4>(s, xb, xe); break;
-         case 6: launch_air_cfg<1, 4, 1>(s, xb, xe); break;
          default: launch_air_cfg<4, 4, 1>(s, xb, xe); break;
       }
    }
 
+   template <int R, int WY> void launch_fused_cfg(hipStream_t s, int xb, int xe) {
+      pf::FusedParams fp;
+      fp.u1 = u1; fp.u0 = u0; fp.mask = mask_bn; fp.adj = d_adj; fp.segstart = segstart;
+      fp.plane = plane;
+      fp.Nx = (int)Nx; fp.Ny = (int)Ny; fp.Nz = (int)Nz; fp.P = (int)P;
+      fp.x_begin = xb; fp.x_end = xe;
+      fp.nzt = fused_nzt;
+      fp.nyt = (int)cdiv(Ny - 2, (int64_t)WY * R);
+      const int nplanes = xe - xb;
+      int chunk = op.air_chunk;
+      if (chunk <= 0) {
+         const int64_t tiles = (int64_t)fp.nzt * fp.nyt;
+         const int64_t want = cdiv(256 * 16, std::max<int64_t>(tiles, 1));
+         chunk = (int)std::max<int64_t>(cdiv(nplanes, std::max<int64_t>(want, 1)), 16);
+      }
+      chunk = std::min(chunk, nplanes);
+      fp.chunk = chunk;
+      fp.nxc = (int)cdiv(nplanes, chunk);
+      fp.swizzle = (op.air_variant & 16) ? 0 : 1;
+      fp.first = op.slab_first; fp.last = op.slab_last;
+      fp.fold = fold ? 1 : 0; fp.parity = sd.fcc_flag == 1 ? 1 : 0;
+      fp.do_abc = 1; fp.do_rigid = (fused_rigid && Nb > 0) ? 1 : 0;
+      dim3 g((uint32_t)fp.nzt * fp.nyt * fp.nxc), b(64 * WY);
+      const bool fma = op.numerics == PF_NUM_FMA;
+      if (fcc) {
+         if (fma) hipLaunchKernelGGL((pf::k_air_fused<Real, true, R, WY, true>), g, b, 0, s, fp, a1, a2, sl2, l);
+         else hipLaunchKernelGGL((pf::k_air_fused<Real, true, R, WY, false>), g, b, 0, s, fp, a1, a2, sl2, l);
+      } else {
+         if (fma) hipLaunchKernelGGL((pf::k_air_fused<Real, false, R, WY, true>), g, b, 0, s, fp, a1, a2, sl2, l);
+         else hipLaunchKernelGGL((pf::k_air_fused<Real, false, R, WY, false>), g, b, 0, s, fp, a1, a2, sl2, l);
+      }
+   }
+   void launch_air_fused(hipStream_t s, int xb, int xe) {
+      switch (op.air_variant & 15) {
+         case 11: launch_fused_cfg<4, 4>(s, xb, xe); break;
+         case 12: launch_fused_cfg<2, 4>(s, xb, xe); break;
+         case 13: launch_fused_cfg<1, 8>(s, xb, xe); break;
+         case 14: launch_fused_cfg<4, 8>(s, xb, xe); break;
+         default: launch_fused_cfg<2, 8>(s, xb, xe); break; // 0 (auto) and 10
+      }
+   }
+
    void launch_pre(hipStream_t s) {
+      if (fused) return; // ghost shell is virtual, u2ba is the old u0 in registers
+      launch_flips(s);
       if (Nba) hipLaunchKernelGGL(pf::k_abc_save<Real>, dim3((unsigned)cdiv(Nba, 256)), dim3(256), 0, s, u0, d_bna, u2ba, Nba);
+   }
+   void launch_flips(hipStream_t s) {
       dim3 gy((unsigned)cdiv(Nz, 256), (unsigned)Nx);
       if (fold) hipLaunchKernelGGL(pf::k_flip_y<Real>, gy, dim3(256), 0, s, u1, Nx, Ny, P, Nz, 4);
       hipLaunchKernelGGL(pf::k_flip_z<Real>, dim3((unsigned)cdiv(Nx * Ny, 256)), dim3(256), 0, s, u1, Nx * Ny, P, Nz);
@@ -374,10 +482,10 @@ template <typename Real> struct Engine : EngineBase {
          hipLaunchKernelGGL(pf::k_flip_x<Real>, dim3((unsigned)cdiv(plane, 256)), dim3(256), 0, s, u1, Nx, plane, op.slab_first, op.slab_last);
    }
    void launch_abc(hipStream_t s, Range r) {
-      if (r.e > r.b) hipLaunchKernelGGL(pf::k_abc_loss<Real>, dim3((unsigned)cdiv(r.e - r.b, 256)), dim3(256), 0, s, u0, d_bna, d_Q, u2ba, l, r.b, r.e);
+      if (!fused && r.e > r.b) hipLaunchKernelGGL(pf::k_abc_loss<Real>, dim3((unsigned)cdiv(r.e - r.b, 256)), dim3(256), 0, s, u0, d_bna, d_Q, u2ba, l, r.b, r.e);
    }
    void launch_rigid(hipStream_t s, Range r) {
-      if (r.e <= r.b) return;
+      if (r.e <= r.b || (fused && fused_rigid)) return;
       dim3 g((unsigned)cdiv(r.e - r.b, 256)), b(256);
       const bool fma = op.numerics == PF_NUM_FMA;
       if (fcc) {
@@ -555,6 +663,10 @@ template <typename Real> struct Engine : EngineBase {
       int rc = sync();
       if (rc) return rc;
       const Real *src = which == 0 ? u0 : u1;
+      if (fused && which == 1) { // write the virtual ghost shell out, exactly as the reference's flips would have
+         launch_flips(s_main);
+         HIPCHK(hipStreamSynchronize(s_main));
+      }
       HIPCHK(hipMemcpy2D(host, Nz * sizeof(Real), src, P * sizeof(Real), Nz * sizeof(Real), Nx * Ny, hipMemcpyDeviceToHost));
       return PF_OK;
    }

@@ -49,25 +49,29 @@ def abc_nodes(Nx, Ny, Nz, fcc_flag):
     Nba = 2 * (Nx * Nyf + Nx * Nz + Nyf * Nz) - 12 * (Nx + Nyf + Nz) + 56
     if fcc_flag > 0:
         Nba //= 2
-    ixs = np.arange(1, Nx - 1, dtype=np.int64)
     iys = np.arange(1, Nyf - 1, dtype=np.int64)
     izs = np.arange(1, Nz - 1, dtype=np.int64)
-    qx = ((ixs == 1) | (ixs == Nx - 2)).astype(np.int8)
     qy = ((iys == 1) | (iys == Nyf - 2)).astype(np.int8)
     qz = ((izs == 1) | (izs == Nz - 2)).astype(np.int8)
+    Q2 = qy[:, None] + qz[None, :]
+    par2 = (iys[:, None] + izs[None, :]) % 2
+    iyf = np.where(iys >= Nyf // 2, Nyf - iys - 1, iys) if fcc_flag == 2 else iys
+    off2 = iyf[:, None] * Nz + izs[None, :]
+    # a plane's node pattern depends only on (is it an x-shell plane, parity of ix): build the <=4 patterns once;
+    # row-major nonzero() order == the reference's iy,iz loop order
+    pats = {}
+    for qx in (0, 1):
+        for par in ((0, 1) if fcc_flag > 0 else (None,)):
+            sel = (Q2 + qx) > 0
+            if par is not None:
+                sel = sel & (par2 == par)  # (ix+iy+iz) even  <=>  (iy+iz)%2 == ix%2
+            pats[(qx, par)] = (off2[sel], (Q2[sel] + qx).astype(np.int8))
     idx_parts, q_parts = [], []
-    for a, ix in enumerate(ixs):  # plane by plane keeps memory O(Ny*Nz) and the order of the reference loops
-        Q2 = qy[:, None] + qz[None, :] + qx[a]
-        sel = Q2 > 0
-        if fcc_flag > 0:
-            sel &= ((ix + iys[:, None] + izs[None, :]) % 2) == 0
-        yy, zz = np.nonzero(sel)
-        iy = iys[yy]
-        iz = izs[zz]
-        if fcc_flag == 2:
-            iy = np.where(iy >= Nyf // 2, Nyf - iy - 1, iy)
-        idx_parts.append(ix * Nz * Ny + iy * Nz + iz)
-        q_parts.append(Q2[yy, zz])
+    for ix in range(1, Nx - 1):
+        key = (1 if ix in (1, Nx - 2) else 0, (ix % 2) if fcc_flag > 0 else None)
+        o, q = pats[key]
+        idx_parts.append(ix * Nz * Ny + o)
+        q_parts.append(q)
     bna = np.concatenate(idx_parts).astype(np.int64)
     Q = np.concatenate(q_parts).astype(np.int8)
     if bna.size != Nba:
@@ -88,7 +92,7 @@ class SimData:
 
     # ---- load_sim_data, fdtd_data.h:99-718 ----
     @classmethod
-    def from_sim(cls, sim, precision="double"):
+    def from_sim(cls, sim, precision="double", build_mask=True):
         sd = cls()
         real = {"double": np.float64, "single": np.float32, 2: np.float64, 1: np.float32}[precision]
         sd.real = real
@@ -179,9 +183,12 @@ class SimData:
         sd.adj_bn = (adj_bool.astype(np.uint16) * weights[None, :]).sum(axis=1).astype(np.uint16)  # :532-538
         sd.K_bn = adj_bool.sum(axis=1).astype(np.int8)  # :553-560
         sd.bn_ixyz = bn_ixyz
-        mask = np.zeros(((sd.Npts - 1) // 8 + 1,), dtype=np.uint8)  # :567-572
-        np.bitwise_or.at(mask, bn_ixyz >> 3, (1 << (bn_ixyz & 7)).astype(np.uint8))
-        sd.bn_mask = mask
+        if build_mask:  # :567-572 (the HIP engine builds its own padded mask and accepts NULL here)
+            flags = np.zeros((((sd.Npts - 1) // 8 + 1) * 8,), dtype=np.uint8)
+            flags[bn_ixyz] = 1
+            sd.bn_mask = np.packbits(flags, bitorder="little")
+        else:
+            sd.bn_mask = None
         lossy = mat_bn >= 0  # :595-614, order preserved
         sd.Nbl = int(lossy.sum())
         sd.mat_bnl = np.ascontiguousarray(mat_bn[lossy])
@@ -238,6 +245,8 @@ class SimData:
         for name in ("bn_ixyz", "bnl_ixyz", "bna_ixyz", "Q_bna", "in_ixyz", "out_ixyz", "out_reorder", "adj_bn",
                      "ssaf_bnl", "bn_mask", "mat_bnl", "K_bn", "in_sigs", "u_out", "Mb", "mat_quads", "mat_beta"):
             a = getattr(self, name)
+            if a is None:
+                continue
             if not a.flags["C_CONTIGUOUS"]:
                 raise ValueError(f"{name} must be contiguous")
             setattr(s, name, _ptr(a))

@@ -28,7 +28,7 @@ def _oracle_run(sd):
 
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("name", list(cases.CASES))
-@pytest.mark.parametrize("variant", [0, 9])
+@pytest.mark.parametrize("variant", [0, 3, 9])
 def test_bit_exact_vs_oracle(name, prec, variant):
     sd = cases.make_sd(name, prec)
     ref_out, ref_u0, ref_u1 = _oracle_run(sd)
@@ -39,10 +39,14 @@ def test_bit_exact_vs_oracle(name, prec, variant):
     eng.close()
     assert np.array_equal(sd.u_out, ref_out), f"u_out max|d|={np.abs(sd.u_out - ref_out).max()}"
     assert np.array_equal(u1, ref_u1), f"u1 max|d|={np.abs(u1 - ref_u1).max()}"
+    # u0's ghost shell holds the flips of the step before; the fused kernel keeps the ghost shell virtual
+    # (never stored), so compare the interior there
+    if variant == 0:
+        u0, ref_u0 = u0[1:-1, 1:-1, 1:-1], ref_u0[1:-1, 1:-1, 1:-1]
     assert np.array_equal(u0, ref_u0), f"u0 max|d|={np.abs(u0 - ref_u0).max()}"
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 10, 11, 12, 13, 14, 10 + 32, 10 + 16])
 @pytest.mark.parametrize("name", ["cart_lossy", "cart_oddz", "fcc2_lossy", "fcc1_lossy"])
 def test_tile_variants_bit_exact(name, variant):
     for prec in PRECS:
