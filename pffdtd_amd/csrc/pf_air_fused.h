@@ -371,4 +371,222 @@ __global__ void k_mask_zero(uint8_t *__restrict__ mask, int64_t nbytes) {
    if (i < nbytes) mask[i] = 0;
 }
 
+
+// =============================================================================================================
+// k_air_cart_lean -- the production 7-point kernel: virtual ghost shell + air update + ABC loss in one pass, with
+// the instruction count per voxel kept close to the bare stencil (the generic k_air_fused above spends most of
+// its issue slots on predication).  Differences from k_air_fused:
+//   * z neighbours come from two extra unit-stride loads per own row (element z0-1 and z0+V of every lane; L1/L2
+//     hits on the lines the 16-byte load just touched) instead of DPP shifts + lane-predicated edge loads;
+//   * ghost columns are patched with per-lane constant selects, halo rows need no patching at all (they are only
+//     used at the same z, and a ghost column's own cell is never updated);
+//   * the skip-mask of pf_kernels.h (boundary nodes + ghost z + pad) decides which cells keep their old value; the
+//     rigid boundary update stays in its own (list) kernel;
+//   * halo rows of the current plane are read from LDS when needed instead of living in registers.
+// Pipeline per plane x: [issue loads: own rows of x+2, old/mask of x+1] [read halo rows of x from LDS slot x&1]
+// [publish first/last own row of x+1 into slot (x+1)&1] [update + store plane x] [barrier] [rotate registers].
+// =============================================================================================================
+struct LeanParams {
+   const void *u1;
+   void *u0;
+   const uint8_t *mask;     // skip-mask (pf_kernels.h), padded layout
+   int64_t plane;
+   int32_t Nx, Ny, Nz, P;
+   int32_t x_begin, x_end, chunk;
+   int32_t nzt, nyt, nxc, swizzle;
+   int32_t first, last;
+   int32_t do_abc;
+   int32_t debug;           // reserved for tuning experiments (unused in production builds)
+};
+
+template <typename Real, int R, int WY, bool FMA>
+__global__ __launch_bounds__(64 * WY) void k_air_cart_lean(LeanParams fp, Real a1, Real a2, Real l) {
+   typedef typename VecOf<Real>::type vec;
+   constexpr int V = VecOf<Real>::V;
+   constexpr int W = 64 * V;
+   constexpr int NROWS = 2 * WY + 2;
+   static_assert(WY >= 2, "top and bottom wave each carry one workgroup halo row");
+   __shared__ __attribute__((aligned(16))) Real lds[2][NROWS][W];
+
+   const Real *__restrict__ u1 = (const Real *)fp.u1;
+   Real *__restrict__ u0 = (Real *)fp.u0;
+   const uint32_t total = (uint32_t)fp.nzt * fp.nyt * fp.nxc;
+   uint32_t b = blockIdx.x;
+   if (fp.swizzle) b = xcd_swizzle(b, total);
+   const int zt = b % fp.nzt;
+   const int yt = (b / fp.nzt) % fp.nyt;
+   const int xc = b / (fp.nzt * fp.nyt);
+   const int lane = threadIdx.x & 63;
+   const int w = threadIdx.x >> 6;
+   const int Nx = fp.Nx, Ny = fp.Ny, Nz = fp.Nz, P = fp.P;
+   const int64_t plane = fp.plane;
+   const int z0 = (zt * 64 + lane) * V;
+   const bool active = z0 < P;
+   const int zl = active ? z0 : 0;
+   const int y0 = 1 + (yt * WY + w) * R;
+   const int xs = fp.x_begin + xc * fp.chunk;
+   const int xe = min(xs + fp.chunk, fp.x_end);
+   const bool top_wave = (w == 0), bot_wave = (w == WY - 1);
+
+   auto rowsrc = [&](int y) {
+      y = min(y, Ny - 1);
+      if (y == 0) return 2;
+      if (y == Ny - 1) return Ny - 3;
+      return y;
+   };
+   auto planesrc = [&](int x) {
+      if (fp.first && x == 0) return 2;
+      if (fp.last && x == Nx - 1) return Nx - 3;
+      return x;
+   };
+   uint32_t ro[R], so[R];
+   bool valid[R];
+#pragma unroll
+   for (int r = 0; r < R; r++) {
+      ro[r] = (uint32_t)rowsrc(y0 + r) * (uint32_t)P + (uint32_t)zl;
+      so[r] = (uint32_t)min(y0 + r, Ny - 1) * (uint32_t)P + (uint32_t)zl;
+      valid[r] = active && (y0 + r <= Ny - 2);
+   }
+   const uint32_t ro_halo = (uint32_t)rowsrc(top_wave ? y0 - 1 : y0 + R) * (uint32_t)P + (uint32_t)zl;
+   const bool halo_wave = top_wave || bot_wave;
+   const int halo_slot = top_wave ? 0 : NROWS - 1;
+
+   // per-lane constants of the virtual z ghost columns (column 0 mirrors column 2, column Nz-1 mirrors Nz-3)
+   const int zzN = Nz - 1 - z0;                 // position of the ghost column Nz-1 inside this lane's vector
+   const bool fix0 = (z0 == 0);
+   const bool fixR = (zzN == V);                // my right neighbour IS the ghost column
+   // shell columns z==1 / z==Nz-2 (ABC)
+   uint32_t qzbits = 0;
+#pragma unroll
+   for (int i = 0; i < V; i++)
+      if (active && (z0 + i == 1 || z0 + i == Nz - 2)) qzbits |= 1u << i;
+   const bool wave_has_qz = __ballot(qzbits != 0) != 0ull;
+
+   // an own row with its z neighbours; ghost columns patched
+   auto load_own_row = [&](const Real *pl, uint32_t off, vec &v, Real &lf, Real &rt) {
+      v = *(const vec *)(pl + off);
+      lf = pl[off - 1];
+      rt = pl[off + V];
+      if (V == 4) {
+         if (fix0) v[0] = v[2];
+         if (zzN == 1) v[1] = lf;
+         if (zzN == 2) v[2] = v[0];
+         if (zzN == 3) v[3] = v[1];
+      } else {
+         if (fix0) v[0] = rt;
+         if (zzN == 1) v[1] = lf;
+      }
+      if (fixR) rt = v[V - 2];
+   };
+
+   vec prev[R], cur[R], nxt[R], nn[R], old[R], oldn[R];
+   Real curL[R], curR[R], nxtL[R], nxtR[R], nnL[R], nnR[R];
+   uint32_t mb[R], mbn[R];
+   vec hv = {}, hvn = {};
+
+   auto load_plane_own = [&](int x, vec *d, Real *dl, Real *dr) {
+      const Real *pl = u1 + (int64_t)planesrc(x) * plane;
+#pragma unroll
+      for (int r = 0; r < R; r++) load_own_row(pl, ro[r], d[r], dl[r], dr[r]);
+   };
+   auto load_old = [&](int x, vec *d, uint32_t *m) {
+      const Real *po = u0 + (int64_t)x * plane;
+      const uint8_t *pm = fp.mask + (((int64_t)x * plane) >> 3);
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+         d[r] = *(const vec *)(po + so[r]);
+         m[r] = pm[so[r] >> 3];
+      }
+   };
+   auto publish = [&](int x, const vec *rows, const vec &h) { // first/last own row (+ workgroup halo row) of plane x
+      Real(*S)[W] = lds[x & 1];
+      *(vec *)&S[1 + 2 * w][lane * V] = rows[0];
+      *(vec *)&S[2 + 2 * w][lane * V] = rows[R - 1];
+      if (halo_wave) *(vec *)&S[halo_slot][lane * V] = h;
+   };
+
+   {  // prologue
+      const Real *pc = u1 + (int64_t)planesrc(xs) * plane;
+      vec hc = {};
+      if (halo_wave) hc = *(const vec *)(pc + ro_halo);
+      load_plane_own(xs, cur, curL, curR);
+      publish(xs, cur, hc);
+      load_plane_own(xs + 1, nxt, nxtL, nxtR);
+      if (halo_wave) hv = *(const vec *)(u1 + (int64_t)planesrc(xs + 1) * plane + ro_halo);
+      Real dl[R], dr[R];
+      load_plane_own(xs - 1, prev, dl, dr);
+      load_old(xs, old, mb);
+      __syncthreads();
+   }
+
+   for (int x = xs; x < xe; x++) {
+      const bool more = (x + 1 < xe);
+      if (more) {
+         load_plane_own(x + 2, nn, nnL, nnR);
+         if (halo_wave) hvn = *(const vec *)(u1 + (int64_t)planesrc(x + 2) * plane + ro_halo);
+         load_old(x + 1, oldn, mbn);
+      }
+      Real(*S)[W] = lds[x & 1];
+      const vec above = *(const vec *)&S[2 * w][lane * V];
+      const vec below = *(const vec *)&S[2 * w + 3][lane * V];
+      publish(x + 1, nxt, hv);
+
+      Real *po = u0 + (int64_t)x * plane;
+      const bool qx = (fp.first && x == 1) || (fp.last && x == Nx - 2);
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+         const vec c = cur[r];
+         const vec ym = (r == 0) ? above : cur[r > 0 ? r - 1 : 0];
+         const vec yp = (r == R - 1) ? below : cur[r < R - 1 ? r + 1 : R - 1];
+         const uint32_t bits = mb[r] >> (so[r] & 7u);
+         vec o;
+#pragma unroll
+         for (int i = 0; i < V; i++) {
+            const Real zp = (i == V - 1) ? curR[r] : c[i < V - 1 ? i + 1 : V - 1];
+            const Real zm = (i == 0) ? curL[r] : c[i > 0 ? i - 1 : 0];
+            Real p = a1 * c[i] - old[r][i];
+            p = acc<FMA>(p, a2, nxt[r][i]);   // +NzNy
+            p = acc<FMA>(p, a2, prev[r][i]);  // -NzNy
+            p = acc<FMA>(p, a2, yp[i]);       // +Nz
+            p = acc<FMA>(p, a2, ym[i]);       // -Nz
+            p = acc<FMA>(p, a2, zp);          // +1
+            p = acc<FMA>(p, a2, zm);          // -1
+            o[i] = p;
+         }
+         if (fp.do_abc) {
+            // ABC loss (cpu_engine.h:225-229): u2ba is the old value of the cell, Q from the coordinates
+            const int y = y0 + r;
+            const int qxy = (qx ? 1 : 0) + ((y == 1 || y == Ny - 2) ? 1 : 0);
+            if (qxy > 0 || wave_has_qz) {
+#pragma unroll
+               for (int i = 0; i < V; i++) {
+                  const bool zq = (qzbits >> i) & 1u;
+                  if (qxy > 0 || __ballot(zq) != 0ull) {
+                     const int Q = qxy + (zq ? 1 : 0);
+                     if (Q > 0) {
+                        const Real lQ = l * (Real)Q;
+                        const Real num = o[i] + lQ * old[r][i];
+                        o[i] = (Real)((double)num / (1.0 + (double)lQ)); // double literal of cpu_engine.h:228
+                     }
+                  }
+               }
+            }
+         }
+#pragma unroll
+         for (int i = 0; i < V; i++)
+            if ((bits >> i) & 1u) o[i] = old[r][i];
+         if (valid[r]) *(vec *)(po + so[r]) = o;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+         prev[r] = cur[r];
+         cur[r] = nxt[r]; curL[r] = nxtL[r]; curR[r] = nxtR[r];
+         nxt[r] = nn[r]; nxtL[r] = nnL[r]; nxtR[r] = nnR[r];
+         old[r] = oldn[r]; mb[r] = mbn[r];
+      }
+      hv = hvn;
+   }
+}
+
 } // namespace pf

@@ -88,7 +88,8 @@ template <typename Real> struct Engine : EngineBase {
    uint8_t *mask = nullptr;      // skip-mask of the unfused kernels (boundary nodes + ghost z + pad + parity)
    uint8_t *mask_bn = nullptr;   // boundary nodes only (fused kernel)
    int32_t *segstart = nullptr;  // first boundary node of every (row, z segment) (fused rigid update)
-   bool fused = false, fused_rigid = false;
+   bool fused = false, fused_rigid = false, lean = false;
+   int vbase = 0;            // air_variant without its flag bits (64: no XCD swizzle, 128: old fused kernel without rigid fusion)
    int fused_nzt = 0;
    int64_t *d_bn = nullptr, *d_bnl = nullptr, *d_bna = nullptr, *d_in = nullptr, *d_out = nullptr;
    uint16_t *d_adj = nullptr;
@@ -274,14 +275,17 @@ template <typename Real> struct Engine : EngineBase {
          if ((rc = upload(&d_bn, idx.data(), Nb))) return rc;
          if ((rc = upload(&d_adj, adj.data(), Nb))) return rc;
          plane_ranges(idx, bn_lo, bn_mid, bn_hi);
-         // which interior path? (0 = auto)
-         const int v = op.air_variant & 15;
-         const bool want_fused = (op.air_variant == 0) || ((op.air_variant & 15) >= 10);
-         (void)v;
-         fused = want_fused && fused_ok();
-         if (!fused && (op.air_variant & 15) >= 10)
+         // which interior path? 0 = auto; 1-3 unfused marching kernels; 9 naive; 10-14 generic fused kernel
+         // (virtual ghosts + ABC + rigid in-kernel); 20-24 lean fused 7-point kernel (virtual ghosts + ABC)
+         vbase = op.air_variant & 63;
+         const bool ok = fused_ok();
+         if (vbase == 0) { lean = ok && !fcc; fused = false; }
+         else if (vbase >= 20) { lean = true; fused = false; }
+         else if (vbase >= 10) { fused = true; lean = false; }
+         if ((lean || fused) && !ok)
             return set_err(PF_ERR_ARG, "air_variant %d (fused kernel) requested but its preconditions do not hold", op.air_variant);
-         fused_rigid = fused && !(op.air_variant & 32);
+         if (lean && fcc) return set_err(PF_ERR_ARG, "the lean fused kernel is 7-point Cartesian only");
+         fused_rigid = fused && !(op.air_variant & 128);
          if (fused && !fused_rigid && !rigid_separable())
             return set_err(PF_ERR_ARG, "unfused rigid update needs boundary nodes away from the folded ghost row");
          HIPCHK(hipDeviceSynchronize()); // memsets above ran on the null stream; our streams are non-blocking
@@ -297,6 +301,7 @@ template <typename Real> struct Engine : EngineBase {
             HIPCHK(hipDeviceSynchronize());
             hipLaunchKernelGGL(pf::k_segstart, dim3((unsigned)cdiv(nseg, 256)), dim3(256), 0, s_main, d_bn, Nb, segstart, Nx * Ny, fused_nzt, P, 64 * V);
          } else {
+            fused_nzt = (int)cdiv(P, 64 * pf::VecOf<Real>::V);
             // skip-mask: ghost z / pad / parity, then the boundary nodes
             if ((rc = dzalloc(&mask, npad / 8))) return rc;
             HIPCHK(hipDeviceSynchronize());
@@ -368,7 +373,7 @@ template <typename Real> struct Engine : EngineBase {
          else { hipEventCreate(&ev.first); hipEventCreate(&ev.second); }
          hipEventRecord(ev.first, s);
       }
-      if (op.air_variant == 9) {
+      if (vbase == 9) {
          dim3 g((unsigned)cdiv(Nz, 256), (unsigned)(Ny - 2), (unsigned)(xe - xb));
          if (fcc) {
             if (op.numerics == PF_NUM_FMA) hipLaunchKernelGGL((pf::k_air_naive<Real, true, true>), g, dim3(256), 0, s, u1, u0, mask, a1, a2, Ny, Nz, P, plane, xb, xe);
@@ -377,6 +382,8 @@ template <typename Real> struct Engine : EngineBase {
             if (op.numerics == PF_NUM_FMA) hipLaunchKernelGGL((pf::k_air_naive<Real, false, true>), g, dim3(256), 0, s, u1, u0, mask, a1, a2, Ny, Nz, P, plane, xb, xe);
             else hipLaunchKernelGGL((pf::k_air_naive<Real, false, false>), g, dim3(256), 0, s, u1, u0, mask, a1, a2, Ny, Nz, P, plane, xb, xe);
          }
+      } else if (lean) {
+         launch_air_lean(s, xb, xe);
       } else if (fused) {
          launch_air_fused(s, xb, xe);
       } else {
@@ -403,7 +410,7 @@ template <typename Real> struct Engine : EngineBase {
       chunk = std::min(chunk, nplanes);
       ap.chunk = chunk;
       ap.nxc = (int)cdiv(nplanes, chunk);
-      ap.swizzle = (op.air_variant & 16) ? 0 : 1;
+      ap.swizzle = (op.air_variant & 64) ? 0 : 1;
       const uint32_t total = (uint32_t)ap.nzt * ap.nyt * ap.nxc;
       dim3 g(total), b(64 * WY * WZ);
       const bool fma = op.numerics == PF_NUM_FMA;
@@ -419,7 +426,7 @@ template <typename Real> struct Engine : EngineBase {
    }
 
    void launch_air_march(hipStream_t s, int xb, int xe) {
-      switch (op.air_variant & 15) {
+      switch (vbase) {
          case 1: launch_air_cfg<2, 4, 1>(s, xb, xe); break;
          case 2: launch_air_cfg<4, 1, 4>(s, xb, xe); break;
          default: launch_air_cfg<4, 4, 1>(s, xb, xe); break;
@@ -444,7 +451,7 @@ template <typename Real> struct Engine : EngineBase {
       chunk = std::min(chunk, nplanes);
       fp.chunk = chunk;
       fp.nxc = (int)cdiv(nplanes, chunk);
-      fp.swizzle = (op.air_variant & 16) ? 0 : 1;
+      fp.swizzle = (op.air_variant & 64) ? 0 : 1;
       fp.first = op.slab_first; fp.last = op.slab_last;
       fp.fold = fold ? 1 : 0; fp.parity = sd.fcc_flag == 1 ? 1 : 0;
       fp.do_abc = 1; fp.do_rigid = (fused_rigid && Nb > 0) ? 1 : 0;
@@ -459,7 +466,7 @@ template <typename Real> struct Engine : EngineBase {
       }
    }
    void launch_air_fused(hipStream_t s, int xb, int xe) {
-      switch (op.air_variant & 15) {
+      switch (vbase) {
          case 11: launch_fused_cfg<4, 4>(s, xb, xe); break;
          case 12: launch_fused_cfg<2, 4>(s, xb, xe); break;
          case 13: launch_fused_cfg<1, 8>(s, xb, xe); break;
@@ -468,8 +475,44 @@ template <typename Real> struct Engine : EngineBase {
       }
    }
 
+   template <int R, int WY> void launch_lean_cfg(hipStream_t s, int xb, int xe) {
+      pf::LeanParams fp;
+      fp.u1 = u1; fp.u0 = u0; fp.mask = mask;
+      fp.plane = plane;
+      fp.Nx = (int)Nx; fp.Ny = (int)Ny; fp.Nz = (int)Nz; fp.P = (int)P;
+      fp.x_begin = xb; fp.x_end = xe;
+      fp.nzt = fused_nzt;
+      fp.nyt = (int)cdiv(Ny - 2, (int64_t)WY * R);
+      const int nplanes = xe - xb;
+      int chunk = op.air_chunk;
+      if (chunk <= 0) {
+         const int64_t tiles = (int64_t)fp.nzt * fp.nyt;
+         const int64_t want = cdiv(256 * 8, std::max<int64_t>(tiles, 1));
+         chunk = (int)std::max<int64_t>(cdiv(nplanes, std::max<int64_t>(want, 1)), 16);
+      }
+      chunk = std::min(chunk, nplanes);
+      fp.chunk = chunk;
+      fp.nxc = (int)cdiv(nplanes, chunk);
+      fp.swizzle = (op.air_variant & 64) ? 0 : 1;
+      fp.first = op.slab_first; fp.last = op.slab_last;
+      fp.do_abc = (op.reserved[0] & 8) ? 0 : 1;
+      fp.debug = op.reserved[0];
+      dim3 g((uint32_t)fp.nzt * fp.nyt * fp.nxc), b(64 * WY);
+      if (op.numerics == PF_NUM_FMA) hipLaunchKernelGGL((pf::k_air_cart_lean<Real, R, WY, true>), g, b, 0, s, fp, a1, a2, l);
+      else hipLaunchKernelGGL((pf::k_air_cart_lean<Real, R, WY, false>), g, b, 0, s, fp, a1, a2, l);
+   }
+   void launch_air_lean(hipStream_t s, int xb, int xe) {
+      switch (vbase) {
+         case 21: launch_lean_cfg<4, 8>(s, xb, xe); break;
+         case 23: launch_lean_cfg<2, 4>(s, xb, xe); break;
+         case 24: launch_lean_cfg<1, 8>(s, xb, xe); break;
+         case 20: launch_lean_cfg<2, 8>(s, xb, xe); break;
+         default: launch_lean_cfg<4, 4>(s, xb, xe); break; // 0 (auto) and 22: fastest measured on MI355X
+      }
+   }
+
    void launch_pre(hipStream_t s) {
-      if (fused) return; // ghost shell is virtual, u2ba is the old u0 in registers
+      if (fused || lean) return; // ghost shell is virtual, u2ba is the old u0 in registers
       launch_flips(s);
       if (Nba) hipLaunchKernelGGL(pf::k_abc_save<Real>, dim3((unsigned)cdiv(Nba, 256)), dim3(256), 0, s, u0, d_bna, u2ba, Nba);
    }
@@ -482,7 +525,7 @@ template <typename Real> struct Engine : EngineBase {
          hipLaunchKernelGGL(pf::k_flip_x<Real>, dim3((unsigned)cdiv(plane, 256)), dim3(256), 0, s, u1, Nx, plane, op.slab_first, op.slab_last);
    }
    void launch_abc(hipStream_t s, Range r) {
-      if (!fused && r.e > r.b) hipLaunchKernelGGL(pf::k_abc_loss<Real>, dim3((unsigned)cdiv(r.e - r.b, 256)), dim3(256), 0, s, u0, d_bna, d_Q, u2ba, l, r.b, r.e);
+      if (!fused && !lean && r.e > r.b) hipLaunchKernelGGL(pf::k_abc_loss<Real>, dim3((unsigned)cdiv(r.e - r.b, 256)), dim3(256), 0, s, u0, d_bna, d_Q, u2ba, l, r.b, r.e);
    }
    void launch_rigid(hipStream_t s, Range r) {
       if (r.e <= r.b || (fused && fused_rigid)) return;
@@ -663,7 +706,7 @@ template <typename Real> struct Engine : EngineBase {
       int rc = sync();
       if (rc) return rc;
       const Real *src = which == 0 ? u0 : u1;
-      if (fused && which == 1) { // write the virtual ghost shell out, exactly as the reference's flips would have
+      if ((fused || lean) && which == 1) { // write the virtual ghost shell out, exactly as the reference's flips would have
          launch_flips(s_main);
          HIPCHK(hipStreamSynchronize(s_main));
       }

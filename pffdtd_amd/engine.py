@@ -106,7 +106,7 @@ class HipEngine:
     """One engine instance = one grid (or one Z-slab) resident on one MI355X."""
 
     def __init__(self, sd, device=0, numerics=PF_NUM_CPU_EXACT, slab_first=True, slab_last=True, air_variant=0,
-                 air_chunk=0, timing=False, readout_chunk=0, ext_u0=None, ext_u1=None):
+                 air_chunk=0, timing=False, readout_chunk=0, ext_u0=None, ext_u1=None, debug=0):
         L = lib()
         self.sd = sd
         self._s = sd.as_struct()
@@ -116,6 +116,7 @@ class HipEngine:
         o.slab_first, o.slab_last = int(bool(slab_first)), int(bool(slab_last))
         o.air_variant, o.air_chunk, o.timing, o.readout_chunk = int(air_variant), int(air_chunk), int(bool(timing)), \
             int(readout_chunk)
+        o.reserved[0] = int(debug)  # kernel ablation switches for tuning runs; 0 in production
         if ext_u0 is not None and ext_u1 is not None:
             o.ext_u0, o.ext_u1 = int(ext_u0), int(ext_u1)
         self._h = ctypes.c_void_p()

@@ -66,10 +66,12 @@ def _ind2sub(ii, Ny, Nz):
 
 
 def shoebox(Nx, Ny, Nz, Nt, fcc=False, wall=3, Nm=1, Mb=2, lossy=True, rigid_every=0,
-            src=None, rcv=None, sig="impulse", diff=True, h=0.05, c=343.2):
+            src=None, rcv=None, sig="impulse", diff=True, h=0.05, c=343.2, box=True):
     """Return the in-memory file contract for a shoebox room: dict of {file: {dataset: array}}.
 
     fcc=True gives fcc_flag 1 (checkerboard subgrid, python engine / C-CPU form); use fold_fcc() for flag 2.
+    box=False gives free space (no boundary nodes: only the ABC shell terminates the grid).  Note that the
+    box is closed: a source inside never reaches the ghost/ABC shell, a source outside (src=...) never enters.
     """
     assert min(Nx, Ny, Nz) >= 2 * wall + 3, "grid too small for the wall offset"
     if fcc:
@@ -79,7 +81,7 @@ def shoebox(Nx, Ny, Nz, Nt, fcc=False, wall=3, Nm=1, Mb=2, lossy=True, rigid_eve
     w = wall
     dims = np.array([Nx, Ny, Nz])
 
-    cand = _shell_candidates(Nx, Ny, Nz, w)
+    cand = _shell_candidates(Nx, Ny, Nz, w) if box else np.zeros((0,), dtype=np.int64)
     cx, cy, cz = _ind2sub(cand, Ny, Nz)
     if fcc:
         keep = ((cx + cy + cz) % 2) == 0

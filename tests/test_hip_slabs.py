@@ -1,0 +1,68 @@
+"""GPU: the Z-slab path on ONE device -- G HIP slab engines in one process ("virtual slabs"), halo planes moved
+with stream-ordered device copies through exactly the split-phase API the multi-process runner uses
+(step_begin / halo tensors on the edge stream / step_end).  Must equal the single-domain oracle bit for bit.
+The RCCL transport itself needs >1 GPU and is exercised by bench.py --gpus N on the multi-GPU node.
+"""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import oracle
+from pffdtd_amd import dist as pdist
+from pffdtd_amd import slab
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference(name, prec):
+    sd = cases.make_sd(name, prec)
+    oracle.run_sim(sd)
+    return sd.u_out.copy()
+
+
+@pytest.mark.parametrize("G", [2, 3])
+@pytest.mark.parametrize("name,prec,variant", [("cart_outside", "single", 0), ("cart_outside", "double", 0),
+                                               ("fcc2_outside", "single", 0), ("cart_lossy", "single", 3),
+                                               ("fcc1_outside", "double", 10)])
+def test_virtual_slabs_equal_single_domain(name, prec, variant, G):
+    ref = _reference(name, prec)
+    sd = cases.make_sd(name, prec)
+    parts = [slab.split(sd, G, r) for r in range(G)]
+    st = [pdist.HipSlabStepper(loc, info, 0, air_variant=variant) for loc, info in parts]
+    for n in range(sd.Nt):
+        for s in st:
+            s.step_begin(n)
+        planes = [s.halo_tensors() for s in st]
+        evs = []
+        for s in st:  # everything the edge streams have produced so far
+            e = torch.cuda.Event()
+            e.record(s.edge_stream)
+            evs.append(e)
+        for r in range(G - 1):
+            with torch.cuda.stream(st[r + 1].edge_stream):
+                st[r + 1].edge_stream.wait_event(evs[r])
+                planes[r + 1][2].copy_(planes[r][1], non_blocking=True)
+            with torch.cuda.stream(st[r].edge_stream):
+                st[r].edge_stream.wait_event(evs[r + 1])
+                planes[r][3].copy_(planes[r + 1][0], non_blocking=True)
+        for s in st:
+            s.step_end(n)
+    for s in st:
+        s.finish()
+    out = slab.merge_outputs(sd, [p[0] for p in parts])
+    for s in st:
+        s.close()
+    assert np.array_equal(out, ref), f"max|d|={np.abs(out - ref).max()}"
+
+
+def test_single_rank_runner_matches():
+    """world_size 1 through SlabRunner (no exchange) == engine.run."""
+    ref = _reference("cart_outside", "single")
+    sd = cases.make_sd("cart_outside", "single")
+    runner, loc, info = pdist.make_hip_runner(sd, 0, 1, 0)
+    runner.run(0, sd.Nt)
+    runner.finish()
+    out = pdist.gather_outputs(sd, loc, info)
+    runner.st.close()
+    assert np.array_equal(out, ref)

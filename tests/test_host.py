@@ -1,0 +1,143 @@
+"""Host logic that needs no GPU: loader checks, ABC list, file I/O, the C-ABI library's exports, slab partition."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import cases
+from pffdtd_amd import engine, h5io, sim_data, slab, synth
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    """libpffdtd_hip.so must load on a CPU-only box and export everything include/pffdtd_hip.h declares."""
+    hdr = (ROOT / "include" / "pffdtd_hip.h").read_text()
+    declared = set(re.findall(r"\b(pf_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 18
+    L = ctypes.CDLL(str(engine.lib_path()))
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    assert set(engine.EXPORTS) == declared
+
+
+def test_struct_layout_matches_header():
+    """ctypes mirror of pf_simdata: same size as the C struct (checked through a tiny compiled probe)."""
+    import subprocess
+    import tempfile
+    src = '#include <stdio.h>\n#include "pffdtd_hip.h"\nint main(){printf("%zu %zu %zu", sizeof(pf_simdata), sizeof(pf_opts), sizeof(pf_timing));}'
+    with tempfile.TemporaryDirectory() as d:
+        c = Path(d) / "p.c"
+        c.write_text(src)
+        subprocess.run(["gcc", "-I", str(ROOT / "include"), str(c), "-o", str(Path(d) / "p")], check=True)
+        out = subprocess.run([str(Path(d) / "p")], capture_output=True, text=True, check=True).stdout.split()
+    assert int(out[0]) == ctypes.sizeof(sim_data.PfSimData)
+    assert int(out[1]) == ctypes.sizeof(engine.PfOpts)
+    assert int(out[2]) == ctypes.sizeof(engine.PfTiming)
+
+
+def test_no_device_is_an_error_not_a_fallback():
+    if engine.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    sd = cases.make_sd("cart_rigid", "double")
+    with pytest.raises(engine.PfError, match="no HIP device"):
+        engine.HipEngine(sd)
+    with pytest.raises(engine.PfError):
+        engine.run_sim(sd)
+
+
+@pytest.mark.parametrize("dims,flag", [((12, 10, 9), 0), ((10, 12, 14), 1), ((10, 8, 14), 2)])
+def test_abc_list_against_bruteforce(dims, flag):
+    """abc_nodes == the triple loop of fdtd_data.h:621-675."""
+    Nx, Ny, Nz = dims
+    Nyf = 2 * (Ny - 1) if flag == 2 else Ny
+    idx, Q = [], []
+    for ix in range(1, Nx - 1):
+        for iy in range(1, Nyf - 1):
+            for iz in range(1, Nz - 1):
+                if flag > 0 and (ix + iy + iz) % 2 == 1:
+                    continue
+                q = int(ix in (1, Nx - 2)) + int(iy in (1, Nyf - 2)) + int(iz in (1, Nz - 2))
+                if q:
+                    y = Nyf - iy - 1 if (flag == 2 and iy >= Nyf // 2) else iy
+                    idx.append(ix * Nz * Ny + y * Nz + iz)
+                    Q.append(q)
+    idx, Q = np.array(idx), np.array(Q)
+    if flag == 2:
+        o = np.argsort(idx, kind="stable")
+        idx, Q = idx[o], Q[o]
+    bna, Qb = sim_data.abc_nodes(Nx, Ny, Nz, flag)
+    assert np.array_equal(bna, idx) and np.array_equal(Qb, Q)
+    if flag == 2:
+        assert np.unique(bna).size == bna.size
+
+
+def test_loader_rejects_what_the_reference_asserts():
+    sim = cases.make_sim("cart_lossy")
+    bad = {k: dict(v) for k, v in sim.items()}
+    bad["sim_consts"]["l2"] = np.float64(0.5)  # CFL: fdtd_data.h:180
+    with pytest.raises(ValueError, match="CFL"):
+        sim_data.SimData.from_sim(bad)
+    bad = {k: dict(v) for k, v in sim.items()}
+    bad["comms_out"]["diff"] = np.int8(0)  # single precision needs a differentiated input: fdtd_data.h:392
+    with pytest.raises(ValueError, match="single precision"):
+        sim_data.SimData.from_sim(bad, "single")
+    sim_data.SimData.from_sim(bad, "double")
+    bad = {k: dict(v) for k, v in sim.items()}
+    bad["vox_out"]["bn_ixyz"] = bad["vox_out"]["bn_ixyz"].copy()
+    bad["vox_out"]["bn_ixyz"][0] = 0  # fdtd_data.h:510
+    with pytest.raises(ValueError, match="interior"):
+        sim_data.SimData.from_sim(bad)
+    bad = {k: dict(v) for k, v in sim.items()}
+    bad["sim_mats"]["Mb"] = np.array([13, 3], dtype=np.int8)  # > MMb
+    with pytest.raises(ValueError):
+        sim_data.SimData.from_sim(bad)
+
+
+def test_scale_input_matches_reference_formula():
+    sd = cases.make_sd("cart_lossy", "single", scale=False)
+    m = np.abs(sd.in_sigs).max()
+    infac = sd.scale_input()
+    assert infac == 1.0 / (4.0 / m)  # norm1 = 2^2, infac = 1/inv_infac: fdtd_data.h:891-896
+    assert np.abs(sd.in_sigs).max() == pytest.approx(4.0, rel=1e-15)
+
+
+def test_h5_folder_roundtrip(tmp_path):
+    sim = cases.make_sim("fcc2_lossy")
+    synth.write_folder(sim, tmp_path, gzip=3)
+    back = synth.read_folder(tmp_path)
+    for f in sim:
+        for k, v in sim[f].items():
+            if k in back[f]:
+                assert np.array_equal(np.asarray(v), np.asarray(back[f][k])), (f, k)
+    assert back["vox_out"]["adj_bn"].dtype == np.bool_  # h5py-style enum
+    assert np.ndim(back["vox_out"]["Nx"]) == 0          # rank-0 scalars, as the reference asserts (fdtd_data.h:830)
+    with pytest.raises(FileNotFoundError):
+        synth.read_folder(tmp_path / "nope")
+
+
+def test_partition_rule():
+    assert slab.partition(10, 3) == [(0, 4), (4, 7), (7, 10)]  # remainder to the first ranks (gpu_engine.h:532-550)
+    assert slab.partition(1024, 8)[3] == (384, 512)
+    with pytest.raises(ValueError):
+        slab.partition(4, 4)  # assert(ngpus < Nx), gpu_engine.h:682
+
+
+@pytest.mark.parametrize("G", [2, 3])
+def test_split_covers_every_list_entry_once(G):
+    sd = cases.make_sd("cart_outside", "double")
+    seen = {k: 0 for k in ("Nb", "Nbl", "Nba", "Ns")}
+    rows = []
+    for r in range(G):
+        loc, info = slab.split(sd, G, r)
+        for k in seen:
+            seen[k] += getattr(loc, k)
+        rows += loc.out_rows.tolist()
+        assert loc.Nx == info.Nxh and loc.Npts == loc.Nx * loc.Ny * loc.Nz
+        for arr in (loc.bn_ixyz, loc.bnl_ixyz, loc.bna_ixyz, loc.in_ixyz):
+            ix = arr // (loc.Ny * loc.Nz)
+            assert ((ix >= 1) & (ix <= loc.Nx - 2)).all()  # everything a slab updates is interior to it
+    assert seen == {k: getattr(sd, k) for k in seen}
+    assert sorted(rows) == list(range(sd.Nr))

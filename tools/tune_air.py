@@ -22,6 +22,7 @@ ap.add_argument("--variants", default="0,1,2,3,4,5,6,9")
 ap.add_argument("--chunks", default="0")
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--numerics", type=int, default=0)
+ap.add_argument("--debug", default="0")
 args = ap.parse_args()
 
 import torch  # noqa: E402
@@ -47,12 +48,13 @@ bpv = 3 * rb + 0.125
 upd = (sd.Nx - 2) * (sd.Ny - 2) * (sd.Nz - 2)
 print(f"{'var':>4} {'chunk':>5} {'air ms':>8} {'air GB/s':>9} {'frac8T':>7} {'step ms':>8} {'Gvox/s':>8}")
 for v in [int(x) for x in args.variants.split(",")]:
+  for dbg in [int(x) for x in args.debug.split(",")]:
     for c in [int(x) for x in args.chunks.split(",")]:
         for g in grids:
             g.copy_((torch.rand(g.shape, device="cuda", dtype=torch.float32) * 2 - 1) * 1e-3)
         torch.cuda.synchronize()
         try:
-            eng = engine.HipEngine(sd, air_variant=v, air_chunk=c, timing=True, numerics=args.numerics,
+            eng = engine.HipEngine(sd, air_variant=v, air_chunk=c, timing=True, numerics=args.numerics, debug=dbg,
                                    ext_u0=grids[0].data_ptr(), ext_u1=grids[1].data_ptr())
             eng.run(0, 3)
             eng.timing(reset=True)
@@ -66,5 +68,5 @@ for v in [int(x) for x in args.variants.split(",")]:
             print(f"{v:4d} {c:5d} EXC {ex}")
             continue
         air = tm["air_ms_total"] / tm["air_launches"]
-        print(f"{v:4d} {c:5d} {air:8.3f} {upd*bpv/air/1e6:9.1f} {upd*bpv/air/1e6/8000:7.3f} {el/args.steps*1e3:8.3f} "
+        print(f"{v:4d}/{dbg:<2d} {c:5d} {air:8.3f} {upd*bpv/air/1e6:9.1f} {upd*bpv/air/1e6/8000:7.3f} {el/args.steps*1e3:8.3f} "
               f"{sd.Npts*args.steps/el/1e9:8.2f}")
