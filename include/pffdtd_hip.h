@@ -91,7 +91,10 @@ typedef struct pf_opts {
    int32_t timing;        /* 1 = bracket the air kernel with HIP events every step (pf_engine_timing) */
    void   *ext_u0;        /* optional caller-owned DEVICE buffers for the two state grids, each of */
    void   *ext_u1;        /*   pf_grid_bytes() bytes, zero-filled by the caller; NULL = engine allocates */
-   int32_t reserved[8];
+   int32_t x_global0;     /* global ix of this grid's plane 0 (slabs): only its parity matters, for the FCC
+                             checkerboard form (fcc_flag 1) whose existing nodes have even ix+iy+iz */
+   int32_t debug;         /* tuning switches, 0 in production */
+   int32_t reserved[6];
 } pf_opts;
 
 typedef struct pf_timing {

@@ -36,7 +36,7 @@ struct FusedParams {
    int32_t x_begin, x_end, chunk;
    int32_t nzt, nyt, nxc, swizzle;
    int32_t first, last;      // slab holds the global ix=0 / ix=Nx-1 ghost plane
-   int32_t fold, parity;     // fcc_flag==2 / fcc_flag==1
+   int32_t fold, parity;     // fcc_flag==2 / fcc_flag==1 (1 + parity of the global ix of plane 0)
    int32_t do_abc, do_rigid;
 };
 
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(64 * WY) void k_air_fused(FusedParams fp, Real a1, 
 #pragma unroll
          for (int i = 0; i < V; i++) {
             bool keep = skipz[i];
-            if (fp.parity) keep = keep || (((x + y + z0 + i) & 1) != 0);
+            if (fp.parity) keep = keep || (((x + y + z0 + i + (fp.parity - 1)) & 1) != 0);
             if (!fp.do_rigid) keep = keep || ((bits >> i) & 1u);
             if (keep) o[i] = old[r][i];
          }

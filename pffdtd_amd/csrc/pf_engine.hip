@@ -172,7 +172,7 @@ template <typename Real> struct Engine : EngineBase {
       for (int64_t i = 0; i < Nb; i++) {
          const int64_t ii = sd.bn_ixyz[i];
          const int64_t iz = ii % Nz, iy = (ii / Nz) % Ny, ix = ii / (Nz * Ny);
-         if (ix == 1 || ix == Nx - 2 || iy == 1 || iz == 1 || iz == Nz - 2) return false;
+         if ((op.slab_first && ix == 1) || (op.slab_last && ix == Nx - 2) || iy == 1 || iz == 1 || iz == Nz - 2) return false;
          if (!fold && iy == Ny - 2) return false;
       }
       // receivers must not read ghost cells (their memory copy is not maintained)
@@ -306,7 +306,7 @@ template <typename Real> struct Engine : EngineBase {
             if ((rc = dzalloc(&mask, npad / 8))) return rc;
             HIPCHK(hipDeviceSynchronize());
             hipLaunchKernelGGL(pf::k_mask_init, dim3((unsigned)cdiv(npad / 8, 256)), dim3(256), 0, s_main, mask, Nx, Ny, P, Nz,
-                               sd.fcc_flag == 1 ? 1 : 0);
+                               sd.fcc_flag == 1 ? 1 + (op.x_global0 & 1) : 0);
             if (Nb) hipLaunchKernelGGL(pf::k_mask_set, dim3((unsigned)cdiv(Nb, 256)), dim3(256), 0, s_main, mask, d_bn, Nb);
          }
          HIPCHK(hipGetLastError());
@@ -453,7 +453,7 @@ template <typename Real> struct Engine : EngineBase {
       fp.nxc = (int)cdiv(nplanes, chunk);
       fp.swizzle = (op.air_variant & 64) ? 0 : 1;
       fp.first = op.slab_first; fp.last = op.slab_last;
-      fp.fold = fold ? 1 : 0; fp.parity = sd.fcc_flag == 1 ? 1 : 0;
+      fp.fold = fold ? 1 : 0; fp.parity = sd.fcc_flag == 1 ? 1 + (op.x_global0 & 1) : 0;
       fp.do_abc = 1; fp.do_rigid = (fused_rigid && Nb > 0) ? 1 : 0;
       dim3 g((uint32_t)fp.nzt * fp.nyt * fp.nxc), b(64 * WY);
       const bool fma = op.numerics == PF_NUM_FMA;
@@ -495,8 +495,8 @@ template <typename Real> struct Engine : EngineBase {
       fp.nxc = (int)cdiv(nplanes, chunk);
       fp.swizzle = (op.air_variant & 64) ? 0 : 1;
       fp.first = op.slab_first; fp.last = op.slab_last;
-      fp.do_abc = (op.reserved[0] & 8) ? 0 : 1;
-      fp.debug = op.reserved[0];
+      fp.do_abc = 1;
+      fp.debug = op.debug;
       dim3 g((uint32_t)fp.nzt * fp.nyt * fp.nxc), b(64 * WY);
       if (op.numerics == PF_NUM_FMA) hipLaunchKernelGGL((pf::k_air_cart_lean<Real, R, WY, true>), g, b, 0, s, fp, a1, a2, l);
       else hipLaunchKernelGGL((pf::k_air_cart_lean<Real, R, WY, false>), g, b, 0, s, fp, a1, a2, l);

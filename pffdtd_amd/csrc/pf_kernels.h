@@ -517,7 +517,7 @@ __global__ void k_mask_init(uint8_t *__restrict__ mask, int64_t Nx, int64_t Ny, 
    for (int i = 0; i < 8; i++) {
       const int64_t iz = iz0 + i;
       bool skip = (iz == 0) || (iz >= Nz - 1);
-      if (parity && (((ix + iy + iz) & 1) != 0)) skip = true;
+      if (parity && (((ix + iy + iz + (parity - 1)) & 1) != 0)) skip = true; // parity-1 = parity of the global ix of plane 0
       if (skip) m |= 1u << i;
    }
    mask[byte] = (uint8_t)m;

@@ -30,7 +30,7 @@ class HipSlabStepper:
         with torch.cuda.device(self.device):
             self.grids = [torch.zeros((loc.Nx, self.plane), dtype=self.tdtype, device=self.device) for _ in range(2)]
             torch.cuda.synchronize()
-        self.eng = engine.HipEngine(loc, device=device, slab_first=info.first, slab_last=info.last,
+        self.eng = engine.HipEngine(loc, device=device, slab_first=info.first, slab_last=info.last, x_global0=info.xlo,
                                     ext_u0=self.grids[0].data_ptr(), ext_u1=self.grids[1].data_ptr(), **engine_kw)
         self.edge_stream = torch.cuda.ExternalStream(self.eng.stream(1), device=self.device)
         self.main_stream = torch.cuda.ExternalStream(self.eng.stream(0), device=self.device)

@@ -20,7 +20,8 @@ class PfOpts(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int32), ("numerics", ctypes.c_int32), ("slab_first", ctypes.c_int32),
                 ("slab_last", ctypes.c_int32), ("readout_chunk", ctypes.c_int32), ("air_variant", ctypes.c_int32),
                 ("air_chunk", ctypes.c_int32), ("timing", ctypes.c_int32), ("ext_u0", ctypes.c_void_p),
-                ("ext_u1", ctypes.c_void_p), ("reserved", ctypes.c_int32 * 8)]
+                ("ext_u1", ctypes.c_void_p), ("x_global0", ctypes.c_int32), ("debug", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 6)]
 
 
 class PfTiming(ctypes.Structure):
@@ -106,7 +107,7 @@ class HipEngine:
     """One engine instance = one grid (or one Z-slab) resident on one MI355X."""
 
     def __init__(self, sd, device=0, numerics=PF_NUM_CPU_EXACT, slab_first=True, slab_last=True, air_variant=0,
-                 air_chunk=0, timing=False, readout_chunk=0, ext_u0=None, ext_u1=None, debug=0):
+                 air_chunk=0, timing=False, readout_chunk=0, ext_u0=None, ext_u1=None, debug=0, x_global0=0):
         L = lib()
         self.sd = sd
         self._s = sd.as_struct()
@@ -116,7 +117,8 @@ class HipEngine:
         o.slab_first, o.slab_last = int(bool(slab_first)), int(bool(slab_last))
         o.air_variant, o.air_chunk, o.timing, o.readout_chunk = int(air_variant), int(air_chunk), int(bool(timing)), \
             int(readout_chunk)
-        o.reserved[0] = int(debug)  # kernel ablation switches for tuning runs; 0 in production
+        o.debug = int(debug)
+        o.x_global0 = int(x_global0)
         if ext_u0 is not None and ext_u1 is not None:
             o.ext_u0, o.ext_u1 = int(ext_u0), int(ext_u1)
         self._h = ctypes.c_void_p()

@@ -52,13 +52,13 @@ def test_bit_exact_vs_oracle(name, prec, variant):
     eng = engine.HipEngine(sd, air_variant=variant, readout_chunk=16)
     eng.run(0, sd.Nt)
     u0, u1 = eng.get_grid(0), eng.get_grid(1)
-    eng_u1_raw = u1
     eng.close()
     assert np.array_equal(sd.u_out, ref_out), f"u_out max|d|={np.abs(sd.u_out - ref_out).max()}"
     if variant == 0:
+        # auto mode may run the fused kernel, whose ghost shell is virtual: get_grid(1) then returns the shell
+        # flipped from the current state, the oracle's copy is one flip older -> bring both to the same flip
         ref_u1 = _flip(ref_u1, sd.fcc_flag == 2)
-        u1 = _flip(u1, sd.fcc_flag == 2)  # no-op if the engine materialised the shell correctly
-        assert np.array_equal(u1, eng_u1_raw)
+        u1 = _flip(u1, sd.fcc_flag == 2)
     assert np.array_equal(u1, ref_u1), f"u1 max|d|={np.abs(u1 - ref_u1).max()}"
     # u0's ghost shell holds the flips of the step before; the fused kernel keeps the ghost shell virtual
     # (never stored), so compare the interior there
@@ -70,6 +70,11 @@ def test_bit_exact_vs_oracle(name, prec, variant):
 @pytest.mark.parametrize("variant", [1, 2, 10, 11, 12, 13, 14, 10 + 128, 10 + 64, 20, 21, 22, 23, 24, 20 + 64])
 @pytest.mark.parametrize("name", ["cart_lossy", "cart_outside_oddz", "cart_outside", "fcc2_outside", "fcc1_outside"])
 def test_tile_variants_bit_exact(name, variant):
+    base = variant & 63
+    if base >= 20 and name.startswith("fcc"):
+        pytest.skip("the lean fused kernel is 7-point Cartesian only")
+    if (variant & 128) and name.startswith("fcc2"):
+        pytest.skip("separate rigid kernel needs boundary nodes away from the folded ghost row")
     for prec in PRECS:
         sd = cases.make_sd(name, prec)
         ref_out, ref_u0, ref_u1 = _oracle_run(sd)

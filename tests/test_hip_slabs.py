@@ -24,7 +24,9 @@ def _reference(name, prec):
 @pytest.mark.parametrize("G", [2, 3])
 @pytest.mark.parametrize("name,prec,variant", [("cart_outside", "single", 0), ("cart_outside", "double", 0),
                                                ("fcc2_outside", "single", 0), ("cart_lossy", "single", 3),
-                                               ("fcc1_outside", "double", 10)])
+                                               ("fcc1_outside", "double", 10), ("fcc1_outside", "single", 3),
+                                               ("fcc2_outside", "double", 10), ("cart_outside", "single", 20),
+                                               ("cart_outside_oddz", "double", 22)])
 def test_virtual_slabs_equal_single_domain(name, prec, variant, G):
     ref = _reference(name, prec)
     sd = cases.make_sd(name, prec)
