@@ -195,12 +195,26 @@ def main():
                        "numerics": "cpu-exact" if args.numerics == 0 else "fma",
                        "parallelism": parallelism, "air_variant": args.variant},
             "achieved_hbm_GBs_whole_step": round(gvox * bpv, 1),
-            "roofline": {"bound": "hbm", "kernel": "k_air_fcc" if args.fcc else "k_air_cart",
+            "roofline": {"bound": "hbm", "kernel": "k_air_fcc" if args.fcc else "k_air_cart_lean",
                          "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
                          "air_ms_per_step": round(air_ms_per_step, 4),
                          "bytes_per_voxel": bpv, "voxels_per_step": upd},
         }
+        # HBM bytes per air launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate runs, gfx950 x2 read correction applied; tools/make_profile_summary.py)
+        tfile = ROOT / "profiles" / "r01_bench_n1_hbm_traffic.json"
+        if (world == 1 and n == 1024 and real_bytes == 4 and not args.fcc and lossy and args.variant == 0
+                and tfile.exists()):
+            try:
+                ks = json.load(open(tfile))["kernels"]
+                hit = [v for k, v in ks.items() if "k_air_cart_lean" in k]
+                if hit:
+                    res["roofline"]["traffic"] = round(hit[0]["total_bytes"] / 1e9, 3)
+                    res["roofline"]["traffic_unit"] = "GB per launch (PMC, profiles/r01_bench_n1_hbm_traffic.json)"
+                    res["roofline"]["algorithmic_GB_per_launch"] = round(upd * bpv / 1e9, 3)
+            except (OSError, KeyError, ValueError):
+                pass
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.precision, args.fcc, args.mb, lossy)
         print(json.dumps(res), flush=True)
