@@ -31,7 +31,7 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 
 
-def build_scene(n, steps_total, prec, fcc, lossy, mb):
+def build_scene(n, steps_total, prec, fcc, lossy, mb, nx=0):
     from pffdtd_amd import sim_data, synth
     if fcc:
         # folded FCC with a stored grid of n x n x n: unfolded Ny = 2(n-1)
@@ -39,7 +39,7 @@ def build_scene(n, steps_total, prec, fcc, lossy, mb):
         synth.fold_fcc(sim)
         synth.sort_sim(sim)
     else:
-        sim = synth.shoebox(n, n, n, Nt=steps_total, Nm=1, Mb=mb, lossy=lossy)
+        sim = synth.shoebox(nx or n, n, n, Nt=steps_total, Nm=1, Mb=mb, lossy=lossy)
     sd = sim_data.SimData.from_sim(sim, prec, build_mask=False)
     sd.scale_input()
     return sd
@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--nx", type=int, default=0, help="override the number of planes along x (experiments only)")
     ap.add_argument("--precision", default="single", choices=["single", "double"])
     ap.add_argument("--fcc", action="store_true")
     ap.add_argument("--rigid", action="store_true", help="rigid walls only (no FD boundary nodes)")
@@ -125,7 +126,7 @@ def main():
     K, W = args.steps, args.warmup
     n = args.size
     lossy = not args.rigid
-    sd = build_scene(n, K + W, args.precision, args.fcc, lossy, args.mb)
+    sd = build_scene(n, K + W, args.precision, args.fcc, lossy, args.mb, args.nx)
     real_bytes = 4 if args.precision == "single" else 8
     ekw = dict(numerics=args.numerics, air_variant=args.variant, air_chunk=args.chunk, timing=True)
 

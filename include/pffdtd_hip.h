@@ -94,7 +94,9 @@ typedef struct pf_opts {
    int32_t x_global0;     /* global ix of this grid's plane 0 (slabs): only its parity matters, for the FCC
                              checkerboard form (fcc_flag 1) whose existing nodes have even ix+iy+iz */
    int32_t debug;         /* tuning switches, 0 in production */
-   int32_t reserved[6];
+   int32_t energy;        /* 1 = keep what the energy diagnostic needs (explicit Laplacian grid, unfused kernel
+                             sequence); then use pf_engine_energy_cfg + pf_engine_run_energy */
+   int32_t reserved[5];
 } pf_opts;
 
 typedef struct pf_timing {
@@ -139,6 +141,14 @@ int  pf_engine_flush_outputs(pf_engine *e);          /* ring -> sd->u_out */
 int  pf_engine_get_grid(pf_engine *e, int32_t which, void *host);
 int  pf_engine_set_grid(pf_engine *e, int32_t which, const void *host);
 int  pf_engine_timing(pf_engine *e, pf_timing *t, int32_t reset);
+
+/* ---- energy-conservation diagnostic of the reference Python engine (python/fdtd/sim_fdtd.py:587-620,671-678) ----
+ * Needs pf_opts.energy=1 at creation.  DEF = the materials' (D,E,F) triplets, double[Nm*PF_MMB*3] (zero padded),
+ * h = grid spacing, c = speed of sound, Ts = time step (sim_consts.h5).  pf_engine_run_energy runs steps like
+ * pf_engine_run and fills H_tot[n], E_lost[n+1], E_in[n+1] (arrays of Nt, Nt+1, Nt+1 doubles; E_*[0] must be
+ * initialised by the caller).  fcc_flag 0 and 1 only, like the reference. */
+int  pf_engine_energy_cfg(pf_engine *e, double h, double c, double Ts, const double *DEF);
+int  pf_engine_run_energy(pf_engine *e, int64_t n0, int64_t nsteps, double *H_tot, double *E_lost, double *E_in);
 
 #ifdef __cplusplus
 }

@@ -589,4 +589,195 @@ __global__ __launch_bounds__(64 * WY) void k_air_cart_lean(LeanParams fp, Real a
    }
 }
 
+
+// =============================================================================================================
+// k_air_cart_lds -- 7-point kernel with the u1 stream landing in LDS by DMA (global_load_lds_dwordx4).
+// Same fused work as k_air_cart_lean (virtual ghost shell + air + ABC), different data path: the tile of plane
+// x+2 ((R*WY + 2) rows x 1 KiB) is in flight into a 3-slot LDS ring while plane x is computed from LDS, so the
+// bytes in flight cost no VGPRs and the register footprint (hence occupancy) is that of the bare stencil.
+// Row layout in LDS: [W values | V-wide chunk left of the segment | V-wide chunk right of it]; the two chunks give
+// the z neighbours of the first / last lane and are fetched by a 2-lane DMA.
+// Per plane x: [vmcnt(0); barrier] -> plane x+1 has landed for every wave; [DMA plane x+2 into slot (x+2)%3 =
+// the slot plane x-1 just left] [prefetch old/mask of x+1 into registers] [read c/up/down/left/right of plane x and
+// the centre of plane x+1 from LDS] [update, ABC, store]; plane x-1's centre values stay in registers.
+// =============================================================================================================
+#define PF_GPTR(p) ((const __attribute__((address_space(1))) void *)(p))
+#define PF_LPTR(p) ((__attribute__((address_space(3))) void *)(p))
+
+template <typename Real, int R, int WY, bool FMA>
+__global__ __launch_bounds__(64 * WY) void k_air_cart_lds(LeanParams fp, Real a1, Real a2, Real l) {
+   typedef typename VecOf<Real>::type vec;
+   constexpr int V = VecOf<Real>::V;
+   constexpr int W = 64 * V;
+   constexpr int TY = R * WY;
+   constexpr int ROW = W + 2 * V;
+   static_assert(WY >= 2, "top and bottom wave each carry one workgroup halo row");
+   __shared__ __attribute__((aligned(16))) Real ring[3][TY + 2][ROW];
+
+   const Real *__restrict__ u1 = (const Real *)fp.u1;
+   Real *__restrict__ u0 = (Real *)fp.u0;
+   const uint32_t total = (uint32_t)fp.nzt * fp.nyt * fp.nxc;
+   uint32_t b = blockIdx.x;
+   if (fp.swizzle) b = xcd_swizzle(b, total);
+   const int zt = b % fp.nzt;
+   const int yt = (b / fp.nzt) % fp.nyt;
+   const int xc = b / (fp.nzt * fp.nyt);
+   const int lane = threadIdx.x & 63;
+   const int w = threadIdx.x >> 6;
+   const int Nx = fp.Nx, Ny = fp.Ny, Nz = fp.Nz, P = fp.P;
+   const int64_t plane = fp.plane;
+   const int zseg = zt * W;
+   const int z0 = zseg + lane * V;
+   const bool active = z0 < P;
+   const int zl = active ? z0 : 0;
+   const int y0 = 1 + (yt * WY + w) * R;
+   const int xs = fp.x_begin + xc * fp.chunk;
+   const int xe = min(xs + fp.chunk, fp.x_end);
+   const bool top_wave = (w == 0), bot_wave = (w == WY - 1);
+   const bool halo_wave = top_wave || bot_wave;
+   const int halo_lrow = top_wave ? 0 : TY + 1;
+
+   auto rowsrc = [&](int y) {
+      y = min(y, Ny - 1);
+      if (y == 0) return 2;
+      if (y == Ny - 1) return Ny - 3;
+      return y;
+   };
+   auto planesrc = [&](int x) {
+      if (fp.first && x == 0) return 2;
+      if (fp.last && x == Nx - 1) return Nx - 3;
+      return x;
+   };
+   uint32_t rb[R], so[R];
+   bool valid[R];
+#pragma unroll
+   for (int r = 0; r < R; r++) {
+      rb[r] = (uint32_t)rowsrc(y0 + r) * (uint32_t)P;
+      so[r] = (uint32_t)min(y0 + r, Ny - 1) * (uint32_t)P + (uint32_t)zl;
+      valid[r] = active && (y0 + r <= Ny - 2);
+   }
+   const uint32_t rb_halo = (uint32_t)rowsrc(top_wave ? y0 - 1 : y0 + R) * (uint32_t)P;
+   const int chunk_col = (lane == 0) ? zseg - V : zseg + W;   // 2-lane chunk DMA (lane 0: left, lane 1: right)
+   // LDS columns of the z neighbours of this lane's first / last element
+   const int col_left = (lane == 0) ? W + V - 1 : lane * V - 1;
+   const int col_right = (lane == 63) ? W + V : lane * V + V;
+
+   const int zzN = Nz - 1 - z0;
+   const bool fix0 = (z0 == 0);
+   const bool fixR = (zzN == V);
+   uint32_t qzbits = 0;
+#pragma unroll
+   for (int i = 0; i < V; i++)
+      if (active && (z0 + i == 1 || z0 + i == Nz - 2)) qzbits |= 1u << i;
+   const bool wave_has_qz = __ballot(qzbits != 0) != 0ull;
+
+   auto dma_plane = [&](int x) {
+      const Real *pl = u1 + (int64_t)planesrc(x) * plane;
+      Real(*S)[ROW] = ring[x % 3];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+         __builtin_amdgcn_global_load_lds(PF_GPTR(pl + rb[r] + zl), PF_LPTR(&S[1 + w * R + r][0]), 16, 0, 0);
+         if (lane < 2)
+            __builtin_amdgcn_global_load_lds(PF_GPTR(pl + (int64_t)rb[r] + chunk_col), PF_LPTR(&S[1 + w * R + r][W]), 16, 0, 0);
+      }
+      if (halo_wave) __builtin_amdgcn_global_load_lds(PF_GPTR(pl + rb_halo + zl), PF_LPTR(&S[halo_lrow][0]), 16, 0, 0);
+   };
+   auto load_old = [&](int x, vec *d, uint32_t *m) {
+      const Real *po = u0 + (int64_t)x * plane;
+      const uint8_t *pm = fp.mask + (((int64_t)x * plane) >> 3);
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+         d[r] = *(const vec *)(po + so[r]);
+         m[r] = pm[so[r] >> 3];
+      }
+   };
+
+   vec prev[R], old[R], oldn[R];
+   uint32_t mb[R], mbn[R];
+   {  // prologue: plane xs-1 centre rows to registers, planes xs and xs+1 to the ring
+      const Real *pm = u1 + (int64_t)planesrc(xs - 1) * plane;
+#pragma unroll
+      for (int r = 0; r < R; r++) prev[r] = *(const vec *)(pm + rb[r] + zl);
+      dma_plane(xs);
+      dma_plane(xs + 1);
+      load_old(xs, old, mb);
+   }
+
+   for (int x = xs; x < xe; x++) {
+      const bool more = (x + 1 < xe);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (more) {
+         dma_plane(x + 2);
+         load_old(x + 1, oldn, mbn);
+      }
+      Real(*SC)[ROW] = ring[x % 3];
+      Real(*SN)[ROW] = ring[(x + 1) % 3];
+      Real *po = u0 + (int64_t)x * plane;
+      const bool qx = (fp.first && x == 1) || (fp.last && x == Nx - 2);
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+         const int lr = 1 + w * R + r;
+         vec c = *(const vec *)&SC[lr][lane * V];
+         const vec ym = *(const vec *)&SC[lr - 1][lane * V];
+         const vec yp = *(const vec *)&SC[lr + 1][lane * V];
+         const vec xp = *(const vec *)&SN[lr][lane * V];
+         Real lf = SC[lr][col_left];
+         Real rt = SC[lr][col_right];
+         const vec craw = c;
+         // virtual z ghost columns (column 0 mirrors column 2, column Nz-1 mirrors Nz-3)
+         if (V == 4) {
+            if (fix0) c[0] = c[2];
+            if (zzN == 1) c[1] = lf;
+            if (zzN == 2) c[2] = c[0];
+            if (zzN == 3) c[3] = c[1];
+         } else {
+            if (fix0) c[0] = rt;
+            if (zzN == 1) c[1] = lf;
+         }
+         if (fixR) rt = c[V - 2];
+         const uint32_t bits = mb[r] >> (so[r] & 7u);
+         vec o;
+#pragma unroll
+         for (int i = 0; i < V; i++) {
+            const Real zp = (i == V - 1) ? rt : c[i < V - 1 ? i + 1 : V - 1];
+            const Real zm = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
+            Real p = a1 * c[i] - old[r][i];
+            p = acc<FMA>(p, a2, xp[i]);       // +NzNy
+            p = acc<FMA>(p, a2, prev[r][i]);  // -NzNy
+            p = acc<FMA>(p, a2, yp[i]);       // +Nz
+            p = acc<FMA>(p, a2, ym[i]);       // -Nz
+            p = acc<FMA>(p, a2, zp);          // +1
+            p = acc<FMA>(p, a2, zm);          // -1
+            o[i] = p;
+         }
+         if (fp.do_abc) {
+            const int y = y0 + r;
+            const int qxy = (qx ? 1 : 0) + ((y == 1 || y == Ny - 2) ? 1 : 0);
+            if (qxy > 0 || wave_has_qz) {
+#pragma unroll
+               for (int i = 0; i < V; i++) {
+                  const bool zq = (qzbits >> i) & 1u;
+                  if (qxy > 0 || __ballot(zq) != 0ull) {
+                     const int Q = qxy + (zq ? 1 : 0);
+                     if (Q > 0) {
+                        const Real lQ = l * (Real)Q;
+                        const Real num = o[i] + lQ * old[r][i];
+                        o[i] = (Real)((double)num / (1.0 + (double)lQ)); // double literal of cpu_engine.h:228
+                     }
+                  }
+               }
+            }
+         }
+#pragma unroll
+         for (int i = 0; i < V; i++)
+            if ((bits >> i) & 1u) o[i] = old[r][i];
+         if (valid[r]) *(vec *)(po + so[r]) = o;
+         prev[r] = craw;
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) { old[r] = oldn[r]; mb[r] = mbn[r]; }
+   }
+}
+
 } // namespace pf

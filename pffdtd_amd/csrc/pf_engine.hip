@@ -16,6 +16,7 @@
 #include "pffdtd_hip.h"
 #include "pf_kernels.h"
 #include "pf_air_fused.h"
+#include "pf_energy.h"
 
 namespace {
 
@@ -72,6 +73,8 @@ struct EngineBase {
    virtual int set_grid(int which, const void *host) = 0;
    virtual int timing(pf_timing *t, int reset) = 0;
    virtual void *stream(int which) = 0;
+   virtual int energy_cfg(double h, double c, double Ts, const double *DEF) = 0;
+   virtual int run_energy(int64_t n0, int64_t nsteps, double *H, double *El, double *Ei) = 0;
 };
 
 template <typename Real> struct Engine : EngineBase {
@@ -108,6 +111,11 @@ template <typename Real> struct Engine : EngineBase {
    hipEvent_t ev_pre = nullptr, ev_edge = nullptr, ev_main = nullptr;
    bool in_step = false;
    int64_t steps_done = 0;
+   // energy diagnostic (pf_energy.h)
+   Real *Lu = nullptr, *vh_old = nullptr, *u2in = nullptr;
+   double *d_acc = nullptr, *d_DEF = nullptr;
+   double en_h = 0, en_c = 0, en_Ts = 0;
+   bool en_ready = false;
    // timing
    std::vector<std::pair<hipEvent_t, hipEvent_t>> air_ev, step_ev, ev_pool;
    pf_timing tm{};
@@ -119,7 +127,7 @@ template <typename Real> struct Engine : EngineBase {
       if (s_edge) hipStreamSynchronize(s_edge);
       auto F = [](void *p) { if (p) hipFree(p); };
       if (own_grids) { F(u0); F(u1); }
-      F(mask); F(mask_bn); F(segstart); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
+      F(mask); F(mask_bn); F(segstart); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
       F(d_beta); F(d_insig); F(d_mq); F(ub[0]); F(ub[1]); F(ub[2]); F(u2ba); F(vh1); F(gh1); F(ring);
       if (h_ring) hipHostFree(h_ring);
       for (auto &p : air_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -279,7 +287,8 @@ template <typename Real> struct Engine : EngineBase {
          // (virtual ghosts + ABC + rigid in-kernel); 20-24 lean fused 7-point kernel (virtual ghosts + ABC)
          vbase = op.air_variant & 63;
          const bool ok = fused_ok();
-         if (vbase == 0) { lean = ok && !fcc; fused = false; }
+         if (op.energy) { if (vbase >= 10) return set_err(PF_ERR_ARG, "the energy diagnostic runs the unfused kernels (air_variant 0-9)"); lean = fused = false; }
+         else if (vbase == 0) { lean = ok && !fcc; fused = false; }
          else if (vbase >= 20) { lean = true; fused = false; }
          else if (vbase >= 10) { fused = true; lean = false; }
          if ((lean || fused) && !ok)
@@ -475,7 +484,7 @@ template <typename Real> struct Engine : EngineBase {
       }
    }
 
-   template <int R, int WY> void launch_lean_cfg(hipStream_t s, int xb, int xe) {
+   template <int R, int WY, bool LDS = false> void launch_lean_cfg(hipStream_t s, int xb, int xe) {
       pf::LeanParams fp;
       fp.u1 = u1; fp.u0 = u0; fp.mask = mask;
       fp.plane = plane;
@@ -498,8 +507,13 @@ template <typename Real> struct Engine : EngineBase {
       fp.do_abc = 1;
       fp.debug = op.debug;
       dim3 g((uint32_t)fp.nzt * fp.nyt * fp.nxc), b(64 * WY);
-      if (op.numerics == PF_NUM_FMA) hipLaunchKernelGGL((pf::k_air_cart_lean<Real, R, WY, true>), g, b, 0, s, fp, a1, a2, l);
-      else hipLaunchKernelGGL((pf::k_air_cart_lean<Real, R, WY, false>), g, b, 0, s, fp, a1, a2, l);
+      if constexpr (LDS) {
+         if (op.numerics == PF_NUM_FMA) hipLaunchKernelGGL((pf::k_air_cart_lds<Real, R, WY, true>), g, b, 0, s, fp, a1, a2, l);
+         else hipLaunchKernelGGL((pf::k_air_cart_lds<Real, R, WY, false>), g, b, 0, s, fp, a1, a2, l);
+      } else {
+         if (op.numerics == PF_NUM_FMA) hipLaunchKernelGGL((pf::k_air_cart_lean<Real, R, WY, true>), g, b, 0, s, fp, a1, a2, l);
+         else hipLaunchKernelGGL((pf::k_air_cart_lean<Real, R, WY, false>), g, b, 0, s, fp, a1, a2, l);
+      }
    }
    void launch_air_lean(hipStream_t s, int xb, int xe) {
       switch (vbase) {
@@ -507,6 +521,12 @@ template <typename Real> struct Engine : EngineBase {
          case 23: launch_lean_cfg<2, 4>(s, xb, xe); break;
          case 24: launch_lean_cfg<1, 8>(s, xb, xe); break;
          case 20: launch_lean_cfg<2, 8>(s, xb, xe); break;
+         case 30: launch_lean_cfg<2, 4, true>(s, xb, xe); break;
+         case 31: launch_lean_cfg<2, 8, true>(s, xb, xe); break;
+         case 32: launch_lean_cfg<4, 4, true>(s, xb, xe); break;
+         case 33: launch_lean_cfg<1, 8, true>(s, xb, xe); break;
+         case 34: launch_lean_cfg<4, 2, true>(s, xb, xe); break;
+         case 35: launch_lean_cfg<1, 4, true>(s, xb, xe); break;
          default: launch_lean_cfg<4, 4>(s, xb, xe); break; // 0 (auto) and 22: fastest measured on MI355X
       }
    }
@@ -582,6 +602,73 @@ template <typename Real> struct Engine : EngineBase {
       HIPCHK(hipGetLastError());
       rotate();
       return after_step(n);
+   }
+
+   // ---------------- energy diagnostic (python/fdtd/sim_fdtd.py:587-620) ----------------
+   int energy_cfg(double h, double c, double Ts, const double *DEF) override {
+      if (!op.energy) return set_err(PF_ERR_STATE, "engine was not created with pf_opts.energy=1");
+      if (sd.fcc_flag == 2) return set_err(PF_ERR_ARG, "the energy diagnostic is defined for fcc_flag 0 and 1 (as in the reference)");
+      HIPCHK(hipSetDevice(op.device));
+      en_h = h; en_c = c; en_Ts = Ts;
+      int rc;
+      if (!Lu) {
+         if ((rc = dzalloc(&Lu, npad))) return rc;
+         if ((rc = dzalloc(&vh_old, Nbl * PF_MMB))) return rc;
+         if ((rc = dzalloc(&u2in, Ns))) return rc;
+         if ((rc = dzalloc(&d_acc, (int64_t)pf::EN_NACC))) return rc;
+         if ((rc = upload(&d_DEF, DEF, (int64_t)std::max<int>(sd.Nm, 1) * PF_MMB * 3))) return rc;
+      }
+      HIPCHK(hipDeviceSynchronize());
+      en_ready = true;
+      return PF_OK;
+   }
+   int run_energy(int64_t n0, int64_t nsteps, double *H, double *El, double *Ei) override {
+      if (!en_ready) return set_err(PF_ERR_STATE, "call pf_engine_energy_cfg first");
+      if (in_step) return set_err(PF_ERR_STATE, "pf_engine_run_energy inside a split-phase step");
+      HIPCHK(hipSetDevice(op.device));
+      hipStream_t s = s_main;
+      const double V = fcc ? 2.0 : 1.0, l2d = sd.l2, ld = sd.l;
+      const dim3 g3((unsigned)cdiv(Nz, 256), (unsigned)(Ny - 2), (unsigned)(Nx - 2));
+      auto g1 = [](int64_t n, int b) { return dim3((unsigned)std::max<int64_t>(cdiv(n, b), 1)); };
+      for (int64_t n = n0; n < n0 + nsteps; n++) {
+         if (n < 0 || n >= Nt) return set_err(PF_ERR_ARG, "step %ld outside [0,Nt=%ld)", (long)n, (long)Nt);
+         double acc[pf::EN_NACC];
+         HIPCHK(hipMemsetAsync(d_acc, 0, sizeof(double) * pf::EN_NACC, s));
+         // state before the step: u0 = u^{n-1} (u2), u1 = u^n, Lu = L(u^{n-1})
+         hipLaunchKernelGGL(pf::k_energy_int<Real>, g3, dim3(256), 0, s, u1, u0, Lu, Nx, Ny, Nz, P, plane, l2d, d_acc);
+         if (Nba) hipLaunchKernelGGL(pf::k_energy_abc<Real>, g1(Nba, 256), dim3(256), 0, s, u1, u0, Lu, d_bna, d_Q, Nba, l2d, d_acc);
+         if (Nbl) hipLaunchKernelGGL(pf::k_energy_stored<Real>, g1(Nbl, 256), dim3(256), 0, s, vh1, gh1, d_ssaf, d_mat, d_Mb, d_DEF, Nbl, en_Ts, d_acc);
+         if (Ns) hipLaunchKernelGGL(pf::k_energy_in<Real>, g1(Ns, 64), dim3(64), 0, s, u0, u2in, d_in, d_insig, Ns, Nt, n, 0, d_acc);
+         if (Nbl) HIPCHK(hipMemcpyAsync(vh_old, vh1, sizeof(Real) * Nbl * PF_MMB, hipMemcpyDeviceToDevice, s));
+         // the step itself (unfused sequence), with Lu = L(u1) taken after the ghost flips
+         launch_pre(s);
+         if (fcc) {
+            hipLaunchKernelGGL((pf::k_lap_air<Real, true>), g3, dim3(256), 0, s, u1, Lu, mask, Nx, Ny, Nz, P, plane);
+            if (Nb) hipLaunchKernelGGL((pf::k_lap_bn<Real, true>), g1(Nb, 256), dim3(256), 0, s, u1, Lu, d_bn, d_adj, P, plane, Nb);
+         } else {
+            hipLaunchKernelGGL((pf::k_lap_air<Real, false>), g3, dim3(256), 0, s, u1, Lu, mask, Nx, Ny, Nz, P, plane);
+            if (Nb) hipLaunchKernelGGL((pf::k_lap_bn<Real, false>), g1(Nb, 256), dim3(256), 0, s, u1, Lu, d_bn, d_adj, P, plane, Nb);
+         }
+         launch_air(s, 1, (int)Nx - 1);
+         launch_abc(s, {0, Nba});
+         launch_rigid(s, {0, Nb});
+         launch_fd(s, {0, Nbl});
+         launch_io(s, n, true, {0, Ns});
+         // after the step (u0 = u^{n+1} until the rotation)
+         if (Nbl) hipLaunchKernelGGL(pf::k_energy_loss<Real>, g1(Nbl, 256), dim3(256), 0, s, vh_old, vh1, d_ssaf, d_mat, d_Mb, d_DEF, Nbl, d_acc);
+         if (Nba) hipLaunchKernelGGL(pf::k_energy_abcloss<Real>, g1(Nba, 256), dim3(256), 0, s, u0, u2ba, d_bna, d_Q, Nba, d_acc);
+         if (Ns) hipLaunchKernelGGL(pf::k_energy_in<Real>, g1(Ns, 64), dim3(64), 0, s, u0, u2in, d_in, d_insig, Ns, Nt, n, 1, d_acc);
+         HIPCHK(hipGetLastError());
+         HIPCHK(hipMemcpyAsync(acc, d_acc, sizeof(acc), hipMemcpyDeviceToHost, s));
+         HIPCHK(hipStreamSynchronize(s));
+         H[n] = V * 0.5 * en_h * acc[pf::EN_INT] - V * 0.5 * en_h * acc[pf::EN_ABC] + V * 0.5 * en_c / l2d * acc[pf::EN_STORED];
+         El[n + 1] = El[n] + V * 0.25 * en_h / ld * acc[pf::EN_LOSS] + 0.5 * V * en_h / ld * acc[pf::EN_ABCLOSS];
+         Ei[n + 1] = Ei[n] + (V * en_h / l2d) * 0.5 * acc[pf::EN_IN];
+         rotate();
+         int rc = after_step(n);
+         if (rc) return rc;
+      }
+      return flush();
    }
 
    int run(int64_t n0, int64_t nsteps) override {
@@ -801,6 +888,12 @@ int pf_engine_flush_outputs(pf_engine *e) { PF_NEED(e); return e->impl->flush();
 int pf_engine_get_grid(pf_engine *e, int32_t which, void *host) { PF_NEED(e); return e->impl->get_grid(which, host); }
 int pf_engine_set_grid(pf_engine *e, int32_t which, const void *host) { PF_NEED(e); return e->impl->set_grid(which, host); }
 int pf_engine_timing(pf_engine *e, pf_timing *t, int32_t reset) { PF_NEED(e); return e->impl->timing(t, reset); }
+int pf_engine_energy_cfg(pf_engine *e, double h, double c, double Ts, const double *DEF) { PF_NEED(e); if (!DEF) return set_err(PF_ERR_ARG, "null DEF"); return e->impl->energy_cfg(h, c, Ts, DEF); }
+int pf_engine_run_energy(pf_engine *e, int64_t n0, int64_t nsteps, double *H_tot, double *E_lost, double *E_in) {
+   PF_NEED(e);
+   if (!H_tot || !E_lost || !E_in) return set_err(PF_ERR_ARG, "null output array");
+   return e->impl->run_energy(n0, nsteps, H_tot, E_lost, E_in);
+}
 
 // double run_sim(struct SimData *sd): cpu_engine.h:52 / gpu_engine.h:665
 double pf_run_sim(pf_simdata *sd) {

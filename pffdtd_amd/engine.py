@@ -21,7 +21,7 @@ class PfOpts(ctypes.Structure):
                 ("slab_last", ctypes.c_int32), ("readout_chunk", ctypes.c_int32), ("air_variant", ctypes.c_int32),
                 ("air_chunk", ctypes.c_int32), ("timing", ctypes.c_int32), ("ext_u0", ctypes.c_void_p),
                 ("ext_u1", ctypes.c_void_p), ("x_global0", ctypes.c_int32), ("debug", ctypes.c_int32),
-                ("reserved", ctypes.c_int32 * 6)]
+                ("energy", ctypes.c_int32), ("reserved", ctypes.c_int32 * 5)]
 
 
 class PfTiming(ctypes.Structure):
@@ -36,7 +36,8 @@ class PfError(RuntimeError):
 EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_grid_bytes", "pf_grid_pitch", "pf_opts_default",
            "pf_run_sim", "pf_engine_create", "pf_engine_destroy", "pf_engine_run", "pf_engine_step_begin",
            "pf_engine_halo_ptrs", "pf_engine_step_end", "pf_engine_stream", "pf_engine_sync",
-           "pf_engine_flush_outputs", "pf_engine_get_grid", "pf_engine_set_grid", "pf_engine_timing"]
+           "pf_engine_flush_outputs", "pf_engine_get_grid", "pf_engine_set_grid", "pf_engine_timing",
+           "pf_engine_energy_cfg", "pf_engine_run_energy"]
 
 
 def lib_path():
@@ -77,6 +78,9 @@ def lib():
         L.pf_engine_get_grid.argtypes = [vp, i32, vp]
         L.pf_engine_set_grid.argtypes = [vp, i32, vp]
         L.pf_engine_timing.argtypes = [vp, ctypes.POINTER(PfTiming), i32]
+        dp = ctypes.POINTER(ctypes.c_double)
+        L.pf_engine_energy_cfg.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, dp]
+        L.pf_engine_run_energy.argtypes = [vp, i64, i64, dp, dp, dp]
         _LIB = L
     return _LIB
 
@@ -107,7 +111,7 @@ class HipEngine:
     """One engine instance = one grid (or one Z-slab) resident on one MI355X."""
 
     def __init__(self, sd, device=0, numerics=PF_NUM_CPU_EXACT, slab_first=True, slab_last=True, air_variant=0,
-                 air_chunk=0, timing=False, readout_chunk=0, ext_u0=None, ext_u1=None, debug=0, x_global0=0):
+                 air_chunk=0, timing=False, readout_chunk=0, ext_u0=None, ext_u1=None, debug=0, x_global0=0, energy=False):
         L = lib()
         self.sd = sd
         self._s = sd.as_struct()
@@ -119,6 +123,7 @@ class HipEngine:
             int(readout_chunk)
         o.debug = int(debug)
         o.x_global0 = int(x_global0)
+        o.energy = int(bool(energy))
         if ext_u0 is not None and ext_u1 is not None:
             o.ext_u0, o.ext_u1 = int(ext_u0), int(ext_u1)
         self._h = ctypes.c_void_p()
@@ -159,6 +164,22 @@ class HipEngine:
         a = np.ascontiguousarray(a, dtype=self.dtype)
         assert a.size == self.sd.Npts
         _check(lib().pf_engine_set_grid(self._h, int(which), a.ctypes.data_as(ctypes.c_void_p)))
+
+    def energy_cfg(self, h, c, Ts, DEF_list):
+        """DEF_list: the materials' (Mb,3) arrays (sim_mats.h5 mat_XX_DEF)."""
+        tab = np.zeros((max(len(DEF_list), 1), 12, 3), dtype=np.float64)
+        for k, d in enumerate(DEF_list):
+            tab[k, :d.shape[0]] = d
+        self._DEF = tab
+        dp = ctypes.POINTER(ctypes.c_double)
+        _check(lib().pf_engine_energy_cfg(self._h, float(h), float(c), float(Ts), tab.ctypes.data_as(dp)))
+
+    def run_energy(self, n0, nsteps, H_tot, E_lost, E_in):
+        dp = ctypes.POINTER(ctypes.c_double)
+        for a in (H_tot, E_lost, E_in):
+            assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+        _check(lib().pf_engine_run_energy(self._h, int(n0), int(nsteps), H_tot.ctypes.data_as(dp),
+                                          E_lost.ctypes.data_as(dp), E_in.ctypes.data_as(dp)))
 
     def timing(self, reset=False):
         t = PfTiming()

@@ -6,7 +6,7 @@ the time loop on the MI355X through the C ABI instead of numba.
 Same method names and call order as the reference's `main()` (sim_fdtd.py:898-937): load_h5_data -> setup_mask ->
 allocate_mem -> set_coeffs -> checks -> run_all -> save_outputs -> print_last_samples.  Like the reference Python
 engine it does not rescale the input (`scale_input` belongs to the C flow: see pffdtd_amd/fdtd_main.py).
-Plotting (`--plot`) is out of scope; `--energy` is not implemented yet and raises.
+Plotting (`--plot`) is out of scope.  `--energy` runs the reference's energy-conservation diagnostic on the device.
 """
 import argparse
 import time
@@ -21,8 +21,8 @@ class SimEngine:
         self.energy_on = energy_on
         self.precision = precision
         self.device = device
-        if energy_on:
-            raise NotImplementedError("the energy diagnostic (sim_fdtd.py:587-620) is not ported yet")
+        if energy_on and precision != "double":
+            raise ValueError("the energy diagnostic runs in double precision (like the reference Python engine)")
         self.print(f"HIP engine: {engine.lib().pf_version().decode()}, {engine.device_count()} device(s)")
 
     def print(self, fstring):
@@ -45,8 +45,17 @@ class SimEngine:
 
     def allocate_mem(self):
         self.print("allocating mem..")
-        self.eng = engine.HipEngine(self.sd, device=self.device)
+        self.eng = engine.HipEngine(self.sd, device=self.device, energy=self.energy_on)
         self.u_out = self.sd.u_out
+        if self.energy_on:  # sim_fdtd.py:181-185
+            import numpy as np
+            sd = self.sd
+            if sd.h is None or sd.c is None:
+                raise ValueError("sim_consts.h5 must hold h and c for the energy diagnostic")
+            self.H_tot = np.zeros((sd.Nt,), dtype=np.float64)
+            self.E_lost = np.zeros((sd.Nt + 1,), dtype=np.float64)
+            self.E_in = np.zeros((sd.Nt + 1,), dtype=np.float64)
+            self.eng.energy_cfg(sd.h, sd.c, sd.Ts, sd.DEF)
 
     def set_coeffs(self):
         pass  # coefficients are derived by the loader (fdtd_data.h:186-194,441-457)
@@ -56,7 +65,10 @@ class SimEngine:
         assert (sd.saf_bnl <= (12 if self.fcc else 6)).all()  # sim_fdtd.py:286-291
 
     def run_steps(self, nstart, nsteps):
-        self.eng.run(nstart, nsteps)
+        if self.energy_on:
+            self.eng.run_energy(nstart, nsteps, self.H_tot, self.E_lost, self.E_in)
+        else:
+            self.eng.run(nstart, nsteps)
 
     def run_all(self, nsteps=1):
         self.print("running..")
@@ -82,32 +94,16 @@ class SimEngine:
                 self.print(f"sample {n}: {sd.u_out[sd.out_reorder[i], n]:.16e}")
 
     def print_last_energy(self, Np):
-        raise NotImplementedError
+        self.print("ENERGY")
+        for n in range(max(self.sd.Nt - Np, 0), self.sd.Nt):
+            self.print(f"normalised energy balance:{rel_diff(self.H_tot[n] + self.E_lost[n], self.E_in[n]):.16e}")
 
 
-def main():
-    p = argparse.ArgumentParser()
-    p.add_argument("--data_dir", type=str, required=True, help="run directory")
-    p.add_argument("--nsteps", type=int, default=1, help="run in batches of steps")
-    p.add_argument("--nthreads", type=int, default=None, help="ignored (kept for CLI compatibility)")
-    p.add_argument("--energy", action="store_true", help="do energy calc")
-    p.add_argument("--plot", action="store_true", help="not supported (visualisation is out of scope)")
-    p.add_argument("--abc", action="store_true", help="unused, as in the reference")
-    p.add_argument("--precision", default="double", choices=["double", "single"])
-    p.add_argument("--gpu", type=int, default=0)
-    a = p.parse_args()
-    if a.plot:
-        raise SystemExit("--plot is not supported")
-    eng = SimEngine(a.data_dir, energy_on=a.energy, nthreads=a.nthreads, precision=a.precision, device=a.gpu)
-    eng.load_h5_data()
-    eng.setup_mask()
-    eng.allocate_mem()
-    eng.set_coeffs()
-    eng.checks()
-    eng.run_all(max(a.nsteps, 1) if a.nsteps else 1)
-    eng.save_outputs()
-    eng.print_last_samples(5)
-
-
-if __name__ == "__main__":
-    main()
+def rel_diff(x0, x1):
+    """(x0-x1)/2^floor(log2(x0)) -- python/common/myfuncs.py:164-165 (0 where x0 is not positive)."""
+    import numpy as np
+    x0, x1 = np.asarray(x0, dtype=np.float64), np.asarray(x1, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = (x0 - x1) / (2.0 ** np.floor(np.log2(x0)))
+    r = np.where(x0 > 0, r, 0.0)
+    return r if r.ndim else float(r)

@@ -15,6 +15,8 @@ print = functools.partial(print, flush=True)
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=1024)
 ap.add_argument("--nx", type=int, default=0, help="planes along x (default: size)")
+ap.add_argument("--ny", type=int, default=0)
+ap.add_argument("--nz", type=int, default=0)
 ap.add_argument("--precision", default="single")
 ap.add_argument("--fcc", action="store_true")
 ap.add_argument("--rigid", action="store_true")
@@ -36,7 +38,7 @@ if args.fcc:
     synth.fold_fcc(sim)
     synth.sort_sim(sim)
 else:
-    sim = synth.shoebox(nx, n, n, Nt=args.steps + 3, Nm=1, Mb=11, lossy=not args.rigid)
+    sim = synth.shoebox(nx, args.ny or n, args.nz or n, Nt=args.steps + 3, Nm=1, Mb=11, lossy=not args.rigid)
 sd = sim_data.SimData.from_sim(sim, args.precision, build_mask=False)
 sd.scale_input()
 print(f"scene {sd.Nx}x{sd.Ny}x{sd.Nz} built in {time.time()-t0:.1f}s Nb={sd.Nb} Nbl={sd.Nbl} Nba={sd.Nba}")
