@@ -17,7 +17,7 @@ import oracle
 from pffdtd_amd import sim_data, synth
 
 GOLDEN = Path(__file__).resolve().parent / "golden"
-FIXTURES = sorted(GOLDEN.glob("*.npz"))
+FIXTURES = sorted(p for p in GOLDEN.glob("*.npz") if not p.name.startswith("energy_"))
 
 
 def _digest(sim):
@@ -87,3 +87,20 @@ def test_fold_is_equivalent_in_double():
     sim2 = synth.fold_fcc(synth.shoebox(24, 28, 20, Nt=80, fcc=True, Nm=2, Mb=[2, 3]))
     u1, u2 = _host_flow(sim1, "double"), _host_flow(sim2, "double")
     assert np.abs(u1 - u2).max() <= 1e-12 * np.abs(u1).max()
+
+
+@pytest.mark.parametrize("fx", sorted(GOLDEN.glob("energy_*.npz")), ids=lambda p: p.stem)
+def test_oracle_agrees_with_python_reference_engine(fx):
+    """C-ordered oracle (fp64, unscaled input) vs the reference PYTHON engine's receivers (captured through
+    test-only shims by tests/golden/make_golden_energy.py): same scheme, different association -> round-off only
+    (1e-14 absolute after 60 steps).  Tolerance 1e-11 of peak."""
+    import sys
+    sys.path.insert(0, str(GOLDEN))
+    from energy_cases import ENERGY_CASES
+    g = np.load(fx)
+    name = fx.stem[len("energy_"):]
+    sim = synth.shoebox(**ENERGY_CASES[name])
+    assert _digest(sim) == str(g["digest"])
+    sd = sim_data.SimData.from_sim(sim, "double")
+    oracle.run_sim(sd)
+    assert np.abs(sd.u_out - g["u_out"]).max() <= 1e-11 * np.abs(g["u_out"]).max()
