@@ -813,6 +813,12 @@ template <typename Real> struct Engine : EngineBase {
 
 } // namespace
 
+template <int R, int WY, int PF, int MODE = 0> static void membench_launch(float *u0, float *u1, pf::LeanParams fp, hipStream_t s) {
+   fp.nyt = (int)cdiv(fp.Ny - 2, (int64_t)WY * R);
+   dim3 g((uint32_t)fp.nzt * fp.nyt * fp.nxc), b(64 * WY);
+   hipLaunchKernelGGL((pf::k_march_stream<float, R, WY, PF, MODE>), g, b, 0, s, u1, u0, fp);
+}
+
 struct pf_engine {
    EngineBase *impl;
 };
@@ -893,6 +899,51 @@ int pf_engine_run_energy(pf_engine *e, int64_t n0, int64_t nsteps, double *H_tot
    PF_NEED(e);
    if (!H_tot || !E_lost || !E_in) return set_err(PF_ERR_ARG, "null output array");
    return e->impl->run_energy(n0, nsteps, H_tot, E_lost, E_in);
+}
+
+double pf_membench(void *u0v, void *u1v, int64_t Nx, int64_t Ny, int64_t Nz, int32_t kind, int32_t R, int32_t WY,
+                   int32_t PF, int32_t chunk, int32_t swizzle, int32_t reps) {
+   float *u0 = (float *)u0v, *u1 = (float *)u1v;
+   const int64_t P = grid_pitch(Nz, 4);
+   pf::LeanParams fp{};
+   fp.plane = Ny * P; fp.Nx = (int)Nx; fp.Ny = (int)Ny; fp.Nz = (int)Nz; fp.P = (int)P;
+   fp.x_begin = 1; fp.x_end = (int)Nx - 1;
+   fp.chunk = chunk > 0 ? chunk : 128;
+   fp.nxc = (int)cdiv(Nx - 2, fp.chunk);
+   fp.nzt = (int)cdiv(P, 256);
+   fp.swizzle = swizzle;
+   hipEvent_t e0, e1;
+   hipEventCreate(&e0); hipEventCreate(&e1);
+   auto launch = [&]() {
+      if (kind == 0) {
+         const int64_t nvec = Nx * Ny * P / 4;
+         // R encodes MODE (bit0 nt loads, bit1 nt stores, bit2 one-shot), WY the unroll
+#define PF_LS(m, u) if (R == m && WY == u) { const int64_t per = 256LL * u; const unsigned nb = (m & 4) ? (unsigned)cdiv(nvec, per) : 256u * 16u; hipLaunchKernelGGL((pf::k_linear_stream<float, m, u>), dim3(nb), dim3(256), 0, 0, u1, u0, nvec); return true; }
+         PF_LS(0, 1) PF_LS(1, 1) PF_LS(2, 1) PF_LS(3, 1) PF_LS(4, 1) PF_LS(7, 1) PF_LS(0, 4) PF_LS(3, 4) PF_LS(4, 4) PF_LS(7, 4) PF_LS(6, 4) PF_LS(5, 4) PF_LS(4, 2) PF_LS(7 + 8 * 3, 4) PF_LS(7 + 8 * 6, 4) PF_LS(7 + 8 * 8, 4) PF_LS(7 + 8 * 10, 4) PF_LS(4 + 8 * 3, 4) PF_LS(4 + 8 * 8, 4)
+#undef PF_LS
+         return false;
+      }
+#define PF_MB(r, wy, pfd) if (kind == 1 && R == r && WY == wy && PF == pfd) { membench_launch<r, wy, pfd>(u0, u1, fp, 0); return true; }
+      PF_MB(4, 4, 1) PF_MB(4, 4, 2) PF_MB(4, 4, 3) PF_MB(2, 4, 1) PF_MB(2, 4, 2) PF_MB(2, 4, 4) PF_MB(1, 4, 2) PF_MB(1, 4, 4) PF_MB(1, 4, 8)
+      PF_MB(2, 8, 2) PF_MB(4, 8, 2) PF_MB(8, 4, 1) PF_MB(8, 4, 2) PF_MB(1, 8, 4)
+#undef PF_MB
+      // kind = 1 + MODE (bit0 nt u1 loads, bit1 nt u0 loads, bit2 nt stores) for R=4, WY=4, PF=1
+#define PF_MM(m) if (kind == 1 + m && R == 4 && WY == 4 && PF == 1) { membench_launch<4, 4, 1, m>(u0, u1, fp, 0); return true; }
+      PF_MM(1) PF_MM(2) PF_MM(3) PF_MM(4) PF_MM(5) PF_MM(6) PF_MM(7)
+#undef PF_MM
+      return false;
+   };
+   if (!launch()) { set_err(PF_ERR_ARG, "membench: unsupported (R,WY,PF)"); return -1.0; }
+   hipDeviceSynchronize();
+   hipEventRecord(e0, 0);
+   for (int i = 0; i < reps; i++) launch();
+   hipEventRecord(e1, 0);
+   hipEventSynchronize(e1);
+   float ms = 0;
+   hipEventElapsedTime(&ms, e0, e1);
+   hipEventDestroy(e0); hipEventDestroy(e1);
+   if (hipGetLastError() != hipSuccess) { set_err(PF_ERR_HIP, "membench launch failed"); return -1.0; }
+   return ms / reps;
 }
 
 // double run_sim(struct SimData *sd): cpu_engine.h:52 / gpu_engine.h:665
