@@ -612,6 +612,8 @@ __global__ __launch_bounds__(64 * WY) void k_air_cart_lds(LeanParams fp, Real a1
    constexpr int TY = R * WY;
    constexpr int ROW = W + 2 * V;
    static_assert(WY >= 2, "top and bottom wave each carry one workgroup halo row");
+   static_assert(R == 1, "EXPERIMENTAL: with more than one DMA row per wave hipcc (ROCm 7.2) clobbers the exec-mask SGPR pair "
+                         "of the 2-lane chunk DMA with the M0 staging register (NaNs on MI355X); R=1 is validated bit-exact");
    __shared__ __attribute__((aligned(16))) Real ring[3][TY + 2][ROW];
 
    const Real *__restrict__ u1 = (const Real *)fp.u1;
@@ -780,6 +782,248 @@ __global__ __launch_bounds__(64 * WY) void k_air_cart_lds(LeanParams fp, Real a1
    }
 }
 
+
+// =============================================================================================================
+// k_air_fcc_lean -- 13-point FCC counterpart of k_air_cart_lean (folded grid fcc_flag 2 and, through the parity bits
+// of the skip-mask, the checkerboard grid fcc_flag 1): virtual ghost shell + air update + ABC loss in one pass.
+// Neighbour / accumulation order of cpu_engine.h:204-216.  Every row that is used with a z offset carries its two
+// z-neighbour columns (lf, rt); rows shared between waves (and the workgroup halo rows) travel through a 4-slot LDS
+// ring as [W values | lf of lane 0 | rt of lane 63]: plane x+1 is published at the top of iteration x, one barrier,
+// then the rows above / below this wave's strip are read for planes x-1, x and x+1.
+// =============================================================================================================
+template <typename Real, int R, int WY, bool FMA>
+__global__ __launch_bounds__(64 * WY) void k_air_fcc_lean(LeanParams fp, Real a1, Real a2, Real l, int fold) {
+   typedef typename VecOf<Real>::type vec;
+   constexpr int V = VecOf<Real>::V;
+   constexpr int W = 64 * V;
+   constexpr int LROW = W + 4;
+   constexpr int NROWS = 2 * WY + 2;
+   static_assert(WY >= 2, "top and bottom wave each carry one workgroup halo row");
+   __shared__ __attribute__((aligned(16))) Real lds[4][NROWS][LROW];
+
+   const Real *__restrict__ u1 = (const Real *)fp.u1;
+   Real *__restrict__ u0 = (Real *)fp.u0;
+   const uint32_t total = (uint32_t)fp.nzt * fp.nyt * fp.nxc;
+   uint32_t b = blockIdx.x;
+   if (fp.swizzle) b = xcd_swizzle(b, total);
+   const int zt = b % fp.nzt;
+   const int yt = (b / fp.nzt) % fp.nyt;
+   const int xc = b / (fp.nzt * fp.nyt);
+   const int lane = threadIdx.x & 63;
+   const int w = threadIdx.x >> 6;
+   const int Nx = fp.Nx, Ny = fp.Ny, Nz = fp.Nz, P = fp.P;
+   const int64_t plane = fp.plane;
+   const int z0 = (zt * 64 + lane) * V;
+   const bool active = z0 < P;
+   const int zl = active ? z0 : 0;
+   const int y0 = 1 + (yt * WY + w) * R;
+   const int xs = fp.x_begin + xc * fp.chunk;
+   const int xe = min(xs + fp.chunk, fp.x_end);
+   const bool top_wave = (w == 0), bot_wave = (w == WY - 1);
+   const bool halo_wave = top_wave || bot_wave;
+   const int halo_slot = top_wave ? 0 : NROWS - 1;
+
+   auto rowsrc = [&](int y) {
+      y = min(y, Ny - 1);
+      if (y == 0) return 2;
+      if (y == Ny - 1) return fold ? Ny - 2 : Ny - 3;
+      return y;
+   };
+   auto planesrc = [&](int x) {
+      if (fp.first && x == 0) return 2;
+      if (fp.last && x == Nx - 1) return Nx - 3;
+      return x;
+   };
+   uint32_t ro[R], so[R];
+   bool valid[R];
+#pragma unroll
+   for (int r = 0; r < R; r++) {
+      ro[r] = (uint32_t)rowsrc(y0 + r) * (uint32_t)P + (uint32_t)zl;
+      so[r] = (uint32_t)min(y0 + r, Ny - 1) * (uint32_t)P + (uint32_t)zl;
+      valid[r] = active && (y0 + r <= Ny - 2);
+   }
+   const uint32_t ro_halo = (uint32_t)rowsrc(top_wave ? y0 - 1 : y0 + R) * (uint32_t)P + (uint32_t)zl;
+   const int zzN = Nz - 1 - z0;
+   const bool fix0 = (z0 == 0);
+   const bool fixR = (zzN == V);
+   uint32_t qzbits = 0;
+#pragma unroll
+   for (int i = 0; i < V; i++)
+      if (active && (z0 + i == 1 || z0 + i == Nz - 2)) qzbits |= 1u << i;
+   const bool wave_has_qz = __ballot(qzbits != 0) != 0ull;
+
+   struct Row { vec v; Real lf, rt; };
+   auto load_row = [&](const Real *pl, uint32_t off) {
+      Row q;
+      q.v = *(const vec *)(pl + off);
+      q.lf = pl[off - 1];
+      q.rt = pl[off + V];
+      if (V == 4) {
+         if (fix0) q.v[0] = q.v[2];
+         if (zzN == 1) q.v[1] = q.lf;
+         if (zzN == 2) q.v[2] = q.v[0];
+         if (zzN == 3) q.v[3] = q.v[1];
+      } else {
+         if (fix0) q.v[0] = q.rt;
+         if (zzN == 1) q.v[1] = q.lf;
+      }
+      if (fixR) q.rt = q.v[V - 2];
+      return q;
+   };
+   auto zlo = [&](const Row &q) { // value at z-1 of every element
+      vec s;
+#pragma unroll
+      for (int i = 0; i < V; i++) s[i] = (i == 0) ? q.lf : q.v[i > 0 ? i - 1 : 0];
+      return s;
+   };
+   auto zhi = [&](const Row &q) { // value at z+1 of every element
+      vec s;
+#pragma unroll
+      for (int i = 0; i < V; i++) s[i] = (i == V - 1) ? q.rt : q.v[i < V - 1 ? i + 1 : V - 1];
+      return s;
+   };
+   auto publish = [&](int x, const Row *rows, const Row &h) {
+      Real(*S)[LROW] = lds[x & 3];
+      *(vec *)&S[1 + 2 * w][lane * V] = rows[0].v;
+      *(vec *)&S[2 + 2 * w][lane * V] = rows[R - 1].v;
+      if (lane == 0) { S[1 + 2 * w][W] = rows[0].lf; S[2 + 2 * w][W] = rows[R - 1].lf; }
+      if (lane == 63) { S[1 + 2 * w][W + 1] = rows[0].rt; S[2 + 2 * w][W + 1] = rows[R - 1].rt; }
+      if (halo_wave) {
+         *(vec *)&S[halo_slot][lane * V] = h.v;
+         if (lane == 0) S[halo_slot][W] = h.lf;
+         if (lane == 63) S[halo_slot][W + 1] = h.rt;
+      }
+   };
+   auto read_halo = [&](int x, int srow, bool with_lr) { // row `srow` of plane x from the ring
+      Real(*S)[LROW] = lds[x & 3];
+      Row q;
+      q.v = *(const vec *)&S[srow][lane * V];
+      q.lf = Real(0);
+      q.rt = Real(0);
+      if (with_lr) {
+         // z neighbours of the first / last element: own lanes' data, or the published wave-edge columns
+         const Real l0 = S[srow][W], r63 = S[srow][W + 1];
+         const Real lm = S[srow][lane == 0 ? 0 : lane * V - 1];
+         const Real rp = S[srow][lane == 63 ? W - 1 : lane * V + V];
+         q.lf = (lane == 0) ? l0 : lm;
+         q.rt = (lane == 63) ? r63 : rp;
+         if (fixR) q.rt = q.v[V - 2]; // my right neighbour is the ghost column: mirror of column Nz-3
+      }
+      return q;
+   };
+
+   Row prev[R], cur[R], nxt[R], nn[R];
+   Row hv = {}, hvn = {};
+   vec old[R], oldn[R];
+   uint32_t mb[R], mbn[R];
+   auto load_plane_own = [&](int x, Row *d) {
+      const Real *pl = u1 + (int64_t)planesrc(x) * plane;
+#pragma unroll
+      for (int r = 0; r < R; r++) d[r] = load_row(pl, ro[r]);
+   };
+   auto load_halo = [&](int x) { return load_row(u1 + (int64_t)planesrc(x) * plane, ro_halo); };
+   auto load_old = [&](int x, vec *d, uint32_t *m) {
+      const Real *po = u0 + (int64_t)x * plane;
+      const uint8_t *pm = fp.mask + (((int64_t)x * plane) >> 3);
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+         d[r] = *(const vec *)(po + so[r]);
+         m[r] = pm[so[r] >> 3];
+      }
+   };
+   {  // prologue: planes xs-1 and xs published, plane xs+1 loaded (published at the top of the first iteration)
+      load_plane_own(xs - 1, prev);
+      Row h = {};
+      if (halo_wave) h = load_halo(xs - 1);
+      publish(xs - 1, prev, h);
+      load_plane_own(xs, cur);
+      if (halo_wave) h = load_halo(xs);
+      publish(xs, cur, h);
+      load_plane_own(xs + 1, nxt);
+      if (halo_wave) hv = load_halo(xs + 1);
+      load_old(xs, old, mb);
+   }
+
+   for (int x = xs; x < xe; x++) {
+      const bool more = (x + 1 < xe);
+      publish(x + 1, nxt, hv);
+      if (more) {
+         load_plane_own(x + 2, nn);
+         if (halo_wave) hvn = load_halo(x + 2);
+         load_old(x + 1, oldn, mbn);
+      }
+      __syncthreads();
+      const Row pa = read_halo(x - 1, 2 * w, false), pb = read_halo(x - 1, 2 * w + 3, false);
+      const Row ca = read_halo(x, 2 * w, true), cb = read_halo(x, 2 * w + 3, true);
+      const Row na = read_halo(x + 1, 2 * w, false), nb_ = read_halo(x + 1, 2 * w + 3, false);
+
+      Real *po = u0 + (int64_t)x * plane;
+      const bool qx = (fp.first && x == 1) || (fp.last && x == Nx - 2);
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+         const Row &c = cur[r];
+         const Row &cu = (r == R - 1) ? cb : cur[r < R - 1 ? r + 1 : R - 1]; // row y+1 of plane x
+         const Row &cd = (r == 0) ? ca : cur[r > 0 ? r - 1 : 0];             // row y-1
+         const vec nu = (r == R - 1) ? nb_.v : nxt[r < R - 1 ? r + 1 : R - 1].v;
+         const vec nd = (r == 0) ? na.v : nxt[r > 0 ? r - 1 : 0].v;
+         const vec pu = (r == R - 1) ? pb.v : prev[r < R - 1 ? r + 1 : R - 1].v;
+         const vec pd = (r == 0) ? pa.v : prev[r > 0 ? r - 1 : 0].v;
+         vec nbv[12];
+         nbv[0] = nu;            // +NzNy+Nz
+         nbv[1] = pd;            // -NzNy-Nz
+         nbv[2] = zhi(cu);       // +Nz+1
+         nbv[3] = zlo(cd);       // -Nz-1
+         nbv[4] = zhi(nxt[r]);   // +NzNy+1
+         nbv[5] = zlo(prev[r]);  // -NzNy-1
+         nbv[6] = nd;            // +NzNy-Nz
+         nbv[7] = pu;            // -NzNy+Nz
+         nbv[8] = zlo(cu);       // +Nz-1
+         nbv[9] = zhi(cd);       // -Nz+1
+         nbv[10] = zlo(nxt[r]);  // +NzNy-1
+         nbv[11] = zhi(prev[r]); // -NzNy+1
+         const uint32_t bits = mb[r] >> (so[r] & 7u);
+         vec o;
+#pragma unroll
+         for (int i = 0; i < V; i++) {
+            Real p = a1 * c.v[i] - old[r][i];
+#pragma unroll
+            for (int k = 0; k < 12; k++) p = acc<FMA>(p, a2, nbv[k][i]);
+            o[i] = p;
+         }
+         if (fp.do_abc) {
+            const int y = y0 + r;
+            const int qxy = (qx ? 1 : 0) + ((y == 1 || (!fold && y == Ny - 2)) ? 1 : 0);
+            if (qxy > 0 || wave_has_qz) {
+#pragma unroll
+               for (int i = 0; i < V; i++) {
+                  const bool zq = (qzbits >> i) & 1u;
+                  if (qxy > 0 || __ballot(zq) != 0ull) {
+                     const int Q = qxy + (zq ? 1 : 0);
+                     if (Q > 0) {
+                        const Real lQ = l * (Real)Q;
+                        const Real num = o[i] + lQ * old[r][i];
+                        o[i] = (Real)((double)num / (1.0 + (double)lQ)); // double literal of cpu_engine.h:228
+                     }
+                  }
+               }
+            }
+         }
+#pragma unroll
+         for (int i = 0; i < V; i++)
+            if ((bits >> i) & 1u) o[i] = old[r][i];
+         if (valid[r]) *(vec *)(po + so[r]) = o;
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+         prev[r] = cur[r];
+         cur[r] = nxt[r];
+         nxt[r] = nn[r];
+         old[r] = oldn[r];
+         mb[r] = mbn[r];
+      }
+      hv = hvn;
+   }
+}
 
 // ---- calibration kernels (tools/membench.py): the marching access pattern with the stencil taken out -----------
 // u0[cell] += u1[cell] over the interior, tiles and x-chunks exactly like k_air_cart_lean (R rows x 16 B per lane,

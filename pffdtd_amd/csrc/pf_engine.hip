@@ -91,7 +91,7 @@ template <typename Real> struct Engine : EngineBase {
    uint8_t *mask = nullptr;      // skip-mask of the unfused kernels (boundary nodes + ghost z + pad + parity)
    uint8_t *mask_bn = nullptr;   // boundary nodes only (fused kernel)
    int32_t *segstart = nullptr;  // first boundary node of every (row, z segment) (fused rigid update)
-   bool fused = false, fused_rigid = false, lean = false;
+   bool fused = false, fused_rigid = false, lean = false, need_fold_row = false;
    int vbase = 0;            // air_variant without its flag bits (64: no XCD swizzle, 128: old fused kernel without rigid fusion)
    int fused_nzt = 0;
    int64_t *d_bn = nullptr, *d_bnl = nullptr, *d_bna = nullptr, *d_in = nullptr, *d_out = nullptr;
@@ -288,15 +288,14 @@ template <typename Real> struct Engine : EngineBase {
          vbase = op.air_variant & 63;
          const bool ok = fused_ok();
          if (op.energy) { if (vbase >= 10) return set_err(PF_ERR_ARG, "the energy diagnostic runs the unfused kernels (air_variant 0-9)"); lean = fused = false; }
-         else if (vbase == 0) { lean = ok && !fcc; fused = false; }
+         else if (vbase == 0) { lean = ok && !fcc; fused = false; } // 13-point: the unfused marching kernel is faster
          else if (vbase >= 20) { lean = true; fused = false; }
          else if (vbase >= 10) { fused = true; lean = false; }
          if ((lean || fused) && !ok)
             return set_err(PF_ERR_ARG, "air_variant %d (fused kernel) requested but its preconditions do not hold", op.air_variant);
-         if (lean && fcc) return set_err(PF_ERR_ARG, "the lean fused kernel is 7-point Cartesian only");
+         if (lean && fcc && (vbase >= 30)) return set_err(PF_ERR_ARG, "the LDS-DMA kernel is 7-point Cartesian only");
          fused_rigid = fused && !(op.air_variant & 128);
-         if (fused && !fused_rigid && !rigid_separable())
-            return set_err(PF_ERR_ARG, "unfused rigid update needs boundary nodes away from the folded ghost row");
+         need_fold_row = fold && !rigid_separable();
          HIPCHK(hipDeviceSynchronize()); // memsets above ran on the null stream; our streams are non-blocking
          if (fused) {
             if ((rc = dzalloc(&mask_bn, npad / 8))) return rc;
@@ -507,7 +506,12 @@ template <typename Real> struct Engine : EngineBase {
       fp.do_abc = 1;
       fp.debug = op.debug;
       dim3 g((uint32_t)fp.nzt * fp.nyt * fp.nxc), b(64 * WY);
-      if constexpr (LDS) {
+      if (fcc) {
+         if constexpr (!LDS && R <= 2) {
+            if (op.numerics == PF_NUM_FMA) hipLaunchKernelGGL((pf::k_air_fcc_lean<Real, R, WY, true>), g, b, 0, s, fp, a1, a2, l, fold ? 1 : 0);
+            else hipLaunchKernelGGL((pf::k_air_fcc_lean<Real, R, WY, false>), g, b, 0, s, fp, a1, a2, l, fold ? 1 : 0);
+         }
+      } else if constexpr (LDS) {
          if (op.numerics == PF_NUM_FMA) hipLaunchKernelGGL((pf::k_air_cart_lds<Real, R, WY, true>), g, b, 0, s, fp, a1, a2, l);
          else hipLaunchKernelGGL((pf::k_air_cart_lds<Real, R, WY, false>), g, b, 0, s, fp, a1, a2, l);
       } else {
@@ -516,16 +520,20 @@ template <typename Real> struct Engine : EngineBase {
       }
    }
    void launch_air_lean(hipStream_t s, int xb, int xe) {
+      if (fcc) { // 13-point: R <= 2 only (register budget)
+         switch (vbase) {
+            case 23: launch_lean_cfg<2, 4>(s, xb, xe); break;
+            case 24: launch_lean_cfg<1, 8>(s, xb, xe); break;
+            default: launch_lean_cfg<2, 8>(s, xb, xe); break;
+         }
+         return;
+      }
       switch (vbase) {
          case 21: launch_lean_cfg<4, 8>(s, xb, xe); break;
          case 23: launch_lean_cfg<2, 4>(s, xb, xe); break;
          case 24: launch_lean_cfg<1, 8>(s, xb, xe); break;
          case 20: launch_lean_cfg<2, 8>(s, xb, xe); break;
-         case 30: launch_lean_cfg<2, 4, true>(s, xb, xe); break;
-         case 31: launch_lean_cfg<2, 8, true>(s, xb, xe); break;
-         case 32: launch_lean_cfg<4, 4, true>(s, xb, xe); break;
          case 33: launch_lean_cfg<1, 8, true>(s, xb, xe); break;
-         case 34: launch_lean_cfg<4, 2, true>(s, xb, xe); break;
          case 35: launch_lean_cfg<1, 4, true>(s, xb, xe); break;
          default: launch_lean_cfg<4, 4>(s, xb, xe); break; // 0 (auto) and 22: fastest measured on MI355X
       }
@@ -549,6 +557,11 @@ template <typename Real> struct Engine : EngineBase {
    }
    void launch_rigid(hipStream_t s, Range r) {
       if (r.e <= r.b || (fused && fused_rigid)) return;
+      if ((lean || fused) && fold && need_fold_row) {
+         // boundary nodes next to the folded ghost row read it from MEMORY: keep that one row materialised
+         dim3 gy((unsigned)cdiv(Nz, 256), (unsigned)Nx);
+         hipLaunchKernelGGL(pf::k_flip_y<Real>, gy, dim3(256), 0, s, u1, Nx, Ny, P, Nz, 4);
+      }
       dim3 g((unsigned)cdiv(r.e - r.b, 256)), b(256);
       const bool fma = op.numerics == PF_NUM_FMA;
       if (fcc) {
