@@ -399,7 +399,7 @@ struct LeanParams {
    int32_t debug;           // reserved for tuning experiments (unused in production builds)
 };
 
-template <typename Real, int R, int WY, bool FMA>
+template <typename Real, int R, int WY, bool FMA, bool NT = false>
 __global__ __launch_bounds__(64 * WY) void k_air_cart_lean(LeanParams fp, Real a1, Real a2, Real l) {
    typedef typename VecOf<Real>::type vec;
    constexpr int V = VecOf<Real>::V;
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(64 * WY) void k_air_cart_lean(LeanParams fp, Real a
       const uint8_t *pm = fp.mask + (((int64_t)x * plane) >> 3);
 #pragma unroll
       for (int r = 0; r < R; r++) {
-         d[r] = *(const vec *)(po + so[r]);
+         d[r] = NT ? __builtin_nontemporal_load((const vec *)(po + so[r])) : *(const vec *)(po + so[r]);
          m[r] = pm[so[r] >> 3];
       }
    };
@@ -575,7 +575,10 @@ __global__ __launch_bounds__(64 * WY) void k_air_cart_lean(LeanParams fp, Real a
 #pragma unroll
          for (int i = 0; i < V; i++)
             if ((bits >> i) & 1u) o[i] = old[r][i];
-         if (valid[r]) *(vec *)(po + so[r]) = o;
+         if (valid[r]) {
+            if (NT) __builtin_nontemporal_store(o, (vec *)(po + so[r]));
+            else *(vec *)(po + so[r]) = o;
+         }
       }
       __syncthreads();
 #pragma unroll
@@ -1029,16 +1032,17 @@ __global__ __launch_bounds__(64 * WY) void k_air_fcc_lean(LeanParams fp, Real a1
 // u0[cell] += u1[cell] over the interior, tiles and x-chunks exactly like k_air_cart_lean (R rows x 16 B per lane,
 // WY waves in y); PF = how many planes ahead the loads are issued.  Tells the access pattern's own ceiling apart
 // from what the stencil kernels lose on top of it.
-template <typename Real, int R, int WY, int PF, int MODE = 0>
-__global__ __launch_bounds__(64 * WY) void k_march_stream(const Real *__restrict__ u1, Real *__restrict__ u0, LeanParams fp) {
+template <typename Real, int R, int WY, int PF, int MODE = 0, int WZ = 1>
+__global__ __launch_bounds__(64 * WY * WZ) void k_march_stream(const Real *__restrict__ u1, Real *__restrict__ u0, LeanParams fp) {
    typedef typename VecOf<Real>::type vec;
    constexpr int V = VecOf<Real>::V;
    const uint32_t total = (uint32_t)fp.nzt * fp.nyt * fp.nxc;
    uint32_t b = blockIdx.x;
    if (fp.swizzle) b = xcd_swizzle(b, total);
    const int zt = b % fp.nzt, yt = (b / fp.nzt) % fp.nyt, xc = b / (fp.nzt * fp.nyt);
-   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-   const int z0 = (zt * 64 + lane) * V;
+   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+   const int w = wv / WZ, wz = wv % WZ;
+   const int z0 = ((zt * WZ + wz) * 64 + lane) * V;
    if (z0 >= fp.P) return;
    const int y0 = 1 + (yt * WY + w) * R;
    const int xs = fp.x_begin + xc * fp.chunk, xe = min(xs + fp.chunk, fp.x_end);

@@ -483,7 +483,7 @@ template <typename Real> struct Engine : EngineBase {
       }
    }
 
-   template <int R, int WY, bool LDS = false> void launch_lean_cfg(hipStream_t s, int xb, int xe) {
+   template <int R, int WY, bool LDS = false, bool NT = false> void launch_lean_cfg(hipStream_t s, int xb, int xe) {
       pf::LeanParams fp;
       fp.u1 = u1; fp.u0 = u0; fp.mask = mask;
       fp.plane = plane;
@@ -495,7 +495,7 @@ template <typename Real> struct Engine : EngineBase {
       int chunk = op.air_chunk;
       if (chunk <= 0) {
          const int64_t tiles = (int64_t)fp.nzt * fp.nyt;
-         const int64_t want = cdiv(256 * 8, std::max<int64_t>(tiles, 1));
+         const int64_t want = cdiv(256 * 32, std::max<int64_t>(tiles, 1));
          chunk = (int)std::max<int64_t>(cdiv(nplanes, std::max<int64_t>(want, 1)), 16);
       }
       chunk = std::min(chunk, nplanes);
@@ -515,8 +515,8 @@ template <typename Real> struct Engine : EngineBase {
          if (op.numerics == PF_NUM_FMA) hipLaunchKernelGGL((pf::k_air_cart_lds<Real, R, WY, true>), g, b, 0, s, fp, a1, a2, l);
          else hipLaunchKernelGGL((pf::k_air_cart_lds<Real, R, WY, false>), g, b, 0, s, fp, a1, a2, l);
       } else {
-         if (op.numerics == PF_NUM_FMA) hipLaunchKernelGGL((pf::k_air_cart_lean<Real, R, WY, true>), g, b, 0, s, fp, a1, a2, l);
-         else hipLaunchKernelGGL((pf::k_air_cart_lean<Real, R, WY, false>), g, b, 0, s, fp, a1, a2, l);
+         if (op.numerics == PF_NUM_FMA) hipLaunchKernelGGL((pf::k_air_cart_lean<Real, R, WY, true, NT>), g, b, 0, s, fp, a1, a2, l);
+         else hipLaunchKernelGGL((pf::k_air_cart_lean<Real, R, WY, false, NT>), g, b, 0, s, fp, a1, a2, l);
       }
    }
    void launch_air_lean(hipStream_t s, int xb, int xe) {
@@ -533,9 +533,12 @@ template <typename Real> struct Engine : EngineBase {
          case 23: launch_lean_cfg<2, 4>(s, xb, xe); break;
          case 24: launch_lean_cfg<1, 8>(s, xb, xe); break;
          case 20: launch_lean_cfg<2, 8>(s, xb, xe); break;
+         case 25: launch_lean_cfg<4, 4, false, true>(s, xb, xe); break;
+         case 26: launch_lean_cfg<2, 8, false, true>(s, xb, xe); break;
          case 33: launch_lean_cfg<1, 8, true>(s, xb, xe); break;
          case 35: launch_lean_cfg<1, 4, true>(s, xb, xe); break;
-         default: launch_lean_cfg<4, 4>(s, xb, xe); break; // 0 (auto) and 22: fastest measured on MI355X
+         case 22: launch_lean_cfg<4, 4>(s, xb, xe); break;
+         default: launch_lean_cfg<4, 4, false, true>(s, xb, xe); break; // 0 (auto), 25: fastest measured on MI355X
       }
    }
 
@@ -826,10 +829,11 @@ template <typename Real> struct Engine : EngineBase {
 
 } // namespace
 
-template <int R, int WY, int PF, int MODE = 0> static void membench_launch(float *u0, float *u1, pf::LeanParams fp, hipStream_t s) {
+template <int R, int WY, int PF, int MODE = 0, int WZ = 1> static void membench_launch(float *u0, float *u1, pf::LeanParams fp, hipStream_t s) {
    fp.nyt = (int)cdiv(fp.Ny - 2, (int64_t)WY * R);
-   dim3 g((uint32_t)fp.nzt * fp.nyt * fp.nxc), b(64 * WY);
-   hipLaunchKernelGGL((pf::k_march_stream<float, R, WY, PF, MODE>), g, b, 0, s, u1, u0, fp);
+   fp.nzt = (int)cdiv(fp.P, 256 * WZ);
+   dim3 g((uint32_t)fp.nzt * fp.nyt * fp.nxc), b(64 * WY * WZ);
+   hipLaunchKernelGGL((pf::k_march_stream<float, R, WY, PF, MODE, WZ>), g, b, 0, s, u1, u0, fp);
 }
 
 struct pf_engine {
@@ -944,6 +948,15 @@ double pf_membench(void *u0v, void *u1v, int64_t Nx, int64_t Ny, int64_t Nz, int
 #define PF_MM(m) if (kind == 1 + m && R == 4 && WY == 4 && PF == 1) { membench_launch<4, 4, 1, m>(u0, u1, fp, 0); return true; }
       PF_MM(1) PF_MM(2) PF_MM(3) PF_MM(4) PF_MM(5) PF_MM(6) PF_MM(7)
 #undef PF_MM
+      // kind 20 + m: full-row tiles (WZ=4 waves side by side), R rows, WY=1|2, nt mode m (0 or 7)
+      if (kind == 20 && R == 4 && WY == 1) { membench_launch<4, 1, 1, 0, 4>(u0, u1, fp, 0); return true; }
+      if (kind == 27 && R == 4 && WY == 1) { membench_launch<4, 1, 1, 7, 4>(u0, u1, fp, 0); return true; }
+      if (kind == 20 && R == 4 && WY == 2) { membench_launch<4, 2, 1, 0, 4>(u0, u1, fp, 0); return true; }
+      if (kind == 27 && R == 4 && WY == 2) { membench_launch<4, 2, 1, 7, 4>(u0, u1, fp, 0); return true; }
+      if (kind == 20 && R == 2 && WY == 2) { membench_launch<2, 2, 1, 0, 4>(u0, u1, fp, 0); return true; }
+      if (kind == 27 && R == 2 && WY == 2) { membench_launch<2, 2, 1, 7, 4>(u0, u1, fp, 0); return true; }
+      if (kind == 27 && R == 1 && WY == 4) { membench_launch<1, 4, 2, 7, 4>(u0, u1, fp, 0); return true; }
+      if (kind == 27 && R == 8 && WY == 1) { membench_launch<8, 1, 1, 7, 4>(u0, u1, fp, 0); return true; }
       return false;
    };
    if (!launch()) { set_err(PF_ERR_ARG, "membench: unsupported (R,WY,PF)"); return -1.0; }

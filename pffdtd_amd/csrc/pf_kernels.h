@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
       for (int j = 0; j < R + 2; j++) nxt[j] = *(const vec *)(pn + roff[j]);
 #pragma unroll
       for (int r = 0; r < R; r++) {
-         old[r] = *(const vec *)(po + roff[r + 1]);
+         old[r] = __builtin_nontemporal_load((const vec *)(po + roff[r + 1]));
          mb[r] = pmk[roff[r + 1] >> 3];
          nxtL[r] = need_l ? pn[roff[r + 1] - 1] : Real(0);
          nxtR[r] = need_r ? pn[roff[r + 1] + V] : Real(0);
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
             p = acc<FMA>(p, a2, left);           // -1
             o[i] = ((bits >> i) & 1u) ? old[r][i] : p;
          }
-         if (active && (y0 + r <= Ny - 2)) *(vec *)(po + roff[r + 1]) = o;
+         if (active && (y0 + r <= Ny - 2)) __builtin_nontemporal_store(o, (vec *)(po + roff[r + 1]));
       }
 #pragma unroll
       for (int r = 0; r < R; r++) {
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict
       }
 #pragma unroll
       for (int r = 0; r < R; r++) {
-         old[r] = *(const vec *)(po + roff[r + 1]);
+         old[r] = __builtin_nontemporal_load((const vec *)(po + roff[r + 1]));
          mb[r] = pmk[roff[r + 1] >> 3];
       }
       // z-shifted views: lo(v)[i] = v[z-1], hi(v)[i] = v[z+1]
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict
             p = acc<FMA>(p, a2, p_hi[i]);        // -NzNy+1
             o[i] = ((bits >> i) & 1u) ? old[r][i] : p;
          }
-         if (active && (y0 + r <= Ny - 2)) *(vec *)(po + roff[j]) = o;
+         if (active && (y0 + r <= Ny - 2)) __builtin_nontemporal_store(o, (vec *)(po + roff[j]));
       }
 #pragma unroll
       for (int j = 0; j < R + 2; j++) {
@@ -468,8 +468,8 @@ __global__ void k_fd_boundary(Real *__restrict__ u0, const int64_t *__restrict__
    for (int m = 0; m < 12; m++) {
       if (m < M) {
          const MatQuadT<Real> q = mq[k * 12 + m];
-         v1[m] = vh1[(int64_t)m * Nbl + nb];
-         g1[m] = gh1[(int64_t)m * Nbl + nb];
+         v1[m] = __builtin_nontemporal_load(&vh1[(int64_t)m * Nbl + nb]);
+         g1[m] = __builtin_nontemporal_load(&gh1[(int64_t)m * Nbl + nb]);
          u -= fac * (two * q.bDh * v1[m] - q.bFh * g1[m]);
       }
    }
@@ -479,8 +479,8 @@ __global__ void k_fd_boundary(Real *__restrict__ u0, const int64_t *__restrict__
       if (m < M) {
          const MatQuadT<Real> q = mq[k * 12 + m];
          const Real v0 = q.b * du + q.bd * v1[m] - two * q.bFh * g1[m];
-         gh1[(int64_t)m * Nbl + nb] = g1[m] + (v0 + v1[m]) / two;
-         vh1[(int64_t)m * Nbl + nb] = v0;
+         __builtin_nontemporal_store(g1[m] + (v0 + v1[m]) / two, &gh1[(int64_t)m * Nbl + nb]);
+         __builtin_nontemporal_store(v0, &vh1[(int64_t)m * Nbl + nb]);
       }
    }
    u0b[nb] = u;

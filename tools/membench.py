@@ -28,6 +28,10 @@ for mode, unr in [(0, 1), (1, 1), (2, 1), (3, 1), (4, 1), (7, 1), (0, 4), (3, 4)
 for m in range(1, 8):
     ms = run(1 + m, 4, 4, 1, 32)
     print(f"march R=4 WY=4 PF=1 chunk=32 nt(u1 ld {m&1}, u0 ld {(m>>1)&1}, st {(m>>2)&1})  {ms:7.3f} ms  {byt/ms/1e6:7.1f} GB/s")
+for kind, R, WY in [(20, 4, 1), (27, 4, 1), (20, 4, 2), (27, 4, 2), (20, 2, 2), (27, 2, 2), (27, 1, 4), (27, 8, 1)]:
+    for chunk in (4, 16, 64, 256):
+        ms = run(kind, R, WY, 1, chunk)
+        print(f"march full-row tiles (WZ=4) R={R} WY={WY} nt={kind-20} chunk={chunk:4d}  {ms:7.3f} ms  {byt/ms/1e6:7.1f} GB/s")
 if len(sys.argv) > 2:
     sys.exit(0)
 for (R, WY, PF) in [(4, 4, 1), (4, 4, 2), (4, 4, 3), (2, 4, 1), (2, 4, 2), (2, 4, 4), (1, 4, 2), (1, 4, 4), (1, 4, 8), (2, 8, 2),
