@@ -365,6 +365,12 @@ __global__ void k_segstart(const int64_t *__restrict__ bn, int64_t Nb, int32_t *
    segstart[t] = (int32_t)lo;
 }
 
+// one adjacency byte per padded cell for the fused rigid update: 0x80 | adjacency bits at boundary nodes, 0 elsewhere
+__global__ void k_adj_dense_set(uint8_t *__restrict__ dense, const int64_t *__restrict__ idx, const uint16_t *__restrict__ adj, int64_t n) {
+   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (i < n) dense[idx[i]] = (uint8_t)(0x80u | (adj[i] & 0x3fu));
+}
+
 // boundary-node-only mask in the padded layout
 __global__ void k_mask_zero(uint8_t *__restrict__ mask, int64_t nbytes) {
    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -389,7 +395,8 @@ __global__ void k_mask_zero(uint8_t *__restrict__ mask, int64_t nbytes) {
 struct LeanParams {
    const void *u1;
    void *u0;
-   const uint8_t *mask;     // skip-mask (pf_kernels.h), padded layout
+   const uint8_t *mask;     // skip-mask (pf_kernels.h), padded layout; boundary nodes only when the rigid update is fused
+   const uint8_t *adj;      // fused rigid update: one byte per padded cell, 0x80 | adjacency bits for boundary nodes
    int64_t plane;
    int32_t Nx, Ny, Nz, P;
    int32_t x_begin, x_end, chunk;
@@ -399,8 +406,8 @@ struct LeanParams {
    int32_t debug;           // reserved for tuning experiments (unused in production builds)
 };
 
-template <typename Real, int R, int WY, bool FMA, bool NT = false>
-__global__ __launch_bounds__(64 * WY) void k_air_cart_lean(LeanParams fp, Real a1, Real a2, Real l) {
+template <typename Real, int R, int WY, bool FMA, bool NT = false, bool RIG = false>
+__global__ __launch_bounds__(64 * WY) void k_air_cart_lean(LeanParams fp, Real a1, Real a2, Real l, Real sl2) {
    typedef typename VecOf<Real>::type vec;
    constexpr int V = VecOf<Real>::V;
    constexpr int W = 64 * V;
@@ -461,6 +468,11 @@ __global__ __launch_bounds__(64 * WY) void k_air_cart_lean(LeanParams fp, Real a
    for (int i = 0; i < V; i++)
       if (active && (z0 + i == 1 || z0 + i == Nz - 2)) qzbits |= 1u << i;
    const bool wave_has_qz = __ballot(qzbits != 0) != 0ull;
+   // RIG: the mask holds boundary nodes only; ghost / pad columns are recognised by position
+   uint32_t skipbits = 0;
+#pragma unroll
+   for (int i = 0; i < V; i++)
+      if (z0 + i == 0 || z0 + i >= Nz - 1) skipbits |= 1u << i;
 
    // an own row with its z neighbours; ghost columns patched
    auto load_own_row = [&](const Real *pl, uint32_t off, vec &v, Real &lf, Real &rt) {
@@ -538,7 +550,7 @@ __global__ __launch_bounds__(64 * WY) void k_air_cart_lean(LeanParams fp, Real a
          const vec c = cur[r];
          const vec ym = (r == 0) ? above : cur[r > 0 ? r - 1 : 0];
          const vec yp = (r == R - 1) ? below : cur[r < R - 1 ? r + 1 : R - 1];
-         const uint32_t bits = mb[r] >> (so[r] & 7u);
+         const uint32_t bits = (mb[r] >> (so[r] & 7u)) & ((1u << V) - 1u);
          vec o;
 #pragma unroll
          for (int i = 0; i < V; i++) {
@@ -572,9 +584,42 @@ __global__ __launch_bounds__(64 * WY) void k_air_cart_lean(LeanParams fp, Real a
                }
             }
          }
+         if (RIG) {
+            // rigid boundary nodes (cpu_engine.h:234-257) from the same registers: centre coefficient 2 - sl2*K,
+            // neighbour k weighted by a2 * adjacency bit k (a2*1 == a2, a2*0 == 0 exactly)
+            if (__ballot(valid[r] && bits != 0) != 0ull) {
+               uint32_t adj4 = 0;
+               if (valid[r] && bits != 0) {
+                  const uint8_t *pa = fp.adj + ((int64_t)x * plane + so[r]);
+                  adj4 = (V == 4) ? *(const uint32_t *)pa : (uint32_t) * (const uint16_t *)pa;
+               }
 #pragma unroll
-         for (int i = 0; i < V; i++)
-            if ((bits >> i) & 1u) o[i] = old[r][i];
+               for (int i = 0; i < V; i++) {
+                  if ((bits >> i) & 1u) {
+                     const uint32_t aw = (adj4 >> (8 * i)) & 0x3fu;
+                     const Real two = 2.0;
+                     const Real cc = two - sl2 * (Real)__popc(aw);
+                     const Real zp = (i == V - 1) ? curR[r] : c[i < V - 1 ? i + 1 : V - 1];
+                     const Real zm = (i == 0) ? curL[r] : c[i > 0 ? i - 1 : 0];
+                     const Real nbk[6] = {nxt[r][i], prev[r][i], yp[i], ym[i], zp, zm};
+                     Real p = cc * c[i] - old[r][i];
+#pragma unroll
+                     for (int k = 0; k < 6; k++) {
+                        const Real wk = ((aw >> k) & 1u) ? a2 : Real(0);
+                        p = FMA ? __builtin_fma(wk, nbk[k], p) : p + wk * nbk[k];
+                     }
+                     o[i] = p;
+                  }
+               }
+            }
+#pragma unroll
+            for (int i = 0; i < V; i++)
+               if ((skipbits >> i) & 1u) o[i] = old[r][i];
+         } else {
+#pragma unroll
+            for (int i = 0; i < V; i++)
+               if ((bits >> i) & 1u) o[i] = old[r][i];
+         }
          if (valid[r]) {
             if (NT) __builtin_nontemporal_store(o, (vec *)(po + so[r]));
             else *(vec *)(po + so[r]) = o;

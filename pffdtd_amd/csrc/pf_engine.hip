@@ -91,6 +91,8 @@ template <typename Real> struct Engine : EngineBase {
    uint8_t *mask = nullptr;      // skip-mask of the unfused kernels (boundary nodes + ghost z + pad + parity)
    uint8_t *mask_bn = nullptr;   // boundary nodes only (fused kernel)
    int32_t *segstart = nullptr;  // first boundary node of every (row, z segment) (fused rigid update)
+   uint8_t *adj_dense = nullptr; // lean kernel with in-kernel rigid update: adjacency byte per padded cell
+   bool lean_rigid = false;
    bool fused = false, fused_rigid = false, lean = false, need_fold_row = false;
    int vbase = 0;            // air_variant without its flag bits (64: no XCD swizzle, 128: old fused kernel without rigid fusion)
    int fused_nzt = 0;
@@ -127,7 +129,7 @@ template <typename Real> struct Engine : EngineBase {
       if (s_edge) hipStreamSynchronize(s_edge);
       auto F = [](void *p) { if (p) hipFree(p); };
       if (own_grids) { F(u0); F(u1); }
-      F(mask); F(mask_bn); F(segstart); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
+      F(mask); F(mask_bn); F(segstart); F(adj_dense); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
       F(d_beta); F(d_insig); F(d_mq); F(ub[0]); F(ub[1]); F(ub[2]); F(u2ba); F(vh1); F(gh1); F(ring);
       if (h_ring) hipHostFree(h_ring);
       for (auto &p : air_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -296,6 +298,8 @@ template <typename Real> struct Engine : EngineBase {
          if (lean && fcc && (vbase >= 30)) return set_err(PF_ERR_ARG, "the LDS-DMA kernel is 7-point Cartesian only");
          fused_rigid = fused && !(op.air_variant & 128);
          need_fold_row = fold && !rigid_separable();
+         // 7-point lean kernel with the rigid boundary update fused in (variants 0/auto, 27, 28)
+         lean_rigid = lean && !fcc && Nb > 0 && (vbase == 27 || vbase == 28); // correct but slower than the list kernel
          HIPCHK(hipDeviceSynchronize()); // memsets above ran on the null stream; our streams are non-blocking
          if (fused) {
             if ((rc = dzalloc(&mask_bn, npad / 8))) return rc;
@@ -308,6 +312,13 @@ template <typename Real> struct Engine : EngineBase {
             if ((rc = dzalloc(&segstart, nseg))) return rc;
             HIPCHK(hipDeviceSynchronize());
             hipLaunchKernelGGL(pf::k_segstart, dim3((unsigned)cdiv(nseg, 256)), dim3(256), 0, s_main, d_bn, Nb, segstart, Nx * Ny, fused_nzt, P, 64 * V);
+         } else if (lean_rigid) {
+            fused_nzt = (int)cdiv(P, 64 * pf::VecOf<Real>::V);
+            if ((rc = dzalloc(&mask_bn, npad / 8))) return rc;
+            if ((rc = dzalloc(&adj_dense, npad + 64))) return rc;
+            HIPCHK(hipDeviceSynchronize());
+            hipLaunchKernelGGL(pf::k_mask_set, dim3((unsigned)cdiv(Nb, 256)), dim3(256), 0, s_main, mask_bn, d_bn, Nb);
+            hipLaunchKernelGGL(pf::k_adj_dense_set, dim3((unsigned)cdiv(Nb, 256)), dim3(256), 0, s_main, adj_dense, d_bn, d_adj, Nb);
          } else {
             fused_nzt = (int)cdiv(P, 64 * pf::VecOf<Real>::V);
             // skip-mask: ghost z / pad / parity, then the boundary nodes
@@ -483,9 +494,9 @@ template <typename Real> struct Engine : EngineBase {
       }
    }
 
-   template <int R, int WY, bool LDS = false, bool NT = false> void launch_lean_cfg(hipStream_t s, int xb, int xe) {
+   template <int R, int WY, bool LDS = false, bool NT = false, bool RIG = false> void launch_lean_cfg(hipStream_t s, int xb, int xe) {
       pf::LeanParams fp;
-      fp.u1 = u1; fp.u0 = u0; fp.mask = mask;
+      fp.u1 = u1; fp.u0 = u0; fp.mask = RIG ? mask_bn : mask; fp.adj = adj_dense;
       fp.plane = plane;
       fp.Nx = (int)Nx; fp.Ny = (int)Ny; fp.Nz = (int)Nz; fp.P = (int)P;
       fp.x_begin = xb; fp.x_end = xe;
@@ -515,8 +526,8 @@ template <typename Real> struct Engine : EngineBase {
          if (op.numerics == PF_NUM_FMA) hipLaunchKernelGGL((pf::k_air_cart_lds<Real, R, WY, true>), g, b, 0, s, fp, a1, a2, l);
          else hipLaunchKernelGGL((pf::k_air_cart_lds<Real, R, WY, false>), g, b, 0, s, fp, a1, a2, l);
       } else {
-         if (op.numerics == PF_NUM_FMA) hipLaunchKernelGGL((pf::k_air_cart_lean<Real, R, WY, true, NT>), g, b, 0, s, fp, a1, a2, l);
-         else hipLaunchKernelGGL((pf::k_air_cart_lean<Real, R, WY, false, NT>), g, b, 0, s, fp, a1, a2, l);
+         if (op.numerics == PF_NUM_FMA) hipLaunchKernelGGL((pf::k_air_cart_lean<Real, R, WY, true, NT, RIG>), g, b, 0, s, fp, a1, a2, l, sl2);
+         else hipLaunchKernelGGL((pf::k_air_cart_lean<Real, R, WY, false, NT, RIG>), g, b, 0, s, fp, a1, a2, l, sl2);
       }
    }
    void launch_air_lean(hipStream_t s, int xb, int xe) {
@@ -533,12 +544,16 @@ template <typename Real> struct Engine : EngineBase {
          case 23: launch_lean_cfg<2, 4>(s, xb, xe); break;
          case 24: launch_lean_cfg<1, 8>(s, xb, xe); break;
          case 20: launch_lean_cfg<2, 8>(s, xb, xe); break;
-         case 25: launch_lean_cfg<4, 4, false, true>(s, xb, xe); break;
          case 26: launch_lean_cfg<2, 8, false, true>(s, xb, xe); break;
          case 33: launch_lean_cfg<1, 8, true>(s, xb, xe); break;
          case 35: launch_lean_cfg<1, 4, true>(s, xb, xe); break;
          case 22: launch_lean_cfg<4, 4>(s, xb, xe); break;
-         default: launch_lean_cfg<4, 4, false, true>(s, xb, xe); break; // 0 (auto), 25: fastest measured on MI355X
+         case 25: launch_lean_cfg<4, 4, false, true>(s, xb, xe); break;
+         case 28: if (lean_rigid) launch_lean_cfg<2, 8, false, true, true>(s, xb, xe); else launch_lean_cfg<2, 8, false, true>(s, xb, xe); break;
+         default: // 0 (auto) and 25: fastest measured on MI355X; 27 = same with the rigid update fused in
+            if (lean_rigid) launch_lean_cfg<4, 4, false, true, true>(s, xb, xe);
+            else launch_lean_cfg<4, 4, false, true>(s, xb, xe);
+            break;
       }
    }
 
@@ -559,7 +574,7 @@ template <typename Real> struct Engine : EngineBase {
       if (!fused && !lean && r.e > r.b) hipLaunchKernelGGL(pf::k_abc_loss<Real>, dim3((unsigned)cdiv(r.e - r.b, 256)), dim3(256), 0, s, u0, d_bna, d_Q, u2ba, l, r.b, r.e);
    }
    void launch_rigid(hipStream_t s, Range r) {
-      if (r.e <= r.b || (fused && fused_rigid)) return;
+      if (r.e <= r.b || (fused && fused_rigid) || lean_rigid) return;
       if ((lean || fused) && fold && need_fold_row) {
          // boundary nodes next to the folded ghost row read it from MEMORY: keep that one row materialised
          dim3 gy((unsigned)cdiv(Nz, 256), (unsigned)Nx);

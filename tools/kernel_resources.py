@@ -23,7 +23,10 @@ for line in out.splitlines():
         rows[cur] = {}
     elif cur:
         rows[cur][m.group(2).strip()] = int(m.group(3))
-dem = subprocess.run(["c++filt"] + list(rows), capture_output=True, text=True).stdout.splitlines()
+if not rows:
+    print(out[-3000:])
+    sys.exit("compile failed or no kernels found")
+dem = subprocess.run(["c++filt"] + list(rows), capture_output=True, text=True, stdin=subprocess.DEVNULL).stdout.splitlines()
 print(f"{'VGPR':>5} {'AGPR':>5} {'SGPR':>5} {'scratch':>7} {'occ':>4} {'LDS':>6}  kernel")
 for (k, v), d in zip(rows.items(), dem):
     d = re.sub(r"\(.*", "", d).replace("void pf::", "")
