@@ -98,6 +98,8 @@ template <typename Real> struct Engine : EngineBase {
    int fused_nzt = 0;
    int64_t *d_bn = nullptr, *d_bnl = nullptr, *d_bna = nullptr, *d_in = nullptr, *d_out = nullptr;
    uint16_t *d_adj = nullptr;
+   int32_t *d_lossy = nullptr;   // per boundary node: index into the lossy-node arrays or -1 (fused boundary pass)
+   bool fuse_boundary = false;
    int8_t *d_Q = nullptr, *d_mat = nullptr, *d_Mb = nullptr;
    Real *d_ssaf = nullptr, *d_beta = nullptr, *d_insig = nullptr;
    pf::MatQuadT<Real> *d_mq = nullptr;
@@ -129,7 +131,7 @@ template <typename Real> struct Engine : EngineBase {
       if (s_edge) hipStreamSynchronize(s_edge);
       auto F = [](void *p) { if (p) hipFree(p); };
       if (own_grids) { F(u0); F(u1); }
-      F(mask); F(mask_bn); F(segstart); F(adj_dense); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
+      F(d_lossy); F(mask); F(mask_bn); F(segstart); F(adj_dense); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
       F(d_beta); F(d_insig); F(d_mq); F(ub[0]); F(ub[1]); F(ub[2]); F(u2ba); F(vh1); F(gh1); F(ring);
       if (h_ring) hipHostFree(h_ring);
       for (auto &p : air_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -350,6 +352,24 @@ template <typename Real> struct Engine : EngineBase {
          if ((rc = upload(&d_mq, (const pf::MatQuadT<Real> *)sd.mat_quads, sd.Nm ? nm * PF_MMB : 0))) return rc;
          if ((rc = upload(&d_beta, (const Real *)sd.mat_beta, sd.Nm))) return rc;
          if ((rc = upload(&d_Mb, sd.Mb, sd.Nm))) return rc;
+      }
+      { // fused boundary pass: map every boundary node to its lossy slot (both lists are sorted by padded index)
+         std::vector<int64_t> hb(Nb), hl(Nbl);
+         if (Nb) HIPCHK(hipMemcpy(hb.data(), d_bn, Nb * sizeof(int64_t), hipMemcpyDeviceToHost));
+         if (Nbl) HIPCHK(hipMemcpy(hl.data(), d_bnl, Nbl * sizeof(int64_t), hipMemcpyDeviceToHost));
+         std::vector<int32_t> lz(Nb, -1);
+         int64_t j = 0;
+         bool subset = Nbl < ((int64_t)1 << 31);
+         for (int64_t i = 0; i < Nb && j < Nbl; i++) {
+            if (hb[i] == hl[j]) {
+               if (j + 1 < Nbl && hl[j + 1] == hl[j]) { subset = false; break; } // duplicate lossy entries: keep the separate kernels
+               lz[i] = (int32_t)j++;
+            } else if (hb[i] > hl[j]) { subset = false; break; }
+         }
+         if (j != Nbl) subset = false; // a lossy node that is not a boundary node: cannot fuse
+         for (int64_t i = 1; i < Nb && subset; i++) if (hb[i] == hb[i - 1]) subset = false;
+         fuse_boundary = subset && Nb > 0 && !(op.air_variant & 256) && !op.energy;
+         if (fuse_boundary) { if ((rc = upload(&d_lossy, lz.data(), Nb))) return rc; }
       }
       { // ABC nodes
          auto perm = sorted_perm(sd.bna_ixyz, Nba, idx);
@@ -573,7 +593,23 @@ template <typename Real> struct Engine : EngineBase {
    void launch_abc(hipStream_t s, Range r) {
       if (!fused && !lean && r.e > r.b) hipLaunchKernelGGL(pf::k_abc_loss<Real>, dim3((unsigned)cdiv(r.e - r.b, 256)), dim3(256), 0, s, u0, d_bna, d_Q, u2ba, l, r.b, r.e);
    }
+   // rigid + FD in one pass over the boundary list (plane range given on the boundary list)
+   void launch_boundary(hipStream_t s, Range r) {
+      if (r.e <= r.b) return;
+      if ((lean || fused) && fold && need_fold_row) {
+         dim3 gy((unsigned)cdiv(Nz, 256), (unsigned)Nx);
+         hipLaunchKernelGGL(pf::k_flip_y<Real>, gy, dim3(256), 0, s, u1, Nx, Ny, P, Nz, 4);
+      }
+      dim3 g((unsigned)cdiv(r.e - r.b, 128)), b(128);
+      const bool fma = op.numerics == PF_NUM_FMA;
+#define PF_BND(F, M) hipLaunchKernelGGL((pf::k_boundary<Real, F, M>), g, b, 0, s, u1, u0, d_bn, d_adj, d_lossy, a2, sl2, P, plane, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq, d_beta, vh1, gh1, lo2, Nbl, r.b, r.e)
+      if (fcc) { if (fma) PF_BND(true, true); else PF_BND(true, false); }
+      else { if (fma) PF_BND(false, true); else PF_BND(false, false); }
+#undef PF_BND
+   }
+   bool boundary_fused() const { return fuse_boundary && !(fused && fused_rigid) && !lean_rigid; }
    void launch_rigid(hipStream_t s, Range r) {
+      if (boundary_fused()) { launch_boundary(s, r); return; }
       if (r.e <= r.b || (fused && fused_rigid) || lean_rigid) return;
       if ((lean || fused) && fold && need_fold_row) {
          // boundary nodes next to the folded ghost row read it from MEMORY: keep that one row materialised
@@ -591,6 +627,7 @@ template <typename Real> struct Engine : EngineBase {
       }
    }
    void launch_fd(hipStream_t s, Range r) {
+      if (boundary_fused()) return; // done by launch_boundary
       if (r.e > r.b)
          hipLaunchKernelGGL(pf::k_fd_boundary<Real>, dim3((unsigned)cdiv(r.e - r.b, 128)), dim3(128), 0, s, u0, d_bnl, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq, d_beta, vh1, gh1, lo2, Nbl, r.b, r.e);
    }
