@@ -182,6 +182,44 @@ def shoebox(Nx, Ny, Nz, Nt, fcc=False, wall=3, Nm=1, Mb=2, lossy=True, rigid_eve
     return sim
 
 
+def rotate_sim(sim, tr=None):
+    """In-place equivalent of rotate_sim_data (python/fdtd/rotate_sim_data.py:30-130): permute the axes so that
+    Nx >= Ny >= Nz (the slab axis is the longest, the plane to exchange the smallest), re-basing every index list and
+    permuting the adjacency columns to the new neighbour order.  tr = new-axis -> old-axis permutation."""
+    v, c = sim["vox_out"], sim["comms_out"]
+    dims = np.array([int(v["Nx"]), int(v["Ny"]), int(v["Nz"])])
+    if tr is None:
+        tr = np.argsort(dims, kind="stable")[::-1]  # descending
+    tr = np.asarray(tr)
+    assert sorted(tr.tolist()) == [0, 1, 2]
+    if np.array_equal(tr, [0, 1, 2]):
+        return sim
+    Nx, Ny, Nz = dims.tolist()
+    Nt = dims[tr]
+
+    def rot(ii):
+        sub = _ind2sub(np.asarray(ii), Ny, Nz)
+        new = [sub[t] for t in tr]
+        return (new[0] * Nt[1] + new[1]) * Nt[2] + new[2]
+
+    offs = FCC_OFFS if v["adj_bn"].shape[1] == 12 else CART_OFFS
+    # column j of the rotated adjacency = the old column whose offset, expressed in the new axes, is offs[j]
+    cols = []
+    for j in range(offs.shape[0]):
+        old = np.zeros(3, dtype=np.int64)
+        old[tr] = offs[j]                 # new axis a carries old axis tr[a]
+        cols.append(int(np.flatnonzero((offs == old).all(axis=1))[0]))
+    v["bn_ixyz"] = rot(v["bn_ixyz"]).astype(np.int64)
+    v["adj_bn"] = np.ascontiguousarray(v["adj_bn"][:, cols])
+    c["in_ixyz"] = rot(c["in_ixyz"]).astype(np.int64)
+    c["out_ixyz"] = rot(c["out_ixyz"]).astype(np.int64)
+    v["Nx"], v["Ny"], v["Nz"] = (np.int64(Nt[0]), np.int64(Nt[1]), np.int64(Nt[2]))
+    xyz = [v.get("xv"), v.get("yv"), v.get("zv")]
+    if all(a is not None for a in xyz):
+        v["xv"], v["yv"], v["zv"] = xyz[tr[0]], xyz[tr[1]], xyz[tr[2]]
+    return sim
+
+
 def sort_sim(sim):
     """In-place equivalent of sort_sim_data (python/fdtd/rotate_sim_data.py:132-189)."""
     v, c = sim["vox_out"], sim["comms_out"]

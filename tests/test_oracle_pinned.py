@@ -104,3 +104,15 @@ def test_oracle_agrees_with_python_reference_engine(fx):
     sd = sim_data.SimData.from_sim(sim, "double")
     oracle.run_sim(sd)
     assert np.abs(sd.u_out - g["u_out"]).max() <= 1e-11 * np.abs(g["u_out"]).max()
+
+
+@pytest.mark.parametrize("fcc", [False, True])
+def test_rotation_is_equivalent(fcc):
+    """rotate_sim (rotate_sim_data.py:30-130): the physics does not care which axis is the slab axis."""
+    kw = dict(Nx=18, Ny=26, Nz=22, Nt=60, fcc=fcc, Nm=2, Mb=[2, 3], wall=6, src=[2, 20, 2], rcv=[[12, 2, 17], [2, 2, 2]])
+    a = synth.shoebox(**kw)
+    b = synth.rotate_sim(synth.shoebox(**kw))
+    assert (int(b["vox_out"]["Nx"]), int(b["vox_out"]["Ny"]), int(b["vox_out"]["Nz"])) == (26, 22, 18)
+    ua, ub = _host_flow(a, "double"), _host_flow(b, "double")
+    assert np.abs(ua).max() > 0
+    assert np.abs(ua - ub).max() <= 1e-12 * np.abs(ua).max()
