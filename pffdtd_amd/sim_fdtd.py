@@ -107,3 +107,33 @@ def rel_diff(x0, x1):
         r = (x0 - x1) / (2.0 ** np.floor(np.log2(x0)))
     r = np.where(x0 > 0, r, 0.0)
     return r if r.ndim else float(r)
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--data_dir", type=str, required=True, help="run directory")
+    p.add_argument("--nsteps", type=int, default=1, help="run in batches of steps")
+    p.add_argument("--nthreads", type=int, default=None, help="ignored (kept for CLI compatibility)")
+    p.add_argument("--energy", action="store_true", help="do energy calc")
+    p.add_argument("--plot", action="store_true", help="not supported (visualisation is out of scope)")
+    p.add_argument("--abc", action="store_true", help="unused, as in the reference")
+    p.add_argument("--precision", default="double", choices=["double", "single"])
+    p.add_argument("--gpu", type=int, default=0)
+    a = p.parse_args()
+    if a.plot:
+        raise SystemExit("--plot is not supported")
+    eng = SimEngine(a.data_dir, energy_on=a.energy, nthreads=a.nthreads, precision=a.precision, device=a.gpu)
+    eng.load_h5_data()
+    eng.setup_mask()
+    eng.allocate_mem()
+    eng.set_coeffs()
+    eng.checks()
+    eng.run_all(max(a.nsteps, 1) if a.nsteps else 1)
+    eng.save_outputs()
+    eng.print_last_samples(5)
+    if a.energy:
+        eng.print_last_energy(5)
+
+
+if __name__ == "__main__":
+    main()
