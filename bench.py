@@ -116,12 +116,20 @@ def main():
     from pffdtd_amd import engine
     if not torch.cuda.is_available() or engine.device_count() == 0:
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
+    # debug only: PFFDTD_BENCH_BACKEND=gloo runs every rank on GPU 0 with host-staged planes (control-flow test of the
+    # N>1 path on a 1-GPU box); the real multi-GPU run uses RCCL with one GPU per rank
+    backend = os.environ.get("PFFDTD_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     group = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     K, W = args.steps, args.warmup
     n = args.size
@@ -167,7 +175,7 @@ def main():
     el = t1 - t0
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        t = torch.tensor([el], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     tm = timing()

@@ -75,6 +75,8 @@ class SlabRunner:
         if self.G == 1:
             return
         s_lo, s_hi, r_lo, r_hi = self.st.halo_tensors()
+        if s_lo.is_cuda and dist.get_backend(self.group) == "gloo":
+            return self._exchange_staged(s_lo, s_hi, r_lo, r_hi)
         ops = []
         if not self.info.first:
             ops.append(dist.P2POp(dist.isend, s_lo, self.rank - 1, self.group))
@@ -85,6 +87,25 @@ class SlabRunner:
         with self.st.comm_context():
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+
+    def _exchange_staged(self, s_lo, s_hi, r_lo, r_hi):
+        """Debug transport (several ranks sharing ONE GPU, gloo): planes staged through host memory.  Exercises the
+        whole multi-rank control flow where RCCL cannot run; never used on a real multi-GPU node."""
+        with self.st.comm_context():
+            torch.cuda.current_stream().synchronize()
+            ops, backs = [], []
+            for send, recv, peer, use in ((s_lo, r_lo, self.rank - 1, not self.info.first),
+                                          (s_hi, r_hi, self.rank + 1, not self.info.last)):
+                if use:
+                    hbuf = torch.empty(recv.shape, dtype=recv.dtype)
+                    ops.append(dist.P2POp(dist.isend, send.cpu(), peer, self.group))
+                    ops.append(dist.P2POp(dist.irecv, hbuf, peer, self.group))
+                    backs.append((recv, hbuf))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            for recv, hbuf in backs:
+                recv.copy_(hbuf)
+            torch.cuda.current_stream().synchronize()
 
     def run(self, n0, nsteps):
         for n in range(n0, n0 + nsteps):
