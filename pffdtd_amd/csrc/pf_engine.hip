@@ -570,7 +570,9 @@ template <typename Real> struct Engine : EngineBase {
          case 22: launch_lean_cfg<4, 4>(s, xb, xe); break;
          case 25: launch_lean_cfg<4, 4, false, true>(s, xb, xe); break;
          case 28: if (lean_rigid) launch_lean_cfg<2, 8, false, true, true>(s, xb, xe); else launch_lean_cfg<2, 8, false, true>(s, xb, xe); break;
-         default: // 0 (auto) and 25: fastest measured on MI355X; 27 = same with the rigid update fused in
+         default: // 0 (auto) and 25: fastest measured on MI355X (fp32: R=4,WY=4; fp64: R=2,WY=8 -- register budget);
+                  // 27 = same with the rigid update fused in
+            if (vbase == 0 && sizeof(Real) == 8) { launch_lean_cfg<2, 8, false, true>(s, xb, xe); break; }
             if (lean_rigid) launch_lean_cfg<4, 4, false, true, true>(s, xb, xe);
             else launch_lean_cfg<4, 4, false, true>(s, xb, xe);
             break;
