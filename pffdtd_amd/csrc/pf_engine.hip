@@ -292,7 +292,14 @@ template <typename Real> struct Engine : EngineBase {
          vbase = op.air_variant & 63;
          const bool ok = fused_ok();
          if (op.energy) { if (vbase >= 10) return set_err(PF_ERR_ARG, "the energy diagnostic runs the unfused kernels (air_variant 0-9)"); lean = fused = false; }
-         else if (vbase == 0) { lean = ok && !fcc; fused = false; } // 13-point: the unfused marching kernel is faster
+         else if (vbase == 0) {
+            // 13-point: the unfused marching kernel is faster; narrow rows (most of the last 256-column segment idle):
+            // the barrier-free unfused kernel loses less to the idle lanes (measured)
+            const int64_t Wseg = 64 * pf::VecOf<Real>::V;
+            const double lane_util = (double)P / (double)(cdiv(P, Wseg) * Wseg);
+            lean = ok && !fcc && lane_util >= 0.8;
+            fused = false;
+         }
          else if (vbase >= 20) { lean = true; fused = false; }
          else if (vbase >= 10) { fused = true; lean = false; }
          if ((lean || fused) && !ok)
