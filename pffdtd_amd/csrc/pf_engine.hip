@@ -333,8 +333,12 @@ template <typename Real> struct Engine : EngineBase {
             // skip-mask: ghost z / pad / parity, then the boundary nodes
             if ((rc = dzalloc(&mask, npad / 8))) return rc;
             HIPCHK(hipDeviceSynchronize());
-            hipLaunchKernelGGL(pf::k_mask_init, dim3((unsigned)cdiv(npad / 8, 256)), dim3(256), 0, s_main, mask, Nx, Ny, P, Nz,
+            {
+               const int64_t nrows = Nx * Ny;
+               dim3 gm((unsigned)cdiv(P / 8, 64), (unsigned)std::min<int64_t>(nrows, 65535), (unsigned)cdiv(nrows, 65535));
+               hipLaunchKernelGGL(pf::k_mask_init, gm, dim3(64), 0, s_main, mask, Nx, Ny, P, Nz,
                                sd.fcc_flag == 1 ? 1 + (op.x_global0 & 1) : 0);
+            }
             if (Nb) hipLaunchKernelGGL(pf::k_mask_set, dim3((unsigned)cdiv(Nb, 256)), dim3(256), 0, s_main, mask, d_bn, Nb);
          }
          HIPCHK(hipGetLastError());

@@ -575,13 +575,12 @@ __global__ void k_io(const Real *__restrict__ u1, Real *__restrict__ u0, const i
 // build the engine's skip-mask rows for ghost z columns / pad / odd parity (boundary-node bits are OR-ed in
 // afterwards by k_mask_set)
 __global__ void k_mask_init(uint8_t *__restrict__ mask, int64_t Nx, int64_t Ny, int64_t P, int64_t Nz, int parity) {
-   const int64_t byte = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-   const int64_t nbytes = Nx * Ny * P / 8;
-   if (byte >= nbytes) return;
-   const int64_t j0 = byte * 8;
-   const int64_t iz0 = j0 % P;
-   const int64_t row = j0 / P;
+   // one thread per mask byte of a row; blockIdx.y = row (ix*Ny + iy): no 64-bit divisions per bit
+   const int64_t bcol = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; // byte within the row
+   const int64_t row = blockIdx.y + (int64_t)blockIdx.z * 65535;
+   if (bcol >= P / 8 || row >= Nx * Ny) return;
    const int64_t iy = row % Ny, ix = row / Ny;
+   const int64_t iz0 = bcol * 8;
    uint32_t m = 0;
    for (int i = 0; i < 8; i++) {
       const int64_t iz = iz0 + i;
@@ -589,7 +588,7 @@ __global__ void k_mask_init(uint8_t *__restrict__ mask, int64_t Nx, int64_t Ny, 
       if (parity && (((ix + iy + iz + (parity - 1)) & 1) != 0)) skip = true; // parity-1 = parity of the global ix of plane 0
       if (skip) m |= 1u << i;
    }
-   mask[byte] = (uint8_t)m;
+   mask[row * (P / 8) + bcol] = (uint8_t)m;
 }
 __global__ void k_mask_set(uint8_t *__restrict__ mask, const int64_t *__restrict__ idx, int64_t n) {
    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
