@@ -94,6 +94,7 @@ template <typename Real> struct Engine : EngineBase {
    uint8_t *adj_dense = nullptr; // lean kernel with in-kernel rigid update: adjacency byte per padded cell
    bool lean_rigid = false;
    bool fused = false, fused_rigid = false, lean = false, need_fold_row = false;
+   bool vg = false;          // unfused marching kernels with virtual ghost shell + in-kernel ABC (variants 4-6)
    int vbase = 0;            // air_variant without its flag bits (64: no XCD swizzle, 128: old fused kernel without rigid fusion)
    int fused_nzt = 0;
    int64_t *d_bn = nullptr, *d_bnl = nullptr, *d_bna = nullptr, *d_in = nullptr, *d_out = nullptr;
@@ -291,7 +292,7 @@ template <typename Real> struct Engine : EngineBase {
          // (virtual ghosts + ABC + rigid in-kernel); 20-24 lean fused 7-point kernel (virtual ghosts + ABC)
          vbase = op.air_variant & 63;
          const bool ok = fused_ok();
-         if (op.energy) { if (vbase >= 10) return set_err(PF_ERR_ARG, "the energy diagnostic runs the unfused kernels (air_variant 0-9)"); lean = fused = false; }
+         if (op.energy) { if (vbase >= 10 || (vbase >= 4 && vbase <= 6)) return set_err(PF_ERR_ARG, "the energy diagnostic runs the unfused kernels (air_variant 0-9)"); lean = fused = false; }
          else if (vbase == 0) {
             // 13-point: the unfused marching kernel is faster; narrow rows (most of the last 256-column segment idle):
             // the barrier-free unfused kernel loses less to the idle lanes (measured)
@@ -299,7 +300,10 @@ template <typename Real> struct Engine : EngineBase {
             const double lane_util = (double)P / (double)(cdiv(P, Wseg) * Wseg);
             lean = ok && !fcc && lane_util >= 0.8;
             fused = false;
+            vg = ok && !lean && !fcc; // narrow 7-point rows: barrier-free marching kernel, still without flip / ABC launches
+                                      // (13-point: the ghost patches on 3x(R+2) rows cost more than the flip kernels they replace)
          }
+         else if (vbase >= 4 && vbase <= 6) { vg = true; if (!ok) return set_err(PF_ERR_ARG, "air_variant %d (virtual ghost shell) requested but its preconditions do not hold", op.air_variant); }
          else if (vbase >= 20) { lean = true; fused = false; }
          else if (vbase >= 10) { fused = true; lean = false; }
          if ((lean || fused) && !ok)
@@ -461,10 +465,12 @@ template <typename Real> struct Engine : EngineBase {
       ap.chunk = chunk;
       ap.nxc = (int)cdiv(nplanes, chunk);
       ap.swizzle = (op.air_variant & 64) ? 0 : 1;
+      ap.Nx = (int)Nx; ap.Nz = (int)Nz; ap.first = op.slab_first; ap.last = op.slab_last; ap.fold = fold ? 1 : 0;
       const uint32_t total = (uint32_t)ap.nzt * ap.nyt * ap.nxc;
       dim3 g(total), b(64 * WY * WZ);
       const bool fma = op.numerics == PF_NUM_FMA;
-#define PF_LAUNCH(K, FMA, DPP) hipLaunchKernelGGL((K<Real, R, WY, WZ, FMA, DPP>), g, b, 0, s, u1, u0, mask, a1, a2, ap)
+#define PF_LAUNCH(K, FMA, DPP) do { if (vg) hipLaunchKernelGGL((K<Real, R, WY, WZ, FMA, DPP, true>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l); \
+                                    else hipLaunchKernelGGL((K<Real, R, WY, WZ, FMA, DPP, false>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l); } while (0)
       if (fcc) {
          if (fma) { if (use_dpp) PF_LAUNCH(pf::k_air_fcc, true, true); else PF_LAUNCH(pf::k_air_fcc, true, false); }
          else { if (use_dpp) PF_LAUNCH(pf::k_air_fcc, false, true); else PF_LAUNCH(pf::k_air_fcc, false, false); }
@@ -477,8 +483,8 @@ template <typename Real> struct Engine : EngineBase {
 
    void launch_air_march(hipStream_t s, int xb, int xe) {
       switch (vbase) {
-         case 1: launch_air_cfg<2, 4, 1>(s, xb, xe); break;
-         case 2: launch_air_cfg<4, 1, 4>(s, xb, xe); break;
+         case 1: case 5: launch_air_cfg<2, 4, 1>(s, xb, xe); break;
+         case 2: case 6: launch_air_cfg<4, 1, 4>(s, xb, xe); break;
          default: launch_air_cfg<4, 4, 1>(s, xb, xe); break;
       }
    }
@@ -591,7 +597,7 @@ template <typename Real> struct Engine : EngineBase {
    }
 
    void launch_pre(hipStream_t s) {
-      if (fused || lean) return; // ghost shell is virtual, u2ba is the old u0 in registers
+      if (fused || lean || vg) return; // ghost shell is virtual, u2ba is the old u0 in registers
       launch_flips(s);
       if (Nba) hipLaunchKernelGGL(pf::k_abc_save<Real>, dim3((unsigned)cdiv(Nba, 256)), dim3(256), 0, s, u0, d_bna, u2ba, Nba);
    }
@@ -604,12 +610,12 @@ template <typename Real> struct Engine : EngineBase {
          hipLaunchKernelGGL(pf::k_flip_x<Real>, dim3((unsigned)cdiv(plane, 256)), dim3(256), 0, s, u1, Nx, plane, op.slab_first, op.slab_last);
    }
    void launch_abc(hipStream_t s, Range r) {
-      if (!fused && !lean && r.e > r.b) hipLaunchKernelGGL(pf::k_abc_loss<Real>, dim3((unsigned)cdiv(r.e - r.b, 256)), dim3(256), 0, s, u0, d_bna, d_Q, u2ba, l, r.b, r.e);
+      if (!fused && !lean && !vg && r.e > r.b) hipLaunchKernelGGL(pf::k_abc_loss<Real>, dim3((unsigned)cdiv(r.e - r.b, 256)), dim3(256), 0, s, u0, d_bna, d_Q, u2ba, l, r.b, r.e);
    }
    // rigid + FD in one pass over the boundary list (plane range given on the boundary list)
    void launch_boundary(hipStream_t s, Range r) {
       if (r.e <= r.b) return;
-      if ((lean || fused) && fold && need_fold_row) {
+      if ((lean || fused || vg) && fold && need_fold_row) {
          dim3 gy((unsigned)cdiv(Nz, 256), (unsigned)Nx);
          hipLaunchKernelGGL(pf::k_flip_y<Real>, gy, dim3(256), 0, s, u1, Nx, Ny, P, Nz, 4);
       }
@@ -624,7 +630,7 @@ template <typename Real> struct Engine : EngineBase {
    void launch_rigid(hipStream_t s, Range r) {
       if (boundary_fused()) { launch_boundary(s, r); return; }
       if (r.e <= r.b || (fused && fused_rigid) || lean_rigid) return;
-      if ((lean || fused) && fold && need_fold_row) {
+      if ((lean || fused || vg) && fold && need_fold_row) {
          // boundary nodes next to the folded ghost row read it from MEMORY: keep that one row materialised
          dim3 gy((unsigned)cdiv(Nz, 256), (unsigned)Nx);
          hipLaunchKernelGGL(pf::k_flip_y<Real>, gy, dim3(256), 0, s, u1, Nx, Ny, P, Nz, 4);
@@ -874,7 +880,7 @@ template <typename Real> struct Engine : EngineBase {
       int rc = sync();
       if (rc) return rc;
       const Real *src = which == 0 ? u0 : u1;
-      if ((fused || lean) && which == 1) { // write the virtual ghost shell out, exactly as the reference's flips would have
+      if ((fused || lean || vg) && which == 1) { // write the virtual ghost shell out, exactly as the reference's flips would have
          launch_flips(s_main);
          HIPCHK(hipStreamSynchronize(s_main));
       }

@@ -86,6 +86,8 @@ struct AirParams {
    int32_t chunk;          // planes marched per workgroup
    int32_t nzt, nyt, nxc;  // tile counts along z, y and x-chunks
    int32_t swizzle;
+   // VG (virtual ghost shell + in-kernel ABC) only:
+   int32_t Nx, Nz, first, last, fold;
 };
 
 // =============================================================================================================
@@ -99,10 +101,12 @@ struct AirParams {
 // a lane's vector are registers and across lanes one DPP wave shift; the two wave-edge columns are loaded by
 // the edge lanes.
 // =============================================================================================================
-template <typename Real, int R, int WY, int WZ, bool FMA, bool DPP>
+// VG = true: the ghost shell is virtual (loads that would touch plane 0 / row 0 / column Nz-1 read their mirror
+// cells, cf. pf_air_fused.h) and the ABC loss is applied in-kernel, so no flip / ABC kernels run around it.
+template <typename Real, int R, int WY, int WZ, bool FMA, bool DPP, bool VG = false>
 __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restrict__ u1, Real *__restrict__ u0,
                                                           const uint8_t *__restrict__ mask, Real a1, Real a2,
-                                                          AirParams ap) {
+                                                          AirParams ap, Real labc) {
    typedef typename VecOf<Real>::type vec;
    constexpr int V = VecOf<Real>::V;
    const uint32_t total = (uint32_t)ap.nzt * ap.nyt * ap.nxc;
@@ -125,18 +129,51 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
    const bool need_r = (lane == 63) && (z0 + V < P);
 
    // row offsets inside a plane, clamped so that halo/invalid rows stay in range
-   int64_t roff[R + 2];
-#pragma unroll
-   for (int j = 0; j < R + 2; j++) {
-      int64_t y = y0 - 1 + j;
+   auto rowsrc = [&](int64_t y) -> int64_t {
       if (y > Ny - 1) y = Ny - 1;
-      roff[j] = y * P + zl;
+      if (VG) { if (y == 0) return 2; if (y == Ny - 1) return Ny - 3; }
+      return y;
+   };
+   auto planesrc = [&](int x) -> int64_t {
+      if (VG) { if (ap.first && x == 0) return 2; if (ap.last && x == ap.Nx - 1) return ap.Nx - 3; }
+      return x;
+   };
+   int64_t roff[R + 2], soff[R];
+#pragma unroll
+   for (int j = 0; j < R + 2; j++) roff[j] = rowsrc(y0 - 1 + j) * P + zl;
+#pragma unroll
+   for (int r = 0; r < R; r++) soff[r] = (y0 + r > Ny - 1 ? Ny - 1 : y0 + r) * P + zl; // true rows: old state, mask, store
+   // virtual z ghost columns: per-lane constants (column 0 mirrors column 2, column Nz-1 mirrors Nz-3)
+   const int zzN = VG ? (int)(ap.Nz - 1 - z0) : -1;
+   const bool fix0 = VG && (z0 == 0);
+   const bool fixR = VG && (zzN == V);
+   uint32_t qzbits = 0;
+   if (VG) {
+#pragma unroll
+      for (int i = 0; i < V; i++)
+         if (active && (z0 + i == 1 || z0 + i == ap.Nz - 2)) qzbits |= 1u << i;
    }
+   const bool wave_has_qz = VG && (__ballot(qzbits != 0) != 0ull);
+   auto patch = [&](vec &v, Real L) { // after a row load: replace the ghost columns by their mirror cells
+      if (!VG) return; // (a wave-uniform early-out for segments without ghost columns measured slower: it fences the loads)
+      Real lm = lane_from_lower<DPP>(v[V - 1]);
+      if (lane == 0) lm = L;
+      if (V == 4) {
+         if (fix0) v[0] = v[2];
+         if (zzN == 1) v[1] = lm;
+         if (zzN == 2) v[2] = v[0];
+         if (zzN == 3) v[3] = v[1];
+      } else {
+         const Real up = lane_from_upper<DPP>(v[0]);
+         if (fix0) v[0] = up;
+         if (zzN == 1) v[1] = lm;
+      }
+   };
    vec prev[R], cur[R + 2], nxt[R + 2];
    Real curL[R], curR[R], nxtL[R], nxtR[R]; // wave-edge columns (meaningful in lanes 0 / 63 only)
    {
-      const Real *pm = u1 + (int64_t)(xs - 1) * plane;
-      const Real *pc = u1 + (int64_t)xs * plane;
+      const Real *pm = u1 + planesrc(xs - 1) * plane;
+      const Real *pc = u1 + planesrc(xs) * plane;
 #pragma unroll
       for (int r = 0; r < R; r++) prev[r] = *(const vec *)(pm + roff[r + 1]);
 #pragma unroll
@@ -145,10 +182,11 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
       for (int r = 0; r < R; r++) {
          curL[r] = need_l ? pc[roff[r + 1] - 1] : Real(0);
          curR[r] = need_r ? pc[roff[r + 1] + V] : Real(0);
+         patch(cur[r + 1], curL[r]);
       }
    }
    for (int x = xs; x < xe; x++) {
-      const Real *pn = u1 + (int64_t)(x + 1) * plane;
+      const Real *pn = u1 + planesrc(x + 1) * plane;
       Real *po = u0 + (int64_t)x * plane;
       const uint8_t *pmk = mask + (((int64_t)x * plane) >> 3);
       vec old[R];
@@ -157,11 +195,13 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
       for (int j = 0; j < R + 2; j++) nxt[j] = *(const vec *)(pn + roff[j]);
 #pragma unroll
       for (int r = 0; r < R; r++) {
-         old[r] = __builtin_nontemporal_load((const vec *)(po + roff[r + 1]));
-         mb[r] = pmk[roff[r + 1] >> 3];
+         old[r] = __builtin_nontemporal_load((const vec *)(po + soff[r]));
+         mb[r] = pmk[soff[r] >> 3];
          nxtL[r] = need_l ? pn[roff[r + 1] - 1] : Real(0);
          nxtR[r] = need_r ? pn[roff[r + 1] + V] : Real(0);
+         patch(nxt[r + 1], nxtL[r]);
       }
+      const bool qx = VG && ((ap.first && x == 1) || (ap.last && x == ap.Nx - 2));
 #pragma unroll
       for (int r = 0; r < R; r++) {
          const vec c = cur[r + 1];
@@ -169,7 +209,8 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
          Real zp = lane_from_upper<DPP>(c[0]);
          if (lane == 0) zm = curL[r];
          if (lane == 63) zp = curR[r];
-         const uint32_t bits = mb[r] >> (uint32_t)(roff[r + 1] & 7);
+         if (fixR) zp = c[V - 2]; // my right neighbour is the ghost column
+         const uint32_t bits = mb[r] >> (uint32_t)(soff[r] & 7);
          vec o;
 #pragma unroll
          for (int i = 0; i < V; i++) {
@@ -182,9 +223,30 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
             p = acc<FMA>(p, a2, cur[r][i]);      // -Nz
             p = acc<FMA>(p, a2, right);          // +1
             p = acc<FMA>(p, a2, left);           // -1
-            o[i] = ((bits >> i) & 1u) ? old[r][i] : p;
+            o[i] = p;
          }
-         if (active && (y0 + r <= Ny - 2)) __builtin_nontemporal_store(o, (vec *)(po + roff[r + 1]));
+         if (VG) { // ABC loss (cpu_engine.h:225-229); u2ba is the old value of the cell
+            const int64_t y = y0 + r;
+            const int qxy = (qx ? 1 : 0) + ((y == 1 || y == Ny - 2) ? 1 : 0);
+            if (qxy > 0 || wave_has_qz) {
+#pragma unroll
+               for (int i = 0; i < V; i++) {
+                  const bool zq = (qzbits >> i) & 1u;
+                  if (qxy > 0 || __ballot(zq) != 0ull) {
+                     const int Q = qxy + (zq ? 1 : 0);
+                     if (Q > 0) {
+                        const Real lQ = labc * (Real)Q;
+                        const Real num = o[i] + lQ * old[r][i];
+                        o[i] = (Real)((double)num / (1.0 + (double)lQ));
+                     }
+                  }
+               }
+            }
+         }
+#pragma unroll
+         for (int i = 0; i < V; i++)
+            if ((bits >> i) & 1u) o[i] = old[r][i];
+         if (active && (y0 + r <= Ny - 2)) __builtin_nontemporal_store(o, (vec *)(po + soff[r]));
       }
 #pragma unroll
       for (int r = 0; r < R; r++) {
@@ -204,10 +266,10 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
 // Same marching scheme; all three planes keep R+2 rows, and every row used with a z offset gets its wave-edge
 // columns from the edge lanes.
 // =============================================================================================================
-template <typename Real, int R, int WY, int WZ, bool FMA, bool DPP>
+template <typename Real, int R, int WY, int WZ, bool FMA, bool DPP, bool VG = false>
 __global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict__ u1, Real *__restrict__ u0,
                                                          const uint8_t *__restrict__ mask, Real a1, Real a2,
-                                                         AirParams ap) {
+                                                         AirParams ap, Real labc) {
    typedef typename VecOf<Real>::type vec;
    constexpr int V = VecOf<Real>::V;
    const uint32_t total = (uint32_t)ap.nzt * ap.nyt * ap.nxc;
@@ -229,19 +291,51 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict
    const bool need_l = (lane == 0) && (z0 > 0);
    const bool need_r = (lane == 63) && (z0 + V < P);
 
-   int64_t roff[R + 2];
-#pragma unroll
-   for (int j = 0; j < R + 2; j++) {
-      int64_t y = y0 - 1 + j;
+   auto rowsrc = [&](int64_t y) -> int64_t {
       if (y > Ny - 1) y = Ny - 1;
-      roff[j] = y * P + zl;
+      if (VG) { if (y == 0) return 2; if (y == Ny - 1) return ap.fold ? Ny - 2 : Ny - 3; }
+      return y;
+   };
+   auto planesrc = [&](int x) -> int64_t {
+      if (VG) { if (ap.first && x == 0) return 2; if (ap.last && x == ap.Nx - 1) return ap.Nx - 3; }
+      return x;
+   };
+   int64_t roff[R + 2], soff[R];
+#pragma unroll
+   for (int j = 0; j < R + 2; j++) roff[j] = rowsrc(y0 - 1 + j) * P + zl;
+#pragma unroll
+   for (int r = 0; r < R; r++) soff[r] = (y0 + r > Ny - 1 ? Ny - 1 : y0 + r) * P + zl;
+   const int zzN = VG ? (int)(ap.Nz - 1 - z0) : -1;
+   const bool fix0 = VG && (z0 == 0);
+   const bool fixR = VG && (zzN == V);
+   uint32_t qzbits = 0;
+   if (VG) {
+#pragma unroll
+      for (int i = 0; i < V; i++)
+         if (active && (z0 + i == 1 || z0 + i == ap.Nz - 2)) qzbits |= 1u << i;
    }
+   const bool wave_has_qz = VG && (__ballot(qzbits != 0) != 0ull);
+   auto patch = [&](vec &v, Real L) {
+      if (!VG) return; // (a wave-uniform early-out for segments without ghost columns measured slower: it fences the loads)
+      Real lm = lane_from_lower<DPP>(v[V - 1]);
+      if (lane == 0) lm = L;
+      if (V == 4) {
+         if (fix0) v[0] = v[2];
+         if (zzN == 1) v[1] = lm;
+         if (zzN == 2) v[2] = v[0];
+         if (zzN == 3) v[3] = v[1];
+      } else {
+         const Real up = lane_from_upper<DPP>(v[0]);
+         if (fix0) v[0] = up;
+         if (zzN == 1) v[1] = lm;
+      }
+   };
    // three planes x (R+2) rows, each with its two wave-edge columns
    vec prev[R + 2], cur[R + 2], nxt[R + 2];
    Real prevL[R + 2], prevR[R + 2], curL[R + 2], curR[R + 2], nxtL[R + 2], nxtR[R + 2];
    {
-      const Real *pm = u1 + (int64_t)(xs - 1) * plane;
-      const Real *pc = u1 + (int64_t)xs * plane;
+      const Real *pm = u1 + planesrc(xs - 1) * plane;
+      const Real *pc = u1 + planesrc(xs) * plane;
 #pragma unroll
       for (int j = 0; j < R + 2; j++) {
          prev[j] = *(const vec *)(pm + roff[j]);
@@ -250,10 +344,12 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict
          prevR[j] = need_r ? pm[roff[j] + V] : Real(0);
          curL[j] = need_l ? pc[roff[j] - 1] : Real(0);
          curR[j] = need_r ? pc[roff[j] + V] : Real(0);
+         patch(prev[j], prevL[j]);
+         patch(cur[j], curL[j]);
       }
    }
    for (int x = xs; x < xe; x++) {
-      const Real *pn = u1 + (int64_t)(x + 1) * plane;
+      const Real *pn = u1 + planesrc(x + 1) * plane;
       Real *po = u0 + (int64_t)x * plane;
       const uint8_t *pmk = mask + (((int64_t)x * plane) >> 3);
       vec old[R];
@@ -263,12 +359,14 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict
          nxt[j] = *(const vec *)(pn + roff[j]);
          nxtL[j] = need_l ? pn[roff[j] - 1] : Real(0);
          nxtR[j] = need_r ? pn[roff[j] + V] : Real(0);
+         patch(nxt[j], nxtL[j]);
       }
 #pragma unroll
       for (int r = 0; r < R; r++) {
-         old[r] = __builtin_nontemporal_load((const vec *)(po + roff[r + 1]));
-         mb[r] = pmk[roff[r + 1] >> 3];
+         old[r] = __builtin_nontemporal_load((const vec *)(po + soff[r]));
+         mb[r] = pmk[soff[r] >> 3];
       }
+      const bool qx = VG && ((ap.first && x == 1) || (ap.last && x == ap.Nx - 2));
       // z-shifted views: lo(v)[i] = v[z-1], hi(v)[i] = v[z+1]
       auto shift_lo = [&](const vec &v, Real edge) {
          Real zm = lane_from_lower<DPP>(v[V - 1]);
@@ -281,6 +379,7 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict
       auto shift_hi = [&](const vec &v, Real edge) {
          Real zp = lane_from_upper<DPP>(v[0]);
          if (lane == 63) zp = edge;
+         if (fixR) zp = v[V - 2]; // my right neighbour is the ghost column
          vec s;
 #pragma unroll
          for (int i = 0; i < V; i++) s[i] = (i == V - 1) ? zp : v[i < V - 1 ? i + 1 : V - 1];
@@ -294,7 +393,7 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict
          const vec cd_lo = shift_lo(cur[j - 1], curL[j - 1]), cd_hi = shift_hi(cur[j - 1], curR[j - 1]);
          const vec n_lo = shift_lo(nxt[j], nxtL[j]), n_hi = shift_hi(nxt[j], nxtR[j]);
          const vec p_lo = shift_lo(prev[j], prevL[j]), p_hi = shift_hi(prev[j], prevR[j]);
-         const uint32_t bits = mb[r] >> (uint32_t)(roff[j] & 7);
+         const uint32_t bits = mb[r] >> (uint32_t)(soff[r] & 7);
          vec o;
 #pragma unroll
          for (int i = 0; i < V; i++) {
@@ -311,9 +410,30 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict
             p = acc<FMA>(p, a2, cd_hi[i]);       // -Nz+1
             p = acc<FMA>(p, a2, n_lo[i]);        // +NzNy-1
             p = acc<FMA>(p, a2, p_hi[i]);        // -NzNy+1
-            o[i] = ((bits >> i) & 1u) ? old[r][i] : p;
+            o[i] = p;
          }
-         if (active && (y0 + r <= Ny - 2)) __builtin_nontemporal_store(o, (vec *)(po + roff[j]));
+         if (VG) { // ABC loss (cpu_engine.h:225-229)
+            const int64_t y = y0 + r;
+            const int qxy = (qx ? 1 : 0) + ((y == 1 || (!ap.fold && y == Ny - 2)) ? 1 : 0);
+            if (qxy > 0 || wave_has_qz) {
+#pragma unroll
+               for (int i = 0; i < V; i++) {
+                  const bool zq = (qzbits >> i) & 1u;
+                  if (qxy > 0 || __ballot(zq) != 0ull) {
+                     const int Q = qxy + (zq ? 1 : 0);
+                     if (Q > 0) {
+                        const Real lQ = labc * (Real)Q;
+                        const Real num = o[i] + lQ * old[r][i];
+                        o[i] = (Real)((double)num / (1.0 + (double)lQ));
+                     }
+                  }
+               }
+            }
+         }
+#pragma unroll
+         for (int i = 0; i < V; i++)
+            if ((bits >> i) & 1u) o[i] = old[r][i];
+         if (active && (y0 + r <= Ny - 2)) __builtin_nontemporal_store(o, (vec *)(po + soff[r]));
       }
 #pragma unroll
       for (int j = 0; j < R + 2; j++) {

@@ -26,7 +26,8 @@ def _reference(name, prec):
                                                ("fcc2_outside", "single", 0), ("cart_lossy", "single", 3),
                                                ("fcc1_outside", "double", 10), ("fcc1_outside", "single", 3),
                                                ("fcc2_outside", "double", 10), ("cart_outside", "single", 20),
-                                               ("cart_outside_oddz", "double", 22)])
+                                               ("cart_outside_oddz", "double", 22), ("fcc2_outside", "single", 4),
+                                               ("fcc1_outside", "double", 5), ("cart_outside", "double", 6)])
 def test_virtual_slabs_equal_single_domain(name, prec, variant, G):
     ref = _reference(name, prec)
     sd = cases.make_sd(name, prec)
