@@ -95,6 +95,7 @@ template <typename Real> struct Engine : EngineBase {
    bool lean_rigid = false;
    bool fused = false, fused_rigid = false, lean = false, need_fold_row = false;
    bool vg = false;          // unfused marching kernels with virtual ghost shell + in-kernel ABC (variants 4-6)
+   bool abck = false;        // unfused marching kernels with memory flips but the ABC loss in-kernel (variants 7, 8)
    int vbase = 0;            // air_variant without its flag bits (64: no XCD swizzle, 128: old fused kernel without rigid fusion)
    int fused_nzt = 0;
    int64_t *d_bn = nullptr, *d_bnl = nullptr, *d_bna = nullptr, *d_in = nullptr, *d_out = nullptr;
@@ -292,7 +293,7 @@ template <typename Real> struct Engine : EngineBase {
          // (virtual ghosts + ABC + rigid in-kernel); 20-24 lean fused 7-point kernel (virtual ghosts + ABC)
          vbase = op.air_variant & 63;
          const bool ok = fused_ok();
-         if (op.energy) { if (vbase >= 10 || (vbase >= 4 && vbase <= 6)) return set_err(PF_ERR_ARG, "the energy diagnostic runs the unfused kernels (air_variant 0-9)"); lean = fused = false; }
+         if (op.energy) { if (vbase >= 10 || (vbase >= 4 && vbase <= 8)) return set_err(PF_ERR_ARG, "the energy diagnostic runs the unfused kernels (air_variant 0-9)"); lean = fused = false; }
          else if (vbase == 0) {
             // 13-point: the unfused marching kernel is faster; narrow rows (most of the last 256-column segment idle):
             // the barrier-free unfused kernel loses less to the idle lanes (measured)
@@ -300,9 +301,11 @@ template <typename Real> struct Engine : EngineBase {
             const double lane_util = (double)P / (double)(cdiv(P, Wseg) * Wseg);
             lean = ok && !fcc && lane_util >= 0.8;
             fused = false;
+            abck = ok && fcc;          // 13-point: flips stay in memory, the ABC loss moves into the interior kernel
             vg = ok && !lean && !fcc; // narrow 7-point rows: barrier-free marching kernel, still without flip / ABC launches
                                       // (13-point: the ghost patches on 3x(R+2) rows cost more than the flip kernels they replace)
          }
+         else if (vbase == 7 || vbase == 8) { abck = true; if (!ok) return set_err(PF_ERR_ARG, "air_variant %d (in-kernel ABC) requested but its preconditions do not hold", op.air_variant); }
          else if (vbase >= 4 && vbase <= 6) { vg = true; if (!ok) return set_err(PF_ERR_ARG, "air_variant %d (virtual ghost shell) requested but its preconditions do not hold", op.air_variant); }
          else if (vbase >= 20) { lean = true; fused = false; }
          else if (vbase >= 10) { fused = true; lean = false; }
@@ -470,6 +473,7 @@ template <typename Real> struct Engine : EngineBase {
       dim3 g(total), b(64 * WY * WZ);
       const bool fma = op.numerics == PF_NUM_FMA;
 #define PF_LAUNCH(K, FMA, DPP) do { if (vg) hipLaunchKernelGGL((K<Real, R, WY, WZ, FMA, DPP, true>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l); \
+                                    else if (abck) hipLaunchKernelGGL((K<Real, R, WY, WZ, FMA, DPP, false, true>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l); \
                                     else hipLaunchKernelGGL((K<Real, R, WY, WZ, FMA, DPP, false>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l); } while (0)
       if (fcc) {
          if (fma) { if (use_dpp) PF_LAUNCH(pf::k_air_fcc, true, true); else PF_LAUNCH(pf::k_air_fcc, true, false); }
@@ -483,7 +487,7 @@ template <typename Real> struct Engine : EngineBase {
 
    void launch_air_march(hipStream_t s, int xb, int xe) {
       switch (vbase) {
-         case 1: case 5: launch_air_cfg<2, 4, 1>(s, xb, xe); break;
+         case 1: case 5: case 8: launch_air_cfg<2, 4, 1>(s, xb, xe); break;
          case 2: case 6: launch_air_cfg<4, 1, 4>(s, xb, xe); break;
          default: launch_air_cfg<4, 4, 1>(s, xb, xe); break;
       }
@@ -599,7 +603,7 @@ template <typename Real> struct Engine : EngineBase {
    void launch_pre(hipStream_t s) {
       if (fused || lean || vg) return; // ghost shell is virtual, u2ba is the old u0 in registers
       launch_flips(s);
-      if (Nba) hipLaunchKernelGGL(pf::k_abc_save<Real>, dim3((unsigned)cdiv(Nba, 256)), dim3(256), 0, s, u0, d_bna, u2ba, Nba);
+      if (Nba && !abck) hipLaunchKernelGGL(pf::k_abc_save<Real>, dim3((unsigned)cdiv(Nba, 256)), dim3(256), 0, s, u0, d_bna, u2ba, Nba);
    }
    void launch_flips(hipStream_t s) {
       dim3 gy((unsigned)cdiv(Nz, 256), (unsigned)Nx);
@@ -610,7 +614,7 @@ template <typename Real> struct Engine : EngineBase {
          hipLaunchKernelGGL(pf::k_flip_x<Real>, dim3((unsigned)cdiv(plane, 256)), dim3(256), 0, s, u1, Nx, plane, op.slab_first, op.slab_last);
    }
    void launch_abc(hipStream_t s, Range r) {
-      if (!fused && !lean && !vg && r.e > r.b) hipLaunchKernelGGL(pf::k_abc_loss<Real>, dim3((unsigned)cdiv(r.e - r.b, 256)), dim3(256), 0, s, u0, d_bna, d_Q, u2ba, l, r.b, r.e);
+      if (!fused && !lean && !vg && !abck && r.e > r.b) hipLaunchKernelGGL(pf::k_abc_loss<Real>, dim3((unsigned)cdiv(r.e - r.b, 256)), dim3(256), 0, s, u0, d_bna, d_Q, u2ba, l, r.b, r.e);
    }
    // rigid + FD in one pass over the boundary list (plane range given on the boundary list)
    void launch_boundary(hipStream_t s, Range r) {

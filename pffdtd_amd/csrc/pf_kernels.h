@@ -103,7 +103,9 @@ struct AirParams {
 // =============================================================================================================
 // VG = true: the ghost shell is virtual (loads that would touch plane 0 / row 0 / column Nz-1 read their mirror
 // cells, cf. pf_air_fused.h) and the ABC loss is applied in-kernel, so no flip / ABC kernels run around it.
-template <typename Real, int R, int WY, int WZ, bool FMA, bool DPP, bool VG = false>
+// ABCK = true (without VG): only the ABC loss moves in-kernel; the ghost shell is still maintained in memory by the
+// flip kernels (cheaper than VG's per-row patches for the 13-point kernel).
+template <typename Real, int R, int WY, int WZ, bool FMA, bool DPP, bool VG = false, bool ABCK = false>
 __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restrict__ u1, Real *__restrict__ u0,
                                                           const uint8_t *__restrict__ mask, Real a1, Real a2,
                                                           AirParams ap, Real labc) {
@@ -148,12 +150,12 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
    const bool fix0 = VG && (z0 == 0);
    const bool fixR = VG && (zzN == V);
    uint32_t qzbits = 0;
-   if (VG) {
+   if (VG || ABCK) {
 #pragma unroll
       for (int i = 0; i < V; i++)
          if (active && (z0 + i == 1 || z0 + i == ap.Nz - 2)) qzbits |= 1u << i;
    }
-   const bool wave_has_qz = VG && (__ballot(qzbits != 0) != 0ull);
+   const bool wave_has_qz = (VG || ABCK) && (__ballot(qzbits != 0) != 0ull);
    auto patch = [&](vec &v, Real L) { // after a row load: replace the ghost columns by their mirror cells
       if (!VG) return; // (a wave-uniform early-out for segments without ghost columns measured slower: it fences the loads)
       Real lm = lane_from_lower<DPP>(v[V - 1]);
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
          nxtR[r] = need_r ? pn[roff[r + 1] + V] : Real(0);
          patch(nxt[r + 1], nxtL[r]);
       }
-      const bool qx = VG && ((ap.first && x == 1) || (ap.last && x == ap.Nx - 2));
+      const bool qx = (VG || ABCK) && ((ap.first && x == 1) || (ap.last && x == ap.Nx - 2));
 #pragma unroll
       for (int r = 0; r < R; r++) {
          const vec c = cur[r + 1];
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
             p = acc<FMA>(p, a2, left);           // -1
             o[i] = p;
          }
-         if (VG) { // ABC loss (cpu_engine.h:225-229); u2ba is the old value of the cell
+         if (VG || ABCK) { // ABC loss (cpu_engine.h:225-229); u2ba is the old value of the cell
             const int64_t y = y0 + r;
             const int qxy = (qx ? 1 : 0) + ((y == 1 || y == Ny - 2) ? 1 : 0);
             if (qxy > 0 || wave_has_qz) {
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
 // Same marching scheme; all three planes keep R+2 rows, and every row used with a z offset gets its wave-edge
 // columns from the edge lanes.
 // =============================================================================================================
-template <typename Real, int R, int WY, int WZ, bool FMA, bool DPP, bool VG = false>
+template <typename Real, int R, int WY, int WZ, bool FMA, bool DPP, bool VG = false, bool ABCK = false>
 __global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict__ u1, Real *__restrict__ u0,
                                                          const uint8_t *__restrict__ mask, Real a1, Real a2,
                                                          AirParams ap, Real labc) {
@@ -309,12 +311,12 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict
    const bool fix0 = VG && (z0 == 0);
    const bool fixR = VG && (zzN == V);
    uint32_t qzbits = 0;
-   if (VG) {
+   if (VG || ABCK) {
 #pragma unroll
       for (int i = 0; i < V; i++)
          if (active && (z0 + i == 1 || z0 + i == ap.Nz - 2)) qzbits |= 1u << i;
    }
-   const bool wave_has_qz = VG && (__ballot(qzbits != 0) != 0ull);
+   const bool wave_has_qz = (VG || ABCK) && (__ballot(qzbits != 0) != 0ull);
    auto patch = [&](vec &v, Real L) {
       if (!VG) return; // (a wave-uniform early-out for segments without ghost columns measured slower: it fences the loads)
       Real lm = lane_from_lower<DPP>(v[V - 1]);
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict
          old[r] = __builtin_nontemporal_load((const vec *)(po + soff[r]));
          mb[r] = pmk[soff[r] >> 3];
       }
-      const bool qx = VG && ((ap.first && x == 1) || (ap.last && x == ap.Nx - 2));
+      const bool qx = (VG || ABCK) && ((ap.first && x == 1) || (ap.last && x == ap.Nx - 2));
       // z-shifted views: lo(v)[i] = v[z-1], hi(v)[i] = v[z+1]
       auto shift_lo = [&](const vec &v, Real edge) {
          Real zm = lane_from_lower<DPP>(v[V - 1]);
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict
             p = acc<FMA>(p, a2, p_hi[i]);        // -NzNy+1
             o[i] = p;
          }
-         if (VG) { // ABC loss (cpu_engine.h:225-229)
+         if (VG || ABCK) { // ABC loss (cpu_engine.h:225-229)
             const int64_t y = y0 + r;
             const int qxy = (qx ? 1 : 0) + ((y == 1 || (!ap.fold && y == Ny - 2)) ? 1 : 0);
             if (qxy > 0 || wave_has_qz) {

@@ -67,7 +67,7 @@ def test_bit_exact_vs_oracle(name, prec, variant):
     assert np.array_equal(u0, ref_u0), f"u0 max|d|={np.abs(u0 - ref_u0).max()}"
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4, 5, 6, 4 + 64, 4 + 256, 10, 11, 12, 13, 14, 10 + 128, 10 + 64, 20, 21, 22, 23, 24, 25, 27, 28, 20 + 64, 27 + 64, 33, 35, 33 + 64, 256, 3 + 256, 25 + 256])
+@pytest.mark.parametrize("variant", [1, 2, 4, 5, 6, 7, 8, 4 + 64, 4 + 256, 10, 11, 12, 13, 14, 10 + 128, 10 + 64, 20, 21, 22, 23, 24, 25, 27, 28, 20 + 64, 27 + 64, 33, 35, 33 + 64, 256, 3 + 256, 25 + 256])
 @pytest.mark.parametrize("name", ["cart_lossy", "cart_outside_oddz", "cart_outside", "fcc2_outside", "fcc1_outside"])
 def test_tile_variants_bit_exact(name, variant):
     base = variant & 63

@@ -27,7 +27,7 @@ def _reference(name, prec):
                                                ("fcc1_outside", "double", 10), ("fcc1_outside", "single", 3),
                                                ("fcc2_outside", "double", 10), ("cart_outside", "single", 20),
                                                ("cart_outside_oddz", "double", 22), ("fcc2_outside", "single", 4),
-                                               ("fcc1_outside", "double", 5), ("cart_outside", "double", 6)])
+                                               ("fcc1_outside", "double", 5), ("cart_outside", "double", 6), ("fcc2_outside", "double", 7)])
 def test_virtual_slabs_equal_single_domain(name, prec, variant, G):
     ref = _reference(name, prec)
     sd = cases.make_sd(name, prec)
