@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--numerics", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split-phase", action="store_true", help="N=1: drive the split-phase step like N>1 does")
+    ap.add_argument("--emulate-slab", default="", help="debug: 'r/N' = run only slab r of an N-way split on this GPU, the exchange\n                    replaced by device copies of the same planes (per-rank cost model; physics is wrong)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -139,14 +140,29 @@ def main():
     ekw = dict(numerics=args.numerics, air_variant=args.variant, air_chunk=args.chunk, timing=True)
 
     from pffdtd_amd import dist as pdist
-    runner, loc, info = pdist.make_hip_runner(sd, rank, world, local_rank, group, **ekw)
+    emu = None
+    if args.emulate_slab:
+        er, eN = (int(v) for v in args.emulate_slab.split("/"))
+        emu = (er, eN)
+        runner, loc, info = pdist.make_hip_runner(sd, er, eN, local_rank, None, **ekw)
+
+        def _fake_exchange(st=runner.st, inf=info):
+            s_lo, s_hi, r_lo, r_hi = st.halo_tensors()
+            with st.comm_context():
+                if not inf.first:
+                    r_lo.copy_(s_lo, non_blocking=True)
+                if not inf.last:
+                    r_hi.copy_(s_hi, non_blocking=True)
+        runner.exchange = _fake_exchange
+    else:
+        runner, loc, info = pdist.make_hip_runner(sd, rank, world, local_rank, group, **ekw)
     eng = runner.st.eng
     gen = torch.Generator(device="cuda")
     gen.manual_seed(1234 + rank)
     for g in runner.st.grids:  # device-side fill of the torch-owned state grids (pad/ghost cells are never read back)
         g.copy_((torch.rand(g.shape, generator=gen, device=g.device, dtype=torch.float32) * 2.0 - 1.0) * 1e-3)
     torch.cuda.synchronize()
-    if world == 1 and not args.split_phase:
+    if world == 1 and not args.split_phase and emu is None:
         run = lambda n0, k: eng.run(n0, k)  # noqa: E731  (whole loop inside the C library, one stream)
         parallelism = "1 GPU"
     else:
@@ -186,6 +202,9 @@ def main():
 
     if rank == 0:
         gvox = sd.Npts * K / el / 1e9
+        if emu is not None:
+            print(f"[emulated slab {emu[0]}/{emu[1]}: {loc.Nx} planes] {el / K * 1e3:.4f} ms/step -> {emu[1]} such ranks would give "
+                  f"{sd.Npts * K / el / 1e9:.1f} Gvox/s if the exchange hides completely", file=sys.stderr)
         bpv = 3 * real_bytes + 0.125  # u1 read, u0 read + write, one mask bit
         # algorithmic bytes of one step's air launches on this rank: the interior voxels they update
         upd = interior_planes * (sd.Ny - 2) * (sd.Nz - 2)

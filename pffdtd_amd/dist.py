@@ -129,7 +129,7 @@ def gather_outputs(sd, loc, info, group=None):
     return sd.u_out
 
 
-def make_hip_runner(sd, rank, world, device, group=None, **engine_kw):
-    loc, info = slab_mod.split(sd, world, rank)
+def make_hip_runner(sd, rank, world, device, group=None, balance=True, **engine_kw):
+    loc, info = slab_mod.split(sd, world, rank, balance=balance)
     st = HipSlabStepper(loc, info, device, **engine_kw)
     return SlabRunner(st, info, group), loc, info

@@ -21,6 +21,42 @@ def partition(Nx, G):
     return [(int(x0[g]), int(x0[g + 1])) for g in range(G)]
 
 
+# measured on MI355X (1024^2 planes): one full plane of lossy (Mb=11) boundary nodes costs about as much as 24 planes
+# of interior update, a full plane of rigid boundary nodes about 5 (k_boundary vs k_air_cart_lean, profiles/r01_*)
+LOSSY_PLANE_EQ = 24.0
+RIGID_PLANE_EQ = 5.0
+
+
+def partition_weighted(sd, G):
+    """Owned plane ranges balanced by estimated cost instead of plane count: the end slabs of a room carry whole
+    wall planes of boundary nodes, which the reference's even split (gpu_engine.h:532-550) leaves unbalanced.
+    Deterministic (every rank computes the same cut)."""
+    Nx = sd.Nx
+    if G < 1 or G >= Nx:
+        raise ValueError(f"need 1 <= ngpus < Nx (got {G}, Nx={Nx})")
+    if G == 1:
+        return [(0, Nx)]
+    NzNy = sd.Ny * sd.Nz
+    nb = np.bincount(sd.bn_ixyz // NzNy, minlength=Nx).astype(np.float64)
+    nl = np.bincount(sd.bnl_ixyz // NzNy, minlength=Nx).astype(np.float64) if sd.Nbl else np.zeros(Nx)
+    mb_scale = 1.0
+    if sd.Nbl:
+        mb_scale = float(np.mean(sd.Mb[sd.mat_bnl])) / 11.0
+    cost = np.ones(Nx)
+    cost[0] = cost[-1] = 0.0  # global ghost planes are not updated
+    cost += (LOSSY_PLANE_EQ * mb_scale * nl + RIGID_PLANE_EQ * (nb - nl)) / NzNy
+    cum = np.concatenate([[0.0], np.cumsum(cost)])
+    cuts = [0]
+    for g in range(1, G):
+        target = cum[-1] * g / G
+        x = int(np.searchsorted(cum, target))
+        x = max(x, cuts[-1] + 2)           # every slab updates at least one plane
+        x = min(x, Nx - 2 * (G - g))
+        cuts.append(x)
+    cuts.append(Nx)
+    return [(cuts[g], cuts[g + 1]) for g in range(G)]
+
+
 class SlabInfo:
     def __init__(self, rank, G, x0, x1, Nx):
         self.rank, self.G, self.x0, self.x1 = rank, G, x0, x1
@@ -33,9 +69,10 @@ class SlabInfo:
         self.upd1 = min(x1, Nx - 1)
 
 
-def split(sd, G, rank):
-    """Local SimData of slab `rank` of `G` (a shallow variant of `sd` with re-based lists) and its SlabInfo."""
-    parts = partition(sd.Nx, G)
+def split(sd, G, rank, balance=False):
+    """Local SimData of slab `rank` of `G` (a shallow variant of `sd` with re-based lists) and its SlabInfo.
+    balance=False: the reference's even split; True: cost-balanced cut (partition_weighted)."""
+    parts = partition_weighted(sd, G) if balance else partition(sd.Nx, G)
     x0, x1 = parts[rank]
     info = SlabInfo(rank, G, x0, x1, sd.Nx)
     if info.upd1 - info.upd0 < 1:

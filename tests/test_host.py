@@ -141,3 +141,30 @@ def test_split_covers_every_list_entry_once(G):
             assert ((ix >= 1) & (ix <= loc.Nx - 2)).all()  # everything a slab updates is interior to it
     assert seen == {k: getattr(sd, k) for k in seen}
     assert sorted(rows) == list(range(sd.Nr))
+
+
+def test_weighted_partition_covers_and_balances():
+    sd = cases.make_sd("cart_lossy", "double")
+    for G in (2, 3, 5):
+        parts = slab.partition_weighted(sd, G)
+        assert parts[0][0] == 0 and parts[-1][1] == sd.Nx
+        assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+        assert all(x1 - x0 >= 2 for x0, x1 in parts)
+    # a scene whose only boundary nodes are two whole wall planes near the ends: the end slabs must get fewer planes
+    import copy
+    big = copy.copy(sd)
+    big.Nx, big.Ny, big.Nz = 200, 32, 32
+    NzNy = big.Ny * big.Nz
+    big.bn_ixyz = np.concatenate([3 * NzNy + np.arange(NzNy), 196 * NzNy + np.arange(NzNy)])
+    big.bnl_ixyz, big.Nbl = big.bn_ixyz, big.bn_ixyz.size
+    big.mat_bnl = np.zeros(big.Nbl, dtype=np.int8)
+    big.Mb = np.array([11], dtype=np.int8)
+    p4 = slab.partition_weighted(big, 4)
+    sizes = [b - a for a, b in p4]
+    assert sizes[0] < sizes[1] and sizes[3] < sizes[2] and sum(sizes) == 200
+    # and the balanced split is still a valid decomposition
+    seen = 0
+    for r in range(3):
+        loc, info = slab.split(sd, 3, r, balance=True)
+        seen += loc.Nb
+    assert seen == sd.Nb

@@ -56,7 +56,7 @@ def test_in_process_slabs_equal_single_domain(name, prec, G):
     """G slabs in one process, planes copied directly: isolates slab.split from the transport."""
     ref = _reference(name, prec)
     sd = cases.make_sd(name, prec)
-    parts = [slab.split(sd, G, r) for r in range(G)]
+    parts = [slab.split(sd, G, r, balance=(G == 3)) for r in range(G)]
     st = [OracleSlabStepper(loc, info) for loc, info in parts]
     for n in range(sd.Nt):
         for s in st:
