@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""Verbose GPU parity diagnostics (prints per-case max differences instead of stopping at the first)."""
+"""Verbose GPU parity diagnostics (prints per-case max differences instead of stopping at the first).
+Part of the test infrastructure (uses the CPU oracle); run as `python tests/gpu_check.py [variants]`."""
 import sys
 from pathlib import Path
 
 import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent
-sys.path[:0] = [str(ROOT), str(ROOT / "oracle"), str(ROOT / "tests")]
+sys.path[:0] = [str(ROOT), str(ROOT / "oracle"), str(ROOT / "tests")]  # test infrastructure: may use the oracle
 import cases  # noqa: E402
 import oracle  # noqa: E402
 from pffdtd_amd import engine  # noqa: E402
