@@ -17,6 +17,7 @@
 #include "pf_kernels.h"
 #include "pf_air_fused.h"
 #include "pf_energy.h"
+#include "pf_tb2.h"
 
 namespace {
 
@@ -1045,6 +1046,38 @@ double pf_membench(void *u0v, void *u1v, int64_t Nx, int64_t Ny, int64_t Nz, int
    hipEventDestroy(e0); hipEventDestroy(e1);
    if (hipGetLastError() != hipSuccess) { set_err(PF_ERR_HIP, "membench launch failed"); return -1.0; }
    return ms / reps;
+}
+
+double pf_tb2_probe(const void *A, const void *B, void *C, void *D, int64_t Nx, int64_t Ny, int64_t Nz, double a1, double a2,
+                    int32_t margin, int32_t tye, int32_t chunk, int32_t reps) {
+   pf::Tb2Params tp{};
+   const int64_t P = grid_pitch(Nz, 4);
+   tp.A = (const float *)A; tp.B = (const float *)B; tp.C = (float *)C; tp.D = (float *)D;
+   tp.plane = Ny * P; tp.Nx = (int)Nx; tp.Ny = (int)Ny; tp.Nz = (int)Nz; tp.P = (int)P;
+   if (margin < 2 || (margin % 4) != 0 || ((Nz - 2 * margin) % 4) != 0) { set_err(PF_ERR_ARG, "tb2 probe: margin must be a multiple of 4 >= 4"); return -1.0; }
+   tp.x_begin = margin; tp.x_end = (int)Nx - margin;
+   tp.y_begin = margin; tp.z_begin = margin;
+   tp.chunk = chunk > 0 ? chunk : 64;
+   tp.nxc = (int)cdiv(tp.x_end - tp.x_begin, tp.chunk);
+   tp.nzt = (int)cdiv(Nz - 2 * margin, 248);
+   hipEvent_t e0, e1;
+   hipEventCreate(&e0); hipEventCreate(&e1);
+   auto launch = [&]() {
+      if (tye == 20) { tp.nyt = (int)cdiv(Ny - 2 * margin, 16); hipLaunchKernelGGL((pf::k_tb2_proto<20, 8>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(512), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 12) { tp.nyt = (int)cdiv(Ny - 2 * margin, 8); hipLaunchKernelGGL((pf::k_tb2_proto<12, 4>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 24) { tp.nyt = (int)cdiv(Ny - 2 * margin, 20); hipLaunchKernelGGL((pf::k_tb2_proto<24, 8>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(512), 0, 0, tp, (float)a1, (float)a2); return true; }
+      return false;
+   };
+   if (!launch()) { set_err(PF_ERR_ARG, "tb2 probe: tye must be 12, 20 or 24"); return -1.0; }
+   if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { set_err(PF_ERR_HIP, "tb2 probe launch failed"); return -1.0; }
+   hipEventRecord(e0, 0);
+   for (int i = 0; i < reps; i++) launch();
+   hipEventRecord(e1, 0);
+   hipEventSynchronize(e1);
+   float ms = 0;
+   hipEventElapsedTime(&ms, e0, e1);
+   hipEventDestroy(e0); hipEventDestroy(e1);
+   return reps > 0 ? ms / reps : 0.0;
 }
 
 // double run_sim(struct SimData *sd): cpu_engine.h:52 / gpu_engine.h:665

@@ -1,0 +1,116 @@
+// pf_tb2.h -- RESEARCH PROTOTYPE (not on the product path; driven only by tools/tb2_probe.py):
+// two leap-frog steps of the pure 7-point air update per pass (temporal blocking), to measure what the interior
+// kernel could gain from halving its HBM traffic per step.  Out of place: reads A = u^{n-1}, B = u^n, writes
+// C = u^{n+1}, D = u^{n+2}.  No mask / ABC / boundary nodes: valid for cells at least 3 away from anything special.
+//
+// Tiling: a workgroup owns TYE rows x 256 columns (one wave-width of float4) and marches x.  Stage 1 computes
+// T = u^{n+1} of plane x+1 on rows 1..TYE-2 of the tile (all 256 columns; the outermost column of each side is
+// garbage and never used), stage 2 computes u^{n+2} of plane x on rows 2..TYE-3, columns 4..251.  Tiles therefore
+// overlap by 4 rows and 8 columns: no edge loads, no cross-workgroup exchange.  u^n planes x..x+2 and u^{n+1} planes
+// x-1..x+1 live in LDS rings; every stencil operand is an LDS read.
+#pragma once
+#include "pf_kernels.h"
+
+namespace pf {
+
+struct Tb2Params {
+   const float *A, *B;
+   float *C, *D;
+   int64_t plane;
+   int32_t Nx, Ny, Nz, P;
+   int32_t x_begin, x_end, chunk; // D planes [x_begin, x_end) (C planes x_begin .. x_end)
+   int32_t nzt, nyt, nxc;
+   int32_t y_begin, z_begin;      // first core row / first core column of tile (0,0)
+};
+
+template <int TYE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_tb2_proto(Tb2Params tp, float a1, float a2) {
+   typedef f32x4 vec;
+   constexpr int W = 256;
+   constexpr int LROW = W + 8; // 4 pad floats each side so that column -1 / W reads stay in the row
+   __shared__ __attribute__((aligned(16))) float Bs[3][TYE][LROW];
+   __shared__ __attribute__((aligned(16))) float Ts[3][TYE][LROW];
+   const uint32_t b = blockIdx.x;
+   const int zt = b % tp.nzt, yt = (b / tp.nzt) % tp.nyt, xc = b / (tp.nzt * tp.nyt);
+   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+   const int ze0 = tp.z_begin - 4 + zt * (W - 8);      // first column of the extended tile
+   const int ye0 = tp.y_begin - 2 + yt * (TYE - 4);    // first row of the extended tile
+   const int xs = tp.x_begin + xc * tp.chunk, xe = min(xs + tp.chunk, tp.x_end);
+   const int P = tp.P;
+   const int64_t plane = tp.plane;
+   const int zc = min(max(ze0 + lane * 4, 0), P - 4);  // clamped load column (tiles at the grid edge)
+   auto grow = [&](int r) { return (int64_t)min(max(ye0 + r, 0), tp.Ny - 1) * P + zc; };
+
+   auto fill_B = [&](int x, int slot) { // u^n plane x, all TYE rows of the tile
+      const float *pl = tp.B + (int64_t)x * plane;
+      for (int r = w; r < TYE; r += WAVES) *(vec *)&Bs[slot][r][4 + lane * 4] = *(const vec *)(pl + grow(r));
+   };
+   auto stage1 = [&](int x, bool write_c) { // T(plane x) from B planes x-1, x, x+1 (slots (x-1)%3 ...) and A plane x; rows 1..TYE-2
+      const float *pa = tp.A + (int64_t)x * plane;
+      float *pc = tp.C + (int64_t)x * plane;
+      float(*Bm)[LROW] = Bs[(x + 2) % 3], (*Bc)[LROW] = Bs[x % 3], (*Bp)[LROW] = Bs[(x + 1) % 3];
+      for (int r = 1 + w; r <= TYE - 2; r += WAVES) {
+         const int col = 4 + lane * 4;
+         const vec c = *(const vec *)&Bc[r][col];
+         const vec yp = *(const vec *)&Bc[r + 1][col], ym = *(const vec *)&Bc[r - 1][col];
+         const vec xp = *(const vec *)&Bp[r][col], xm = *(const vec *)&Bm[r][col];
+         const float lf = Bc[r][col - 1], rt = Bc[r][col + 4];
+         const vec old = *(const vec *)(pa + grow(r));
+         vec o;
+#pragma unroll
+         for (int i = 0; i < 4; i++) {
+            const float zp = (i == 3) ? rt : c[i < 3 ? i + 1 : 3];
+            const float zm = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
+            float p = a1 * c[i] - old[i];
+            p = p + a2 * xp[i]; p = p + a2 * xm[i]; p = p + a2 * yp[i]; p = p + a2 * ym[i]; p = p + a2 * zp; p = p + a2 * zm;
+            o[i] = p;
+         }
+         *(vec *)&Ts[x % 3][r][col] = o;
+         // core cells of this tile own the C (u^{n+1}) output
+         const bool core_row = (r >= 2 && r <= TYE - 3) && (ye0 + r >= tp.y_begin) && (ye0 + r < tp.Ny - tp.y_begin);
+         const bool core_col = (lane >= 1 && lane <= 62) && (ze0 + lane * 4 + 3 < tp.Nz - tp.z_begin);
+         if (write_c && core_row && core_col) __builtin_nontemporal_store(o, (vec *)(pc + grow(r)));
+      }
+   };
+   auto stage2 = [&](int x) { // D(plane x) from T planes x-1, x, x+1 and B plane x; rows 2..TYE-3, lanes 1..62
+      float *pd = tp.D + (int64_t)x * plane;
+      float(*Tm)[LROW] = Ts[(x + 2) % 3], (*Tc)[LROW] = Ts[x % 3], (*Tp)[LROW] = Ts[(x + 1) % 3];
+      float(*Bc)[LROW] = Bs[x % 3];
+      for (int r = 2 + w; r <= TYE - 3; r += WAVES) {
+         const int col = 4 + lane * 4;
+         const vec c = *(const vec *)&Tc[r][col];
+         const vec yp = *(const vec *)&Tc[r + 1][col], ym = *(const vec *)&Tc[r - 1][col];
+         const vec xp = *(const vec *)&Tp[r][col], xm = *(const vec *)&Tm[r][col];
+         const float lf = Tc[r][col - 1], rt = Tc[r][col + 4];
+         const vec old = *(const vec *)&Bc[r][col];
+         vec o;
+#pragma unroll
+         for (int i = 0; i < 4; i++) {
+            const float zp = (i == 3) ? rt : c[i < 3 ? i + 1 : 3];
+            const float zm = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
+            float p = a1 * c[i] - old[i];
+            p = p + a2 * xp[i]; p = p + a2 * xm[i]; p = p + a2 * yp[i]; p = p + a2 * ym[i]; p = p + a2 * zp; p = p + a2 * zm;
+            o[i] = p;
+         }
+         const bool ok_row = (ye0 + r >= tp.y_begin) && (ye0 + r < tp.Ny - tp.y_begin);
+         if (ok_row && lane >= 1 && lane <= 62 && ze0 + lane * 4 + 3 < tp.Nz - tp.z_begin) __builtin_nontemporal_store(o, (vec *)(pd + grow(r)));
+      }
+   };
+   // D planes [xs, xe) need T planes xs-1 .. xe, which need B planes xs-2 .. xe+1
+   fill_B(xs - 2, (xs - 2) % 3);
+   fill_B(xs - 1, (xs - 1) % 3);
+   fill_B(xs, xs % 3);
+   __syncthreads();
+   stage1(xs - 1, false);
+   __syncthreads();
+   for (int x = xs; x <= xe; x++) {
+      fill_B(x + 1, (x + 1) % 3);    // overwrites the slot of plane x-2 (no longer needed)
+      __syncthreads();
+      stage1(x, x < xe);              // T(x) -> Ts[x%3]; this chunk owns C planes [xs, xe)
+      __syncthreads();
+      if (x - 1 >= xs) stage2(x - 1); // D(x-1) from T x-2, x-1, x and B x-1
+      __syncthreads();
+   }
+}
+
+} // namespace pf
