@@ -81,6 +81,25 @@ class SimEngine:
         t = time.perf_counter() - t0
         self.print(f"Run-time loop: {t:.6f}, {sd.Nt * sd.Npts / 1e6 / t:.2f} MVox/s")
 
+    def gather_slice(self, ix=None, iy=None, iz=None):
+        """One plane of the current field u1 (sim_fdtd.py:630-658); the reference fills the checkerboard holes of an FCC
+        subgrid for plotting (nb_fcc_fill_plot_holes, :888-895), reproduced with numpy."""
+        import numpy as np
+        u1 = self.eng.get_grid(1)
+        if ix is not None:
+            sl, k = u1[ix, :, :].copy(), ix
+        elif iy is not None:
+            sl, k = u1[:, iy, :].copy(), iy
+        else:
+            sl, k = u1[:, :, iz].copy(), iz
+        if self.fcc and self.sd.fcc_flag == 1:
+            i1, i2 = np.meshgrid(np.arange(1, sl.shape[0] - 1), np.arange(1, sl.shape[1] - 1), indexing="ij")
+            holes = ((i1 + i2 + k) % 2) == 1
+            avg = 0.25 * (sl[2:, 1:-1] + sl[:-2, 1:-1] + sl[1:-1, 2:] + sl[1:-1, :-2])
+            inner = sl[1:-1, 1:-1]
+            inner[holes] = avg[holes]
+        return sl
+
     def save_outputs(self):
         self.sd.write_outputs(self.data_dir)
         self.print(f"saved outputs in {self.data_dir}")
