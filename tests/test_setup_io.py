@@ -1,0 +1,72 @@
+"""Setup-side writers (pffdtd_amd/setup_io.py) against golden values captured from the reference's own
+SimConsts / SimComms classes (tests/golden/make_golden_setup.py), plus folder round trips of prep_folder."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import cases
+import oracle
+from pffdtd_amd import h5io, setup_io, sim_data, synth
+
+G = np.load(Path(__file__).resolve().parent / "golden" / "setup_reference.npz")
+
+
+@pytest.mark.parametrize("tag,fcc", [("cart", False), ("fcc", True)])
+def test_consts_and_comms_match_reference(tag, fcc):
+    sc = setup_io.SimConsts(Tc=20, rh=50, fmax=700.0, PPW=8.0, fcc=fcc)
+    for k in ("h", "c", "Ts", "SR", "l", "l2"):
+        assert getattr(sc, k) == G[f"{tag}_{k}"], k
+    N = (20, 18, 16)
+    xv, yv, zv = (np.arange(n) * sc.h + o for n, o in zip(N, (-0.3, 0.1, 0.05)))
+    cm = setup_io.SimComms(h=sc.h, Ts=sc.Ts, l2=sc.l2, fcc_flag=int(fcc), xv=xv, yv=yv, zv=zv)
+    cm.prepare_source_pts(G[f"{tag}_S"])
+    cm.prepare_receiver_pts(G[f"{tag}_R"])
+    cm.prepare_source_signals(60 * sc.Ts, sig_type="dhann30")
+    assert np.array_equal(cm.in_ixyz, G[f"{tag}_in_ixyz"]) and np.array_equal(cm.out_ixyz, G[f"{tag}_out_ixyz"])
+    assert np.array_equal(cm.in_alpha, G[f"{tag}_in_alpha"]) and np.array_equal(cm.out_alpha, G[f"{tag}_out_alpha"])
+    assert np.array_equal(cm.in_sigs, G[f"{tag}_in_sigs"])
+    cm.diff_source()
+    ref = G[f"{tag}_in_sigs_diff"]  # scipy.signal.lfilter in the reference: same recurrence, allow its rounding order
+    assert np.abs(cm.in_sigs - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_setup_folder_runs_through_the_engine_flow(tmp_path):
+    """consts + grid + comms + mats written by setup_io, boundary nodes by the synthetic generator: a complete
+    sim_data folder that the loader accepts and the oracle runs."""
+    sc = setup_io.SimConsts(Tc=20, rh=50, h=0.05, fcc=False)
+    sc.save(tmp_path)
+    cg = setup_io.CartGrid(h=sc.h, offset=3.5, bmin=[0, 0, 0], bmax=[0.9, 0.8, 0.7])
+    cg.save(tmp_path)
+    cm = setup_io.SimComms(save_folder=tmp_path)
+    cm.prepare_source_pts(np.array([0.45, 0.4, 0.35]))
+    cm.prepare_receiver_pts(np.array([[0.2, 0.2, 0.2], [0.7, 0.6, 0.5]]))
+    cm.prepare_source_signals(40 * sc.Ts, sig_type="impulse")
+    cm.diff_source()
+    cm.save()
+    box = synth.shoebox(cg.Nx, cg.Ny, cg.Nz, Nt=40, Nm=2, Mb=[3, 2])
+    for name in ("mat_00", "mat_01"):
+        h5io.write(tmp_path / f"{name}.h5", "DEF", box["sim_mats"][f"{name}_DEF"], append=False)
+    setup_io.SimMats(tmp_path).package({"a_wall": "mat_00.h5", "b_floor": "mat_01.h5"}, ["a_wall", "_RIGID", "b_floor"], tmp_path)
+    first = True
+    for k, v in box["vox_out"].items():
+        h5io.write(tmp_path / "vox_out.h5", k, v, append=not first)
+        first = False
+    cm.check_for_clashes(box["vox_out"]["bn_ixyz"])
+    sd = sim_data.SimData.from_folder(tmp_path, "single")
+    sd.scale_input()
+    oracle.run_sim(sd)
+    assert sd.Nr == 16 and sd.Ns == 8 and np.isfinite(sd.u_out).all() and np.abs(sd.u_out).max() > 0
+
+
+def test_prep_folder_matches_in_memory_transforms(tmp_path):
+    sim = cases.make_sim("fcc1_outside")
+    synth.write_folder(sim, tmp_path / "a")
+    setup_io.prep_folder(tmp_path / "a", out_dir=tmp_path / "b")
+    got = synth.read_folder(tmp_path / "b")
+    want = synth.sort_sim(synth.fold_fcc(synth.rotate_sim(cases.make_sim("fcc1_outside"))))
+    assert int(got["sim_consts"]["fcc_flag"]) == 2
+    for f in ("vox_out", "comms_out"):
+        for k in ("bn_ixyz", "adj_bn", "in_ixyz", "out_ixyz", "out_reorder", "in_sigs"):
+            if k in want[f]:
+                assert np.array_equal(np.asarray(got[f][k]), np.asarray(want[f][k])), (f, k)
