@@ -37,3 +37,40 @@ for tag, fcc in (("cart", False), ("fcc", True)):
     out[f"{tag}_in_sigs_diff"] = cm.in_sigs.copy()
 np.savez_compressed(HERE / "setup_reference.npz", **out)
 print("wrote", HERE / "setup_reference.npz", len(out), "arrays")
+
+# ---- post-processing (python/fdtd/process_outputs.py) on a synthetic receiver set ----
+for m in ("resampy", "matplotlib", "matplotlib.pyplot"):
+    sys.modules.setdefault(m, types.ModuleType(m))
+sys.modules["resampy"].resample = lambda *a, **k: None
+air = types.ModuleType("air_abs"); sys.modules.setdefault("air_abs", air)
+for sub, fn in (("visco_filter", "apply_visco_filter"), ("modal_filter", "apply_modal_filter"), ("ola_filter", "apply_ola_filter")):
+    mod = types.ModuleType(f"air_abs.{sub}"); setattr(mod, fn, None); sys.modules.setdefault(f"air_abs.{sub}", mod)
+
+
+class _FakeH5:  # initial_process() stores r_out into sim_outs.h5 midway (process_outputs.py:97-104): swallow that
+    def __init__(self, *a, **k): pass
+    def __delitem__(self, k): raise KeyError(k)
+    def create_dataset(self, *a, **k): pass
+    def close(self): pass
+
+
+sys.modules["h5py"].File = _FakeH5
+from fdtd.process_outputs import ProcessOutputs  # noqa: E402
+
+rng = np.random.default_rng(5)
+Ts = 1 / 25000.0
+u_out = rng.standard_normal((16, 400)) * np.exp(-np.arange(400) / 80.0)
+alpha = rng.random((2, 8)); alpha /= alpha.sum(axis=1, keepdims=True)
+post = {"post_u_out": u_out, "post_alpha": alpha, "post_Ts": np.float64(Ts)}
+for diff in (True, False):
+    po = ProcessOutputs.__new__(ProcessOutputs)
+    po.u_out, po.out_alpha, po.data_dir, po.diff, po.Ts = u_out, alpha, Path("/nonexistent"), diff, Ts
+    po.Ts_f, po.Fs_f, po.Fs, po.Nt, po.Nt_f = Ts, 1 / Ts, 1 / Ts, 400, 400
+    po.initial_process(fcut=10.0, N_order=4)
+    r_out = po.r_out
+    post[f"post_r_out_f_diff{int(diff)}"] = po.r_out_f.copy()
+    po.apply_lowpass(fcut=4000.0, N_order=8, symmetric=True)
+    post[f"post_lowpass_diff{int(diff)}"] = po.r_out_f.copy()
+post["post_r_out"] = r_out
+np.savez_compressed(HERE / "post_reference.npz", **post)
+print("wrote post_reference.npz")

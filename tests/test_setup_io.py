@@ -70,3 +70,29 @@ def test_prep_folder_matches_in_memory_transforms(tmp_path):
         for k in ("bn_ixyz", "adj_bn", "in_ixyz", "out_ixyz", "out_reorder", "in_sigs"):
             if k in want[f]:
                 assert np.array_equal(np.asarray(got[f][k]), np.asarray(want[f][k])), (f, k)
+
+
+@pytest.mark.parametrize("diff", [True, False])
+def test_process_outputs_matches_reference(diff, tmp_path):
+    """Recombination, integrator + low-cut and symmetric low-pass vs the reference's ProcessOutputs methods
+    (golden: tests/golden/post_reference.npz, produced by running the reference class behind a fake h5py)."""
+    from pffdtd_amd import process_outputs
+    g = np.load(Path(__file__).resolve().parent / "golden" / "post_reference.npz")
+    Ts = float(g["post_Ts"])
+    h5io.write(tmp_path / "sim_consts.h5", "Ts", np.float64(Ts), append=False)
+    c = tmp_path / "comms_out.h5"
+    h5io.write(c, "out_alpha", g["post_alpha"], append=False)
+    h5io.write(c, "Nr", np.int64(16)); h5io.write(c, "Nt", np.int64(400)); h5io.write(c, "diff", np.int8(diff))
+    h5io.write(tmp_path / "sim_outs.h5", "u_out", g["post_u_out"], append=False)
+    po = process_outputs.ProcessOutputs(tmp_path)
+    po.initial_process(fcut=10.0, N_order=4)
+    assert np.array_equal(po.r_out, g["post_r_out"])
+    assert np.array_equal(h5io.read(tmp_path / "sim_outs.h5", "r_out"), g["post_r_out"])       # appended next to u_out
+    assert np.array_equal(h5io.read(tmp_path / "sim_outs.h5", "u_out"), g["post_u_out"])       # and u_out kept
+    assert np.allclose(po.r_out_f, g[f"post_r_out_f_diff{int(diff)}"], rtol=1e-12, atol=0)
+    po.apply_lowpass(fcut=4000.0, N_order=8, symmetric=True)
+    assert np.allclose(po.r_out_f, g[f"post_lowpass_diff{int(diff)}"], rtol=1e-12, atol=1e-300)
+    po.resample(48e3)
+    assert abs(po.Fs_f - 48e3) < 1e-6 and po.r_out_f.shape == (2, 768)
+    po.save_h5()
+    assert h5io.read(tmp_path / "sim_outs_processed.h5", "r_out_f").shape == (2, 768)
