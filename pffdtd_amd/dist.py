@@ -10,7 +10,6 @@ that stream only, and the interior planes run concurrently on the main stream.
 The per-slab work is behind a small `stepper` interface so that the exchange schedule itself can be
 tested on CPU with gloo (tests inject an oracle-backed stepper; the product stepper is HIP only).
 """
-import numpy as np
 import torch
 import torch.distributed as dist
 
