@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split-phase", action="store_true", help="N=1: drive the split-phase step like N>1 does")
     ap.add_argument("--emulate-slab", default="", help="debug: 'r/N' = run only slab r of an N-way split on this GPU, the exchange\n                    replaced by device copies of the same planes (per-rank cost model; physics is wrong)")
+    ap.add_argument("--emulate-transport", default="copy", choices=["copy", "rccl"],
+                    help="with --emulate-slab: 'rccl' sends the planes to this same rank through RCCL (real launch cost)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,6 +126,11 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     group = None
+    if args.emulate_slab and args.emulate_transport == "rccl":
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29731")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -154,6 +161,20 @@ def main():
                 if not inf.last:
                     r_hi.copy_(s_hi, non_blocking=True)
         runner.exchange = _fake_exchange
+        if args.emulate_transport == "rccl":
+            import torch.distributed as dist
+
+            def _self_exchange(st=runner.st, inf=info):
+                s_lo, s_hi, r_lo, r_hi = st.halo_tensors()
+                ops = []
+                if not inf.first:
+                    ops += [dist.P2POp(dist.isend, s_lo, 0), dist.P2POp(dist.irecv, r_lo, 0)]
+                if not inf.last:
+                    ops += [dist.P2POp(dist.isend, s_hi, 0), dist.P2POp(dist.irecv, r_hi, 0)]
+                with st.comm_context():
+                    for w in dist.batch_isend_irecv(ops):
+                        w.wait()
+            runner.exchange = _self_exchange
     else:
         runner, loc, info = pdist.make_hip_runner(sd, rank, world, local_rank, group, **ekw)
     eng = runner.st.eng
@@ -184,6 +205,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(W, K)
+    t_enq = time.perf_counter() - t0  # host time to enqueue K steps (diagnostic: is the loop CPU-bound?)
     sync()
     torch.cuda.synchronize()
     barrier()
@@ -203,7 +225,8 @@ def main():
     if rank == 0:
         gvox = sd.Npts * K / el / 1e9
         if emu is not None:
-            print(f"[emulated slab {emu[0]}/{emu[1]}: {loc.Nx} planes] {el / K * 1e3:.4f} ms/step -> {emu[1]} such ranks would give "
+            print(f"[emulated slab {emu[0]}/{emu[1]}: {loc.Nx} planes] host enqueue {t_enq / K * 1e3:.4f} ms/step; "
+                  f"{el / K * 1e3:.4f} ms/step -> {emu[1]} such ranks would give "
                   f"{sd.Npts * K / el / 1e9:.1f} Gvox/s if the exchange hides completely", file=sys.stderr)
         bpv = 3 * real_bytes + 0.125  # u1 read, u0 read + write, one mask bit
         # algorithmic bytes of one step's air launches on this rank: the interior voxels they update

@@ -450,6 +450,30 @@ template <typename Real> struct Engine : EngineBase {
       if (op.timing) { hipEventRecord(ev.second, s); air_ev.push_back(ev); }
    }
 
+   // x-chunk length of the marching kernels.  op.air_chunk > 0: that many planes; < 0: -air_chunk equal chunks;
+   // 0: automatic, from sweeps on MI355X (tools/tune_air.py --chunks=-2,-4,...; 1024^3, 512^3, 256^3, 1/2..1/8 slabs):
+   //   lean kernels (lean=true): ~64-plane chunks, but between 512 and 2048 workgroups in total -- fewer starve the
+   //   CUs, more only add 2-plane prologues; barrier-free v1 kernels: ~12k workgroups, chunks of >= 6 planes.
+   // The split is always even (a short last chunk idles its XCD at the end) and the chunk count even (XCD swizzle).
+   int pick_chunk(int nplanes, int64_t tiles, bool lean_rule) const {
+      int chunk = op.air_chunk;
+      if (chunk < 0) chunk = (int)cdiv(nplanes, std::min<int64_t>(-(int64_t)chunk, nplanes));
+      else if (chunk == 0) {
+         tiles = std::max<int64_t>(tiles, 1);
+         int64_t n;
+         if (lean_rule) {
+            const int64_t lo = cdiv(512, tiles), hi = std::max(cdiv(2048, tiles), lo);
+            n = std::min(std::max<int64_t>(nplanes / 64, lo), hi);
+         } else {
+            n = std::min<int64_t>(cdiv(256 * 48, tiles), std::max(nplanes / 6, 1));
+         }
+         if (n > 1 && (n & 1)) n++;
+         n = std::max<int64_t>(1, std::min<int64_t>(n, nplanes));
+         chunk = (int)cdiv(nplanes, n);
+      }
+      return std::max(1, std::min(chunk, nplanes));
+   }
+
    template <int R, int WY, int WZ> void launch_air_cfg(hipStream_t s, int xb, int xe) {
       constexpr int V = pf::VecOf<Real>::V;
       pf::AirParams ap;
@@ -457,15 +481,8 @@ template <typename Real> struct Engine : EngineBase {
       ap.x_begin = xb; ap.x_end = xe;
       ap.nzt = (int)cdiv(P, (int64_t)WZ * 64 * V);
       ap.nyt = (int)cdiv(Ny - 2, (int64_t)WY * R);
-      int chunk = op.air_chunk;
       const int nplanes = xe - xb;
-      if (chunk <= 0) {
-         // enough workgroups to fill 256 CUs several times over, but keep the 2-plane chunk prologue small
-         const int64_t tiles = (int64_t)ap.nzt * ap.nyt;
-         int64_t want = cdiv(256 * 24, std::max<int64_t>(tiles, 1));
-         chunk = (int)std::max<int64_t>(cdiv(nplanes, std::max<int64_t>(want, 1)), 16);
-      }
-      chunk = std::min(chunk, nplanes);
+      const int chunk = pick_chunk(nplanes, (int64_t)ap.nzt * ap.nyt, false);
       ap.chunk = chunk;
       ap.nxc = (int)cdiv(nplanes, chunk);
       ap.swizzle = (op.air_variant & 64) ? 0 : 1;
@@ -503,13 +520,7 @@ template <typename Real> struct Engine : EngineBase {
       fp.nzt = fused_nzt;
       fp.nyt = (int)cdiv(Ny - 2, (int64_t)WY * R);
       const int nplanes = xe - xb;
-      int chunk = op.air_chunk;
-      if (chunk <= 0) {
-         const int64_t tiles = (int64_t)fp.nzt * fp.nyt;
-         const int64_t want = cdiv(256 * 16, std::max<int64_t>(tiles, 1));
-         chunk = (int)std::max<int64_t>(cdiv(nplanes, std::max<int64_t>(want, 1)), 16);
-      }
-      chunk = std::min(chunk, nplanes);
+      const int chunk = pick_chunk(nplanes, (int64_t)fp.nzt * fp.nyt, true);
       fp.chunk = chunk;
       fp.nxc = (int)cdiv(nplanes, chunk);
       fp.swizzle = (op.air_variant & 64) ? 0 : 1;
@@ -545,13 +556,7 @@ template <typename Real> struct Engine : EngineBase {
       fp.nzt = fused_nzt;
       fp.nyt = (int)cdiv(Ny - 2, (int64_t)WY * R);
       const int nplanes = xe - xb;
-      int chunk = op.air_chunk;
-      if (chunk <= 0) {
-         const int64_t tiles = (int64_t)fp.nzt * fp.nyt;
-         const int64_t want = cdiv(256 * 32, std::max<int64_t>(tiles, 1));
-         chunk = (int)std::max<int64_t>(cdiv(nplanes, std::max<int64_t>(want, 1)), 16);
-      }
-      chunk = std::min(chunk, nplanes);
+      const int chunk = pick_chunk(nplanes, (int64_t)fp.nzt * fp.nyt, true);
       fp.chunk = chunk;
       fp.nxc = (int)cdiv(nplanes, chunk);
       fp.swizzle = (op.air_variant & 64) ? 0 : 1;
