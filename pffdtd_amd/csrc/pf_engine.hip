@@ -462,7 +462,10 @@ template <typename Real> struct Engine : EngineBase {
          tiles = std::max<int64_t>(tiles, 1);
          int64_t n;
          if (lean_rule) {
-            const int64_t lo = cdiv(512, tiles), hi = std::max(cdiv(2048, tiles), lo);
+            // slab engines keep >= 1024 WGs: with fewer, every WG is resident for the whole launch and the edge-stream
+            // kernels / the RCCL transfer kernel find no free CU slot until the interior launch has finished
+            const bool slab = !(op.slab_first && op.slab_last);
+            const int64_t lo = cdiv(slab ? 1024 : 512, tiles), hi = std::max(cdiv(2048, tiles), lo);
             n = std::min(std::max<int64_t>(nplanes / 64, lo), hi);
          } else {
             n = std::min<int64_t>(cdiv(256 * 48, tiles), std::max(nplanes / 6, 1));
@@ -622,13 +625,19 @@ template <typename Real> struct Engine : EngineBase {
    void launch_abc(hipStream_t s, Range r) {
       if (!fused && !lean && !vg && !abck && r.e > r.b) hipLaunchKernelGGL(pf::k_abc_loss<Real>, dim3((unsigned)cdiv(r.e - r.b, 256)), dim3(256), 0, s, u0, d_bna, d_Q, u2ba, l, r.b, r.e);
    }
+   // Virtual-ghost modes: boundary nodes next to the folded ghost row read it from MEMORY, so that one row is kept
+   // materialised.  In a split-phase step the main stream only touches planes [1, Nx-1): the slab's ghost planes may
+   // be receiving the neighbours' data at that moment (the edge stream, ordered after the exchange, does those).
+   int fold_x0 = 0, fold_x1 = 0; // plane range of the next launch_fold_row (set by the step drivers)
+   void launch_fold_row(hipStream_t s) {
+      if (!((lean || fused || vg) && fold && need_fold_row) || fold_x1 <= fold_x0) return;
+      dim3 gy((unsigned)cdiv(Nz, 256), (unsigned)(fold_x1 - fold_x0));
+      hipLaunchKernelGGL(pf::k_flip_y<Real>, gy, dim3(256), 0, s, u1 + (int64_t)fold_x0 * plane, (int64_t)(fold_x1 - fold_x0), Ny, P, Nz, 4);
+   }
    // rigid + FD in one pass over the boundary list (plane range given on the boundary list)
    void launch_boundary(hipStream_t s, Range r) {
       if (r.e <= r.b) return;
-      if ((lean || fused || vg) && fold && need_fold_row) {
-         dim3 gy((unsigned)cdiv(Nz, 256), (unsigned)Nx);
-         hipLaunchKernelGGL(pf::k_flip_y<Real>, gy, dim3(256), 0, s, u1, Nx, Ny, P, Nz, 4);
-      }
+      launch_fold_row(s);
       dim3 g((unsigned)cdiv(r.e - r.b, 128)), b(128);
       const bool fma = op.numerics == PF_NUM_FMA;
 #define PF_BND(F, M) hipLaunchKernelGGL((pf::k_boundary<Real, F, M>), g, b, 0, s, u1, u0, d_bn, d_adj, d_lossy, a2, sl2, P, plane, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq, d_beta, vh1, gh1, lo2, Nbl, r.b, r.e)
@@ -640,11 +649,7 @@ template <typename Real> struct Engine : EngineBase {
    void launch_rigid(hipStream_t s, Range r) {
       if (boundary_fused()) { launch_boundary(s, r); return; }
       if (r.e <= r.b || (fused && fused_rigid) || lean_rigid) return;
-      if ((lean || fused || vg) && fold && need_fold_row) {
-         // boundary nodes next to the folded ghost row read it from MEMORY: keep that one row materialised
-         dim3 gy((unsigned)cdiv(Nz, 256), (unsigned)Nx);
-         hipLaunchKernelGGL(pf::k_flip_y<Real>, gy, dim3(256), 0, s, u1, Nx, Ny, P, Nz, 4);
-      }
+      launch_fold_row(s);
       dim3 g((unsigned)cdiv(r.e - r.b, 256)), b(256);
       const bool fma = op.numerics == PF_NUM_FMA;
       if (fcc) {
@@ -689,6 +694,7 @@ template <typename Real> struct Engine : EngineBase {
          else { hipEventCreate(&ev.first); hipEventCreate(&ev.second); }
          hipEventRecord(ev.first, s_main);
       }
+      fold_x0 = 0; fold_x1 = (int)Nx;
       launch_pre(s_main);
       launch_air(s_main, 1, (int)Nx - 1);
       launch_abc(s_main, {0, Nba});
@@ -738,6 +744,7 @@ template <typename Real> struct Engine : EngineBase {
          if (Ns) hipLaunchKernelGGL(pf::k_energy_in<Real>, g1(Ns, 64), dim3(64), 0, s, u0, u2in, d_in, d_insig, Ns, Nt, n, 0, d_acc);
          if (Nbl) HIPCHK(hipMemcpyAsync(vh_old, vh1, sizeof(Real) * Nbl * PF_MMB, hipMemcpyDeviceToDevice, s));
          // the step itself (unfused sequence), with Lu = L(u1) taken after the ghost flips
+         fold_x0 = 0; fold_x1 = (int)Nx;
          launch_pre(s);
          if (fcc) {
             hipLaunchKernelGGL((pf::k_lap_air<Real, true>), g3, dim3(256), 0, s, u1, Lu, mask, Nx, Ny, Nz, P, plane);
@@ -788,10 +795,13 @@ template <typename Real> struct Engine : EngineBase {
       if (n < 0 || n >= Nt) return set_err(PF_ERR_ARG, "step %ld outside [0,Nt=%ld)", (long)n, (long)Nt);
       HIPCHK(hipSetDevice(op.device));
       const int xl = 1, xh = (int)Nx - 2;
-      launch_pre(s_edge);
-      HIPCHK(hipEventRecord(ev_pre, s_edge));
-      HIPCHK(hipStreamWaitEvent(s_main, ev_pre, 0));
+      if (!(fused || lean || vg)) { // ghost flips / ABC save touch the whole grid: the interior must see them
+         launch_pre(s_edge);
+         HIPCHK(hipEventRecord(ev_pre, s_edge));
+         HIPCHK(hipStreamWaitEvent(s_main, ev_pre, 0));
+      }
       // edge stream: first / last owned plane
+      fold_x0 = 0; fold_x1 = (int)Nx;
       launch_air(s_edge, xl, xl + 1);
       if (xh > xl) launch_air(s_edge, xh, xh + 1);
       launch_abc(s_edge, bna_lo); launch_abc(s_edge, bna_hi);
@@ -800,6 +810,7 @@ template <typename Real> struct Engine : EngineBase {
       launch_io(s_edge, n, false, in_lo); launch_io(s_edge, n, false, in_hi);
       HIPCHK(hipEventRecord(ev_edge, s_edge));
       // main stream: interior planes
+      fold_x0 = 1; fold_x1 = (int)Nx - 1;
       launch_air(s_main, xl + 1, xh);
       launch_abc(s_main, bna_mid);
       launch_rigid(s_main, bn_mid);
@@ -821,10 +832,12 @@ template <typename Real> struct Engine : EngineBase {
    int step_end(int64_t n) override {
       if (!in_step) return set_err(PF_ERR_STATE, "step_end without step_begin");
       HIPCHK(hipSetDevice(op.device));
-      // join: next step's ghost work (edge stream) must see the interior, and the main stream the exchange
+      // join.  The next step's edge planes (edge stream) read interior plane 2 / Nx-3: wait for the main stream.
+      // The next step's interior (main stream) reads the edge planes but never the ghost planes, so it waits for
+      // the edge *compute* only (ev_edge, recorded in step_begin before the exchange was issued) -- the exchange
+      // itself stays off the main stream's critical path and only orders the edge stream.
       HIPCHK(hipEventRecord(ev_main, s_main));
       HIPCHK(hipStreamWaitEvent(s_edge, ev_main, 0));
-      HIPCHK(hipEventRecord(ev_edge, s_edge));
       HIPCHK(hipStreamWaitEvent(s_main, ev_edge, 0));
       in_step = false;
       rotate();
