@@ -33,6 +33,13 @@ int set_err(int code, const char *fmt, ...) {
    return code;
 }
 
+} // namespace
+
+// internal: lets the other translation units of this library (pf_vox.hip) feed pf_last_error()
+extern "C" void pf__set_error(const char *msg) { g_err = msg ? msg : ""; }
+
+namespace {
+
 #define HIPCHK(expr)                                                                                          \
    do {                                                                                                       \
       hipError_t _e = (expr);                                                                                 \

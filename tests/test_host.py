@@ -13,14 +13,16 @@ ROOT = Path(__file__).resolve().parent.parent
 
 
 def test_library_exports_every_declared_symbol():
-    """libpffdtd_hip.so must load on a CPU-only box and export everything include/pffdtd_hip.h declares."""
-    hdr = (ROOT / "include" / "pffdtd_hip.h").read_text()
-    declared = set(re.findall(r"\b(pf_[a-z_0-9]+)\s*\(", hdr))
-    assert len(declared) >= 18
+    """libpffdtd_hip.so must load on a CPU-only box and export everything include/*.h declares."""
+    from pffdtd_amd import voxelizer
     L = ctypes.CDLL(str(engine.lib_path()))
-    missing = [s for s in sorted(declared) if not hasattr(L, s)]
-    assert not missing, missing
-    assert set(engine.EXPORTS) == declared
+    for header, exports, nmin in (("pffdtd_hip.h", engine.EXPORTS, 18), ("pffdtd_vox.h", voxelizer.EXPORTS, 5)):
+        hdr = (ROOT / "include" / header).read_text()
+        declared = set(re.findall(r"\b(pf_[a-z_0-9]+)\s*\(", hdr))
+        assert len(declared) >= nmin
+        missing = [s for s in sorted(declared) if not hasattr(L, s)]
+        assert not missing, missing
+        assert set(exports) == declared
 
 
 def test_struct_layout_matches_header():
