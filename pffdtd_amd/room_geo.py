@@ -68,8 +68,13 @@ class RoomGeo:
         print(f"--ROOM_GEO: {fstring}")
 
     def load_json(self, json_filename):
-        with open(json_filename) as f:
-            data = json.load(f)
+        if str(json_filename).endswith(".gz"):
+            import gzip
+            with gzip.open(json_filename, "rt") as f:
+                data = json.load(f)
+        else:
+            with open(json_filename) as f:
+                data = json.load(f)
         mats = data["mats_hash"]
         names = sorted(mats.keys())  # alphabetical, '_RIGID' (unmarked, index -1) last: room_geo.py:78-86
         Nmat = len(names)

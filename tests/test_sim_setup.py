@@ -1,0 +1,63 @@
+"""End-to-end `sim_setup` (scene export -> sim folder) against the reference's own sim_setup() output on coarse
+versions of its test-script configurations (tests/golden/setup_e2e_*.npz, made by make_golden_setup_e2e.py), then the
+folder is GPU-prepared and run on the HIP engine against the CPU oracle."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from pffdtd_amd import h5io, scenes
+
+GOLD = Path(__file__).resolve().parent / "golden"
+CASES = {
+    "ctk_cart": ("ctk_cart_viz", dict(duration=0.02, PPW=6.0, fmax=250.0)),
+    "ctk_fcc": ("ctk_cart_gpu", dict(source_num=2, duration=0.02, fcc_flag=True, PPW=6.0, fmax=350.0)),
+    "mv_fcc": ("mv_fcc_gpu", dict(duration=0.01, PPW=5.0, fmax=500.0)),
+}
+
+
+def test_scene_configs_name_the_reference_test_scripts():
+    assert set(scenes.CONFIGS) == {"ctk_cart_viz", "ctk_cart_gpu", "mv_fcc_gpu", "mv_fcc_viz"}
+    assert scenes.model_path("CTK").exists() and scenes.model_path("MV").exists()
+    z = np.load(GOLD / "materials_DEF.npz")
+    for cfg in scenes.CONFIGS.values():
+        assert set(cfg["mat_files_dict"].values()) <= set(z.files)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", [t for t in CASES if (GOLD / f"setup_e2e_{t}.npz").exists()])
+def test_sim_setup_matches_reference_folder(tag, tmp_path):
+    from pffdtd_amd.sim_setup import sim_setup
+    g = np.load(GOLD / f"setup_e2e_{tag}.npz")
+    name, override = CASES[tag]
+    mats = scenes.write_materials(tmp_path / "materials")
+    folder = tmp_path / "sim"
+    sim_setup(**scenes.setup_kwargs(name, folder, mats, compress=0, **override))
+    for key in g.files:
+        f, ds = key.split("/")
+        got = np.asarray(h5io.read(folder / f"{f}.h5", ds))
+        want = g[key]
+        if key == "vox_out/adj_bn":
+            got = np.packbits(got.astype(bool), axis=1, bitorder="little")
+        assert got.shape == want.shape, key
+        assert np.array_equal(got, want), key  # bit-exact, doubles included
+
+
+@pytest.mark.gpu
+def test_setup_to_engine_end_to_end(tmp_path):
+    """scene export -> sim_setup (+GPU prep) -> HIP engine, against the CPU oracle on the same folder."""
+    import oracle
+    from pffdtd_amd import engine, sim_data
+    from pffdtd_amd.sim_setup import sim_setup
+    mats = scenes.write_materials(tmp_path / "materials")
+    folder, gpu = tmp_path / "sim", tmp_path / "gpu"
+    sim_setup(**scenes.setup_kwargs("ctk_cart_gpu", folder, mats, save_folder_gpu=gpu, compress=0, duration=0.03, PPW=6.0, fmax=300.0))
+    for prec in ("single", "double"):
+        sd = sim_data.SimData.from_folder(gpu, prec)
+        sd.scale_input()
+        ref = sim_data.SimData.from_folder(gpu, prec)
+        ref.scale_input()
+        oracle.run_sim(ref)
+        engine.run_sim(sd)
+        assert np.abs(ref.u_out).max() > 0
+        assert np.array_equal(sd.u_out, ref.u_out), prec
