@@ -17,7 +17,7 @@ import oracle
 from pffdtd_amd import sim_data, synth
 
 GOLDEN = Path(__file__).resolve().parent / "golden"
-FIXTURES = sorted(p for p in GOLDEN.glob("*.npz") if not p.name.startswith(("energy_", "setup_", "post_", "vox_")))
+FIXTURES = sorted(p for p in GOLDEN.glob("*.npz") if p.stem.endswith(("_single", "_double")) and not p.name.startswith("energy_"))
 
 
 def _digest(sim):
