@@ -206,8 +206,8 @@ class SimData:
         return sd
 
     @classmethod
-    def from_folder(cls, data_dir, precision="double"):
-        sd = cls.from_sim(synth.read_folder(data_dir), precision)
+    def from_folder(cls, data_dir, precision="double", build_mask=True):
+        sd = cls.from_sim(synth.read_folder(data_dir), precision, build_mask=build_mask)
         sd.data_dir = Path(data_dir)
         return sd
 

@@ -72,13 +72,18 @@ CASES = [  # tag, h, fcc, az_el, Nh
     ("ctk_cart_h0915", 0.0915, False, [0.0, 0.0], None),  # BASELINE cfg1 spacing (test_script_CTK_cart_viz.py)
     # BASELINE cfg2 (test_script_CTK_cart_gpu.py: fmax=1400, PPW=10.5 -> h = c/(fmax*PPW), 894x579x309): digests only
     ("ctk_cart_cfg2_digest", 343.2 / (1400.0 * 10.5), False, [0.0, 0.0], None),
+    # Musikverein export (32k triangles, mostly chairs): coarse full arrays + test_script_MV_fcc_viz.py resolution digests
+    ("mv_fcc_h20", 0.20, True, [0.0, 0.0], None),
+    ("mv_cart_h25", 0.25, False, [0.0, 0.0], None),
+    ("mv_fcc_viz_digest", 343.2 / (1000.0 * 5.6), True, [0.0, 0.0], None),
 ]
+MV_MODEL = REF / "data/models/Musikverein_ConcertHall/model_export.json"
 only = sys.argv[1:]
 for tag, h, fcc, az_el, Nh in CASES:
     if only and tag not in only:
         continue
     t0 = time.time()
-    rg = RoomGeo(str(MODEL), az_el=az_el)
+    rg = RoomGeo(str(MV_MODEL if tag.startswith("mv_") else MODEL), az_el=az_el)
     cg = CartGrid(h=h, offset=3.5, bmin=rg.bmin, bmax=rg.bmax, fcc=fcc)
     vg = VoxGrid(rg, cg, Nh=Nh)
     vg.fill(Nprocs=1)
