@@ -17,13 +17,14 @@ from pffdtd_amd import h5io, setup_io
 from pffdtd_amd.room_geo import RoomGeo, tris_precompute
 
 GOLD = Path(__file__).resolve().parent / "golden"
-MODEL = GOLD / "models" / "CTK_Church_model_export.json"
+MODELS = {"ctk": GOLD / "models" / "CTK_Church_model_export.json", "mv": GOLD / "models" / "MV_model_export.json.gz"}
 SMALL = ["ctk_cart_h40", "ctk_fcc_h40", "ctk_cart_h25_rot", "ctk_fcc_h30_rot"]
+MV = ["mv_fcc_h20", "mv_cart_h25"]  # Musikverein export: 32k triangles (rows of chairs)
 
 
 def scene(tag):
     g = np.load(GOLD / f"vox_{tag}.npz")
-    rg = RoomGeo(str(MODEL), az_el=tuple(g["az_el"]))
+    rg = RoomGeo(str(MODELS[tag.split("_")[0]]), az_el=tuple(g["az_el"]))
     cg = setup_io.CartGrid(h=float(g["h"]), offset=3.5, bmin=rg.bmin, bmax=rg.bmax, fcc=bool(g["fcc"]))
     return g, rg, cg
 
@@ -33,7 +34,7 @@ def bits_of(adj):
     return (adj.astype(np.uint16) << np.arange(NN, dtype=np.uint16)).sum(axis=1).astype(np.uint16)
 
 
-@pytest.mark.parametrize("tag", SMALL + ["ctk_cart_h0915"])
+@pytest.mark.parametrize("tag", SMALL + ["ctk_cart_h0915"] + MV)
 def test_room_geo_and_grid_match_reference(tag):
     g, rg, cg = scene(tag)
     assert np.array_equal(rg.bmin, g["bmin"]) and np.array_equal(rg.bmax, g["bmax"])
@@ -45,7 +46,7 @@ def test_room_geo_and_grid_match_reference(tag):
     assert np.array_equal(np.array([cg.xv[0], cg.yv[0], cg.zv[0]]), g["xyzmin"])
 
 
-@pytest.mark.parametrize("tag", SMALL + ["ctk_cart_h0915"])
+@pytest.mark.parametrize("tag", SMALL + ["ctk_cart_h0915", "mv_cart_h25"])
 def test_oracle_pinned_to_reference_voxelizer(tag):
     g, rg, cg = scene(tag)
     fcc, h = bool(g["fcc"]), float(g["h"])
@@ -88,7 +89,7 @@ def test_oracle_partition_independence():
 
 # ------------------------------------------------------------------ GPU ------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", SMALL + ["ctk_cart_h0915"])
+@pytest.mark.parametrize("tag", SMALL + ["ctk_cart_h0915"] + MV)
 def test_hip_voxelizer_matches_reference(tag):
     from pffdtd_amd.voxelizer import VoxScene
     g, rg, cg = scene(tag)
@@ -98,7 +99,7 @@ def test_hip_voxelizer_matches_reference(tag):
     assert np.array_equal(bits_of(vs.adj_bn), g["adj_bits"])
     assert np.array_equal(vs.mat_bn, g["mat_bn"])
     assert np.array_equal(vs.saf_bn, g["saf_bn"])
-    assert vs.check_adj_full() == 0
+    assert vs.check_adj_full() <= (0 if tag.startswith("ctk") else 4)  # the reference's own output; see sim_setup.py
 
 
 @pytest.mark.gpu
