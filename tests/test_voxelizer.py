@@ -99,7 +99,7 @@ def test_hip_voxelizer_matches_reference(tag):
     assert np.array_equal(bits_of(vs.adj_bn), g["adj_bits"])
     assert np.array_equal(vs.mat_bn, g["mat_bn"])
     assert np.array_equal(vs.saf_bn, g["saf_bn"])
-    assert vs.check_adj_full() <= (0 if tag.startswith("ctk") else 4)  # the reference's own output; see sim_setup.py
+    assert vs.check_adj_full() <= (0 if tag.startswith("ctk") else 16)  # the reference's own output; see sim_setup.py
 
 
 @pytest.mark.gpu
@@ -143,3 +143,17 @@ def test_hip_voxelizer_cfg2_resolution_digests(tmp_path):
     assert np.array_equal(h5io.read(f, "bn_ixyz"), vs.bn_ixyz)
     assert np.array_equal(h5io.read(f, "adj_bn").astype(bool), vs.adj_bn)
     assert int(h5io.read(f, "Nb")) == vs.bn_ixyz.size and int(h5io.read(f, "Nx")) == 894
+
+
+@pytest.mark.gpu
+def test_hip_voxelizer_mv_viz_resolution_digests():
+    """Musikverein at the spacing of test_script_MV_fcc_viz.py (836x328x254 FCC, 1.57 M boundary nodes): SHA-256 of the
+    reference's arrays (436 s on one core there)."""
+    from pffdtd_amd.voxelizer import VoxScene
+    g, rg, cg = scene("mv_fcc_viz_digest")
+    assert [cg.Nx, cg.Ny, cg.Nz] == g["Nxyz"].tolist()
+    vs = VoxScene(rg, cg, fcc=True)
+    vs.calc_adj()
+    assert vs.bn_ixyz.size == int(g["Nb"])
+    for name, arr in (("bn_ixyz", vs.bn_ixyz), ("adj_bits", bits_of(vs.adj_bn)), ("mat_bn", vs.mat_bn), ("saf_bn", vs.saf_bn)):
+        assert hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest() == str(g[name + "_sha256"]), name
