@@ -484,13 +484,37 @@ template <typename Real> struct Engine : EngineBase {
       return std::max(1, std::min(chunk, nplanes));
    }
 
+   // Lanes per row segment of the barrier-free kernels: 64 lanes x 16 B = 1 KiB of z per wave row wastes lanes on narrow
+   // grids (Nz=309 -> pitch 320: two 256-column segments, 62 % used).  With 32 or 16 lanes per segment a wave stacks 2 or
+   // 4 segments in y instead; pick the width with the least padding (ties: the widest).
+   int pick_lw() const {
+      constexpr int V = pf::VecOf<Real>::V;
+      if (op.debug & 0x300) return (op.debug & 0x100) ? 32 : 16; // tuning override
+      int best = 64;
+      int64_t best_w = cdiv(P, (int64_t)64 * V) * 64 * V;
+      for (int lw : {32, 16}) {
+         const int64_t w = cdiv(P, (int64_t)lw * V) * lw * V;
+         if (w < best_w) { best_w = w; best = lw; }
+      }
+      return best;
+   }
    template <int R, int WY, int WZ> void launch_air_cfg(hipStream_t s, int xb, int xe) {
+      if constexpr (R == 4 && WY == 4 && WZ == 1) {
+         if (use_dpp && !(op.debug & 0x400)) {
+            const int lw = pick_lw();
+            if (lw == 32) return launch_air_cfg_lw<R, WY, WZ, 32>(s, xb, xe);
+            if (lw == 16) return launch_air_cfg_lw<R, WY, WZ, 16>(s, xb, xe);
+         }
+      }
+      launch_air_cfg_lw<R, WY, WZ, 64>(s, xb, xe);
+   }
+   template <int R, int WY, int WZ, int LW> void launch_air_cfg_lw(hipStream_t s, int xb, int xe) {
       constexpr int V = pf::VecOf<Real>::V;
       pf::AirParams ap;
       ap.Ny = Ny; ap.P = P; ap.plane = plane;
       ap.x_begin = xb; ap.x_end = xe;
-      ap.nzt = (int)cdiv(P, (int64_t)WZ * 64 * V);
-      ap.nyt = (int)cdiv(Ny - 2, (int64_t)WY * R);
+      ap.nzt = (int)cdiv(P, (int64_t)WZ * LW * V);
+      ap.nyt = (int)cdiv(Ny - 2, (int64_t)WY * R * (64 / LW));
       const int nplanes = xe - xb;
       const int chunk = pick_chunk(nplanes, (int64_t)ap.nzt * ap.nyt, false);
       ap.chunk = chunk;
@@ -500,15 +524,20 @@ template <typename Real> struct Engine : EngineBase {
       const uint32_t total = (uint32_t)ap.nzt * ap.nyt * ap.nxc;
       dim3 g(total), b(64 * WY * WZ);
       const bool fma = op.numerics == PF_NUM_FMA;
-#define PF_LAUNCH(K, FMA, DPP) do { if (vg) hipLaunchKernelGGL((K<Real, R, WY, WZ, FMA, DPP, true>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l); \
-                                    else if (abck) hipLaunchKernelGGL((K<Real, R, WY, WZ, FMA, DPP, false, true>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l); \
-                                    else hipLaunchKernelGGL((K<Real, R, WY, WZ, FMA, DPP, false>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l); } while (0)
-      if (fcc) {
-         if (fma) { if (use_dpp) PF_LAUNCH(pf::k_air_fcc, true, true); else PF_LAUNCH(pf::k_air_fcc, true, false); }
-         else { if (use_dpp) PF_LAUNCH(pf::k_air_fcc, false, true); else PF_LAUNCH(pf::k_air_fcc, false, false); }
-      } else {
-         if (fma) { if (use_dpp) PF_LAUNCH(pf::k_air_cart, true, true); else PF_LAUNCH(pf::k_air_cart, true, false); }
-         else { if (use_dpp) PF_LAUNCH(pf::k_air_cart, false, true); else PF_LAUNCH(pf::k_air_cart, false, false); }
+#define PF_LAUNCH(K, FMA, DPP) do { if (vg) hipLaunchKernelGGL((K<Real, R, WY, WZ, FMA, DPP, true, false, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l); \
+                                    else if (abck) hipLaunchKernelGGL((K<Real, R, WY, WZ, FMA, DPP, false, true, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l); \
+                                    else hipLaunchKernelGGL((K<Real, R, WY, WZ, FMA, DPP, false, false, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l); } while (0)
+      if constexpr (LW == 64) {
+         if (fcc) {
+            if (fma) { if (use_dpp) PF_LAUNCH(pf::k_air_fcc, true, true); else PF_LAUNCH(pf::k_air_fcc, true, false); }
+            else { if (use_dpp) PF_LAUNCH(pf::k_air_fcc, false, true); else PF_LAUNCH(pf::k_air_fcc, false, false); }
+         } else {
+            if (fma) { if (use_dpp) PF_LAUNCH(pf::k_air_cart, true, true); else PF_LAUNCH(pf::k_air_cart, true, false); }
+            else { if (use_dpp) PF_LAUNCH(pf::k_air_cart, false, true); else PF_LAUNCH(pf::k_air_cart, false, false); }
+         }
+      } else { // narrow row segments: DPP builds only
+         if (fcc) { if (fma) PF_LAUNCH(pf::k_air_fcc, true, true); else PF_LAUNCH(pf::k_air_fcc, false, true); }
+         else { if (fma) PF_LAUNCH(pf::k_air_cart, true, true); else PF_LAUNCH(pf::k_air_cart, false, true); }
       }
 #undef PF_LAUNCH
    }

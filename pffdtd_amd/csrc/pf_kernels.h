@@ -105,7 +105,7 @@ struct AirParams {
 // cells, cf. pf_air_fused.h) and the ABC loss is applied in-kernel, so no flip / ABC kernels run around it.
 // ABCK = true (without VG): only the ABC loss moves in-kernel; the ghost shell is still maintained in memory by the
 // flip kernels (cheaper than VG's per-row patches for the 13-point kernel).
-template <typename Real, int R, int WY, int WZ, bool FMA, bool DPP, bool VG = false, bool ABCK = false>
+template <typename Real, int R, int WY, int WZ, bool FMA, bool DPP, bool VG = false, bool ABCK = false, int LW = 64>
 __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restrict__ u1, Real *__restrict__ u0,
                                                           const uint8_t *__restrict__ mask, Real a1, Real a2,
                                                           AirParams ap, Real labc) {
@@ -117,18 +117,22 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
    const int zt = b % ap.nzt;
    const int yt = (b / ap.nzt) % ap.nyt;
    const int xc = b / (ap.nzt * ap.nyt);
-   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   // LW lanes span a row segment; a wave stacks 64/LW such segments in y (LW < 64: narrow grids, cf. Engine::pick_lw)
+   static_assert(LW == 64 || LW == 32 || LW == 16, "row segments are 64, 32 or 16 lanes wide");
+   constexpr int NSUB = 64 / LW;
+   const int wlane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   const int lane = wlane % LW, sub = wlane / LW; // `lane` = position inside the row segment
    const int wz = wave % WZ, wy = wave / WZ;
-   const int64_t z0 = ((int64_t)(zt * WZ + wz) * 64 + lane) * V;
-   const int64_t y0 = 1 + (int64_t)(yt * WY + wy) * R;
+   const int64_t z0 = ((int64_t)(zt * WZ + wz) * LW + lane) * V;
+   const int64_t y0 = 1 + ((int64_t)(yt * WY + wy) * NSUB + sub) * R;
    const int xs = ap.x_begin + xc * ap.chunk;
    const int xe = min(xs + ap.chunk, ap.x_end);
    const int64_t Ny = ap.Ny, P = ap.P, plane = ap.plane;
    const bool active = z0 < P;
-   if (y0 > Ny - 2) return; // whole wave out of rows (uniform per wave)
+   if (y0 - (int64_t)sub * R > Ny - 2) return; // whole wave out of rows (uniform per wave)
    const int64_t zl = active ? z0 : 0; // inactive lanes read column 0 (in range), never store
    const bool need_l = (lane == 0) && (z0 > 0);
-   const bool need_r = (lane == 63) && (z0 + V < P);
+   const bool need_r = (lane == LW - 1) && (z0 + V < P);
 
    // row offsets inside a plane, clamped so that halo/invalid rows stay in range
    auto rowsrc = [&](int64_t y) -> int64_t {
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
          Real zm = lane_from_lower<DPP>(c[V - 1]);
          Real zp = lane_from_upper<DPP>(c[0]);
          if (lane == 0) zm = curL[r];
-         if (lane == 63) zp = curR[r];
+         if (lane == LW - 1) zp = curR[r];
          if (fixR) zp = c[V - 2]; // my right neighbour is the ghost column
          const uint32_t bits = mb[r] >> (uint32_t)(soff[r] & 7);
          vec o;
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
 // Same marching scheme; all three planes keep R+2 rows, and every row used with a z offset gets its wave-edge
 // columns from the edge lanes.
 // =============================================================================================================
-template <typename Real, int R, int WY, int WZ, bool FMA, bool DPP, bool VG = false, bool ABCK = false>
+template <typename Real, int R, int WY, int WZ, bool FMA, bool DPP, bool VG = false, bool ABCK = false, int LW = 64>
 __global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict__ u1, Real *__restrict__ u0,
                                                          const uint8_t *__restrict__ mask, Real a1, Real a2,
                                                          AirParams ap, Real labc) {
@@ -280,18 +284,22 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict
    const int zt = b % ap.nzt;
    const int yt = (b / ap.nzt) % ap.nyt;
    const int xc = b / (ap.nzt * ap.nyt);
-   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   // LW lanes span a row segment; a wave stacks 64/LW such segments in y (LW < 64: narrow grids, cf. Engine::pick_lw)
+   static_assert(LW == 64 || LW == 32 || LW == 16, "row segments are 64, 32 or 16 lanes wide");
+   constexpr int NSUB = 64 / LW;
+   const int wlane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   const int lane = wlane % LW, sub = wlane / LW; // `lane` = position inside the row segment
    const int wz = wave % WZ, wy = wave / WZ;
-   const int64_t z0 = ((int64_t)(zt * WZ + wz) * 64 + lane) * V;
-   const int64_t y0 = 1 + (int64_t)(yt * WY + wy) * R;
+   const int64_t z0 = ((int64_t)(zt * WZ + wz) * LW + lane) * V;
+   const int64_t y0 = 1 + ((int64_t)(yt * WY + wy) * NSUB + sub) * R;
    const int xs = ap.x_begin + xc * ap.chunk;
    const int xe = min(xs + ap.chunk, ap.x_end);
    const int64_t Ny = ap.Ny, P = ap.P, plane = ap.plane;
    const bool active = z0 < P;
-   if (y0 > Ny - 2) return;
+   if (y0 - (int64_t)sub * R > Ny - 2) return;
    const int64_t zl = active ? z0 : 0;
    const bool need_l = (lane == 0) && (z0 > 0);
-   const bool need_r = (lane == 63) && (z0 + V < P);
+   const bool need_r = (lane == LW - 1) && (z0 + V < P);
 
    auto rowsrc = [&](int64_t y) -> int64_t {
       if (y > Ny - 1) y = Ny - 1;
@@ -380,7 +388,7 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict
       };
       auto shift_hi = [&](const vec &v, Real edge) {
          Real zp = lane_from_upper<DPP>(v[0]);
-         if (lane == 63) zp = edge;
+         if (lane == LW - 1) zp = edge;
          if (fixR) zp = v[V - 2]; // my right neighbour is the ghost column
          vec s;
 #pragma unroll
