@@ -3,10 +3,11 @@ on top of pffdtd_amd.h5io -- recombination of the 8-node receivers with `out_alp
 source differentiation), optional symmetric low-pass, resampling, WAV / h5 export.
 
     python -m pffdtd_amd.process_outputs --data_dir D [--fcut_lowcut 10 --N_order_lowcut 4 --fcut_lowpass F
-                                         --N_order_lowpass 8 --symmetric_lowpass --resample_Fs 48000 --save_wav]
+                                         --N_order_lowpass 8 --symmetric_lowpass --resample_Fs 48000 --save_wav
+                                         --air_abs_filter stokes|modal|OLA]
 
-Differences from the reference: resampling uses scipy's polyphase `resample_poly` (resampy is not available here; the
-reference uses resampy 'kaiser_best'), and the air-absorption filters (python/air_abs/*) are out of scope.
+Difference from the reference: resampling uses scipy's polyphase `resample_poly` (resampy is not available here; the
+reference uses resampy 'kaiser_best').  The air-absorption filters are in pffdtd_amd/air_abs.py.
 """
 import argparse
 from fractions import Fraction
@@ -76,6 +77,23 @@ class ProcessOutputs:
         self.Fs_f = self.Fs * fr.numerator / fr.denominator
         self.Ts_f, self.Nt_f = 1 / self.Fs_f, self.r_out_f.shape[-1]
 
+    def _air(self, name, fn, **kw):
+        from . import air_abs
+        if self.Tc is None or self.rh is None:
+            raise ValueError("sim_consts.h5 must hold Tc and rh for the air-absorption filters")
+        self.print(f"applying {name} air absorption filter")
+        self.r_out_f = getattr(air_abs, fn)(self.r_out_f, self.Fs_f, Tc=self.Tc, rh=self.rh, **kw)
+        self.Nt_f = self.r_out_f.shape[-1]  # the filters lengthen the responses
+
+    def apply_stokes_filter(self, NdB=120):  # process_outputs.py:169-180
+        self._air("Stokes'", "apply_visco_filter", NdB=NdB)
+
+    def apply_modal_filter(self):  # :182-193
+        self._air("modal", "apply_modal_filter")
+
+    def apply_ola_filter(self):  # :195-206
+        self._air("OLA", "apply_ola_filter")
+
     def save_wav(self):
         from scipy.io.wavfile import write as wavwrite
         r = np.atleast_2d(self.r_out_f)
@@ -101,6 +119,7 @@ def main():
     p.add_argument("--N_order_lowpass", type=int, default=8)
     p.add_argument("--symmetric_lowpass", action="store_true")
     p.add_argument("--save_wav", action="store_true")
+    p.add_argument("--air_abs_filter", type=str, default="none", help="stokes, modal, OLA, or none")
     a = p.parse_args()
     po = ProcessOutputs(a.data_dir)
     po.initial_process(fcut=a.fcut_lowcut, N_order=a.N_order_lowcut)
@@ -108,6 +127,15 @@ def main():
         po.apply_lowpass(fcut=a.fcut_lowpass, N_order=a.N_order_lowpass, symmetric=a.symmetric_lowpass)
     if a.resample_Fs:
         po.resample(a.resample_Fs)
+    flt = a.air_abs_filter.lower()  # process_outputs.py:338-343
+    if flt == "modal":
+        po.apply_modal_filter()
+    elif flt == "stokes":
+        po.apply_stokes_filter()
+    elif flt == "ola":
+        po.apply_ola_filter()
+    elif flt != "none":
+        raise SystemExit("--air_abs_filter: stokes, modal, OLA or none")
     po.save_h5()
     if a.save_wav:
         po.save_wav()
