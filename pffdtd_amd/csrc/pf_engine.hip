@@ -1119,10 +1119,21 @@ double pf_tb2_probe(const void *A, const void *B, void *C, void *D, int64_t Nx, 
    auto launch = [&]() {
       if (tye == 20) { tp.nyt = (int)cdiv(Ny - 2 * margin, 16); hipLaunchKernelGGL((pf::k_tb2_proto<20, 8>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(512), 0, 0, tp, (float)a1, (float)a2); return true; }
       if (tye == 12) { tp.nyt = (int)cdiv(Ny - 2 * margin, 8); hipLaunchKernelGGL((pf::k_tb2_proto<12, 4>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
+      // register-resident variants: tye = 100*R + WY
+      if (tye == 204) { tp.nyt = (int)cdiv(Ny - 2 * margin, 8); hipLaunchKernelGGL((pf::k_tb2_reg<2, 4>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 202) { tp.nyt = (int)cdiv(Ny - 2 * margin, 4); hipLaunchKernelGGL((pf::k_tb2_reg<2, 2>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(128), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 104) { tp.nyt = (int)cdiv(Ny - 2 * margin, 4); hipLaunchKernelGGL((pf::k_tb2_reg<1, 4>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 304) { tp.nyt = (int)cdiv(Ny - 2 * margin, 12); hipLaunchKernelGGL((pf::k_tb2_reg<3, 4>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 1308) { tp.nyt = (int)cdiv(Ny - 2 * margin, 24); hipLaunchKernelGGL((pf::k_tb2_reg<3, 8, false>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(512), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 1304) { tp.nyt = (int)cdiv(Ny - 2 * margin, 12); hipLaunchKernelGGL((pf::k_tb2_reg<3, 4, false>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 308) { tp.nyt = (int)cdiv(Ny - 2 * margin, 24); hipLaunchKernelGGL((pf::k_tb2_reg<3, 8>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(512), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 302) { tp.nyt = (int)cdiv(Ny - 2 * margin, 6); hipLaunchKernelGGL((pf::k_tb2_reg<3, 2>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(128), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 408) { tp.nyt = (int)cdiv(Ny - 2 * margin, 32); hipLaunchKernelGGL((pf::k_tb2_reg<4, 8>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(512), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 404) { tp.nyt = (int)cdiv(Ny - 2 * margin, 16); hipLaunchKernelGGL((pf::k_tb2_reg<4, 4>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
       if (tye == 24) { tp.nyt = (int)cdiv(Ny - 2 * margin, 20); hipLaunchKernelGGL((pf::k_tb2_proto<24, 8>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(512), 0, 0, tp, (float)a1, (float)a2); return true; }
       return false;
    };
-   if (!launch()) { set_err(PF_ERR_ARG, "tb2 probe: tye must be 12, 20 or 24"); return -1.0; }
+   if (!launch()) { set_err(PF_ERR_ARG, "tb2 probe: tye must be 12, 20, 24 (LDS) or 100*R+WY (registers)"); return -1.0; }
    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { set_err(PF_ERR_HIP, "tb2 probe launch failed"); return -1.0; }
    hipEventRecord(e0, 0);
    for (int i = 0; i < reps; i++) launch();

@@ -113,4 +113,100 @@ __global__ __launch_bounds__(64 * WAVES) void k_tb2_proto(Tb2Params tp, float a1
    }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_tb2_reg -- the same two-steps-per-pass scheme with every operand in registers (no LDS, no barriers).
+// A wave owns 256 columns x R rows of the u^{n+2} output and marches x.  Lanes 0 and 63 are z halo (their u^{n+1}
+// values feed lanes 1 / 62 through the DPP wave shifts), so tiles overlap by 8 columns; in y every lane computes
+// u^{n+1} on its R rows + 1 above + 1 below from u^n rows R+4 (halo rows re-read through L1/L2 by the waves above and
+// below).  Per plane and lane: R+4 row loads of u^n, R+2 of u^{n-1}, R stores of u^{n+1}, R of u^{n+2}.
+// ---------------------------------------------------------------------------------------------------------------
+template <int R, int WY, bool NTA = true>
+__global__ __launch_bounds__(64 * WY) void k_tb2_reg(Tb2Params tp, float a1, float a2) {
+   typedef f32x4 vec;
+   const uint32_t b = blockIdx.x; // plain order: the XCD swizzle of the single-step kernels costs 12 % here (measured)
+   const int zt = b % tp.nzt, yt = (b / tp.nzt) % tp.nyt, xc = b / (tp.nzt * tp.nyt);
+   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+   const int ze0 = tp.z_begin - 4 + zt * 248;
+   const int yo = tp.y_begin + (yt * WY + w) * R;           // first output row of this wave
+   const int xs = tp.x_begin + xc * tp.chunk, xe = min(xs + tp.chunk, tp.x_end);
+   const int P = tp.P;
+   const int64_t plane = tp.plane;
+   const int zc = min(max(ze0 + lane * 4, 0), P - 4);
+   int64_t offB[R + 4];                                       // rows yo-2 .. yo+R+1
+#pragma unroll
+   for (int i = 0; i < R + 4; i++) offB[i] = (int64_t)min(max(yo - 2 + i, 0), tp.Ny - 1) * P + zc;
+   const bool core_col = (lane >= 1 && lane <= 62) && (ze0 + lane * 4 + 3 < tp.Nz - tp.z_begin);
+   bool core_row[R];
+#pragma unroll
+   for (int r = 0; r < R; r++) core_row[r] = (yo + r < tp.Ny - tp.y_begin);
+
+   auto loadB = [&](int x, vec *d) {
+      const float *pl = tp.B + (int64_t)x * plane;
+#pragma unroll
+      for (int i = 0; i < R + 4; i++) d[i] = *(const vec *)(pl + offB[i]);
+   };
+   auto loadA = [&](int x, vec *d) { // rows yo-1 .. yo+R
+      const float *pl = tp.A + (int64_t)x * plane;
+#pragma unroll
+      for (int j = 0; j < R + 2; j++) d[j] = NTA ? __builtin_nontemporal_load((const vec *)(pl + offB[j + 1])) : *(const vec *)(pl + offB[j + 1]);
+   };
+   auto stencil = [&](const vec &c, const vec &xp, const vec &xm, const vec &yp, const vec &ym, const vec &old) {
+      const float lf = lane_from_lower<true>(c[3]);
+      const float rt = lane_from_upper<true>(c[0]);
+      vec o;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+         const float zp = (i == 3) ? rt : c[i < 3 ? i + 1 : 3];
+         const float zm = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
+         float p = a1 * c[i] - old[i];
+         p = p + a2 * xp[i]; p = p + a2 * xm[i]; p = p + a2 * yp[i]; p = p + a2 * ym[i]; p = p + a2 * zp; p = p + a2 * zm;
+         o[i] = p;
+      }
+      return o;
+   };
+
+   vec Bp[R + 2], Bc[R + 4], Bn[R + 4], Bnn[R + 4], Ar[R + 2], Arn[R + 2];
+   vec vm[R], vc[R + 2], vn[R + 2];
+   {
+      vec t[R + 4];
+      loadB(xs - 2, t);
+#pragma unroll
+      for (int j = 0; j < R + 2; j++) Bp[j] = t[j + 1];
+      loadB(xs - 1, Bc);
+      loadB(xs, Bn);
+      loadA(xs - 1, Ar);
+   }
+#pragma unroll
+   for (int r = 0; r < R; r++) vm[r] = vec{0, 0, 0, 0};
+#pragma unroll
+   for (int j = 0; j < R + 2; j++) vc[j] = vec{0, 0, 0, 0};
+   for (int x1 = xs - 1; x1 <= xe; x1++) {                    // x1: plane of the u^{n+1} values computed this turn
+      if (x1 < xe) { loadB(x1 + 2, Bnn); loadA(x1 + 1, Arn); }
+      // stage 1: u^{n+1}(x1) on rows yo-1 .. yo+R
+#pragma unroll
+      for (int j = 0; j < R + 2; j++) vn[j] = stencil(Bc[j + 1], Bn[j + 1], Bp[j], Bc[j + 2], Bc[j], Ar[j]);
+      if (x1 >= xs && x1 < xe) {
+         float *pc = tp.C + (int64_t)x1 * plane;
+#pragma unroll
+         for (int r = 0; r < R; r++)
+            if (core_col && core_row[r]) __builtin_nontemporal_store(vn[r + 1], (vec *)(pc + offB[r + 2]));
+      }
+      // stage 2: u^{n+2}(x1-1) from u^{n+1} planes x1-2 (vm), x1-1 (vc), x1 (vn) and u^n plane x1-1 (Bp)
+      if (x1 - 1 >= xs) {
+         float *pd = tp.D + (int64_t)(x1 - 1) * plane;
+#pragma unroll
+         for (int r = 0; r < R; r++) {
+            const vec o = stencil(vc[r + 1], vn[r + 1], vm[r], vc[r + 2], vc[r], Bp[r + 1]);
+            if (core_col && core_row[r]) __builtin_nontemporal_store(o, (vec *)(pd + offB[r + 2]));
+         }
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) vm[r] = vc[r + 1];
+#pragma unroll
+      for (int j = 0; j < R + 2; j++) { vc[j] = vn[j]; Bp[j] = Bc[j + 1]; Ar[j] = Arn[j]; }
+#pragma unroll
+      for (int i = 0; i < R + 4; i++) { Bc[i] = Bn[i]; Bn[i] = Bnn[i]; }
+   }
+}
+
 } // namespace pf

@@ -40,8 +40,8 @@ ref_n1 = g[0].clone().view(n, n, P)   # u^{n+1}: written into u0's array at step
 ref_n2 = g[1].clone().view(n, n, P)
 # engine state after 2 steps: u1 = u^{n+2}; which storage? step0 writes n+1 into g[0]; step1 writes n+2 into g[1]
 g[0].copy_(A0); g[1].copy_(B0); g[2].zero_(); g[3].zero_()
-for tye in (12, 20, 24):
-    for chunk in (32, 128):
+for tye in [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "204,304,404,308,302,408".split(","))]:
+    for chunk in [int(v) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else "16,32,64".split(","))]:
         ms = L.pf_tb2_probe(g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), g[3].data_ptr(), n, n, n, float(sd.a1), float(sd.a2), m, tye, chunk, 5)
         if ms < 0:
             print("probe failed:", L.pf_last_error().decode()); continue
