@@ -490,11 +490,16 @@ template <typename Real> struct Engine : EngineBase {
    int pick_lw() const {
       constexpr int V = pf::VecOf<Real>::V;
       if (op.debug & 0x300) return (op.debug & 0x100) ? 32 : 16; // tuning override
+      // narrower segments cost extra edge-column loads (two per segment and row; the 13-point kernel needs them on every
+      // row of all three planes): worth it only when they save >= 10 % of the padded width (7-point) / 25 % (13-point);
+      // measured: Nz=309 7-pt +10 % with 16 lanes, Nz=850 13-pt -4 % with 32 lanes
+      const int64_t w64 = cdiv(P, (int64_t)64 * V) * 64 * V;
+      const double need = fcc ? 0.75 : 0.90;
       int best = 64;
-      int64_t best_w = cdiv(P, (int64_t)64 * V) * 64 * V;
+      int64_t best_w = w64;
       for (int lw : {32, 16}) {
          const int64_t w = cdiv(P, (int64_t)lw * V) * lw * V;
-         if (w < best_w) { best_w = w; best = lw; }
+         if (w < best_w && (double)w <= need * (double)w64) { best_w = w; best = lw; }
       }
       return best;
    }
