@@ -78,12 +78,18 @@ CASES = [  # tag, h, fcc, az_el, Nh
     ("mv_fcc_viz_digest", 343.2 / (1000.0 * 5.6), True, [0.0, 0.0], None),
 ]
 MV_MODEL = REF / "data/models/Musikverein_ConcertHall/model_export.json"
+OPEN_MODEL = HERE / "models" / "open_scene.json"  # make_open_scene.py: _RIGID triangles, open top, custom bounds
+OPEN_BOUNDS = (np.array([-0.4, -0.4, -0.3]), np.array([4.5, 3.7, 3.4]))
+CASES += [("open_cart_h10", 0.10, False, [0.0, 0.0], None), ("open_fcc_h12", 0.12, True, [20.0, 0.0], None)]
 only = sys.argv[1:]
 for tag, h, fcc, az_el, Nh in CASES:
     if only and tag not in only:
         continue
     t0 = time.time()
-    rg = RoomGeo(str(MV_MODEL if tag.startswith("mv_") else MODEL), az_el=az_el)
+    if tag.startswith("open_"):
+        rg = RoomGeo(str(OPEN_MODEL), az_el=az_el, bmin=OPEN_BOUNDS[0].copy(), bmax=OPEN_BOUNDS[1].copy())
+    else:
+        rg = RoomGeo(str(MV_MODEL if tag.startswith("mv_") else MODEL), az_el=az_el)
     cg = CartGrid(h=h, offset=3.5, bmin=rg.bmin, bmax=rg.bmax, fcc=fcc)
     vg = VoxGrid(rg, cg, Nh=Nh)
     vg.fill(Nprocs=1)

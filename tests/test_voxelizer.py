@@ -20,11 +20,17 @@ GOLD = Path(__file__).resolve().parent / "golden"
 MODELS = {"ctk": GOLD / "models" / "CTK_Church_model_export.json", "mv": GOLD / "models" / "MV_model_export.json.gz"}
 SMALL = ["ctk_cart_h40", "ctk_fcc_h40", "ctk_cart_h25_rot", "ctk_fcc_h30_rot"]
 MV = ["mv_fcc_h20", "mv_cart_h25"]  # Musikverein export: 32k triangles (rows of chairs)
+# hand-made export (tests/golden/make_open_scene.py): unmarked _RIGID triangles, open top with custom bounds, two-sided
+# panel, tilted one-sided reflector; goldens from the reference voxelizer like the others
+OPEN = ["open_cart_h10", "open_fcc_h12"]
+OPEN_BOUNDS = (np.array([-0.4, -0.4, -0.3]), np.array([4.5, 3.7, 3.4]))
+MODELS["open"] = GOLD / "models" / "open_scene.json"
 
 
 def scene(tag):
     g = np.load(GOLD / f"vox_{tag}.npz")
-    rg = RoomGeo(str(MODELS[tag.split("_")[0]]), az_el=tuple(g["az_el"]))
+    kw = dict(bmin=OPEN_BOUNDS[0].copy(), bmax=OPEN_BOUNDS[1].copy()) if tag.startswith("open") else {}
+    rg = RoomGeo(str(MODELS[tag.split("_")[0]]), az_el=tuple(g["az_el"]), **kw)
     cg = setup_io.CartGrid(h=float(g["h"]), offset=3.5, bmin=rg.bmin, bmax=rg.bmax, fcc=bool(g["fcc"]))
     return g, rg, cg
 
@@ -34,7 +40,7 @@ def bits_of(adj):
     return (adj.astype(np.uint16) << np.arange(NN, dtype=np.uint16)).sum(axis=1).astype(np.uint16)
 
 
-@pytest.mark.parametrize("tag", SMALL + ["ctk_cart_h0915"] + MV)
+@pytest.mark.parametrize("tag", SMALL + ["ctk_cart_h0915"] + MV + OPEN)
 def test_room_geo_and_grid_match_reference(tag):
     g, rg, cg = scene(tag)
     assert np.array_equal(rg.bmin, g["bmin"]) and np.array_equal(rg.bmax, g["bmax"])
@@ -46,7 +52,7 @@ def test_room_geo_and_grid_match_reference(tag):
     assert np.array_equal(np.array([cg.xv[0], cg.yv[0], cg.zv[0]]), g["xyzmin"])
 
 
-@pytest.mark.parametrize("tag", SMALL + ["ctk_cart_h0915", "mv_cart_h25"])
+@pytest.mark.parametrize("tag", SMALL + ["ctk_cart_h0915", "mv_cart_h25"] + OPEN)
 def test_oracle_pinned_to_reference_voxelizer(tag):
     g, rg, cg = scene(tag)
     fcc, h = bool(g["fcc"]), float(g["h"])
@@ -89,7 +95,7 @@ def test_oracle_partition_independence():
 
 # ------------------------------------------------------------------ GPU ------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", SMALL + ["ctk_cart_h0915"] + MV)
+@pytest.mark.parametrize("tag", SMALL + ["ctk_cart_h0915"] + MV + OPEN)
 def test_hip_voxelizer_matches_reference(tag):
     from pffdtd_amd.voxelizer import VoxScene
     g, rg, cg = scene(tag)
@@ -99,7 +105,9 @@ def test_hip_voxelizer_matches_reference(tag):
     assert np.array_equal(bits_of(vs.adj_bn), g["adj_bits"])
     assert np.array_equal(vs.mat_bn, g["mat_bn"])
     assert np.array_equal(vs.saf_bn, g["saf_bn"])
-    assert vs.check_adj_full() <= (0 if tag.startswith("ctk") else 16)  # the reference's own output; see sim_setup.py
+    if tag.startswith("open"):
+        assert (vs.mat_bn == -1).sum() > 500 and rg.mat_str[-1] == "_RIGID"  # the rigid floor
+    assert vs.check_adj_full() <= (16 if tag.startswith("mv") else 0)  # the reference's own output; see sim_setup.py
 
 
 @pytest.mark.gpu
