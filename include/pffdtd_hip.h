@@ -104,6 +104,9 @@ typedef struct pf_timing {
    int64_t air_launches;
    double  step_ms_total;   /* sum of HIP-event durations of whole steps (pre .. readout) */
    int64_t steps;
+   double  tb2_ms_total;    /* temporal blocking: sum of the two-steps-per-pass kernel's launch durations (included in air_ms_total) */
+   int64_t tb2_launches;    /* 0 when the engine steps one step per pass */
+   int64_t tb2_cells;       /* cells that kernel advances by two steps per launch */
 } pf_timing;
 
 typedef struct pf_engine pf_engine;

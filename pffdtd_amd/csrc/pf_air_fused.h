@@ -404,6 +404,8 @@ struct LeanParams {
    int32_t first, last;
    int32_t do_abc;
    int32_t debug;           // reserved for tuning experiments (unused in production builds)
+   const void *u0_src;      // out-of-place step: u^{n-1} is read from here, u^{n+1} written to u0 (null: in place)
+   int32_t yt0;             // first y tile of this launch (row-strip launches); nyt counts from there
 };
 
 template <typename Real, int R, int WY, bool FMA, bool NT = false, bool RIG = false>
@@ -416,12 +418,13 @@ __global__ __launch_bounds__(64 * WY) void k_air_cart_lean(LeanParams fp, Real a
    __shared__ __attribute__((aligned(16))) Real lds[2][NROWS][W];
 
    const Real *__restrict__ u1 = (const Real *)fp.u1;
-   Real *__restrict__ u0 = (Real *)fp.u0;
+   Real *u0 = (Real *)fp.u0;
+   const Real *u0s = fp.u0_src ? (const Real *)fp.u0_src : (const Real *)fp.u0;
    const uint32_t total = (uint32_t)fp.nzt * fp.nyt * fp.nxc;
    uint32_t b = blockIdx.x;
    if (fp.swizzle) b = xcd_swizzle(b, total);
    const int zt = b % fp.nzt;
-   const int yt = (b / fp.nzt) % fp.nyt;
+   const int yt = fp.yt0 + (b / fp.nzt) % fp.nyt;
    const int xc = b / (fp.nzt * fp.nyt);
    const int lane = threadIdx.x & 63;
    const int w = threadIdx.x >> 6;
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(64 * WY) void k_air_cart_lean(LeanParams fp, Real a
       for (int r = 0; r < R; r++) load_own_row(pl, ro[r], d[r], dl[r], dr[r]);
    };
    auto load_old = [&](int x, vec *d, uint32_t *m) {
-      const Real *po = u0 + (int64_t)x * plane;
+      const Real *po = u0s + (int64_t)x * plane;
       const uint8_t *pm = fp.mask + (((int64_t)x * plane) >> 3);
 #pragma unroll
       for (int r = 0; r < R; r++) {

@@ -96,6 +96,7 @@ template <typename Real> struct Engine : EngineBase {
    // device state
    Real *u0 = nullptr, *u1 = nullptr;
    bool own_grids = true;
+   std::vector<Real *> own_list;
    uint8_t *mask = nullptr;      // skip-mask of the unfused kernels (boundary nodes + ghost z + pad + parity)
    uint8_t *mask_bn = nullptr;   // boundary nodes only (fused kernel)
    int32_t *segstart = nullptr;  // first boundary node of every (row, z segment) (fused rigid update)
@@ -125,13 +126,20 @@ template <typename Real> struct Engine : EngineBase {
    hipEvent_t ev_pre = nullptr, ev_edge = nullptr, ev_main = nullptr;
    bool in_step = false;
    int64_t steps_done = 0;
+   // temporal blocking (pf_tb2.h): pairs of steps over a boundary-free box, single-step strips around it
+   bool tb2 = false;
+   Real *bufC = nullptr, *bufD = nullptr;                 // the two extra state grids of the out-of-place pair
+   int tbx0 = 0, tbx1 = 0, tby0 = 0, tby1 = 0, tbz0 = 0, tbz1 = 0; // box of cells k_tb2_reg produces
+   std::vector<std::pair<int, int>> tb_xr;                // its x ranges (planes next to a source are cut out)
+   const Real *u0_src = nullptr;                          // out-of-place single-step launches read u^{n-1} here
+   int lean_yt0 = 0, lean_nyt = -1;                       // row-strip launches of the lean kernel (-1: all tiles)
    // energy diagnostic (pf_energy.h)
    Real *Lu = nullptr, *vh_old = nullptr, *u2in = nullptr;
    double *d_acc = nullptr, *d_DEF = nullptr;
    double en_h = 0, en_c = 0, en_Ts = 0;
    bool en_ready = false;
    // timing
-   std::vector<std::pair<hipEvent_t, hipEvent_t>> air_ev, step_ev, ev_pool;
+   std::vector<std::pair<hipEvent_t, hipEvent_t>> air_ev, step_ev, tb2_ev, ev_pool;
    pf_timing tm{};
 
    ~Engine() override { destroy(); }
@@ -140,12 +148,14 @@ template <typename Real> struct Engine : EngineBase {
       if (s_main) hipStreamSynchronize(s_main);
       if (s_edge) hipStreamSynchronize(s_edge);
       auto F = [](void *p) { if (p) hipFree(p); };
-      if (own_grids) { F(u0); F(u1); }
+      for (Real *g : own_list) F(g); // state grids this engine allocated (u0/u1 unless external, the temporal-blocking spares)
+      own_list.clear();
       F(d_lossy); F(mask); F(mask_bn); F(segstart); F(adj_dense); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
       F(d_beta); F(d_insig); F(d_mq); F(ub[0]); F(ub[1]); F(ub[2]); F(u2ba); F(vh1); F(gh1); F(ring);
       if (h_ring) hipHostFree(h_ring);
       for (auto &p : air_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
       for (auto &p : step_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+      for (auto &p : tb2_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
       for (auto &p : ev_pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
       if (ev_pre) hipEventDestroy(ev_pre);
       if (ev_edge) hipEventDestroy(ev_edge);
@@ -258,6 +268,7 @@ template <typename Real> struct Engine : EngineBase {
          int rc;
          if ((rc = dzalloc(&u0, npad))) return rc;
          if ((rc = dzalloc(&u1, npad))) return rc;
+         own_list.push_back(u0); own_list.push_back(u1);
       }
 
       // ---- sorted, re-based node lists ----
@@ -425,7 +436,133 @@ template <typename Real> struct Engine : EngineBase {
          if ((rc = dzalloc(&ring, Nr * ring_depth))) return rc;
          HIPCHK(hipHostMalloc((void **)&h_ring, std::max<int64_t>(Nr * ring_depth, 1) * sizeof(Real), hipHostMallocDefault));
       }
+      { int rc = init_tb2(); if (rc) return rc; }
       HIPCHK(hipDeviceSynchronize());
+      return PF_OK;
+   }
+
+   // ---------------- temporal blocking: two steps per pass over the boundary-free box ----------------
+   // Every boundary node of a box-shaped room sits within a few cells of a grid face; the box of cells at least two
+   // cells deeper than the deepest boundary node (and off the ABC shell) sees nothing but the plain air update for two
+   // consecutive steps, so k_tb2_reg may produce u^{n+1} and u^{n+2} there in one pass (16 B per cell instead of 24).
+   // The shell around the box (x slabs, row strips, column strips; all boundary / ABC / source cells live there) is
+   // stepped twice by the single-step kernels, out of place.  Rooms with interior geometry have no such box: tb2 stays
+   // off and nothing changes.  air_variant 0 (auto) and 40 enable it, 41 = same driver with the box disabled (tests).
+   int init_tb2() {
+      tb2 = false;
+      if (sizeof(Real) != 4 || fcc || !lean || lean_rigid || op.energy || !(op.slab_first && op.slab_last)) return PF_OK;
+      if (!(vbase == 0 || vbase == 40 || vbase == 41) || op.numerics != PF_NUM_CPU_EXACT || !use_dpp) return PF_OK;
+      if (Nb > 0 && !boundary_fused()) return PF_OK;
+      int64_t dmax = 0; // depth of the deepest boundary node below the nearest grid face
+      const int64_t NzNy = Nz * Ny;
+      for (int64_t i = 0; i < Nb; i++) {
+         const int64_t ii = sd.bn_ixyz[i], ix = ii / NzNy, iy = (ii / Nz) % Ny, iz = ii % Nz;
+         const int64_t d = std::min({ix, Nx - 1 - ix, iy, Ny - 1 - iy, iz, Nz - 1 - iz});
+         dmax = std::max(dmax, d);
+      }
+      const int m = (int)std::max<int64_t>(dmax + 2, 3), mz = (m + 3) / 4 * 4;
+      tbx0 = m; tbx1 = (int)Nx - m; tby0 = m; tby1 = (int)Ny - m; tbz0 = mz; tbz1 = (int)((Nz - mz) / 4 * 4);
+      if (vbase == 41) tbx1 = tbx0; // driver test: everything goes through the out-of-place single-step path
+      tb_xr.clear();
+      if (tbx1 - tbx0 >= 16 && tby1 - tby0 >= 48 && tbz1 - tbz0 >= 248) {
+         std::vector<int> cut; // planes the box must leave to the single-step kernels: sources (+-1 plane)
+         for (int64_t i = 0; i < Ns; i++) { const int ix = (int)(sd.in_ixyz[i] / NzNy); for (int d = -1; d <= 1; d++) cut.push_back(ix + d); }
+         std::sort(cut.begin(), cut.end());
+         int xa = tbx0;
+         for (int c : cut) {
+            if (c < xa || c >= tbx1) continue;
+            if (c - xa >= 8) tb_xr.push_back({xa, c});
+            xa = c + 1;
+         }
+         if (tbx1 - xa >= 8) tb_xr.push_back({xa, tbx1});
+      }
+      int64_t vol = 0;
+      for (auto &r : tb_xr) vol += (int64_t)(r.second - r.first) * (tby1 - tby0) * (tbz1 - tbz0);
+      if (vbase == 40 && vol == 0) return set_err(PF_ERR_ARG, "air_variant 40 (temporal blocking) requested but the scene has no boundary-free box");
+      if (vbase == 0 && (double)vol < 0.6 * (double)(Nx * Ny * Nz)) return PF_OK; // auto: not worth two extra grids
+      int rc;
+      if ((rc = dzalloc(&bufC, npad))) return rc;
+      if ((rc = dzalloc(&bufD, npad))) return rc;
+      own_list.push_back(bufC); own_list.push_back(bufD);
+      tb2 = true;
+      return PF_OK;
+   }
+   void launch_tb2(hipStream_t s, const Real *A, const Real *B, Real *C, Real *D) {
+      if constexpr (sizeof(Real) == 4) {
+         for (auto &r : tb_xr) {
+            pf::Tb2Params tp{};
+            tp.A = (const float *)A; tp.B = (const float *)B; tp.C = (float *)C; tp.D = (float *)D;
+            tp.plane = plane; tp.Nx = (int)Nx; tp.Ny = (int)Ny; tp.Nz = (int)Nz; tp.P = (int)P;
+            tp.x_begin = r.first; tp.x_end = r.second;
+            tp.y_begin = tby0; tp.y_end = tby1; tp.z_begin = tbz0; tp.z_end = tbz1;
+            const int np = r.second - r.first;
+            tp.chunk = (int)cdiv(np, std::max<int64_t>(cdiv(np, 24), 1)); // ~24-plane chunks, even split (tools/tb2_probe.py)
+            tp.nxc = (int)cdiv(np, tp.chunk);
+            tp.nzt = (int)cdiv(tbz1 - tbz0, 248);
+            tp.nyt = (int)cdiv(tby1 - tby0, 12);
+            hipLaunchKernelGGL((pf::k_tb2_reg<3, 4, false>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(256), 0, s, tp, (float)a1, (float)a2);
+         }
+      }
+   }
+   // one out-of-place single step of everything outside the box: u1 -> (u0_src old) -> u0
+   void launch_shell(hipStream_t s) {
+      int xa = 1;
+      auto slab = [&](int xb, int xe) { if (xe > xb) launch_air_lean(s, xb, xe); };
+      for (auto &r : tb_xr) {
+         slab(xa, r.first);
+         // row strips (tile height of the default lean configuration: 16 rows) and column strips beside the box
+         const int th = 16, nyt_all = (int)cdiv(Ny - 2, th);
+         lean_yt0 = 0; lean_nyt = (int)cdiv(tby0 - 1, th);
+         launch_air_lean(s, r.first, r.second);
+         lean_yt0 = (tby1 - 1) / th; lean_nyt = nyt_all - lean_yt0;
+         launch_air_lean(s, r.first, r.second);
+         lean_nyt = -1; lean_yt0 = 0;
+         if constexpr (sizeof(Real) == 4) {
+            pf::ZStripParams zp{};
+            zp.u1 = (const float *)u1; zp.u0s = (const float *)(u0_src ? u0_src : u0); zp.u0 = (float *)u0; zp.mask = mask;
+            zp.plane = plane; zp.Nx = (int)Nx; zp.Ny = (int)Ny; zp.Nz = (int)Nz; zp.P = (int)P;
+            zp.x_begin = r.first; zp.x_end = r.second; zp.zl = tbz0; zp.zr = tbz1; zp.first = op.slab_first; zp.last = op.slab_last;
+            const int64_t nthreads = (int64_t)(zp.zl / 4 + (P - zp.zr) / 4) * (Ny - 2) * (r.second - r.first);
+            hipLaunchKernelGGL(pf::k_air_zstrip, dim3((unsigned)cdiv(nthreads, 256)), dim3(256), 0, s, zp, (float)a1, (float)a2, (float)l);
+         }
+         xa = r.second;
+      }
+      slab(xa, (int)Nx - 1);
+   }
+   // steps n and n+1 in one go; the state moves from (u0, u1) to (bufC, bufD), which swap roles with them
+   int step_pair(int64_t n) {
+      if (n < 0 || n + 1 >= Nt) return set_err(PF_ERR_ARG, "step pair %ld outside [0,Nt=%ld)", (long)n, (long)Nt);
+      hipStream_t s = s_main;
+      Real *A = u0, *B = u1, *C = bufC, *D = bufD;
+      std::pair<hipEvent_t, hipEvent_t> ev{}, eva{};
+      auto get_ev = [&]() { std::pair<hipEvent_t, hipEvent_t> e{}; if (!ev_pool.empty()) { e = ev_pool.back(); ev_pool.pop_back(); } else { hipEventCreate(&e.first); hipEventCreate(&e.second); } return e; };
+      if (op.timing) { ev = get_ev(); eva = get_ev(); hipEventRecord(ev.first, s); hipEventRecord(eva.first, s); } // step events: one per step
+      std::pair<hipEvent_t, hipEvent_t> evt{};
+      if (op.timing) { evt = get_ev(); hipEventRecord(evt.first, s); }
+      launch_tb2(s, A, B, C, D);
+      if (op.timing) { hipEventRecord(evt.second, s); tb2_ev.push_back(evt); }
+      u0_src = A; u1 = B; u0 = C;
+      launch_shell(s);
+      if (op.timing) { hipEventRecord(eva.second, s); air_ev.push_back(eva); eva = get_ev(); }
+      launch_rigid(s, {0, Nb});
+      launch_fd(s, {0, Nbl});
+      launch_io(s, n, true, {0, Ns});
+      { Real *t = ub[2]; ub[2] = ub[1]; ub[1] = ub[0]; ub[0] = t; }
+      if (ring_fill == 0) ring_n0 = n;
+      ring_fill++; steps_done++;
+      u0_src = B; u1 = C; u0 = D;
+      if (op.timing) { hipEventRecord(ev.second, s); step_ev.push_back(ev); ev = get_ev(); hipEventRecord(ev.first, s); hipEventRecord(eva.first, s); }
+      launch_shell(s);
+      if (op.timing) { hipEventRecord(eva.second, s); air_ev.push_back(eva); }
+      launch_rigid(s, {0, Nb});
+      launch_fd(s, {0, Nbl});
+      launch_io(s, n + 1, true, {0, Ns});
+      { Real *t = ub[2]; ub[2] = ub[1]; ub[1] = ub[0]; ub[0] = t; }
+      ring_fill++; steps_done++;
+      u0_src = nullptr; u0 = C; u1 = D; bufC = A; bufD = B;
+      if (op.timing) { hipEventRecord(ev.second, s); step_ev.push_back(ev); }
+      HIPCHK(hipGetLastError());
+      if (ring_fill == ring_depth) return flush();
       return PF_OK;
    }
 
@@ -599,6 +736,12 @@ template <typename Real> struct Engine : EngineBase {
       fp.x_begin = xb; fp.x_end = xe;
       fp.nzt = fused_nzt;
       fp.nyt = (int)cdiv(Ny - 2, (int64_t)WY * R);
+      fp.u0_src = u0_src; fp.yt0 = 0;
+      if (lean_nyt >= 0) { // row strip [lean_yt0, lean_yt0 + lean_nyt) in units of this configuration's tile height
+         fp.yt0 = std::min(lean_yt0, fp.nyt);
+         fp.nyt = std::min(lean_nyt, fp.nyt - fp.yt0);
+         if (fp.nyt <= 0) return;
+      }
       const int nplanes = xe - xb;
       const int chunk = pick_chunk(nplanes, (int64_t)fp.nzt * fp.nyt, true);
       fp.chunk = chunk;
@@ -681,7 +824,7 @@ template <typename Real> struct Engine : EngineBase {
       launch_fold_row(s);
       dim3 g((unsigned)cdiv(r.e - r.b, 128)), b(128);
       const bool fma = op.numerics == PF_NUM_FMA;
-#define PF_BND(F, M) hipLaunchKernelGGL((pf::k_boundary<Real, F, M>), g, b, 0, s, u1, u0, d_bn, d_adj, d_lossy, a2, sl2, P, plane, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq, d_beta, vh1, gh1, lo2, Nbl, r.b, r.e)
+#define PF_BND(F, M) hipLaunchKernelGGL((pf::k_boundary<Real, F, M>), g, b, 0, s, u1, u0, d_bn, d_adj, d_lossy, a2, sl2, P, plane, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq, d_beta, vh1, gh1, lo2, Nbl, r.b, r.e, u0_src ? u0_src : (const Real *)u0)
       if (fcc) { if (fma) PF_BND(true, true); else PF_BND(true, false); }
       else { if (fma) PF_BND(false, true); else PF_BND(false, false); }
 #undef PF_BND
@@ -819,9 +962,17 @@ template <typename Real> struct Engine : EngineBase {
    int run(int64_t n0, int64_t nsteps) override {
       if (in_step) return set_err(PF_ERR_STATE, "pf_engine_run inside a split-phase step");
       HIPCHK(hipSetDevice(op.device));
-      for (int64_t n = n0; n < n0 + nsteps; n++) {
-         int rc = step_single(n);
-         if (rc) return rc;
+      for (int64_t n = n0; n < n0 + nsteps;) {
+         int rc;
+         // temporally blocked pairs come in twos, so that the state is back in the caller's two grids afterwards
+         if (tb2 && n + 4 <= n0 + nsteps && ring_fill + 4 <= ring_depth) {
+            if ((rc = step_pair(n))) return rc;
+            if ((rc = step_pair(n + 2))) return rc;
+            n += 4;
+         } else {
+            if ((rc = step_single(n))) return rc;
+            n++;
+         }
          if (op.timing && air_ev.size() >= 512) { rc = harvest(); if (rc) return rc; }
       }
       int rc = flush();
@@ -922,6 +1073,15 @@ template <typename Real> struct Engine : EngineBase {
          ev_pool.push_back(p);
       }
       air_ev.clear();
+      for (auto &p : tb2_ev) {
+         float ms = 0;
+         HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));
+         tm.tb2_ms_total += ms; tm.tb2_launches++;
+         ev_pool.push_back(p);
+      }
+      tb2_ev.clear();
+      tm.tb2_cells = 0;
+      for (auto &r : tb_xr) tm.tb2_cells += (int64_t)(r.second - r.first) * (tby1 - tby0) * (tbz1 - tbz0);
       for (auto &p : step_ev) {
          float ms = 0;
          HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));

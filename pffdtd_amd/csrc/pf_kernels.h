@@ -622,18 +622,19 @@ __global__ void k_fd_boundary(Real *__restrict__ u0, const int64_t *__restrict__
 // between the two is a register).  lossy[nb] = index into the lossy-node arrays, or -1 for a rigid node; lossy
 // indices increase along the (sorted) boundary list, so the branch-state accesses stay coalesced.
 template <typename Real, bool FCC, bool FMA>
-__global__ void k_boundary(const Real *__restrict__ u1, Real *__restrict__ u0, const int64_t *__restrict__ idx,
+__global__ void k_boundary(const Real *__restrict__ u1, Real *u0, const int64_t *__restrict__ idx,
                            const uint16_t *__restrict__ adjv, const int32_t *__restrict__ lossy, Real a2, Real sl2,
                            int64_t P, int64_t plane, Real *__restrict__ u0b, const Real *__restrict__ u2b,
                            const Real *__restrict__ ssaf, const int8_t *__restrict__ mat, const int8_t *__restrict__ Mb,
                            const MatQuadT<Real> *__restrict__ mq, const Real *__restrict__ beta, Real *__restrict__ vh1,
-                           Real *__restrict__ gh1, Real lo2, int64_t Nbl, int64_t begin, int64_t end) {
+                           Real *__restrict__ gh1, Real lo2, int64_t Nbl, int64_t begin, int64_t end,
+                           const Real *u0_old) { // u0_old: where u^{n-1} lives (== u0 for the in-place step)
    const int64_t nb = begin + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (nb >= end) return;
    const int64_t ii = idx[nb];
    const uint32_t adj = adjv[nb];
    const Real two = 2.0, one = 1.0, K = (Real)__popc(adj), b2 = a2, b1 = (two - sl2 * K);
-   Real p = b1 * u1[ii] - u0[ii];
+   Real p = b1 * u1[ii] - u0_old[ii];
    if (!FCC) {
       const int64_t off[6] = {plane, -plane, P, -P, 1, -1};
 #pragma unroll

@@ -1,4 +1,6 @@
-// pf_tb2.h -- RESEARCH PROTOTYPE (not on the product path; driven only by tools/tb2_probe.py):
+// pf_tb2.h -- temporal blocking.  k_tb2_reg + k_air_zstrip are on the product path (Engine::step_pair, 7-point fp32
+// scenes with a large boundary-free box); k_tb2_proto is the earlier LDS-based research prototype
+// (driven only by tools/tb2_probe.py):
 // two leap-frog steps of the pure 7-point air update per pass (temporal blocking), to measure what the interior
 // kernel could gain from halving its HBM traffic per step.  Out of place: reads A = u^{n-1}, B = u^n, writes
 // C = u^{n+1}, D = u^{n+2}.  No mask / ABC / boundary nodes: valid for cells at least 3 away from anything special.
@@ -21,6 +23,7 @@ struct Tb2Params {
    int32_t x_begin, x_end, chunk; // D planes [x_begin, x_end) (C planes x_begin .. x_end)
    int32_t nzt, nyt, nxc;
    int32_t y_begin, z_begin;      // first core row / first core column of tile (0,0)
+   int32_t y_end, z_end;          // one past the last core row / column (0: Ny - y_begin / Nz - z_begin)
 };
 
 template <int TYE, int WAVES>
@@ -135,10 +138,11 @@ __global__ __launch_bounds__(64 * WY) void k_tb2_reg(Tb2Params tp, float a1, flo
    int64_t offB[R + 4];                                       // rows yo-2 .. yo+R+1
 #pragma unroll
    for (int i = 0; i < R + 4; i++) offB[i] = (int64_t)min(max(yo - 2 + i, 0), tp.Ny - 1) * P + zc;
-   const bool core_col = (lane >= 1 && lane <= 62) && (ze0 + lane * 4 + 3 < tp.Nz - tp.z_begin);
+   const int z_end = tp.z_end ? tp.z_end : tp.Nz - tp.z_begin, y_end = tp.y_end ? tp.y_end : tp.Ny - tp.y_begin;
+   const bool core_col = (lane >= 1 && lane <= 62) && (ze0 + lane * 4 + 3 < z_end);
    bool core_row[R];
 #pragma unroll
-   for (int r = 0; r < R; r++) core_row[r] = (yo + r < tp.Ny - tp.y_begin);
+   for (int r = 0; r < R; r++) core_row[r] = (yo + r < y_end);
 
    auto loadB = [&](int x, vec *d) {
       const float *pl = tp.B + (int64_t)x * plane;
@@ -207,6 +211,70 @@ __global__ __launch_bounds__(64 * WY) void k_tb2_reg(Tb2Params tp, float a1, flo
 #pragma unroll
       for (int i = 0; i < R + 4; i++) { Bc[i] = Bn[i]; Bn[i] = Bnn[i]; }
    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_air_zstrip -- single-step 7-point air update (virtual ghost shell + ABC loss, as k_air_cart_lean) of the thin
+// column strips z in [0, zl) and [zr, P) left over next to the temporally blocked box: one thread per 16-byte vector.
+// Out of place: u^{n-1} from u0s, u^{n+1} to u0.  Same expression order as the marching kernels (bit-identical).
+// ---------------------------------------------------------------------------------------------------------------
+struct ZStripParams {
+   const float *u1, *u0s;
+   float *u0;
+   const uint8_t *mask;
+   int64_t plane;
+   int32_t Nx, Ny, Nz, P;
+   int32_t x_begin, x_end;   // planes [x_begin, x_end)
+   int32_t zl, zr;           // strips [0, zl) and [zr, P), multiples of 4
+   int32_t first, last;
+};
+
+__global__ __launch_bounds__(256) void k_air_zstrip(ZStripParams zp, float a1, float a2, float l) {
+   typedef f32x4 vec;
+   const int nl = zp.zl / 4, nr = (zp.P - zp.zr) / 4, nv = nl + nr;
+   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   const int64_t rows = (int64_t)(zp.Ny - 2) * (zp.x_end - zp.x_begin);
+   if (t >= rows * nv) return;
+   const int v = (int)(t % nv);
+   const int y = 1 + (int)((t / nv) % (zp.Ny - 2));
+   const int x = zp.x_begin + (int)(t / ((int64_t)nv * (zp.Ny - 2)));
+   const int z0 = v < nl ? v * 4 : zp.zr + (v - nl) * 4;
+   const int Nx = zp.Nx, Ny = zp.Ny, Nz = zp.Nz, P = zp.P;
+   auto rowsrc = [&](int yy) { return yy == 0 ? 2 : (yy == Ny - 1 ? Ny - 3 : yy); };
+   auto planesrc = [&](int xx) { return (zp.first && xx == 0) ? 2 : ((zp.last && xx == Nx - 1) ? Nx - 3 : xx); };
+   const int64_t off = (int64_t)y * P + z0;
+   const float *pc = zp.u1 + (int64_t)x * zp.plane;
+   vec c = *(const vec *)(pc + off);
+   float lf = z0 > 0 ? pc[off - 1] : 0.f, rt = z0 + 4 < P ? pc[off + 4] : 0.f;
+   const int zzN = Nz - 1 - z0; // position of the ghost column Nz-1 relative to this vector
+   if (z0 == 0) c[0] = c[2];
+   if (zzN == 1) c[1] = lf;
+   if (zzN == 2) c[2] = c[0];
+   if (zzN == 3) c[3] = c[1];
+   if (zzN == 4) rt = c[2];
+   const vec xp = *(const vec *)(zp.u1 + (int64_t)planesrc(x + 1) * zp.plane + off);
+   const vec xm = *(const vec *)(zp.u1 + (int64_t)planesrc(x - 1) * zp.plane + off);
+   const vec yp = *(const vec *)(pc + (int64_t)rowsrc(y + 1) * P + z0);
+   const vec ym = *(const vec *)(pc + (int64_t)rowsrc(y - 1) * P + z0);
+   const vec old = *(const vec *)(zp.u0s + (int64_t)x * zp.plane + off);
+   const uint32_t bits = (zp.mask[((int64_t)x * zp.plane + off) >> 3] >> (off & 7)) & 0xfu;
+   const int qxy = (((zp.first && x == 1) || (zp.last && x == Nx - 2)) ? 1 : 0) + ((y == 1 || y == Ny - 2) ? 1 : 0);
+   vec o;
+#pragma unroll
+   for (int i = 0; i < 4; i++) {
+      const float zpv = (i == 3) ? rt : c[i < 3 ? i + 1 : 3];
+      const float zmv = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
+      float p = a1 * c[i] - old[i];
+      p = p + a2 * xp[i]; p = p + a2 * xm[i]; p = p + a2 * yp[i]; p = p + a2 * ym[i]; p = p + a2 * zpv; p = p + a2 * zmv;
+      const int Q = qxy + ((z0 + i == 1 || z0 + i == Nz - 2) ? 1 : 0);
+      if (Q > 0) { // ABC loss (cpu_engine.h:225-229), double literal of :228
+         const float lQ = l * (float)Q;
+         const float num = p + lQ * old[i];
+         p = (float)((double)num / (1.0 + (double)lQ));
+      }
+      o[i] = ((bits >> i) & 1u) ? old[i] : p;
+   }
+   *(vec *)(zp.u0 + (int64_t)x * zp.plane + off) = o;
 }
 
 } // namespace pf

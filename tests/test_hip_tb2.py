@@ -1,0 +1,75 @@
+"""GPU: temporal blocking (two steps per pass over the boundary-free box, pf_tb2.h / Engine::step_pair) must leave
+every bit where the single-step engine and the CPU oracle put it.  Grids here are the smallest that qualify
+(the box needs >= 248 columns), with step counts that mix quads of blocked steps, single steps and ring flushes."""
+import numpy as np
+import pytest
+
+import oracle
+from pffdtd_amd import engine, sim_data, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def scene(src, Nt=23, n=(36, 64, 280), **kw):
+    w = kw.get("wall", 3) + 3  # receivers stay clear of the wall layers
+    rcv = [[n[0] // 2 + 3, n[1] // 2, n[2] // 2 - 2], [w, w + 1, w + 2], [n[0] - w - 3, n[1] - w - 4, 200]]
+    if src is not None and src[0] < kw.get("wall", 3):
+        rcv.append([src[0], src[1] + 9, src[2] + 11])  # a receiver on the source's side of the wall (the box is closed)
+    return synth.shoebox(*n, Nt=Nt, Nm=2, Mb=[11, 3], src=src, rcv=rcv, **kw)
+
+
+def run(sim, variant, **kw):
+    sd = sim_data.SimData.from_sim(sim, "single", build_mask=False)
+    sd.scale_input()
+    eng = engine.HipEngine(sd, air_variant=variant, timing=True, **kw)
+    eng.run(0, sd.Nt)
+    tm = eng.timing()
+    g = [eng.get_grid(0).copy(), eng.get_grid(1).copy()]
+    eng.close()
+    return sd.u_out.copy(), g, tm
+
+
+@pytest.mark.parametrize("src,kw", [(None, {}), ([3, 30, 140], dict(n=(36, 72, 280), wall=6)), ([18, 8, 12], {})],
+                         ids=["centre", "outside_wall", "near_corner"])
+def test_blocked_steps_match_single_steps_and_oracle(src, kw):
+    sim = scene(src, **kw)
+    ref = sim_data.SimData.from_sim(sim, "single")
+    ref.scale_input()
+    oracle.run_sim(ref)
+    assert np.abs(ref.u_out).max() > 0
+    base_out, base_g, tm0 = run(sim, 20)            # plain single-step lean kernel
+    assert np.array_equal(base_out, ref.u_out) and tm0["tb2_launches"] == 0
+    for variant, chunk in ((41, 0), (40, 0), (0, 0), (40, 7)):
+        out, g, tm = run(sim, variant, readout_chunk=chunk)
+        assert np.array_equal(out, ref.u_out), (variant, chunk)
+        for a, b in zip(g, base_g):                   # whole fields, interior (ghost shell is materialised on request)
+            assert np.abs(b).max() > 0
+            assert np.array_equal(a[1:-1, 1:-1, 1:-1], b[1:-1, 1:-1, 1:-1]), (variant, chunk)
+        if variant == 40:  # (auto engages only when the box holds >= 60 % of the grid: not at this size)
+            assert tm["tb2_launches"] > 0 and tm["tb2_cells"] > 0.25 * 36 * 64 * 280, (variant, tm)
+        nx, ny, nz = (int(sim["vox_out"][k]) for k in ("Nx", "Ny", "Nz"))
+        assert tm["steps"] == sim["comms_out"]["Nt"]
+
+
+def test_rooms_without_a_box_keep_the_single_step_path():
+    sim = scene(None, n=(36, 64, 280), rigid_every=0)
+    # a slab of boundary nodes through the middle of the room: no boundary-free box
+    from pffdtd_amd import synth as sy  # noqa: F401
+    sd = sim_data.SimData.from_sim(sim, "single", build_mask=False)
+    mid = (18 * 64 + 32) * 280 + 140
+    if mid not in set(sd.bn_ixyz.tolist()):
+        v = sim["vox_out"]
+        order = np.argsort(np.append(v["bn_ixyz"], mid))
+        v["bn_ixyz"] = np.append(v["bn_ixyz"], mid)[order]
+        v["adj_bn"] = np.vstack([v["adj_bn"], np.zeros((1, v["adj_bn"].shape[1]), dtype=v["adj_bn"].dtype)])[order]
+        v["mat_bn"] = np.append(v["mat_bn"], -1)[order].astype(v["mat_bn"].dtype)
+        v["saf_bn"] = np.append(v["saf_bn"], 6.0)[order]
+        v["Nb"] = np.int64(v["bn_ixyz"].size)
+    ref = sim_data.SimData.from_sim(sim, "single")
+    ref.scale_input()
+    oracle.run_sim(ref)
+    out, _, tm = run(sim, 0)
+    assert tm["tb2_launches"] == 0
+    assert np.array_equal(out, ref.u_out)
+    with pytest.raises(engine.PfError):
+        run(sim, 40)
