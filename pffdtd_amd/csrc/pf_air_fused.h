@@ -406,6 +406,7 @@ struct LeanParams {
    int32_t debug;           // reserved for tuning experiments (unused in production builds)
    const void *u0_src;      // out-of-place step: u^{n-1} is read from here, u^{n+1} written to u0 (null: in place)
    int32_t yt0;             // first y tile of this launch (row-strip launches); nyt counts from there
+   int32_t yt_split, yt_hi0; // two row strips in one launch: tiles [yt0, yt0+yt_split) and [yt_hi0, ...) (yt_split < 0: off)
 };
 
 template <typename Real, int R, int WY, bool FMA, bool NT = false, bool RIG = false>
@@ -424,7 +425,8 @@ __global__ __launch_bounds__(64 * WY) void k_air_cart_lean(LeanParams fp, Real a
    uint32_t b = blockIdx.x;
    if (fp.swizzle) b = xcd_swizzle(b, total);
    const int zt = b % fp.nzt;
-   const int yt = fp.yt0 + (b / fp.nzt) % fp.nyt;
+   int yt = (b / fp.nzt) % fp.nyt;
+   yt = (fp.yt_split >= 0 && yt >= fp.yt_split) ? fp.yt_hi0 + (yt - fp.yt_split) : fp.yt0 + yt;
    const int xc = b / (fp.nzt * fp.nyt);
    const int lane = threadIdx.x & 63;
    const int w = threadIdx.x >> 6;

@@ -507,27 +507,27 @@ template <typename Real> struct Engine : EngineBase {
    // one out-of-place single step of everything outside the box: u1 -> (u0_src old) -> u0
    void launch_shell(hipStream_t s) {
       int xa = 1;
-      auto slab = [&](int xb, int xe) { if (xe > xb) launch_air_lean(s, xb, xe); };
-      for (auto &r : tb_xr) {
-         slab(xa, r.first);
-         // row strips (tile height of the default lean configuration: 16 rows) and column strips beside the box
-         const int th = 16, nyt_all = (int)cdiv(Ny - 2, th);
-         lean_yt0 = 0; lean_nyt = (int)cdiv(tby0 - 1, th);
-         launch_air_lean(s, r.first, r.second);
-         lean_yt0 = (tby1 - 1) / th; lean_nyt = nyt_all - lean_yt0;
-         launch_air_lean(s, r.first, r.second);
-         lean_nyt = -1; lean_yt0 = 0;
-         if constexpr (sizeof(Real) == 4) {
-            pf::ZStripParams zp{};
-            zp.u1 = (const float *)u1; zp.u0s = (const float *)(u0_src ? u0_src : u0); zp.u0 = (float *)u0; zp.mask = mask;
-            zp.plane = plane; zp.Nx = (int)Nx; zp.Ny = (int)Ny; zp.Nz = (int)Nz; zp.P = (int)P;
-            zp.x_begin = r.first; zp.x_end = r.second; zp.zl = tbz0; zp.zr = tbz1; zp.first = op.slab_first; zp.last = op.slab_last;
-            const int64_t nthreads = (int64_t)(zp.zl / 4 + (P - zp.zr) / 4) * (Ny - 2) * (r.second - r.first);
-            hipLaunchKernelGGL(pf::k_air_zstrip, dim3((unsigned)cdiv(nthreads, 256)), dim3(256), 0, s, zp, (float)a1, (float)a2, (float)l);
-         }
+      for (auto &r : tb_xr) { // x slabs: everything before / between / after the box's plane ranges, full planes
+         if (r.first > xa) launch_air_lean(s, xa, r.first);
          xa = r.second;
       }
-      slab(xa, (int)Nx - 1);
+      if ((int)Nx - 1 > xa) launch_air_lean(s, xa, (int)Nx - 1);
+      if (tb_xr.empty()) return;
+      const int xb = tb_xr.front().first, xe = tb_xr.back().second;
+      // beside the box: the two row strips in one lean launch (tile height of the default configuration: 16 rows) ...
+      const int th = 16;
+      lean_nyt = (int)cdiv(tby0 - 1, th); lean_yt0 = (tby1 - 1) / th;
+      launch_air_lean(s, xb, xe);
+      lean_nyt = -1; lean_yt0 = 0;
+      // ... and the two column strips
+      if constexpr (sizeof(Real) == 4) {
+         pf::ZStripParams zp{};
+         zp.u1 = (const float *)u1; zp.u0s = (const float *)(u0_src ? u0_src : u0); zp.u0 = (float *)u0; zp.mask = mask;
+         zp.plane = plane; zp.Nx = (int)Nx; zp.Ny = (int)Ny; zp.Nz = (int)Nz; zp.P = (int)P;
+         zp.x_begin = xb; zp.x_end = xe; zp.zl = tbz0; zp.zr = tbz1; zp.first = op.slab_first; zp.last = op.slab_last;
+         const int64_t nthreads = (int64_t)(zp.zl / 4 + (P - zp.zr) / 4) * (Ny - 2) * (xe - xb);
+         hipLaunchKernelGGL(pf::k_air_zstrip, dim3((unsigned)cdiv(nthreads, 256)), dim3(256), 0, s, zp, (float)a1, (float)a2, (float)l);
+      }
    }
    // steps n and n+1 in one go; the state moves from (u0, u1) to (bufC, bufD), which swap roles with them
    int step_pair(int64_t n) {
@@ -736,10 +736,11 @@ template <typename Real> struct Engine : EngineBase {
       fp.x_begin = xb; fp.x_end = xe;
       fp.nzt = fused_nzt;
       fp.nyt = (int)cdiv(Ny - 2, (int64_t)WY * R);
-      fp.u0_src = u0_src; fp.yt0 = 0;
-      if (lean_nyt >= 0) { // row strip [lean_yt0, lean_yt0 + lean_nyt) in units of this configuration's tile height
-         fp.yt0 = std::min(lean_yt0, fp.nyt);
-         fp.nyt = std::min(lean_nyt, fp.nyt - fp.yt0);
+      fp.u0_src = u0_src; fp.yt0 = 0; fp.yt_split = -1; fp.yt_hi0 = 0;
+      if (lean_nyt >= 0) { // row strips: tiles [0, lean_nyt) and [lean_yt0, all) in units of this configuration's tile height
+         const int all = fp.nyt, lo = std::min(lean_nyt, all), hi0 = std::max(std::min(lean_yt0, all), lo);
+         fp.yt_split = lo; fp.yt_hi0 = hi0;
+         fp.nyt = lo + (all - hi0);
          if (fp.nyt <= 0) return;
       }
       const int nplanes = xe - xb;
