@@ -105,8 +105,8 @@ typedef struct pf_timing {
    double  step_ms_total;   /* sum of HIP-event durations of whole steps (pre .. readout) */
    int64_t steps;
    double  tb2_ms_total;    /* temporal blocking: sum of the two-steps-per-pass kernel's launch durations (included in air_ms_total) */
-   int64_t tb2_launches;    /* 0 when the engine steps one step per pass */
-   int64_t tb2_cells;       /* cells that kernel advances by two steps per launch */
+   int64_t tb2_launches;    /* kernel launches behind tb2_ms_total; 0 when the engine steps one step per pass */
+   int64_t tb2_cells;       /* cells one such launch advances by two steps (average over the x ranges of the box) */
 } pf_timing;
 
 typedef struct pf_engine pf_engine;

@@ -515,9 +515,9 @@ template <typename Real> struct Engine : EngineBase {
       if (tb_xr.empty()) return;
       const int xb = tb_xr.front().first, xe = tb_xr.back().second;
       // beside the box: the two row strips in one lean launch (tile height of the default configuration: 16 rows) ...
-      const int th = 16;
+      const int th = 8; // lean<2,4>: 8-row tiles (the strips are 5-7 rows thick in a box-shaped room)
       lean_nyt = (int)cdiv(tby0 - 1, th); lean_yt0 = (tby1 - 1) / th;
-      launch_air_lean(s, xb, xe);
+      launch_lean_cfg<2, 4, false, true>(s, xb, xe);
       lean_nyt = -1; lean_yt0 = 0;
       // ... and the two column strips
       if constexpr (sizeof(Real) == 4) {
@@ -1077,12 +1077,13 @@ template <typename Real> struct Engine : EngineBase {
       for (auto &p : tb2_ev) {
          float ms = 0;
          HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));
-         tm.tb2_ms_total += ms; tm.tb2_launches++;
+         tm.tb2_ms_total += ms; tm.tb2_launches += (int64_t)tb_xr.size(); // one kernel launch per x range
          ev_pool.push_back(p);
       }
       tb2_ev.clear();
       tm.tb2_cells = 0;
       for (auto &r : tb_xr) tm.tb2_cells += (int64_t)(r.second - r.first) * (tby1 - tby0) * (tbz1 - tbz0);
+      if (!tb_xr.empty()) tm.tb2_cells /= (int64_t)tb_xr.size(); // per launch, on average
       for (auto &p : step_ev) {
          float ms = 0;
          HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));

@@ -46,7 +46,7 @@ def test_blocked_steps_match_single_steps_and_oracle(src, kw):
             assert np.abs(b).max() > 0
             assert np.array_equal(a[1:-1, 1:-1, 1:-1], b[1:-1, 1:-1, 1:-1]), (variant, chunk)
         if variant == 40:  # (auto engages only when the box holds >= 60 % of the grid: not at this size)
-            assert tm["tb2_launches"] > 0 and tm["tb2_cells"] > 0.25 * 36 * 64 * 280, (variant, tm)
+            assert tm["tb2_launches"] > 0 and tm["tb2_cells"] > 0.1 * 36 * 64 * 280, (variant, tm)
         nx, ny, nz = (int(sim["vox_out"][k]) for k in ("Nx", "Ny", "Nz"))
         assert tm["steps"] == sim["comms_out"]["Nt"]
 
