@@ -229,10 +229,17 @@ def main():
                   f"{el / K * 1e3:.4f} ms/step -> {emu[1]} such ranks would give "
                   f"{sd.Npts * K / el / 1e9:.1f} Gvox/s if the exchange hides completely", file=sys.stderr)
         bpv = 3 * real_bytes + 0.125  # u1 read, u0 read + write, one mask bit
-        # algorithmic bytes of one step's air launches on this rank: the interior voxels they update
+        # interior update of one step on this rank: the voxels it updates, and the time of all its interior launches
         upd = interior_planes * (sd.Ny - 2) * (sd.Nz - 2)
         air_ms_per_step = tm["air_ms_total"] / max(tm["steps"] if tm["steps"] else K, 1)
-        achieved = upd * bpv / (air_ms_per_step * 1e-3) / 1e9 if air_ms_per_step > 0 else None
+        if tm.get("tb2_launches", 0) > 0:
+            # temporal blocking: the dominant kernel advances `tb2_cells` cells by TWO steps per launch; its algorithmic
+            # bytes are therefore 2 x 12.125 B per cell and launch (SURVEY 8d's per-update figure x the updates it performs)
+            kernel, kernel_ms = "k_tb2_reg", tm["tb2_ms_total"] / tm["tb2_launches"]
+            units = 2 * tm["tb2_cells"]
+        else:
+            kernel, kernel_ms, units = ("k_air_fcc" if args.fcc else "k_air_cart_lean"), air_ms_per_step, upd
+        achieved = units * bpv / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
         res = {
             "metric": "Gvoxel-updates/s", "value": round(gvox, 3), "unit": "Gvoxel-updates/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(el / K * 1e3, 4),
@@ -246,11 +253,12 @@ def main():
                        "numerics": "cpu-exact" if args.numerics == 0 else "fma",
                        "parallelism": parallelism, "air_variant": args.variant},
             "achieved_hbm_GBs_whole_step": round(gvox * bpv, 1),
-            "roofline": {"bound": "hbm", "kernel": "k_air_fcc" if args.fcc else "k_air_cart_lean",
+            "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
-                         "air_ms_per_step": round(air_ms_per_step, 4),
-                         "bytes_per_voxel": bpv, "voxels_per_step": upd},
+                         "kernel_ms_per_launch": round(kernel_ms, 4), "voxel_updates_per_launch": int(units),
+                         "bytes_per_voxel_update": bpv, "air_ms_per_step": round(air_ms_per_step, 4),
+                         "interior_voxels_per_step": upd},
         }
         # HBM bytes per air launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE in separate runs, gfx950 x2 read correction applied; tools/make_profile_summary.py)
@@ -259,11 +267,11 @@ def main():
                 and tfile.exists()):
             try:
                 ks = json.load(open(tfile))["kernels"]
-                hit = [v for k, v in ks.items() if "k_air_cart_lean" in k]
+                hit = [v for k, v in ks.items() if kernel in k]
                 if hit:
                     res["roofline"]["traffic"] = round(hit[0]["total_bytes"] / 1e9, 3)
                     res["roofline"]["traffic_unit"] = "GB per launch (PMC, profiles/r01_bench_n1_hbm_traffic.json)"
-                    res["roofline"]["algorithmic_GB_per_launch"] = round(upd * bpv / 1e9, 3)
+                    res["roofline"]["algorithmic_GB_per_launch"] = round(units * bpv / 1e9, 3)
             except (OSError, KeyError, ValueError):
                 pass
         if not args.no_cpu_baseline and world == 1:

@@ -525,8 +525,10 @@ template <typename Real> struct Engine : EngineBase {
          zp.u1 = (const float *)u1; zp.u0s = (const float *)(u0_src ? u0_src : u0); zp.u0 = (float *)u0; zp.mask = mask;
          zp.plane = plane; zp.Nx = (int)Nx; zp.Ny = (int)Ny; zp.Nz = (int)Nz; zp.P = (int)P;
          zp.x_begin = xb; zp.x_end = xe; zp.zl = tbz0; zp.zr = tbz1; zp.first = op.slab_first; zp.last = op.slab_last;
-         const int64_t nthreads = (int64_t)(zp.zl / 4 + (P - zp.zr) / 4) * (Ny - 2) * (xe - xb);
-         hipLaunchKernelGGL(pf::k_air_zstrip, dim3((unsigned)cdiv(nthreads, 256)), dim3(256), 0, s, zp, (float)a1, (float)a2, (float)l);
+         const int64_t nthreads = (int64_t)(zp.zl / 4 + (P - zp.zr) / 4) * (Ny - 2);
+         const int xchunk = 16;
+         hipLaunchKernelGGL(pf::k_air_zstrip, dim3((unsigned)cdiv(nthreads, 256), (unsigned)cdiv(xe - xb, xchunk)), dim3(256), 0, s, zp,
+                            (float)a1, (float)a2, (float)l, xchunk);
       }
    }
    // steps n and n+1 in one go; the state moves from (u0, u1) to (bufC, bufD), which swap roles with them

@@ -229,52 +229,64 @@ struct ZStripParams {
    int32_t first, last;
 };
 
-__global__ __launch_bounds__(256) void k_air_zstrip(ZStripParams zp, float a1, float a2, float l) {
+__global__ __launch_bounds__(256) void k_air_zstrip(ZStripParams zp, float a1, float a2, float l, int xchunk) {
+   // thread = one 16-byte vector of one row; it marches xchunk planes with the x neighbours in registers, so every
+   // 128-byte line of u1 / u0s next to the strip is fetched once (a thread-per-cell version re-fetched the x neighbours
+   // from other XCDs: 7x the compulsory bytes)
    typedef f32x4 vec;
    const int nl = zp.zl / 4, nr = (zp.P - zp.zr) / 4, nv = nl + nr;
    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-   const int64_t rows = (int64_t)(zp.Ny - 2) * (zp.x_end - zp.x_begin);
-   if (t >= rows * nv) return;
+   if (t >= (int64_t)(zp.Ny - 2) * nv) return;
    const int v = (int)(t % nv);
-   const int y = 1 + (int)((t / nv) % (zp.Ny - 2));
-   const int x = zp.x_begin + (int)(t / ((int64_t)nv * (zp.Ny - 2)));
+   const int y = 1 + (int)(t / nv);
+   const int xs = zp.x_begin + blockIdx.y * xchunk, xe = min(xs + xchunk, zp.x_end);
    const int z0 = v < nl ? v * 4 : zp.zr + (v - nl) * 4;
    const int Nx = zp.Nx, Ny = zp.Ny, Nz = zp.Nz, P = zp.P;
    auto rowsrc = [&](int yy) { return yy == 0 ? 2 : (yy == Ny - 1 ? Ny - 3 : yy); };
    auto planesrc = [&](int xx) { return (zp.first && xx == 0) ? 2 : ((zp.last && xx == Nx - 1) ? Nx - 3 : xx); };
-   const int64_t off = (int64_t)y * P + z0;
-   const float *pc = zp.u1 + (int64_t)x * zp.plane;
-   vec c = *(const vec *)(pc + off);
-   float lf = z0 > 0 ? pc[off - 1] : 0.f, rt = z0 + 4 < P ? pc[off + 4] : 0.f;
+   const int64_t off = (int64_t)y * P + z0, offp = (int64_t)rowsrc(y + 1) * P + z0, offm = (int64_t)rowsrc(y - 1) * P + z0;
    const int zzN = Nz - 1 - z0; // position of the ghost column Nz-1 relative to this vector
-   if (z0 == 0) c[0] = c[2];
-   if (zzN == 1) c[1] = lf;
-   if (zzN == 2) c[2] = c[0];
-   if (zzN == 3) c[3] = c[1];
-   if (zzN == 4) rt = c[2];
-   const vec xp = *(const vec *)(zp.u1 + (int64_t)planesrc(x + 1) * zp.plane + off);
-   const vec xm = *(const vec *)(zp.u1 + (int64_t)planesrc(x - 1) * zp.plane + off);
-   const vec yp = *(const vec *)(pc + (int64_t)rowsrc(y + 1) * P + z0);
-   const vec ym = *(const vec *)(pc + (int64_t)rowsrc(y - 1) * P + z0);
-   const vec old = *(const vec *)(zp.u0s + (int64_t)x * zp.plane + off);
-   const uint32_t bits = (zp.mask[((int64_t)x * zp.plane + off) >> 3] >> (off & 7)) & 0xfu;
-   const int qxy = (((zp.first && x == 1) || (zp.last && x == Nx - 2)) ? 1 : 0) + ((y == 1 || y == Ny - 2) ? 1 : 0);
-   vec o;
+   const bool yq = (y == 1 || y == Ny - 2);
+   auto centre = [&](int x, vec &c, float &lf, float &rt) { // a row of plane x with its z neighbours, ghost columns patched
+      const float *pc = zp.u1 + (int64_t)planesrc(x) * zp.plane;
+      c = *(const vec *)(pc + off);
+      lf = z0 > 0 ? pc[off - 1] : 0.f;
+      rt = z0 + 4 < P ? pc[off + 4] : 0.f;
+      if (z0 == 0) c[0] = c[2];
+      if (zzN == 1) c[1] = lf;
+      if (zzN == 2) c[2] = c[0];
+      if (zzN == 3) c[3] = c[1];
+      if (zzN == 4) rt = c[2];
+   };
+   vec cm, c, cp;
+   float lf, rt, lfn, rtn, dl, dr;
+   centre(xs - 1, cm, dl, dr);
+   centre(xs, c, lf, rt);
+   for (int x = xs; x < xe; x++) {
+      centre(x + 1, cp, lfn, rtn);
+      const float *pc = zp.u1 + (int64_t)x * zp.plane;
+      const vec yp = *(const vec *)(pc + offp), ym = *(const vec *)(pc + offm);
+      const vec old = *(const vec *)(zp.u0s + (int64_t)x * zp.plane + off);
+      const uint32_t bits = (zp.mask[((int64_t)x * zp.plane + off) >> 3] >> (off & 7)) & 0xfu;
+      const int qxy = (((zp.first && x == 1) || (zp.last && x == Nx - 2)) ? 1 : 0) + (yq ? 1 : 0);
+      vec o;
 #pragma unroll
-   for (int i = 0; i < 4; i++) {
-      const float zpv = (i == 3) ? rt : c[i < 3 ? i + 1 : 3];
-      const float zmv = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
-      float p = a1 * c[i] - old[i];
-      p = p + a2 * xp[i]; p = p + a2 * xm[i]; p = p + a2 * yp[i]; p = p + a2 * ym[i]; p = p + a2 * zpv; p = p + a2 * zmv;
-      const int Q = qxy + ((z0 + i == 1 || z0 + i == Nz - 2) ? 1 : 0);
-      if (Q > 0) { // ABC loss (cpu_engine.h:225-229), double literal of :228
-         const float lQ = l * (float)Q;
-         const float num = p + lQ * old[i];
-         p = (float)((double)num / (1.0 + (double)lQ));
+      for (int i = 0; i < 4; i++) {
+         const float zpv = (i == 3) ? rt : c[i < 3 ? i + 1 : 3];
+         const float zmv = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
+         float p = a1 * c[i] - old[i];
+         p = p + a2 * cp[i]; p = p + a2 * cm[i]; p = p + a2 * yp[i]; p = p + a2 * ym[i]; p = p + a2 * zpv; p = p + a2 * zmv;
+         const int Q = qxy + ((z0 + i == 1 || z0 + i == Nz - 2) ? 1 : 0);
+         if (Q > 0) { // ABC loss (cpu_engine.h:225-229), double literal of :228
+            const float lQ = l * (float)Q;
+            const float num = p + lQ * old[i];
+            p = (float)((double)num / (1.0 + (double)lQ));
+         }
+         o[i] = ((bits >> i) & 1u) ? old[i] : p;
       }
-      o[i] = ((bits >> i) & 1u) ? old[i] : p;
+      *(vec *)(zp.u0 + (int64_t)x * zp.plane + off) = o;
+      cm = c; c = cp; lf = lfn; rt = rtn;
    }
-   *(vec *)(zp.u0 + (int64_t)x * zp.plane + off) = o;
 }
 
 } // namespace pf
