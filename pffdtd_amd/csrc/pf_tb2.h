@@ -24,6 +24,7 @@ struct Tb2Params {
    int32_t nzt, nyt, nxc;
    int32_t y_begin, z_begin;      // first core row / first core column of tile (0,0)
    int32_t y_end, z_end;          // one past the last core row / column (0: Ny - y_begin / Nz - z_begin)
+   int32_t band;                  // 1: XCD k (blocks k, k+8, ...) works on a contiguous band of y-z tiles of every x chunk
 };
 
 template <int TYE, int WAVES>
@@ -126,8 +127,19 @@ __global__ __launch_bounds__(64 * WAVES) void k_tb2_proto(Tb2Params tp, float a1
 template <int R, int WY, bool NTA = true>
 __global__ __launch_bounds__(64 * WY) void k_tb2_reg(Tb2Params tp, float a1, float a2) {
    typedef f32x4 vec;
-   const uint32_t b = blockIdx.x; // plain order: the XCD swizzle of the single-step kernels costs 12 % here (measured)
-   const int zt = b % tp.nzt, yt = (b / tp.nzt) % tp.nyt, xc = b / (tp.nzt * tp.nyt);
+   // plain order by default: the XCD swizzle of the single-step kernels costs 12 % here (measured).  band: all XCDs
+   // stay on the same x chunk, but each takes a contiguous band of its y-z tiles, so tiles that share halo rows share an L2.
+   uint32_t b = blockIdx.x;
+   int zt, yt, xc;
+   if (tp.band) {
+      const uint32_t T = (uint32_t)tp.nzt * tp.nyt, Tp = (T + 7) / 8;
+      xc = b / (8 * Tp);
+      const uint32_t r = b % (8 * Tp), j = (r % 8) * Tp + r / 8;
+      if (j >= T || xc >= tp.nxc) return;
+      zt = j % tp.nzt; yt = j / tp.nzt;
+   } else {
+      zt = b % tp.nzt; yt = (b / tp.nzt) % tp.nyt; xc = b / (tp.nzt * tp.nyt);
+   }
    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
    const int ze0 = tp.z_begin - 4 + zt * 248;
    const int yo = tp.y_begin + (yt * WY + w) * R;           // first output row of this wave
