@@ -70,11 +70,13 @@ class SimEngine:
         else:
             self.eng.run(nstart, nsteps)
 
-    def run_all(self, nsteps=1):
+    def run_all(self, nsteps=0):
+        """nsteps: steps per engine call (the reference's batch size for progress / plotting); 0 = the whole run in one
+        call, which lets the engine keep its receiver ring and step-pair schedule uninterrupted."""
         self.print("running..")
         sd = self.sd
         t0 = time.perf_counter()
-        nsteps = max(int(nsteps), 1)
+        nsteps = int(nsteps) if int(nsteps) > 0 else max(int(sd.Nt), 1)
         for n in range(0, sd.Nt, nsteps):
             self.run_steps(n, min(nsteps, sd.Nt - n))
         self.eng.sync()
@@ -131,7 +133,7 @@ def rel_diff(x0, x1):
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--data_dir", type=str, required=True, help="run directory")
-    p.add_argument("--nsteps", type=int, default=1, help="run in batches of steps")
+    p.add_argument("--nsteps", type=int, default=0, help="run in batches of steps (0 = all at once)")
     p.add_argument("--nthreads", type=int, default=None, help="ignored (kept for CLI compatibility)")
     p.add_argument("--energy", action="store_true", help="do energy calc")
     p.add_argument("--plot", action="store_true", help="not supported (visualisation is out of scope)")
@@ -147,7 +149,7 @@ def main():
     eng.allocate_mem()
     eng.set_coeffs()
     eng.checks()
-    eng.run_all(max(a.nsteps, 1) if a.nsteps else 1)
+    eng.run_all(a.nsteps)
     eng.save_outputs()
     eng.print_last_samples(5)
     if a.energy:
