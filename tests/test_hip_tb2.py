@@ -73,3 +73,19 @@ def test_rooms_without_a_box_keep_the_single_step_path():
     assert np.array_equal(out, ref.u_out)
     with pytest.raises(engine.PfError):
         run(sim, 40)
+
+
+@pytest.mark.parametrize("n,wall", [((37, 67, 283), 3), ((41, 75, 291), 5), ((34, 62, 270), 4)], ids=["odd", "deep_walls", "tight"])
+def test_blocked_steps_on_awkward_sizes(n, wall):
+    """Row counts that are not multiples of the strip tile height, column counts that are not multiples of 4, pitch
+    padding next to the right column strip, wall depths that move the box."""
+    sim = scene([n[0] // 2, n[1] // 2 - 3, n[2] // 2 + 5], Nt=14, n=n, wall=wall)
+    ref = sim_data.SimData.from_sim(sim, "single")
+    ref.scale_input()
+    oracle.run_sim(ref)
+    out, g, tm = run(sim, 40)
+    assert tm["tb2_launches"] > 0
+    assert np.array_equal(out, ref.u_out)
+    _, base_g, _ = run(sim, 25)
+    for a, b in zip(g, base_g):
+        assert np.array_equal(a[1:-1, 1:-1, 1:-1], b[1:-1, 1:-1, 1:-1])
