@@ -89,3 +89,14 @@ def test_blocked_steps_on_awkward_sizes(n, wall):
     _, base_g, _ = run(sim, 25)
     for a, b in zip(g, base_g):
         assert np.array_equal(a[1:-1, 1:-1, 1:-1], b[1:-1, 1:-1, 1:-1])
+
+
+def test_blocked_steps_long_run():
+    """300 steps (75 quads) with reflections off the lossy walls back into the box; receiver ring of 64 wraps 4 times."""
+    sim = scene(None, Nt=301, n=(36, 64, 280))
+    ref = sim_data.SimData.from_sim(sim, "single")
+    ref.scale_input()
+    oracle.run_sim(ref)
+    out, _, tm = run(sim, 40, readout_chunk=64)
+    assert tm["tb2_launches"] >= 2 * 140 and tm["steps"] == 301
+    assert np.array_equal(out, ref.u_out)
