@@ -205,7 +205,6 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(W, K)
-    t_enq = time.perf_counter() - t0  # host time to enqueue K steps (diagnostic: is the loop CPU-bound?)
     sync()
     torch.cuda.synchronize()
     barrier()
@@ -225,7 +224,7 @@ def main():
     if rank == 0:
         gvox = sd.Npts * K / el / 1e9
         if emu is not None:
-            print(f"[emulated slab {emu[0]}/{emu[1]}: {loc.Nx} planes] host enqueue {t_enq / K * 1e3:.4f} ms/step; "
+            print(f"[emulated slab {emu[0]}/{emu[1]}: {loc.Nx} planes, exchange = {args.emulate_transport}] "
                   f"{el / K * 1e3:.4f} ms/step -> {emu[1]} such ranks would give "
                   f"{sd.Npts * K / el / 1e9:.1f} Gvox/s if the exchange hides completely", file=sys.stderr)
         bpv = 3 * real_bytes + 0.125  # u1 read, u0 read + write, one mask bit
