@@ -226,6 +226,137 @@ __global__ __launch_bounds__(64 * WY) void k_tb2_reg(Tb2Params tp, float a1, flo
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// k_tb2_lds -- k_tb2_reg with the y-halo rows of u^n and u^{n-1} exchanged between the waves of a workgroup through
+// LDS instead of being re-read through L1: a wave loads its own R rows of a plane from global memory (the top / bottom
+// wave of the workgroup also the two rows beyond it), and one iteration later -- when the plane is first needed with
+// halos -- publishes them to a double-buffered LDS tile, one barrier, and picks up its neighbours' rows.
+// Global row loads per workgroup and plane: WY*R+4 (u^n) + WY*R+2 (u^{n-1}) instead of WY*(2R+6).
+// ---------------------------------------------------------------------------------------------------------------
+template <int R, int WY>
+__global__ __launch_bounds__(64 * WY) void k_tb2_lds(Tb2Params tp, float a1, float a2) {
+   typedef f32x4 vec;
+   __shared__ __attribute__((aligned(16))) float sB[2][WY * R][256];
+   __shared__ __attribute__((aligned(16))) float sA[2][WY * R][256];
+   const uint32_t b = blockIdx.x;
+   const int zt = b % tp.nzt, yt = (b / tp.nzt) % tp.nyt, xc = b / (tp.nzt * tp.nyt);
+   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+   const int ze0 = tp.z_begin - 4 + zt * 248;
+   const int yo = tp.y_begin + (yt * WY + w) * R;
+   const int xs = tp.x_begin + xc * tp.chunk, xe = min(xs + tp.chunk, tp.x_end);
+   const int P = tp.P;
+   const int64_t plane = tp.plane;
+   const int zc = min(max(ze0 + lane * 4, 0), P - 4);
+   int64_t offB[R + 4];
+#pragma unroll
+   for (int i = 0; i < R + 4; i++) offB[i] = (int64_t)min(max(yo - 2 + i, 0), tp.Ny - 1) * P + zc;
+   const int z_end = tp.z_end ? tp.z_end : tp.Nz - tp.z_begin, y_end = tp.y_end ? tp.y_end : tp.Ny - tp.y_begin;
+   const bool core_col = (lane >= 1 && lane <= 62) && (ze0 + lane * 4 + 3 < z_end);
+   bool core_row[R];
+#pragma unroll
+   for (int r = 0; r < R; r++) core_row[r] = (yo + r < y_end);
+   const bool top = (w == 0), bot = (w == WY - 1);
+
+   // own rows (+ the rows beyond the workgroup for its first / last wave) of a plane from global memory
+   auto loadB_own = [&](int x, vec *d) {
+      const float *pl = tp.B + (int64_t)x * plane;
+#pragma unroll
+      for (int r = 0; r < R; r++) d[r + 2] = *(const vec *)(pl + offB[r + 2]);
+      if (top) { d[0] = *(const vec *)(pl + offB[0]); d[1] = *(const vec *)(pl + offB[1]); }
+      if (bot) { d[R + 2] = *(const vec *)(pl + offB[R + 2]); d[R + 3] = *(const vec *)(pl + offB[R + 3]); }
+   };
+   auto loadA_own = [&](int x, vec *d) { // d: rows yo-1 .. yo+R
+      const float *pl = tp.A + (int64_t)x * plane;
+#pragma unroll
+      for (int r = 0; r < R; r++) d[r + 1] = *(const vec *)(pl + offB[r + 2]);
+      if (top) d[0] = *(const vec *)(pl + offB[1]);
+      if (bot) d[R + 1] = *(const vec *)(pl + offB[R + 2]);
+   };
+   // halo rows of the planes held in Bv (R+4 rows) and Av (R+2 rows) from the neighbouring waves
+   auto exchange = [&](int slot, vec *Bv, vec *Av) {
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+         *(vec *)&sB[slot][w * R + r][lane * 4] = Bv[r + 2];
+         *(vec *)&sA[slot][w * R + r][lane * 4] = Av[r + 1];
+      }
+      __syncthreads();
+      if (!top) {
+         Bv[0] = *(const vec *)&sB[slot][w * R - 2][lane * 4];
+         Bv[1] = *(const vec *)&sB[slot][w * R - 1][lane * 4];
+         Av[0] = *(const vec *)&sA[slot][w * R - 1][lane * 4];
+      }
+      if (!bot) {
+         Bv[R + 2] = *(const vec *)&sB[slot][w * R + R][lane * 4];
+         Bv[R + 3] = *(const vec *)&sB[slot][w * R + R + 1][lane * 4];
+         Av[R + 1] = *(const vec *)&sA[slot][w * R + R][lane * 4];
+      }
+   };
+   auto stencil = [&](const vec &c, const vec &xp, const vec &xm, const vec &yp, const vec &ym, const vec &old) {
+      const float lf = lane_from_lower<true>(c[3]);
+      const float rt = lane_from_upper<true>(c[0]);
+      vec o;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+         const float zp = (i == 3) ? rt : c[i < 3 ? i + 1 : 3];
+         const float zm = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
+         float p = a1 * c[i] - old[i];
+         p = p + a2 * xp[i]; p = p + a2 * xm[i]; p = p + a2 * yp[i]; p = p + a2 * ym[i]; p = p + a2 * zp; p = p + a2 * zm;
+         o[i] = p;
+      }
+      return o;
+   };
+
+   vec Bp[R + 2], Bc[R + 4], Bn[R + 4], Bnn[R + 4], Ar[R + 2], Arn[R + 2];
+   vec vm[R], vc[R + 2], vn[R + 2];
+   {  // prologue: planes xs-2 (rows R+2 needed), xs-1, xs of u^n and xs-1 of u^{n-1}, halos through the same exchange
+      vec t[R + 4], ta[R + 2];
+      loadB_own(xs - 2, t);
+      loadA_own(xs - 1, ta);
+      exchange(0, t, ta);
+#pragma unroll
+      for (int j = 0; j < R + 2; j++) { Bp[j] = t[j + 1]; Ar[j] = ta[j]; }
+      loadB_own(xs - 1, Bc);
+      loadA_own(xs - 1, ta);
+      exchange(1, Bc, ta);
+      loadB_own(xs, Bn);       // its halos arrive at the top of the first iteration, together with Arn's
+      loadA_own(xs, Arn);      // (u^{n-1} plane xs: used from the second iteration on)
+   }
+#pragma unroll
+   for (int r = 0; r < R; r++) vm[r] = vec{0, 0, 0, 0};
+#pragma unroll
+   for (int j = 0; j < R + 2; j++) vc[j] = vec{0, 0, 0, 0};
+   int it = 0;
+   for (int x1 = xs - 1; x1 <= xe; x1++, it++) {
+      // Bn = u^n plane x1+1 and Arn = u^{n-1} plane x1+1 arrived during the previous turn: complete them with halos
+      exchange(it & 1, Bn, Arn);
+      if (x1 < xe) loadB_own(x1 + 2, Bnn);
+      // stage 1: u^{n+1}(x1) on rows yo-1 .. yo+R
+#pragma unroll
+      for (int j = 0; j < R + 2; j++) vn[j] = stencil(Bc[j + 1], Bn[j + 1], Bp[j], Bc[j + 2], Bc[j], Ar[j]);
+      if (x1 >= xs && x1 < xe) {
+         float *pc = tp.C + (int64_t)x1 * plane;
+#pragma unroll
+         for (int r = 0; r < R; r++)
+            if (core_col && core_row[r]) __builtin_nontemporal_store(vn[r + 1], (vec *)(pc + offB[r + 2]));
+      }
+      if (x1 - 1 >= xs) {
+         float *pd = tp.D + (int64_t)(x1 - 1) * plane;
+#pragma unroll
+         for (int r = 0; r < R; r++) {
+            const vec o = stencil(vc[r + 1], vn[r + 1], vm[r], vc[r + 2], vc[r], Bp[r + 1]);
+            if (core_col && core_row[r]) __builtin_nontemporal_store(o, (vec *)(pd + offB[r + 2]));
+         }
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) vm[r] = vc[r + 1];
+#pragma unroll
+      for (int j = 0; j < R + 2; j++) { vc[j] = vn[j]; Bp[j] = Bc[j + 1]; Ar[j] = Arn[j]; }
+#pragma unroll
+      for (int i = 0; i < R + 4; i++) { Bc[i] = Bn[i]; Bn[i] = Bnn[i]; }
+      if (x1 + 1 < xe) loadA_own(x1 + 2, Arn);
+   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // k_air_zstrip -- single-step 7-point air update (virtual ghost shell + ABC loss, as k_air_cart_lean) of the thin
 // column strips z in [0, zl) and [zr, P) left over next to the temporally blocked box: one thread per 16-byte vector.
 // Out of place: u^{n-1} from u0s, u^{n+1} to u0.  Same expression order as the marching kernels (bit-identical).
