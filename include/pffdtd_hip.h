@@ -86,7 +86,8 @@ typedef struct pf_opts {
    int32_t slab_first;    /* 1 if this grid holds the global ix=0 ghost plane (gpu_engine.h:1030-1032) */
    int32_t slab_last;     /* 1 if this grid holds the global ix=Nx-1 ghost plane (gpu_engine.h:1033-1035) */
    int32_t readout_chunk; /* receiver ring depth in steps before a D2H flush (0 = default) */
-   int32_t air_variant;   /* 0 = default air kernel; others are tuning variants */
+   int32_t air_variant;   /* 0 = automatic; 1-9 unfused marching kernels, 10-14 generic fused, 20-28 lean fused 7-point
+                             (25 = the single-step default), 40/41 temporal blocking forced / driver only; see DESIGN.md 4 */
    int32_t air_chunk;     /* planes marched per workgroup (0 = auto, <0 = that many equal chunks) */
    int32_t timing;        /* 1 = bracket the air kernel with HIP events every step (pf_engine_timing) */
    void   *ext_u0;        /* optional caller-owned DEVICE buffers for the two state grids, each of */

@@ -1,7 +1,9 @@
 """pffdtd_amd -- MI355X-native FDTD time-step engine behind bsxfun/pffdtd's engine seam and file contract.
 
-Modules: engine (ctypes binding of libpffdtd_hip.so, HIP only), sim_data (loader = load_sim_data mirror), h5io,
-synth (synthetic scenes + rotate/fold/sort), slab + dist (Z-slab multi-GPU), sim_fdtd / fdtd_main (drop-in CLIs),
-setup_io (SimConsts / SimComms / SimMats writers), process_outputs (receiver post-processing).
+Hot path: engine (ctypes binding of libpffdtd_hip.so, HIP only), sim_data (loader = load_sim_data mirror), h5io,
+slab + dist (Z-slab multi-GPU), sim_fdtd / fdtd_main (drop-in CLIs).
+Around it: materials (absorption -> impedance branch tables), room_geo + voxelizer (scene export -> boundary nodes, on
+the device), setup_io + sim_setup + scenes (sim folders; the reference's test-script configurations), synth (synthetic
+box scenes, rotate / fold / sort), process_outputs + air_abs (receivers -> room impulse responses).
 """
-__version__ = "0.1.0"
+__version__ = "0.2.0"

@@ -1144,7 +1144,7 @@ struct pf_engine {
 extern "C" {
 
 const char *pf_last_error(void) { return g_err.c_str(); }
-const char *pf_version(void) { return "pffdtd_hip 0.1 (gfx950)"; }
+const char *pf_version(void) { return "pffdtd_hip 0.2 (gfx950)"; }
 
 int pf_device_count(void) {
    int n = 0;
