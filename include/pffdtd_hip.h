@@ -138,6 +138,12 @@ int  pf_engine_step_begin(pf_engine *e, int64_t n);
 int  pf_engine_halo_ptrs(pf_engine *e, void **send_lo, void **send_hi, void **recv_lo, void **recv_hi,
                          size_t *plane_bytes);
 int  pf_engine_step_end(pf_engine *e, int64_t n);
+/* Slab engines created on caller-owned grids (pf_opts.ext_u0/ext_u1): hand over two more grids of the same size, so
+ * that the engine may advance in temporally blocked pairs (two split-phase steps per pair, the state then cycles
+ * through the four grids: pf_engine_halo_ptrs always names the grid being written).  Returns 0 when pairs are on,
+ * 1 when this engine keeps stepping singly (scene without a boundary-free box, fp64, 13-point, ...); other values
+ * are pf_status errors.  No counterpart in the reference. */
+int  pf_engine_set_spares(pf_engine *e, void *grid2, void *grid3);
 void *pf_engine_stream(pf_engine *e, int32_t which); /* 0 main, 1 edge: hipStream_t */
 int  pf_engine_sync(pf_engine *e);
 int  pf_engine_flush_outputs(pf_engine *e);          /* ring -> sd->u_out */

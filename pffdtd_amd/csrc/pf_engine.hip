@@ -77,6 +77,7 @@ struct EngineBase {
    virtual int halo_ptrs(void **slo, void **shi, void **rlo, void **rhi, size_t *bytes) = 0;
    virtual int sync() = 0;
    virtual int flush() = 0;
+   virtual int set_spares(void *g2, void *g3) = 0;
    virtual int get_grid(int which, void *host) = 0;
    virtual int set_grid(int which, const void *host) = 0;
    virtual int timing(pf_timing *t, int reset) = 0;
@@ -127,7 +128,12 @@ template <typename Real> struct Engine : EngineBase {
    bool in_step = false;
    int64_t steps_done = 0;
    // temporal blocking (pf_tb2.h): pairs of steps over a boundary-free box, single-step strips around it
-   bool tb2 = false;
+   bool tb2 = false;                                      // pairs inside pf_engine_run (single-domain engines)
+   bool tb2_geom = false, tb2_slab = false;               // slab engines: pairs across two split-phase steps (set_spares)
+   int pair_phase = 0;                                    // 1: between the two steps of a split-phase pair
+   bool pair_now = false;                                 // the step in flight is half of a pair
+   Real *pA = nullptr, *pB = nullptr;                     // u^{n-1}, u^n of the pair in flight
+   hipEvent_t ev_xchg = nullptr;                          // edge stream after the exchange of the latest step
    Real *bufC = nullptr, *bufD = nullptr;                 // the two extra state grids of the out-of-place pair
    int tbx0 = 0, tbx1 = 0, tby0 = 0, tby1 = 0, tbz0 = 0, tbz1 = 0; // box of cells k_tb2_reg produces
    std::vector<std::pair<int, int>> tb_xr;                // its x ranges (planes next to a source are cut out)
@@ -160,6 +166,7 @@ template <typename Real> struct Engine : EngineBase {
       if (ev_pre) hipEventDestroy(ev_pre);
       if (ev_edge) hipEventDestroy(ev_edge);
       if (ev_main) hipEventDestroy(ev_main);
+      if (ev_xchg) hipEventDestroy(ev_xchg);
       if (s_main) hipStreamDestroy(s_main);
       if (s_edge) hipStreamDestroy(s_edge);
       u0 = u1 = nullptr; s_main = s_edge = nullptr;
@@ -259,6 +266,7 @@ template <typename Real> struct Engine : EngineBase {
       HIPCHK(hipEventCreateWithFlags(&ev_pre, hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&ev_edge, hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&ev_xchg, hipEventDisableTiming));
       use_dpp = check_dpp(s_main) == 1;
 
       // ---- state grids ----
@@ -449,19 +457,23 @@ template <typename Real> struct Engine : EngineBase {
    // stepped twice by the single-step kernels, out of place.  Rooms with interior geometry have no such box: tb2 stays
    // off and nothing changes.  air_variant 0 (auto) and 40 enable it, 41 = same driver with the box disabled (tests).
    int init_tb2() {
-      tb2 = false;
-      if (sizeof(Real) != 4 || fcc || !lean || lean_rigid || op.energy || !(op.slab_first && op.slab_last)) return PF_OK;
+      tb2 = tb2_geom = tb2_slab = false;
+      const bool single = op.slab_first && op.slab_last;
+      if (sizeof(Real) != 4 || fcc || !lean || lean_rigid || op.energy) return PF_OK;
       if (!(vbase == 0 || vbase == 40 || vbase == 41) || op.numerics != PF_NUM_CPU_EXACT || !use_dpp) return PF_OK;
       if (Nb > 0 && !boundary_fused()) return PF_OK;
-      int64_t dmax = 0; // depth of the deepest boundary node below the nearest grid face
-      const int64_t NzNy = Nz * Ny;
+      int64_t dmax = 0; // depth of the deepest boundary node below the nearest grid face (slab faces towards a neighbour are no faces)
+      const int64_t NzNy = Nz * Ny, INF = (int64_t)1 << 40;
       for (int64_t i = 0; i < Nb; i++) {
          const int64_t ii = sd.bn_ixyz[i], ix = ii / NzNy, iy = (ii / Nz) % Ny, iz = ii % Nz;
-         const int64_t d = std::min({ix, Nx - 1 - ix, iy, Ny - 1 - iy, iz, Nz - 1 - iz});
+         const int64_t d = std::min({op.slab_first ? ix : INF, op.slab_last ? Nx - 1 - ix : INF, iy, Ny - 1 - iy, iz, Nz - 1 - iz});
          dmax = std::max(dmax, d);
       }
       const int m = (int)std::max<int64_t>(dmax + 2, 3), mz = (m + 3) / 4 * 4;
-      tbx0 = m; tbx1 = (int)Nx - m; tby0 = m; tby1 = (int)Ny - m; tbz0 = mz; tbz1 = (int)((Nz - mz) / 4 * 4);
+      // towards a neighbouring slab the box stops two planes short of the ghost plane: plane 1 / Nx-2 are the edge planes
+      // of the split-phase step (they need the neighbour's data between the two steps of a pair)
+      tbx0 = op.slab_first ? m : 2; tbx1 = op.slab_last ? (int)Nx - m : (int)Nx - 2;
+      tby0 = m; tby1 = (int)Ny - m; tbz0 = mz; tbz1 = (int)((Nz - mz) / 4 * 4);
       if (vbase == 41) tbx1 = tbx0; // driver test: everything goes through the out-of-place single-step path
       tb_xr.clear();
       if (tbx1 - tbx0 >= 16 && tby1 - tby0 >= 48 && tbz1 - tbz0 >= 248) {
@@ -482,11 +494,21 @@ template <typename Real> struct Engine : EngineBase {
       // auto: the shell costs grow with the perimeter of the y-z cross-section, the gain with its area -- measured on
       // MI355X: 512^2 planes -4.5 %, 768^2 +9 %, 1024^2 +13 %; and two extra grids must be worth it
       if (vbase == 0 && ((double)vol < 0.6 * (double)(Nx * Ny * Nz) || tby1 - tby0 < 600 || tbz1 - tbz0 < 600)) return PF_OK;
+      tb2_geom = true;
+      if (!single) return PF_OK; // slab engines wait for pf_engine_set_spares (all four grids must be the caller's)
       int rc;
       if ((rc = dzalloc(&bufC, npad))) return rc;
       if ((rc = dzalloc(&bufD, npad))) return rc;
       own_list.push_back(bufC); own_list.push_back(bufD);
       tb2 = true;
+      return PF_OK;
+   }
+   int set_spares(void *g2, void *g3) override {
+      if (in_step || pair_phase) return set_err(PF_ERR_STATE, "pf_engine_set_spares inside a step");
+      if (!g2 || !g3) return set_err(PF_ERR_ARG, "pf_engine_set_spares: null grid");
+      if (!tb2_geom || (op.slab_first && op.slab_last)) return 1; // not an error: this engine keeps stepping singly
+      bufC = (Real *)g2; bufD = (Real *)g3;
+      tb2_slab = true;
       return PF_OK;
    }
    void launch_tb2(hipStream_t s, const Real *A, const Real *B, Real *C, Real *D) {
@@ -507,13 +529,14 @@ template <typename Real> struct Engine : EngineBase {
       }
    }
    // one out-of-place single step of everything outside the box: u1 -> (u0_src old) -> u0
-   void launch_shell(hipStream_t s) {
-      int xa = 1;
+   void launch_shell(hipStream_t s) { launch_shell(s, 1, (int)Nx - 1); }
+   void launch_shell(hipStream_t s, int xlo, int xhi) { // planes [xlo, xhi) (the box lies inside)
+      int xa = xlo;
       for (auto &r : tb_xr) { // x slabs: everything before / between / after the box's plane ranges, full planes
          if (r.first > xa) launch_air_lean(s, xa, r.first);
          xa = r.second;
       }
-      if ((int)Nx - 1 > xa) launch_air_lean(s, xa, (int)Nx - 1);
+      if (xhi > xa) launch_air_lean(s, xa, xhi);
       if (tb_xr.empty()) return;
       const int xb = tb_xr.front().first, xe = tb_xr.back().second;
       // beside the box: the two row strips in one lean launch (tile height of the default configuration: 16 rows) ...
@@ -965,7 +988,7 @@ template <typename Real> struct Engine : EngineBase {
    }
 
    int run(int64_t n0, int64_t nsteps) override {
-      if (in_step) return set_err(PF_ERR_STATE, "pf_engine_run inside a split-phase step");
+      if (in_step || pair_phase) return set_err(PF_ERR_STATE, "pf_engine_run inside a split-phase step (pair)");
       HIPCHK(hipSetDevice(op.device));
       for (int64_t n = n0; n < n0 + nsteps;) {
          int rc;
@@ -992,6 +1015,38 @@ template <typename Real> struct Engine : EngineBase {
       if (n < 0 || n >= Nt) return set_err(PF_ERR_ARG, "step %ld outside [0,Nt=%ld)", (long)n, (long)Nt);
       HIPCHK(hipSetDevice(op.device));
       const int xl = 1, xh = (int)Nx - 2;
+      // Slab engines with all four grids at hand step in temporally blocked pairs that span two split-phase steps:
+      // phase 0 (step n): edge planes n -> n+1 on the edge stream; box n -> n+1, n+2 plus the shell n -> n+1 on the
+      // main stream; phase 1 (step n+1): edge planes and shell n+1 -> n+2.  The exchanges in between are the usual ones.
+      if (tb2_slab && (pair_phase == 1 || (n + 1 < Nt && ring_fill + 2 <= ring_depth && xh - xl >= 4))) {
+         const bool first_half = pair_phase == 0;
+         if (first_half) { pA = u0; pB = u1; u0_src = pA; u1 = pB; u0 = bufC; }
+         fold_x0 = 0; fold_x1 = 0; // (7-point only: no fold row)
+         launch_air(s_edge, xl, xl + 1);
+         launch_air(s_edge, xh, xh + 1);
+         launch_rigid(s_edge, bn_lo); launch_rigid(s_edge, bn_hi);
+         launch_fd(s_edge, bnl_lo); launch_fd(s_edge, bnl_hi);
+         launch_io(s_edge, n, false, in_lo); launch_io(s_edge, n, false, in_hi);
+         HIPCHK(hipEventRecord(ev_edge, s_edge));
+         std::pair<hipEvent_t, hipEvent_t> eva{}, evt{};
+         auto get_ev = [&]() { std::pair<hipEvent_t, hipEvent_t> e{}; if (!ev_pool.empty()) { e = ev_pool.back(); ev_pool.pop_back(); } else { hipEventCreate(&e.first); hipEventCreate(&e.second); } return e; };
+         if (op.timing) { eva = get_ev(); hipEventRecord(eva.first, s_main); }
+         if (first_half) {
+            HIPCHK(hipStreamWaitEvent(s_main, ev_xchg, 0)); // the box kernel reads the ghost planes of u^n (level-1 values of plane 1)
+            if (op.timing) { evt = get_ev(); hipEventRecord(evt.first, s_main); }
+            launch_tb2(s_main, pA, pB, bufC, bufD);
+            if (op.timing) { hipEventRecord(evt.second, s_main); tb2_ev.push_back(evt); }
+         }
+         launch_shell(s_main, xl + 1, xh);
+         if (op.timing) { hipEventRecord(eva.second, s_main); air_ev.push_back(eva); }
+         launch_rigid(s_main, bn_mid);
+         launch_fd(s_main, bnl_mid);
+         launch_io(s_main, n, true, in_mid);
+         HIPCHK(hipGetLastError());
+         in_step = true;
+         pair_now = true;
+         return PF_OK;
+      }
       if (!(fused || lean || vg)) { // ghost flips / ABC save touch the whole grid: the interior must see them
          launch_pre(s_edge);
          HIPCHK(hipEventRecord(ev_pre, s_edge));
@@ -1034,9 +1089,23 @@ template <typename Real> struct Engine : EngineBase {
       // the edge *compute* only (ev_edge, recorded in step_begin before the exchange was issued) -- the exchange
       // itself stays off the main stream's critical path and only orders the edge stream.
       HIPCHK(hipEventRecord(ev_main, s_main));
+      HIPCHK(hipEventRecord(ev_xchg, s_edge)); // everything the caller queued on the edge stream for this step's exchange
       HIPCHK(hipStreamWaitEvent(s_edge, ev_main, 0));
       HIPCHK(hipStreamWaitEvent(s_main, ev_edge, 0));
       in_step = false;
+      if (pair_now) {
+         pair_now = false;
+         { Real *t = ub[2]; ub[2] = ub[1]; ub[1] = ub[0]; ub[0] = t; }
+         if (pair_phase == 0) { // u^{n+1} is complete in bufC: second half reads u^n as the old state and writes bufD
+            u0_src = pB; u1 = bufC; u0 = bufD;
+            pair_phase = 1;
+         } else {               // pair done: state = (bufC, bufD), the former state grids become the spares
+            Real *C = bufC, *D = bufD;
+            u0_src = nullptr; u0 = C; u1 = D; bufC = pA; bufD = pB;
+            pair_phase = 0;
+         }
+         return after_step(n);
+      }
       rotate();
       return after_step(n);
    }
@@ -1109,7 +1178,7 @@ template <typename Real> struct Engine : EngineBase {
       HIPCHK(hipSetDevice(op.device));
       int rc = sync();
       if (rc) return rc;
-      const Real *src = which == 0 ? u0 : u1;
+      const Real *src = which == 0 ? (pair_phase == 1 ? pB : u0) : u1; // mid-pair u0 already names the grid being written
       if ((fused || lean || vg) && which == 1) { // write the virtual ghost shell out, exactly as the reference's flips would have
          launch_flips(s_main);
          HIPCHK(hipStreamSynchronize(s_main));
@@ -1206,6 +1275,7 @@ int pf_engine_halo_ptrs(pf_engine *e, void **send_lo, void **send_hi, void **rec
    return e->impl->halo_ptrs(send_lo, send_hi, recv_lo, recv_hi, plane_bytes);
 }
 int pf_engine_step_end(pf_engine *e, int64_t n) { PF_NEED(e); return e->impl->step_end(n); }
+int pf_engine_set_spares(pf_engine *e, void *g2, void *g3) { PF_NEED(e); return e->impl->set_spares(g2, g3); }
 void *pf_engine_stream(pf_engine *e, int32_t which) { return (e && e->impl) ? e->impl->stream(which) : nullptr; }
 int pf_engine_sync(pf_engine *e) { PF_NEED(e); return e->impl->sync(); }
 int pf_engine_flush_outputs(pf_engine *e) { PF_NEED(e); return e->impl->flush(); }

@@ -19,7 +19,7 @@ from . import slab as slab_mod
 class HipSlabStepper:
     """HIP engine of one slab with torch-owned state grids (so the halo planes are addressable as tensors)."""
 
-    def __init__(self, loc, info, device, **engine_kw):
+    def __init__(self, loc, info, device, pairs=True, **engine_kw):
         from . import engine
         self.loc, self.info = loc, info
         self.device = torch.device("cuda", device)
@@ -31,15 +31,26 @@ class HipSlabStepper:
             torch.cuda.synchronize()
         self.eng = engine.HipEngine(loc, device=device, slab_first=info.first, slab_last=info.last, x_global0=info.xlo,
                                     ext_u0=self.grids[0].data_ptr(), ext_u1=self.grids[1].data_ptr(), **engine_kw)
+        # Two more grids let a slab engine with a boundary-free box advance in temporally blocked pairs (the state
+        # then cycles through all four); engines that cannot use them say so and the grids are dropped again.
+        self.paired = False
+        if info.G > 1 and pairs:
+            with torch.cuda.device(self.device):
+                spare = [torch.zeros((loc.Nx, self.plane), dtype=self.tdtype, device=self.device) for _ in range(2)]
+                torch.cuda.synchronize()
+            if self.eng.set_spares(spare[0].data_ptr(), spare[1].data_ptr()):
+                self.grids += spare
+                self.paired = True
+        self._by_ptr = {g.data_ptr(): g for g in self.grids}
         self.edge_stream = torch.cuda.ExternalStream(self.eng.stream(1), device=self.device)
         self.main_stream = torch.cuda.ExternalStream(self.eng.stream(0), device=self.device)
-        self.k = 0  # steps completed: the new state is written into grids[k % 2]
+        self.k = 0  # steps completed
 
     def step_begin(self, n):
         self.eng.step_begin(n)
 
     def halo_tensors(self):
-        g = self.grids[self.k % 2]
+        g = self._by_ptr[self.eng.halo_ptrs()[2]]  # the grid the step in flight writes (its plane 0 = recv_lo)
         Nx = self.loc.Nx
         return g[1], g[Nx - 2], g[0], g[Nx - 1]  # send_lo, send_hi, recv_lo, recv_hi
 
@@ -129,6 +140,8 @@ def gather_outputs(sd, loc, info, group=None):
 
 
 def make_hip_runner(sd, rank, world, device, group=None, balance=True, **engine_kw):
+    import os
     loc, info = slab_mod.split(sd, world, rank, balance=balance)
+    engine_kw.setdefault("pairs", os.environ.get("PFFDTD_SLAB_PAIRS", "1") != "0")  # temporally blocked step pairs
     st = HipSlabStepper(loc, info, device, **engine_kw)
     return SlabRunner(st, info, group), loc, info

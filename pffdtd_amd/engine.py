@@ -36,7 +36,7 @@ class PfError(RuntimeError):
 
 EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_grid_bytes", "pf_grid_pitch", "pf_opts_default",
            "pf_run_sim", "pf_engine_create", "pf_engine_destroy", "pf_engine_run", "pf_engine_step_begin",
-           "pf_engine_halo_ptrs", "pf_engine_step_end", "pf_engine_stream", "pf_engine_sync",
+           "pf_engine_halo_ptrs", "pf_engine_step_end", "pf_engine_set_spares", "pf_engine_stream", "pf_engine_sync",
            "pf_engine_flush_outputs", "pf_engine_get_grid", "pf_engine_set_grid", "pf_engine_timing",
            "pf_engine_energy_cfg", "pf_engine_run_energy", "pf_membench", "pf_tb2_probe"]
 
@@ -150,6 +150,16 @@ class HipEngine:
         _check(lib().pf_engine_halo_ptrs(self._h, ctypes.byref(slo), ctypes.byref(shi), ctypes.byref(rlo),
                                          ctypes.byref(rhi), ctypes.byref(nb)))
         return slo.value, shi.value, rlo.value, rhi.value, nb.value
+
+    def set_spares(self, ptr2, ptr3):
+        """Two more caller-owned state grids: lets a slab engine step in temporally blocked pairs.  -> True if it will."""
+        L = lib()
+        L.pf_engine_set_spares.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.pf_engine_set_spares.restype = ctypes.c_int
+        rc = L.pf_engine_set_spares(self._h, ctypes.c_void_p(ptr2), ctypes.c_void_p(ptr3))
+        if rc not in (0, 1):
+            _check(rc)
+        return rc == 0
 
     def stream(self, which):
         return lib().pf_engine_stream(self._h, int(which))
