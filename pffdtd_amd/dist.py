@@ -19,7 +19,7 @@ from . import slab as slab_mod
 class HipSlabStepper:
     """HIP engine of one slab with torch-owned state grids (so the halo planes are addressable as tensors)."""
 
-    def __init__(self, loc, info, device, pairs=True, **engine_kw):
+    def __init__(self, loc, info, device, pairs=False, **engine_kw):
         from . import engine
         self.loc, self.info = loc, info
         self.device = torch.device("cuda", device)
@@ -142,6 +142,8 @@ def gather_outputs(sd, loc, info, group=None):
 def make_hip_runner(sd, rank, world, device, group=None, balance=True, **engine_kw):
     import os
     loc, info = slab_mod.split(sd, world, rank, balance=balance)
-    engine_kw.setdefault("pairs", os.environ.get("PFFDTD_SLAB_PAIRS", "1") != "0")  # temporally blocked step pairs
+    # temporally blocked step pairs in slab engines: measured on MI355X (1024^3, per-rank cost model) +2 % at 2 and 4
+    # ranks, -2..0 % at 8 (thin slabs: the extra launches eat the gain), so opt-in: PFFDTD_SLAB_PAIRS=1
+    engine_kw.setdefault("pairs", os.environ.get("PFFDTD_SLAB_PAIRS", "0") == "1")
     st = HipSlabStepper(loc, info, device, **engine_kw)
     return SlabRunner(st, info, group), loc, info

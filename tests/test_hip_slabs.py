@@ -86,7 +86,7 @@ def test_virtual_slabs_with_blocked_pairs(G, Nt, src):
     sd = sim_data.SimData.from_sim(sim, "single", build_mask=False)
     sd.scale_input()
     parts = [slab.split(sd, G, r) for r in range(G)]
-    st = [pdist.HipSlabStepper(loc, info, 0, air_variant=40, timing=True) for loc, info in parts]
+    st = [pdist.HipSlabStepper(loc, info, 0, pairs=True, air_variant=40, timing=True) for loc, info in parts]
     assert all(s.paired for s in st)
     for k in range(sd.Nt):
         for s in st:
