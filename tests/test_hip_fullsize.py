@@ -33,7 +33,7 @@ def _run(sd, **kw):
 def test_kernel_families_agree_bitwise_at_512(scene):
     ref_out, ref_plane = _run(scene, air_variant=9)
     assert np.abs(ref_out).max() > 0
-    for v in (0, 3, 4, 20, 10):
+    for v in (0, 3, 4, 20, 10, 40):  # 40: temporally blocked pairs (auto keeps them for >= 600-cell cross-sections)
         out, plane = _run(scene, air_variant=v)
         assert np.array_equal(out, ref_out), f"variant {v}"
         assert np.array_equal(plane[1:-1, 1:-1], ref_plane[1:-1, 1:-1]), f"variant {v}"
