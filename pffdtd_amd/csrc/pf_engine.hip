@@ -103,6 +103,8 @@ template <typename Real> struct Engine : EngineBase {
    int32_t *segstart = nullptr;  // first boundary node of every (row, z segment) (fused rigid update)
    uint8_t *adj_dense = nullptr; // lean kernel with in-kernel rigid update: adjacency byte per padded cell
    bool lean_rigid = false;
+   bool v1_rigb = false;         // barrier-free 7-point kernel with the rigid update in-kernel from a cell-byte grid
+   uint8_t *cellb = nullptr;     // that grid: 0 air, 0x40 skip, 0x80|adjacency at boundary nodes
    bool fused = false, fused_rigid = false, lean = false, need_fold_row = false;
    bool vg = false;          // unfused marching kernels with virtual ghost shell + in-kernel ABC (variants 4-6)
    bool abck = false;        // unfused marching kernels with memory flips but the ABC loss in-kernel (variants 7, 8)
@@ -156,7 +158,7 @@ template <typename Real> struct Engine : EngineBase {
       auto F = [](void *p) { if (p) hipFree(p); };
       for (Real *g : own_list) F(g); // state grids this engine allocated (u0/u1 unless external, the temporal-blocking spares)
       own_list.clear();
-      F(d_lossy); F(mask); F(mask_bn); F(segstart); F(adj_dense); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
+      F(d_lossy); F(mask); F(mask_bn); F(cellb); F(segstart); F(adj_dense); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
       F(d_beta); F(d_insig); F(d_mq); F(ub[0]); F(ub[1]); F(ub[2]); F(u2ba); F(vh1); F(gh1); F(ring);
       if (h_ring) hipHostFree(h_ring);
       for (auto &p : air_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -343,6 +345,7 @@ template <typename Real> struct Engine : EngineBase {
          need_fold_row = fold && !rigid_separable();
          // 7-point lean kernel with the rigid boundary update fused in (variants 0/auto, 27, 28)
          lean_rigid = lean && !fcc && Nb > 0 && (vbase == 27 || vbase == 28); // correct but slower than the list kernel
+         v1_rigb = vg && !fcc && Nb > 0 && use_dpp && (vbase == 0 || vbase == 4) && want_rigb();
          HIPCHK(hipDeviceSynchronize()); // memsets above ran on the null stream; our streams are non-blocking
          if (fused) {
             if ((rc = dzalloc(&mask_bn, npad / 8))) return rc;
@@ -374,6 +377,12 @@ template <typename Real> struct Engine : EngineBase {
                                sd.fcc_flag == 1 ? 1 + (op.x_global0 & 1) : 0);
             }
             if (Nb) hipLaunchKernelGGL(pf::k_mask_set, dim3((unsigned)cdiv(Nb, 256)), dim3(256), 0, s_main, mask, d_bn, Nb);
+            if (v1_rigb) {
+               if ((rc = dzalloc(&cellb, npad + 64))) return rc;
+               HIPCHK(hipDeviceSynchronize());
+               hipLaunchKernelGGL(pf::k_cellbytes_init, dim3((unsigned)cdiv(npad, 256)), dim3(256), 0, s_main, cellb, Nx * Ny, P, Nz);
+               hipLaunchKernelGGL(pf::k_adj_dense_set, dim3((unsigned)cdiv(Nb, 256)), dim3(256), 0, s_main, cellb, d_bn, d_adj, Nb);
+            }
          }
          HIPCHK(hipGetLastError());
       }
@@ -651,6 +660,11 @@ template <typename Real> struct Engine : EngineBase {
    // Lanes per row segment of the barrier-free kernels: 64 lanes x 16 B = 1 KiB of z per wave row wastes lanes on narrow
    // grids (Nz=309 -> pitch 320: two 256-column segments, 62 % used).  With 32 or 16 lanes per segment a wave stacks 2 or
    // 4 segments in y instead; pick the width with the least padding (ties: the widest).
+   // in-kernel rigid update for the barrier-free 7-point kernel (meant for rooms with scattered boundary nodes, where the
+   // list kernel's neighbour gathers fetch a 128-byte line per 4 useful bytes).  Measured on the CTK church at
+   // 894x579x309: the interior kernel +73 us (one more byte per cell, the rigid arithmetic), the boundary pass -78 us:
+   // +0.8 % overall -- kept as a tested option (debug 0x800), off by default.
+   bool want_rigb() const { return (op.debug & 0x800) != 0; }
    int pick_lw() const {
       constexpr int V = pf::VecOf<Real>::V;
       if (op.debug & 0x300) return (op.debug & 0x100) ? 32 : 16; // tuning override
@@ -693,6 +707,13 @@ template <typename Real> struct Engine : EngineBase {
       const uint32_t total = (uint32_t)ap.nzt * ap.nyt * ap.nxc;
       dim3 g(total), b(64 * WY * WZ);
       const bool fma = op.numerics == PF_NUM_FMA;
+      if constexpr (R == 4 && WY == 4 && WZ == 1) {
+         if (v1_rigb && vg && !fcc) { // 7-point, virtual ghosts, rigid update in-kernel from the cell-byte grid
+            if (fma) hipLaunchKernelGGL((pf::k_air_cart<Real, R, WY, WZ, true, true, true, false, LW, true>), g, b, 0, s, u1, u0, cellb, a1, a2, ap, l, sl2);
+            else hipLaunchKernelGGL((pf::k_air_cart<Real, R, WY, WZ, false, true, true, false, LW, true>), g, b, 0, s, u1, u0, cellb, a1, a2, ap, l, sl2);
+            return;
+         }
+      }
 #define PF_LAUNCH(K, FMA, DPP) do { if (vg) hipLaunchKernelGGL((K<Real, R, WY, WZ, FMA, DPP, true, false, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l); \
                                     else if (abck) hipLaunchKernelGGL((K<Real, R, WY, WZ, FMA, DPP, false, true, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l); \
                                     else hipLaunchKernelGGL((K<Real, R, WY, WZ, FMA, DPP, false, false, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l); } while (0)
@@ -857,10 +878,10 @@ template <typename Real> struct Engine : EngineBase {
       else { if (fma) PF_BND(false, true); else PF_BND(false, false); }
 #undef PF_BND
    }
-   bool boundary_fused() const { return fuse_boundary && !(fused && fused_rigid) && !lean_rigid; }
+   bool boundary_fused() const { return fuse_boundary && !(fused && fused_rigid) && !lean_rigid && !v1_rigb; }
    void launch_rigid(hipStream_t s, Range r) {
       if (boundary_fused()) { launch_boundary(s, r); return; }
-      if (r.e <= r.b || (fused && fused_rigid) || lean_rigid) return;
+      if (r.e <= r.b || (fused && fused_rigid) || lean_rigid || v1_rigb) return;
       launch_fold_row(s);
       dim3 g((unsigned)cdiv(r.e - r.b, 256)), b(256);
       const bool fma = op.numerics == PF_NUM_FMA;

@@ -105,10 +105,14 @@ struct AirParams {
 // cells, cf. pf_air_fused.h) and the ABC loss is applied in-kernel, so no flip / ABC kernels run around it.
 // ABCK = true (without VG): only the ABC loss moves in-kernel; the ghost shell is still maintained in memory by the
 // flip kernels (cheaper than VG's per-row patches for the 13-point kernel).
-template <typename Real, int R, int WY, int WZ, bool FMA, bool DPP, bool VG = false, bool ABCK = false, int LW = 64>
+// RIGB = true (with VG): `mask` is not the 1-bit skip-mask but one byte per padded cell -- 0 air, 0x40 skip (ghost column /
+// pad), 0x80|adjacency bits at a boundary node -- and the rigid boundary update (cpu_engine.h:234-257) is done here, from
+// the neighbour values the stencil already holds, instead of by gathers in the boundary-list kernel: in rooms with
+// scattered geometry those gathers fetch a 128-byte line per neighbour for 4 useful bytes.
+template <typename Real, int R, int WY, int WZ, bool FMA, bool DPP, bool VG = false, bool ABCK = false, int LW = 64, bool RIGB = false>
 __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restrict__ u1, Real *__restrict__ u0,
                                                           const uint8_t *__restrict__ mask, Real a1, Real a2,
-                                                          AirParams ap, Real labc) {
+                                                          AirParams ap, Real labc, Real sl2 = Real(0)) {
    typedef typename VecOf<Real>::type vec;
    constexpr int V = VecOf<Real>::V;
    const uint32_t total = (uint32_t)ap.nzt * ap.nyt * ap.nxc;
@@ -202,7 +206,12 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
 #pragma unroll
       for (int r = 0; r < R; r++) {
          old[r] = __builtin_nontemporal_load((const vec *)(po + soff[r]));
-         mb[r] = pmk[soff[r] >> 3];
+         if (RIGB) {
+            const uint8_t *pb = mask + (int64_t)x * plane + soff[r];
+            mb[r] = (V == 4) ? *(const uint32_t *)pb : (uint32_t) * (const uint16_t *)pb;
+         } else {
+            mb[r] = pmk[soff[r] >> 3];
+         }
          nxtL[r] = need_l ? pn[roff[r + 1] - 1] : Real(0);
          nxtR[r] = need_r ? pn[roff[r + 1] + V] : Real(0);
          patch(nxt[r + 1], nxtL[r]);
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
          if (lane == 0) zm = curL[r];
          if (lane == LW - 1) zp = curR[r];
          if (fixR) zp = c[V - 2]; // my right neighbour is the ghost column
-         const uint32_t bits = mb[r] >> (uint32_t)(soff[r] & 7);
+         const uint32_t bits = RIGB ? 0u : mb[r] >> (uint32_t)(soff[r] & 7);
          vec o;
 #pragma unroll
          for (int i = 0; i < V; i++) {
@@ -249,9 +258,36 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
                }
             }
          }
+         if (RIGB) {
+            const uint32_t cb = mb[r];
+            if (__ballot((cb & 0x80808080u) != 0u) != 0ull) { // some lane of the wave holds a boundary node in this row
 #pragma unroll
-         for (int i = 0; i < V; i++)
-            if ((bits >> i) & 1u) o[i] = old[r][i];
+               for (int i = 0; i < V; i++) {
+                  const uint32_t a = (cb >> (8 * i)) & 0xffu;
+                  if (a & 0x80u) {
+                     const Real left = (i == 0) ? zm : c[i > 0 ? i - 1 : 0];
+                     const Real right = (i == V - 1) ? zp : c[i < V - 1 ? i + 1 : V - 1];
+                     const Real nbk[6] = {nxt[r + 1][i], prev[r][i], cur[r + 2][i], cur[r][i], right, left};
+                     const Real two = 2.0;
+                     const Real b1 = two - sl2 * (Real)__popc(a & 0x3fu);
+                     Real p = b1 * c[i] - old[r][i];
+#pragma unroll
+                     for (int k = 0; k < 6; k++) {
+                        const Real wk = a2 * (Real)((a >> k) & 1u);
+                        p = FMA ? __builtin_fma(wk, nbk[k], p) : p + wk * nbk[k];
+                     }
+                     o[i] = p;
+                  }
+               }
+            }
+#pragma unroll
+            for (int i = 0; i < V; i++)
+               if ((cb >> (8 * i)) & 0x40u) o[i] = old[r][i];
+         } else {
+#pragma unroll
+            for (int i = 0; i < V; i++)
+               if ((bits >> i) & 1u) o[i] = old[r][i];
+         }
          if (active && (y0 + r <= Ny - 2)) __builtin_nontemporal_store(o, (vec *)(po + soff[r]));
       }
 #pragma unroll
@@ -685,6 +721,15 @@ __global__ void k_boundary(const Real *__restrict__ u1, Real *u0, const int64_t 
       p = u;
    }
    u0[ii] = p;
+}
+
+// one byte per padded cell for the RIGB kernels: 0x40 at ghost z columns and pad columns (never updated), 0 elsewhere;
+// boundary nodes are then stamped with 0x80 | adjacency bits (k_adj_dense_set)
+__global__ void k_cellbytes_init(uint8_t *__restrict__ cb, int64_t nrows, int64_t P, int64_t Nz) {
+   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (i >= nrows * P) return;
+   const int64_t z = i % P;
+   cb[i] = (z == 0 || z >= Nz - 1) ? 0x40 : 0x00;
 }
 
 // ---- receivers (read time n from u1) and sources (add to time n+1 in u0), cpu_engine.h:304-313 --------------

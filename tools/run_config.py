@@ -31,6 +31,7 @@ ap.add_argument("--fmax-scale", type=float, default=1.0, help="scale fmax (grid 
 ap.add_argument("--fmax", type=float, default=None, help="override fmax (Hz)")
 ap.add_argument("--ppw", type=float, default=None, help="override points per wavelength")
 ap.add_argument("--duration", type=float, default=None, help="override the simulated duration (s)")
+ap.add_argument("--debug", type=lambda v: int(v, 0), default=0, help="pf_opts.debug (tuning switches)")
 ap.add_argument("--energy", action="store_true", help="run all Nt steps with the energy diagnostic (double only)")
 ap.add_argument("--keep", default=None, help="keep the sim folder here instead of a temp dir")
 a = ap.parse_args()
@@ -73,7 +74,7 @@ if a.energy:
                gvox_per_s=round(sd.Npts * sd.Nt / el / 1e9, 3))
 else:
     K, W = min(a.steps, sd.Nt - a.warmup), a.warmup
-    eng = engine.HipEngine(sd, timing=True)
+    eng = engine.HipEngine(sd, timing=True, debug=a.debug)
     eng.run(0, W)
     eng.sync()
     eng.timing(reset=True)
