@@ -144,9 +144,12 @@ class VoxScene:
         iz = bn_ixyz % Nz
         iy = (bn_ixyz - iz) // Nz % Ny
         ix = ((bn_ixyz - iz) // Nz - iy) // Ny
-        xyz_bn = np.c_[cg.xv[ix], cg.yv[iy], cg.zv[iz]]
         pre = rg.tris_pre
-        dv = _dotv(xyz_bn - pre["cent"][tidx_bn], pre["unor"][tidx_bn])
+        U, C = pre["unor"][tidx_bn], pre["cent"][tidx_bn]  # nearest triangle's unit normal and centroid, gathered once
+
+        def dot3(a0, a1, a2, b):  # np.sum(a*b, axis=-1) over three elements, as (p0+p1)+p2 column-wise (much faster)
+            return (a0 * b[:, 0] + a1 * b[:, 1]) + a2 * b[:, 2]
+        dv = dot3(cg.xv[ix] - C[:, 0], cg.yv[iy] - C[:, 1], cg.zv[iz] - C[:, 2], U)
         side = rg.mat_side[tidx_bn]
         mat_bn = rg.mat_ind[tidx_bn].copy()
         mat_bn[(dv > 0) & (side == 1)] = -1
@@ -156,12 +159,12 @@ class VoxScene:
         # surface-area factors: |leg direction . unit normal| per cut leg pair (vox_scene.py:412-419)
         saf_bn = np.zeros(bn_ixyz.size, dtype=np.float64)
         for j in range(0, self.NN, 2):
-            saf = np.abs(_dotv(self.uvv[j], pre["unor"][tidx_bn]))
+            saf = np.abs(dot3(self.uvv[j][0], self.uvv[j][1], self.uvv[j][2], U))
             saf_bn += (~adj_bn[:, j] + ~adj_bn[:, j + 1]) * saf
-        sa = np.zeros(rg.Nmat + 1)
-        sa0 = np.zeros(rg.Nmat + 1)
-        np.add.at(sa, mat_bn, self.face_area * saf_bn)  # -1 (rigid) goes to the end
-        np.add.at(sa0, mat_bn, self.face_area * np.sum(~adj_bn, axis=-1))
+        # per-material surface totals, for the printout only (the reference uses np.add.at; bincount is the same sums)
+        mi = np.where(mat_bn < 0, rg.Nmat, mat_bn).astype(np.int64)  # -1 (rigid) goes to the end
+        sa = np.bincount(mi, weights=self.face_area * saf_bn, minlength=rg.Nmat + 1)
+        sa0 = np.bincount(mi, weights=self.face_area * np.sum(~adj_bn, axis=-1), minlength=rg.Nmat + 1)
         for i in range(rg.Nmat):
             if rg.mat_area[i] > 0:
                 self.print(f"mat: {rg.mat_str[i]}, original: {(sa0[i] / rg.mat_area[i] - 1) * 100.:.3f}% over, "
