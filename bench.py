@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--numerics", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug", type=lambda v: int(v, 0), default=0, help="pf_opts.debug (tuning switches)")
     ap.add_argument("--split-phase", action="store_true", help="N=1: drive the split-phase step like N>1 does")
     ap.add_argument("--emulate-slab", default="", help="debug: 'r/N' = run only slab r of an N-way split on this GPU, the exchange\n                    replaced by device copies of the same planes (per-rank cost model; physics is wrong)")
     ap.add_argument("--emulate-transport", default="copy", choices=["copy", "rccl"],
@@ -144,7 +145,7 @@ def main():
     lossy = not args.rigid
     sd = build_scene(n, K + W, args.precision, args.fcc, lossy, args.mb, args.nx)
     real_bytes = 4 if args.precision == "single" else 8
-    ekw = dict(numerics=args.numerics, air_variant=args.variant, air_chunk=args.chunk, timing=True)
+    ekw = dict(numerics=args.numerics, air_variant=args.variant, air_chunk=args.chunk, timing=True, debug=args.debug)
 
     from pffdtd_amd import dist as pdist
     emu = None

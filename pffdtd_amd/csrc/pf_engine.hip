@@ -141,6 +141,11 @@ template <typename Real> struct Engine : EngineBase {
    std::vector<std::pair<int, int>> tb_xr;                // its x ranges (planes next to a source are cut out)
    const Real *u0_src = nullptr;                          // out-of-place single-step launches read u^{n-1} here
    int lean_yt0 = 0, lean_nyt = -1;                       // row-strip launches of the lean kernel (-1: all tiles)
+   // boundary nodes inside the column strips are updated by k_air_zstrip itself (it streams their lines anyway; in
+   // the list kernel the floor / ceiling nodes of a box room cost half of the whole boundary pass)
+   int32_t *zs_map = nullptr, *zs_rest = nullptr;         // strip cell -> boundary list position; the other nodes
+   int64_t zs_nrest = 0;
+   const int32_t *bnd_sel = nullptr;                      // launch_boundary visits bnd_sel[range] when set
    // energy diagnostic (pf_energy.h)
    Real *Lu = nullptr, *vh_old = nullptr, *u2in = nullptr;
    double *d_acc = nullptr, *d_DEF = nullptr;
@@ -158,7 +163,7 @@ template <typename Real> struct Engine : EngineBase {
       auto F = [](void *p) { if (p) hipFree(p); };
       for (Real *g : own_list) F(g); // state grids this engine allocated (u0/u1 unless external, the temporal-blocking spares)
       own_list.clear();
-      F(d_lossy); F(mask); F(mask_bn); F(cellb); F(segstart); F(adj_dense); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
+      F(d_lossy); F(mask); F(mask_bn); F(cellb); F(zs_map); F(zs_rest); F(segstart); F(adj_dense); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
       F(d_beta); F(d_insig); F(d_mq); F(ub[0]); F(ub[1]); F(ub[2]); F(u2ba); F(vh1); F(gh1); F(ring);
       if (h_ring) hipHostFree(h_ring);
       for (auto &p : air_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -510,6 +515,28 @@ template <typename Real> struct Engine : EngineBase {
       if ((rc = dzalloc(&bufD, npad))) return rc;
       own_list.push_back(bufC); own_list.push_back(bufD);
       tb2 = true;
+      // Experiment (debug 0x2000, off by default): boundary nodes inside the column strips move from the list kernel to
+      // k_air_zstrip, which streams their lines anyway (in k_boundary the floor / ceiling nodes of a box room cost half of
+      // the pass: 0.30 of 0.63 ms at 1024^3).  Bit-identical, but slower: the FD branches run on the few lanes per wave
+      // that hold a node (2.92 vs 2.59 ms per step), so the list kernel keeps them.
+      if (Nb > 0 && !tb_xr.empty() && (op.debug & 0x2000)) {
+         const int xb = tb_xr.front().first, xe = tb_xr.back().second;
+         const int nl = tbz0 / 4, nv = nl + (int)(P - tbz1) / 4;
+         std::vector<int64_t> hb(Nb);
+         HIPCHK(hipMemcpy(hb.data(), d_bn, Nb * sizeof(int64_t), hipMemcpyDeviceToHost));
+         std::vector<int32_t> zm((size_t)(Nx * Ny * nv * 4), -1), rest;
+         rest.reserve(Nb);
+         for (int64_t nb = 0; nb < Nb; nb++) {
+            const int64_t ix = hb[nb] / plane, rem = hb[nb] % plane, iy = rem / P, iz = rem % P;
+            const bool in_strip = ix >= xb && ix < xe && (iz < tbz0 || iz >= tbz1);
+            if (!in_strip) { rest.push_back((int32_t)nb); continue; }
+            const int64_t v = iz < tbz0 ? iz / 4 : nl + (iz - tbz1) / 4, i = iz < tbz0 ? iz % 4 : (iz - tbz1) % 4;
+            zm[(size_t)(((ix * Ny + iy) * nv + v) * 4 + i)] = (int32_t)nb;
+         }
+         zs_nrest = (int64_t)rest.size();
+         if ((rc = upload(&zs_map, zm.data(), (int64_t)zm.size()))) return rc;
+         if ((rc = upload(&zs_rest, rest.data(), zs_nrest))) return rc;
+      }
       return PF_OK;
    }
    int set_spares(void *g2, void *g3) override {
@@ -559,8 +586,14 @@ template <typename Real> struct Engine : EngineBase {
          zp.u1 = (const float *)u1; zp.u0s = (const float *)(u0_src ? u0_src : u0); zp.u0 = (float *)u0; zp.mask = mask;
          zp.plane = plane; zp.Nx = (int)Nx; zp.Ny = (int)Ny; zp.Nz = (int)Nz; zp.P = (int)P;
          zp.x_begin = xb; zp.x_end = xe; zp.zl = tbz0; zp.zr = tbz1; zp.first = op.slab_first; zp.last = op.slab_last;
+         if (zs_map && bnd_sel) { // (inside step_pair) the strips' boundary nodes are updated right here
+            zp.zmap = zs_map; zp.adjv = d_adj; zp.lossy = d_lossy; zp.u0b = (float *)ub[0]; zp.u2b = (const float *)ub[2];
+            zp.ssaf = (const float *)d_ssaf; zp.beta = (const float *)d_beta; zp.mat = d_mat; zp.Mb = d_Mb;
+            zp.mq = (const pf::MatQuadT<float> *)d_mq; zp.vh1 = (float *)vh1; zp.gh1 = (float *)gh1;
+            zp.lo2 = (float)lo2; zp.sl2 = (float)sl2; zp.Nbl = Nbl;
+         }
          const int64_t nthreads = (int64_t)(zp.zl / 4 + (P - zp.zr) / 4) * (Ny - 2);
-         const int xchunk = 16;
+         const int xchunk = (op.debug >> 16) & 0xff ? (op.debug >> 16) & 0xff : 16;
          hipLaunchKernelGGL(pf::k_air_zstrip, dim3((unsigned)cdiv(nthreads, 256), (unsigned)cdiv(xe - xb, xchunk)), dim3(256), 0, s, zp,
                             (float)a1, (float)a2, (float)l, xchunk);
       }
@@ -578,9 +611,11 @@ template <typename Real> struct Engine : EngineBase {
       launch_tb2(s, A, B, C, D);
       if (op.timing) { hipEventRecord(evt.second, s); tb2_ev.push_back(evt); }
       u0_src = A; u1 = B; u0 = C;
+      const Range bnd = zs_map ? Range{0, zs_nrest} : Range{0, Nb};
+      bnd_sel = zs_map ? zs_rest : nullptr;
       launch_shell(s);
       if (op.timing) { hipEventRecord(eva.second, s); air_ev.push_back(eva); eva = get_ev(); }
-      launch_rigid(s, {0, Nb});
+      launch_rigid(s, bnd);
       launch_fd(s, {0, Nbl});
       launch_io(s, n, true, {0, Ns});
       { Real *t = ub[2]; ub[2] = ub[1]; ub[1] = ub[0]; ub[0] = t; }
@@ -590,7 +625,8 @@ template <typename Real> struct Engine : EngineBase {
       if (op.timing) { hipEventRecord(ev.second, s); step_ev.push_back(ev); ev = get_ev(); hipEventRecord(ev.first, s); hipEventRecord(eva.first, s); }
       launch_shell(s);
       if (op.timing) { hipEventRecord(eva.second, s); air_ev.push_back(eva); }
-      launch_rigid(s, {0, Nb});
+      launch_rigid(s, bnd);
+      bnd_sel = nullptr;
       launch_fd(s, {0, Nbl});
       launch_io(s, n + 1, true, {0, Ns});
       { Real *t = ub[2]; ub[2] = ub[1]; ub[1] = ub[0]; ub[0] = t; }
@@ -873,7 +909,7 @@ template <typename Real> struct Engine : EngineBase {
       launch_fold_row(s);
       dim3 g((unsigned)cdiv(r.e - r.b, 128)), b(128);
       const bool fma = op.numerics == PF_NUM_FMA;
-#define PF_BND(F, M) hipLaunchKernelGGL((pf::k_boundary<Real, F, M>), g, b, 0, s, u1, u0, d_bn, d_adj, d_lossy, a2, sl2, P, plane, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq, d_beta, vh1, gh1, lo2, Nbl, r.b, r.e, u0_src ? u0_src : (const Real *)u0)
+#define PF_BND(F, M) hipLaunchKernelGGL((pf::k_boundary<Real, F, M>), g, b, 0, s, u1, u0, d_bn, d_adj, d_lossy, a2, sl2, P, plane, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq, d_beta, vh1, gh1, lo2, Nbl, r.b, r.e, u0_src ? u0_src : (const Real *)u0, bnd_sel)
       if (fcc) { if (fma) PF_BND(true, true); else PF_BND(true, false); }
       else { if (fma) PF_BND(false, true); else PF_BND(false, false); }
 #undef PF_BND

@@ -653,10 +653,53 @@ __global__ void k_fd_boundary(Real *__restrict__ u0, const int64_t *__restrict__
    u0[ii] = u;
 }
 
+// ---- FD (RLC-branch) update of one lossy node, cpu_engine.h:363-405: p = the node's value after the rigid update ------
+// (shared by k_boundary and the column-strip kernel of pf_tb2.h, so that both produce the same bits)
+template <typename Real>
+__device__ __forceinline__ Real fd_node_update(Real p, int32_t li, Real *__restrict__ u0b, const Real *__restrict__ u2b,
+                                               const Real *__restrict__ ssaf, const int8_t *__restrict__ mat,
+                                               const int8_t *__restrict__ Mb, const MatQuadT<Real> *__restrict__ mq,
+                                               const Real *__restrict__ beta, Real *__restrict__ vh1, Real *__restrict__ gh1,
+                                               Real lo2, int64_t Nbl) {
+   const Real two = 2.0, one = 1.0;
+   const int32_t k = mat[li];
+   const int M = Mb[k];
+   const Real sf = ssaf[li];
+   const Real g = lo2 * sf * beta[k];
+   const Real fac = two * lo2 * sf / (one + g);
+   Real u = p;
+   const Real u2 = u2b[li];
+   u = (u + g * u2) / (one + g);
+   Real v1[12], g1[12];
+#pragma unroll
+   for (int m = 0; m < 12; m++) {
+      if (m < M) {
+         const MatQuadT<Real> q = mq[k * 12 + m];
+         v1[m] = __builtin_nontemporal_load(&vh1[(int64_t)m * Nbl + li]);
+         g1[m] = __builtin_nontemporal_load(&gh1[(int64_t)m * Nbl + li]);
+         u -= fac * (two * q.bDh * v1[m] - q.bFh * g1[m]);
+      }
+   }
+   const Real du = u - u2;
+#pragma unroll
+   for (int m = 0; m < 12; m++) {
+      if (m < M) {
+         const MatQuadT<Real> q = mq[k * 12 + m];
+         const Real v0 = q.b * du + q.bd * v1[m] - two * q.bFh * g1[m];
+         __builtin_nontemporal_store(g1[m] + (v0 + v1[m]) / two, &gh1[(int64_t)m * Nbl + li]);
+         __builtin_nontemporal_store(v0, &vh1[(int64_t)m * Nbl + li]);
+      }
+   }
+   u0b[li] = u;
+   return u;
+}
+
 // ---- fused boundary pass: rigid update of every boundary node + FD update of the lossy ones in one visit ----------
 // (cpu_engine.h:234-287 then :290-301,363-405 for the same node: identical arithmetic, the gather / scatter of u0
 // between the two is a register).  lossy[nb] = index into the lossy-node arrays, or -1 for a rigid node; lossy
 // indices increase along the (sorted) boundary list, so the branch-state accesses stay coalesced.
+// sel != null: visit the nodes sel[begin..end) instead of begin..end (temporal blocking leaves the column-strip nodes
+// to k_air_zstrip).
 template <typename Real, bool FCC, bool FMA>
 __global__ void k_boundary(const Real *__restrict__ u1, Real *u0, const int64_t *__restrict__ idx,
                            const uint16_t *__restrict__ adjv, const int32_t *__restrict__ lossy, Real a2, Real sl2,
@@ -664,12 +707,13 @@ __global__ void k_boundary(const Real *__restrict__ u1, Real *u0, const int64_t 
                            const Real *__restrict__ ssaf, const int8_t *__restrict__ mat, const int8_t *__restrict__ Mb,
                            const MatQuadT<Real> *__restrict__ mq, const Real *__restrict__ beta, Real *__restrict__ vh1,
                            Real *__restrict__ gh1, Real lo2, int64_t Nbl, int64_t begin, int64_t end,
-                           const Real *u0_old) { // u0_old: where u^{n-1} lives (== u0 for the in-place step)
-   const int64_t nb = begin + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-   if (nb >= end) return;
+                           const Real *u0_old, const int32_t *__restrict__ sel) { // u0_old: where u^{n-1} lives (== u0 in place)
+   const int64_t t = begin + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (t >= end) return;
+   const int64_t nb = sel ? (int64_t)sel[t] : t;
    const int64_t ii = idx[nb];
    const uint32_t adj = adjv[nb];
-   const Real two = 2.0, one = 1.0, K = (Real)__popc(adj), b2 = a2, b1 = (two - sl2 * K);
+   const Real two = 2.0, K = (Real)__popc(adj), b2 = a2, b1 = (two - sl2 * K);
    Real p = b1 * u1[ii] - u0_old[ii];
    if (!FCC) {
       const int64_t off[6] = {plane, -plane, P, -P, 1, -1};
@@ -688,38 +732,7 @@ __global__ void k_boundary(const Real *__restrict__ u1, Real *u0, const int64_t 
       }
    }
    const int32_t li = lossy[nb];
-   if (li >= 0) {
-      const int32_t k = mat[li];
-      const int M = Mb[k];
-      const Real sf = ssaf[li];
-      const Real g = lo2 * sf * beta[k];
-      const Real fac = two * lo2 * sf / (one + g);
-      Real u = p;
-      const Real u2 = u2b[li];
-      u = (u + g * u2) / (one + g);
-      Real v1[12], g1[12];
-#pragma unroll
-      for (int m = 0; m < 12; m++) {
-         if (m < M) {
-            const MatQuadT<Real> q = mq[k * 12 + m];
-            v1[m] = __builtin_nontemporal_load(&vh1[(int64_t)m * Nbl + li]);
-            g1[m] = __builtin_nontemporal_load(&gh1[(int64_t)m * Nbl + li]);
-            u -= fac * (two * q.bDh * v1[m] - q.bFh * g1[m]);
-         }
-      }
-      const Real du = u - u2;
-#pragma unroll
-      for (int m = 0; m < 12; m++) {
-         if (m < M) {
-            const MatQuadT<Real> q = mq[k * 12 + m];
-            const Real v0 = q.b * du + q.bd * v1[m] - two * q.bFh * g1[m];
-            __builtin_nontemporal_store(g1[m] + (v0 + v1[m]) / two, &gh1[(int64_t)m * Nbl + li]);
-            __builtin_nontemporal_store(v0, &vh1[(int64_t)m * Nbl + li]);
-         }
-      }
-      u0b[li] = u;
-      p = u;
-   }
+   if (li >= 0) p = fd_node_update<Real>(p, li, u0b, u2b, ssaf, mat, Mb, mq, beta, vh1, gh1, lo2, Nbl);
    u0[ii] = p;
 }
 

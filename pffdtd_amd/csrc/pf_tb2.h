@@ -370,6 +370,18 @@ struct ZStripParams {
    int32_t x_begin, x_end;   // planes [x_begin, x_end)
    int32_t zl, zr;           // strips [0, zl) and [zr, P), multiples of 4
    int32_t first, last;
+   // boundary nodes inside the strips (optional; zmap == null: the boundary-list kernel does them, masked cells keep
+   // their old value here): zmap[((x*Ny + y)*nv + v)*4 + i] = position in the boundary list or -1
+   const int32_t *zmap;
+   const uint16_t *adjv;
+   const int32_t *lossy;
+   float *u0b;
+   const float *u2b, *ssaf, *beta;
+   const int8_t *mat, *Mb;
+   const MatQuadT<float> *mq;
+   float *vh1, *gh1;
+   float lo2, sl2;
+   int64_t Nbl;
 };
 
 __global__ __launch_bounds__(256) void k_air_zstrip(ZStripParams zp, float a1, float a2, float l, int xchunk) {
@@ -425,7 +437,24 @@ __global__ __launch_bounds__(256) void k_air_zstrip(ZStripParams zp, float a1, f
             const float num = p + lQ * old[i];
             p = (float)((double)num / (1.0 + (double)lQ));
          }
-         o[i] = ((bits >> i) & 1u) ? old[i] : p;
+         if ((bits >> i) & 1u) {
+            p = old[i]; // ghost / pad column, or a boundary node that the list kernel updates
+            const int32_t nb = zp.zmap ? zp.zmap[(((int64_t)x * Ny + y) * nv + v) * 4 + i] : -1;
+            if (nb >= 0) { // boundary node: rigid update from the registers (k_boundary's expression), then the FD branches
+               const uint32_t adj = zp.adjv[nb];
+               const float nbk[6] = {cp[i], cm[i], yp[i], ym[i], zpv, zmv};
+               const float two = 2.0f, b1 = two - zp.sl2 * (float)__popc(adj);
+               p = b1 * c[i] - old[i];
+#pragma unroll
+               for (int k = 0; k < 6; k++) {
+                  const float w = a2 * (float)((adj >> k) & 1u);
+                  p = p + w * nbk[k];
+               }
+               const int32_t li = zp.lossy[nb];
+               if (li >= 0) p = fd_node_update<float>(p, li, zp.u0b, zp.u2b, zp.ssaf, zp.mat, zp.Mb, zp.mq, zp.beta, zp.vh1, zp.gh1, zp.lo2, zp.Nbl);
+            }
+         }
+         o[i] = p;
       }
       *(vec *)(zp.u0 + (int64_t)x * zp.plane + off) = o;
       cm = c; c = cp; lf = lfn; rt = rtn;

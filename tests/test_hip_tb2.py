@@ -100,3 +100,15 @@ def test_blocked_steps_long_run():
     out, _, tm = run(sim, 40, readout_chunk=64)
     assert tm["tb2_launches"] >= 2 * 140 and tm["steps"] == 301
     assert np.array_equal(out, ref.u_out)
+
+
+def test_strip_kernel_can_update_its_boundary_nodes():
+    """debug 0x2000: the column-strip kernel also does the rigid + FD update of the boundary nodes inside its strips
+    (an experiment that stays off by default: slower).  Same bits."""
+    sim = scene([18, 8, 12], Nt=18)
+    ref = sim_data.SimData.from_sim(sim, "single")
+    ref.scale_input()
+    oracle.run_sim(ref)
+    for dbg in (0x2000, 0x2000 | (1 << 16)):
+        out, _, tm = run(sim, 40, debug=dbg)
+        assert tm["tb2_launches"] > 0 and np.array_equal(out, ref.u_out)
