@@ -736,6 +736,10 @@ __global__ void k_boundary(const Real *__restrict__ u1, Real *u0, const int64_t 
    u0[ii] = p;
 }
 
+// device-side step counters of the graph-replayed loop: ctr[0] = step index, ctr[1] = receiver ring column
+__global__ void k_ctr_set(int64_t *ctr, int64_t n, int64_t col) { ctr[0] = n; ctr[1] = col; }
+__global__ void k_ctr_tick(int64_t *ctr) { ctr[0]++; ctr[1]++; }
+
 // one byte per padded cell for the RIGB kernels: 0x40 at ghost z columns and pad columns (never updated), 0 elsewhere;
 // boundary nodes are then stamped with 0x80 | adjacency bits (k_adj_dense_set)
 __global__ void k_cellbytes_init(uint8_t *__restrict__ cb, int64_t nrows, int64_t P, int64_t Nz) {
@@ -752,7 +756,8 @@ template <typename Real>
 __global__ void k_io(const Real *__restrict__ u1, Real *__restrict__ u0, const int64_t *__restrict__ out_idx,
                      Real *__restrict__ ring, int64_t Nr, int64_t ring_col, int64_t ring_depth,
                      const int64_t *__restrict__ in_idx, const Real *__restrict__ in_sigs, int64_t Ns, int64_t Nt,
-                     int64_t n) {
+                     int64_t n, const int64_t *__restrict__ ctr = nullptr) {
+   if (ctr) { n = ctr[0]; ring_col = ctr[1]; } // replayed from a hipGraph: step index and ring column live on the device
    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (t < Nr) {
       ring[t * ring_depth + ring_col] = u1[out_idx[t]];
