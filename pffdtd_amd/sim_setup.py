@@ -75,3 +75,28 @@ def sim_setup(insig_type=None, fmax=None, PPW=None, save_folder=None, model_json
                 shutil.copyfile(f, Path(save_folder_gpu) / f.name)
         setup_io.prep_folder(save_folder_gpu, rotate=True, fold=bool(fcc_flag), sort=True, compress=int(compress or 0))
     return vox_scene
+
+
+def main():
+    """python -m pffdtd_amd.sim_setup --config ctk_cart_gpu --save_folder DIR [--save_folder_gpu DIR2] [--mat_folder M]
+    [--fmax F --PPW P --duration T]: one of the reference's test-script configurations (pffdtd_amd/scenes.py), from the
+    scene exports and wall-impedance fits that travel with the tests."""
+    import argparse
+    from . import scenes
+    p = argparse.ArgumentParser()
+    p.add_argument("--config", required=True, choices=sorted(scenes.CONFIGS))
+    p.add_argument("--save_folder", required=True)
+    p.add_argument("--save_folder_gpu", default=None)
+    p.add_argument("--mat_folder", default=None, help="folder with the material .h5 files (default: written from the fixtures)")
+    p.add_argument("--fmax", type=float, default=None)
+    p.add_argument("--PPW", type=float, default=None)
+    p.add_argument("--duration", type=float, default=None)
+    p.add_argument("--gpu", type=int, default=0)
+    a = p.parse_args()
+    mats = a.mat_folder or scenes.write_materials(Path(a.save_folder) / "materials")
+    over = {k: v for k, v in (("fmax", a.fmax), ("PPW", a.PPW), ("duration", a.duration)) if v is not None}
+    sim_setup(**scenes.setup_kwargs(a.config, a.save_folder, mats, save_folder_gpu=a.save_folder_gpu, compress=0, device=a.gpu, **over))
+
+
+if __name__ == "__main__":
+    main()
