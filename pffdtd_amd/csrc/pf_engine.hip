@@ -488,7 +488,7 @@ template <typename Real> struct Engine : EngineBase {
    int init_tb2() {
       tb2 = tb2_geom = tb2_slab = false;
       const bool single = op.slab_first && op.slab_last;
-      if (sizeof(Real) != 4 || fcc || !lean || lean_rigid || op.energy) return PF_OK;
+      if (fcc || !lean || lean_rigid || op.energy) return PF_OK;
       if (!(vbase == 0 || vbase == 40 || vbase == 41) || op.numerics != PF_NUM_CPU_EXACT || !use_dpp) return PF_OK;
       if (Nb > 0 && !boundary_fused()) return PF_OK;
       int64_t dmax = 0; // depth of the deepest boundary node below the nearest grid face (slab faces towards a neighbour are no faces)
@@ -505,7 +505,7 @@ template <typename Real> struct Engine : EngineBase {
       tby0 = m; tby1 = (int)Ny - m; tbz0 = mz; tbz1 = (int)((Nz - mz) / 4 * 4);
       if (vbase == 41) tbx1 = tbx0; // driver test: everything goes through the out-of-place single-step path
       tb_xr.clear();
-      if (tbx1 - tbx0 >= 16 && tby1 - tby0 >= 48 && tbz1 - tbz0 >= 248) {
+      if (tbx1 - tbx0 >= 16 && tby1 - tby0 >= 48 && tbz1 - tbz0 >= 62 * pf::VecOf<Real>::V) {
          std::vector<int> cut; // planes the box must leave to the single-step kernels: sources (+-1 plane)
          for (int64_t i = 0; i < Ns; i++) { const int ix = (int)(sd.in_ixyz[i] / NzNy); for (int d = -1; d <= 1; d++) cut.push_back(ix + d); }
          std::sort(cut.begin(), cut.end());
@@ -536,17 +536,18 @@ template <typename Real> struct Engine : EngineBase {
       // that hold a node (2.92 vs 2.59 ms per step), so the list kernel keeps them.
       if (Nb > 0 && !tb_xr.empty() && (op.debug & 0x2000)) {
          const int xb = tb_xr.front().first, xe = tb_xr.back().second;
-         const int nl = tbz0 / 4, nv = nl + (int)(P - tbz1) / 4;
+         constexpr int V = pf::VecOf<Real>::V;
+         const int nl = tbz0 / V, nv = nl + (int)(P - tbz1) / V;
          std::vector<int64_t> hb(Nb);
          HIPCHK(hipMemcpy(hb.data(), d_bn, Nb * sizeof(int64_t), hipMemcpyDeviceToHost));
-         std::vector<int32_t> zm((size_t)(Nx * Ny * nv * 4), -1), rest;
+         std::vector<int32_t> zm((size_t)(Nx * Ny * nv * V), -1), rest;
          rest.reserve(Nb);
          for (int64_t nb = 0; nb < Nb; nb++) {
             const int64_t ix = hb[nb] / plane, rem = hb[nb] % plane, iy = rem / P, iz = rem % P;
             const bool in_strip = ix >= xb && ix < xe && (iz < tbz0 || iz >= tbz1);
             if (!in_strip) { rest.push_back((int32_t)nb); continue; }
-            const int64_t v = iz < tbz0 ? iz / 4 : nl + (iz - tbz1) / 4, i = iz < tbz0 ? iz % 4 : (iz - tbz1) % 4;
-            zm[(size_t)(((ix * Ny + iy) * nv + v) * 4 + i)] = (int32_t)nb;
+            const int64_t v = iz < tbz0 ? iz / V : nl + (iz - tbz1) / V, i = iz < tbz0 ? iz % V : (iz - tbz1) % V;
+            zm[(size_t)(((ix * Ny + iy) * nv + v) * V + i)] = (int32_t)nb;
          }
          zs_nrest = (int64_t)rest.size();
          if ((rc = upload(&zs_map, zm.data(), (int64_t)zm.size()))) return rc;
@@ -563,20 +564,19 @@ template <typename Real> struct Engine : EngineBase {
       return PF_OK;
    }
    void launch_tb2(hipStream_t s, const Real *A, const Real *B, Real *C, Real *D) {
-      if constexpr (sizeof(Real) == 4) {
-         for (auto &r : tb_xr) {
-            pf::Tb2Params tp{};
-            tp.A = (const float *)A; tp.B = (const float *)B; tp.C = (float *)C; tp.D = (float *)D;
-            tp.plane = plane; tp.Nx = (int)Nx; tp.Ny = (int)Ny; tp.Nz = (int)Nz; tp.P = (int)P;
-            tp.x_begin = r.first; tp.x_end = r.second;
-            tp.y_begin = tby0; tp.y_end = tby1; tp.z_begin = tbz0; tp.z_end = tbz1;
-            const int np = r.second - r.first;
-            tp.chunk = (int)cdiv(np, std::max<int64_t>(cdiv(np, 24), 1)); // ~24-plane chunks, even split (tools/tb2_probe.py)
-            tp.nxc = (int)cdiv(np, tp.chunk);
-            tp.nzt = (int)cdiv(tbz1 - tbz0, 248);
-            tp.nyt = (int)cdiv(tby1 - tby0, 12);
-            hipLaunchKernelGGL((pf::k_tb2_reg<3, 4, false>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(256), 0, s, tp, (float)a1, (float)a2);
-         }
+      constexpr int V = pf::VecOf<Real>::V, WC = 64 * V - 2 * V; // core columns of a wave (lanes 1..62)
+      for (auto &r : tb_xr) {
+         pf::Tb2Params tp{};
+         tp.A = A; tp.B = B; tp.C = C; tp.D = D;
+         tp.plane = plane; tp.Nx = (int)Nx; tp.Ny = (int)Ny; tp.Nz = (int)Nz; tp.P = (int)P;
+         tp.x_begin = r.first; tp.x_end = r.second;
+         tp.y_begin = tby0; tp.y_end = tby1; tp.z_begin = tbz0; tp.z_end = tbz1;
+         const int np = r.second - r.first;
+         tp.chunk = (int)cdiv(np, std::max<int64_t>(cdiv(np, 24), 1)); // ~24-plane chunks, even split (tools/tb2_probe.py)
+         tp.nxc = (int)cdiv(np, tp.chunk);
+         tp.nzt = (int)cdiv(tbz1 - tbz0, WC);
+         tp.nyt = (int)cdiv(tby1 - tby0, 12);
+         hipLaunchKernelGGL((pf::k_tb2_reg<Real, 3, 4, false>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(256), 0, s, tp, a1, a2);
       }
    }
    // one out-of-place single step of everything outside the box: u1 -> (u0_src old) -> u0
@@ -596,21 +596,22 @@ template <typename Real> struct Engine : EngineBase {
       launch_lean_cfg<2, 4, false, true>(s, xb, xe);
       lean_nyt = -1; lean_yt0 = 0;
       // ... and the two column strips
-      if constexpr (sizeof(Real) == 4) {
-         pf::ZStripParams zp{};
-         zp.u1 = (const float *)u1; zp.u0s = (const float *)(u0_src ? u0_src : u0); zp.u0 = (float *)u0; zp.mask = mask;
+      {
+         constexpr int V = pf::VecOf<Real>::V;
+         pf::ZStripParams<Real> zp{};
+         zp.u1 = u1; zp.u0s = u0_src ? u0_src : u0; zp.u0 = u0; zp.mask = mask;
          zp.plane = plane; zp.Nx = (int)Nx; zp.Ny = (int)Ny; zp.Nz = (int)Nz; zp.P = (int)P;
          zp.x_begin = xb; zp.x_end = xe; zp.zl = tbz0; zp.zr = tbz1; zp.first = op.slab_first; zp.last = op.slab_last;
          if (zs_map && bnd_sel) { // (inside step_pair) the strips' boundary nodes are updated right here
-            zp.zmap = zs_map; zp.adjv = d_adj; zp.lossy = d_lossy; zp.u0b = (float *)ub[0]; zp.u2b = (const float *)ub[2];
-            zp.ssaf = (const float *)d_ssaf; zp.beta = (const float *)d_beta; zp.mat = d_mat; zp.Mb = d_Mb;
-            zp.mq = (const pf::MatQuadT<float> *)d_mq; zp.vh1 = (float *)vh1; zp.gh1 = (float *)gh1;
-            zp.lo2 = (float)lo2; zp.sl2 = (float)sl2; zp.Nbl = Nbl;
+            zp.zmap = zs_map; zp.adjv = d_adj; zp.lossy = d_lossy; zp.u0b = ub[0]; zp.u2b = ub[2];
+            zp.ssaf = d_ssaf; zp.beta = d_beta; zp.mat = d_mat; zp.Mb = d_Mb;
+            zp.mq = d_mq; zp.vh1 = vh1; zp.gh1 = gh1;
+            zp.lo2 = lo2; zp.sl2 = sl2; zp.Nbl = Nbl;
          }
-         const int64_t nthreads = (int64_t)(zp.zl / 4 + (P - zp.zr) / 4) * (Ny - 2);
+         const int64_t nthreads = (int64_t)(zp.zl / V + (P - zp.zr) / V) * (Ny - 2);
          const int xchunk = (op.debug >> 16) & 0xff ? (op.debug >> 16) & 0xff : 16;
-         hipLaunchKernelGGL(pf::k_air_zstrip, dim3((unsigned)cdiv(nthreads, 256), (unsigned)cdiv(xe - xb, xchunk)), dim3(256), 0, s, zp,
-                            (float)a1, (float)a2, (float)l, xchunk);
+         hipLaunchKernelGGL(pf::k_air_zstrip<Real>, dim3((unsigned)cdiv(nthreads, 256), (unsigned)cdiv(xe - xb, xchunk)), dim3(256), 0, s, zp,
+                            a1, a2, l, xchunk);
       }
    }
    // steps n and n+1 in one go; the state moves from (u0, u1) to (bufC, bufD), which swap roles with them
@@ -1476,22 +1477,22 @@ double pf_tb2_probe(const void *A, const void *B, void *C, void *D, int64_t Nx, 
       if (tye == 20) { tp.nyt = (int)cdiv(Ny - 2 * margin, 16); hipLaunchKernelGGL((pf::k_tb2_proto<20, 8>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(512), 0, 0, tp, (float)a1, (float)a2); return true; }
       if (tye == 12) { tp.nyt = (int)cdiv(Ny - 2 * margin, 8); hipLaunchKernelGGL((pf::k_tb2_proto<12, 4>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
       // register-resident variants: tye = 100*R + WY
-      if (tye == 204) { tp.nyt = (int)cdiv(Ny - 2 * margin, 8); hipLaunchKernelGGL((pf::k_tb2_reg<2, 4>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
-      if (tye == 202) { tp.nyt = (int)cdiv(Ny - 2 * margin, 4); hipLaunchKernelGGL((pf::k_tb2_reg<2, 2>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(128), 0, 0, tp, (float)a1, (float)a2); return true; }
-      if (tye == 104) { tp.nyt = (int)cdiv(Ny - 2 * margin, 4); hipLaunchKernelGGL((pf::k_tb2_reg<1, 4>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
-      if (tye == 304) { tp.nyt = (int)cdiv(Ny - 2 * margin, 12); hipLaunchKernelGGL((pf::k_tb2_reg<3, 4>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 204) { tp.nyt = (int)cdiv(Ny - 2 * margin, 8); hipLaunchKernelGGL((pf::k_tb2_reg<float, 2, 4>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 202) { tp.nyt = (int)cdiv(Ny - 2 * margin, 4); hipLaunchKernelGGL((pf::k_tb2_reg<float, 2, 2>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(128), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 104) { tp.nyt = (int)cdiv(Ny - 2 * margin, 4); hipLaunchKernelGGL((pf::k_tb2_reg<float, 1, 4>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 304) { tp.nyt = (int)cdiv(Ny - 2 * margin, 12); hipLaunchKernelGGL((pf::k_tb2_reg<float, 3, 4>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
       // +2000: halo rows through LDS (k_tb2_lds)
       if (tye == 2304) { tp.nyt = (int)cdiv(Ny - 2 * margin, 12); hipLaunchKernelGGL((pf::k_tb2_lds<3, 4>), dim3(nblk()), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
       if (tye == 2308) { tp.nyt = (int)cdiv(Ny - 2 * margin, 24); hipLaunchKernelGGL((pf::k_tb2_lds<3, 8>), dim3(nblk()), dim3(512), 0, 0, tp, (float)a1, (float)a2); return true; }
       if (tye == 2404) { tp.nyt = (int)cdiv(Ny - 2 * margin, 16); hipLaunchKernelGGL((pf::k_tb2_lds<4, 4>), dim3(nblk()), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
       if (tye == 2204) { tp.nyt = (int)cdiv(Ny - 2 * margin, 8); hipLaunchKernelGGL((pf::k_tb2_lds<2, 4>), dim3(nblk()), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
       if (tye == 2208) { tp.nyt = (int)cdiv(Ny - 2 * margin, 16); hipLaunchKernelGGL((pf::k_tb2_lds<2, 8>), dim3(nblk()), dim3(512), 0, 0, tp, (float)a1, (float)a2); return true; }
-      if (tye == 1308) { tp.nyt = (int)cdiv(Ny - 2 * margin, 24); hipLaunchKernelGGL((pf::k_tb2_reg<3, 8, false>), dim3(nblk()), dim3(512), 0, 0, tp, (float)a1, (float)a2); return true; }
-      if (tye == 1304) { tp.nyt = (int)cdiv(Ny - 2 * margin, 12); hipLaunchKernelGGL((pf::k_tb2_reg<3, 4, false>), dim3(nblk()), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
-      if (tye == 308) { tp.nyt = (int)cdiv(Ny - 2 * margin, 24); hipLaunchKernelGGL((pf::k_tb2_reg<3, 8>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(512), 0, 0, tp, (float)a1, (float)a2); return true; }
-      if (tye == 302) { tp.nyt = (int)cdiv(Ny - 2 * margin, 6); hipLaunchKernelGGL((pf::k_tb2_reg<3, 2>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(128), 0, 0, tp, (float)a1, (float)a2); return true; }
-      if (tye == 408) { tp.nyt = (int)cdiv(Ny - 2 * margin, 32); hipLaunchKernelGGL((pf::k_tb2_reg<4, 8>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(512), 0, 0, tp, (float)a1, (float)a2); return true; }
-      if (tye == 404) { tp.nyt = (int)cdiv(Ny - 2 * margin, 16); hipLaunchKernelGGL((pf::k_tb2_reg<4, 4>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 1308) { tp.nyt = (int)cdiv(Ny - 2 * margin, 24); hipLaunchKernelGGL((pf::k_tb2_reg<float, 3, 8, false>), dim3(nblk()), dim3(512), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 1304) { tp.nyt = (int)cdiv(Ny - 2 * margin, 12); hipLaunchKernelGGL((pf::k_tb2_reg<float, 3, 4, false>), dim3(nblk()), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 308) { tp.nyt = (int)cdiv(Ny - 2 * margin, 24); hipLaunchKernelGGL((pf::k_tb2_reg<float, 3, 8>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(512), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 302) { tp.nyt = (int)cdiv(Ny - 2 * margin, 6); hipLaunchKernelGGL((pf::k_tb2_reg<float, 3, 2>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(128), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 408) { tp.nyt = (int)cdiv(Ny - 2 * margin, 32); hipLaunchKernelGGL((pf::k_tb2_reg<float, 4, 8>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(512), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 404) { tp.nyt = (int)cdiv(Ny - 2 * margin, 16); hipLaunchKernelGGL((pf::k_tb2_reg<float, 4, 4>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
       if (tye == 24) { tp.nyt = (int)cdiv(Ny - 2 * margin, 20); hipLaunchKernelGGL((pf::k_tb2_proto<24, 8>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(512), 0, 0, tp, (float)a1, (float)a2); return true; }
       return false;
    };

@@ -16,8 +16,8 @@
 namespace pf {
 
 struct Tb2Params {
-   const float *A, *B;
-   float *C, *D;
+   const void *A, *B;             // float for the prototypes, Real for k_tb2_reg / k_tb2_lds
+   void *C, *D;
    int64_t plane;
    int32_t Nx, Ny, Nz, P;
    int32_t x_begin, x_end, chunk; // D planes [x_begin, x_end) (C planes x_begin .. x_end)
@@ -46,12 +46,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_tb2_proto(Tb2Params tp, float a1
    auto grow = [&](int r) { return (int64_t)min(max(ye0 + r, 0), tp.Ny - 1) * P + zc; };
 
    auto fill_B = [&](int x, int slot) { // u^n plane x, all TYE rows of the tile
-      const float *pl = tp.B + (int64_t)x * plane;
+      const float *pl = (const float *)tp.B + (int64_t)x * plane;
       for (int r = w; r < TYE; r += WAVES) *(vec *)&Bs[slot][r][4 + lane * 4] = *(const vec *)(pl + grow(r));
    };
    auto stage1 = [&](int x, bool write_c) { // T(plane x) from B planes x-1, x, x+1 (slots (x-1)%3 ...) and A plane x; rows 1..TYE-2
-      const float *pa = tp.A + (int64_t)x * plane;
-      float *pc = tp.C + (int64_t)x * plane;
+      const float *pa = (const float *)tp.A + (int64_t)x * plane;
+      float *pc = (float *)tp.C + (int64_t)x * plane;
       float(*Bm)[LROW] = Bs[(x + 2) % 3], (*Bc)[LROW] = Bs[x % 3], (*Bp)[LROW] = Bs[(x + 1) % 3];
       for (int r = 1 + w; r <= TYE - 2; r += WAVES) {
          const int col = 4 + lane * 4;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_tb2_proto(Tb2Params tp, float a1
       }
    };
    auto stage2 = [&](int x) { // D(plane x) from T planes x-1, x, x+1 and B plane x; rows 2..TYE-3, lanes 1..62
-      float *pd = tp.D + (int64_t)x * plane;
+      float *pd = (float *)tp.D + (int64_t)x * plane;
       float(*Tm)[LROW] = Ts[(x + 2) % 3], (*Tc)[LROW] = Ts[x % 3], (*Tp)[LROW] = Ts[(x + 1) % 3];
       float(*Bc)[LROW] = Bs[x % 3];
       for (int r = 2 + w; r <= TYE - 3; r += WAVES) {
@@ -124,9 +124,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_tb2_proto(Tb2Params tp, float a1
 // u^{n+1} on its R rows + 1 above + 1 below from u^n rows R+4 (halo rows re-read through L1/L2 by the waves above and
 // below).  Per plane and lane: R+4 row loads of u^n, R+2 of u^{n-1}, R stores of u^{n+1}, R of u^{n+2}.
 // ---------------------------------------------------------------------------------------------------------------
-template <int R, int WY, bool NTA = true>
-__global__ __launch_bounds__(64 * WY) void k_tb2_reg(Tb2Params tp, float a1, float a2) {
-   typedef f32x4 vec;
+template <typename Real, int R, int WY, bool NTA = true>
+__global__ __launch_bounds__(64 * WY) void k_tb2_reg(Tb2Params tp, Real a1, Real a2) {
+   typedef typename VecOf<Real>::type vec;
+   constexpr int V = VecOf<Real>::V, W = 64 * V; // columns per lane / per wave (256 fp32, 128 fp64); lanes 0 and 63 are halo
    // plain order by default: the XCD swizzle of the single-step kernels costs 12 % here (measured).  band: all XCDs
    // stay on the same x chunk, but each takes a contiguous band of its y-z tiles, so tiles that share halo rows share an L2.
    uint32_t b = blockIdx.x;
@@ -141,40 +142,40 @@ __global__ __launch_bounds__(64 * WY) void k_tb2_reg(Tb2Params tp, float a1, flo
       zt = b % tp.nzt; yt = (b / tp.nzt) % tp.nyt; xc = b / (tp.nzt * tp.nyt);
    }
    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-   const int ze0 = tp.z_begin - 4 + zt * 248;
+   const int ze0 = tp.z_begin - V + zt * (W - 2 * V);
    const int yo = tp.y_begin + (yt * WY + w) * R;           // first output row of this wave
    const int xs = tp.x_begin + xc * tp.chunk, xe = min(xs + tp.chunk, tp.x_end);
    const int P = tp.P;
    const int64_t plane = tp.plane;
-   const int zc = min(max(ze0 + lane * 4, 0), P - 4);
+   const int zc = min(max(ze0 + lane * V, 0), P - V);
    int64_t offB[R + 4];                                       // rows yo-2 .. yo+R+1
 #pragma unroll
    for (int i = 0; i < R + 4; i++) offB[i] = (int64_t)min(max(yo - 2 + i, 0), tp.Ny - 1) * P + zc;
    const int z_end = tp.z_end ? tp.z_end : tp.Nz - tp.z_begin, y_end = tp.y_end ? tp.y_end : tp.Ny - tp.y_begin;
-   const bool core_col = (lane >= 1 && lane <= 62) && (ze0 + lane * 4 + 3 < z_end);
+   const bool core_col = (lane >= 1 && lane <= 62) && (ze0 + lane * V + V - 1 < z_end);
    bool core_row[R];
 #pragma unroll
    for (int r = 0; r < R; r++) core_row[r] = (yo + r < y_end);
 
    auto loadB = [&](int x, vec *d) {
-      const float *pl = tp.B + (int64_t)x * plane;
+      const Real *pl = (const Real *)tp.B + (int64_t)x * plane;
 #pragma unroll
       for (int i = 0; i < R + 4; i++) d[i] = *(const vec *)(pl + offB[i]);
    };
    auto loadA = [&](int x, vec *d) { // rows yo-1 .. yo+R
-      const float *pl = tp.A + (int64_t)x * plane;
+      const Real *pl = (const Real *)tp.A + (int64_t)x * plane;
 #pragma unroll
       for (int j = 0; j < R + 2; j++) d[j] = NTA ? __builtin_nontemporal_load((const vec *)(pl + offB[j + 1])) : *(const vec *)(pl + offB[j + 1]);
    };
    auto stencil = [&](const vec &c, const vec &xp, const vec &xm, const vec &yp, const vec &ym, const vec &old) {
-      const float lf = lane_from_lower<true>(c[3]);
-      const float rt = lane_from_upper<true>(c[0]);
+      const Real lf = lane_from_lower<true>(c[V - 1]);
+      const Real rt = lane_from_upper<true>(c[0]);
       vec o;
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-         const float zp = (i == 3) ? rt : c[i < 3 ? i + 1 : 3];
-         const float zm = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
-         float p = a1 * c[i] - old[i];
+      for (int i = 0; i < V; i++) {
+         const Real zp = (i == V - 1) ? rt : c[i < V - 1 ? i + 1 : V - 1];
+         const Real zm = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
+         Real p = a1 * c[i] - old[i];
          p = p + a2 * xp[i]; p = p + a2 * xm[i]; p = p + a2 * yp[i]; p = p + a2 * ym[i]; p = p + a2 * zp; p = p + a2 * zm;
          o[i] = p;
       }
@@ -193,23 +194,23 @@ __global__ __launch_bounds__(64 * WY) void k_tb2_reg(Tb2Params tp, float a1, flo
       loadA(xs - 1, Ar);
    }
 #pragma unroll
-   for (int r = 0; r < R; r++) vm[r] = vec{0, 0, 0, 0};
+   for (int r = 0; r < R; r++) vm[r] = vec{};
 #pragma unroll
-   for (int j = 0; j < R + 2; j++) vc[j] = vec{0, 0, 0, 0};
+   for (int j = 0; j < R + 2; j++) vc[j] = vec{};
    for (int x1 = xs - 1; x1 <= xe; x1++) {                    // x1: plane of the u^{n+1} values computed this turn
       if (x1 < xe) { loadB(x1 + 2, Bnn); loadA(x1 + 1, Arn); }
       // stage 1: u^{n+1}(x1) on rows yo-1 .. yo+R
 #pragma unroll
       for (int j = 0; j < R + 2; j++) vn[j] = stencil(Bc[j + 1], Bn[j + 1], Bp[j], Bc[j + 2], Bc[j], Ar[j]);
       if (x1 >= xs && x1 < xe) {
-         float *pc = tp.C + (int64_t)x1 * plane;
+         Real *pc = (Real *)tp.C + (int64_t)x1 * plane;
 #pragma unroll
          for (int r = 0; r < R; r++)
             if (core_col && core_row[r]) __builtin_nontemporal_store(vn[r + 1], (vec *)(pc + offB[r + 2]));
       }
       // stage 2: u^{n+2}(x1-1) from u^{n+1} planes x1-2 (vm), x1-1 (vc), x1 (vn) and u^n plane x1-1 (Bp)
       if (x1 - 1 >= xs) {
-         float *pd = tp.D + (int64_t)(x1 - 1) * plane;
+         Real *pd = (Real *)tp.D + (int64_t)(x1 - 1) * plane;
 #pragma unroll
          for (int r = 0; r < R; r++) {
             const vec o = stencil(vc[r + 1], vn[r + 1], vm[r], vc[r + 2], vc[r], Bp[r + 1]);
@@ -258,14 +259,14 @@ __global__ __launch_bounds__(64 * WY) void k_tb2_lds(Tb2Params tp, float a1, flo
 
    // own rows (+ the rows beyond the workgroup for its first / last wave) of a plane from global memory
    auto loadB_own = [&](int x, vec *d) {
-      const float *pl = tp.B + (int64_t)x * plane;
+      const float *pl = (const float *)tp.B + (int64_t)x * plane;
 #pragma unroll
       for (int r = 0; r < R; r++) d[r + 2] = *(const vec *)(pl + offB[r + 2]);
       if (top) { d[0] = *(const vec *)(pl + offB[0]); d[1] = *(const vec *)(pl + offB[1]); }
       if (bot) { d[R + 2] = *(const vec *)(pl + offB[R + 2]); d[R + 3] = *(const vec *)(pl + offB[R + 3]); }
    };
    auto loadA_own = [&](int x, vec *d) { // d: rows yo-1 .. yo+R
-      const float *pl = tp.A + (int64_t)x * plane;
+      const float *pl = (const float *)tp.A + (int64_t)x * plane;
 #pragma unroll
       for (int r = 0; r < R; r++) d[r + 1] = *(const vec *)(pl + offB[r + 2]);
       if (top) d[0] = *(const vec *)(pl + offB[1]);
@@ -333,13 +334,13 @@ __global__ __launch_bounds__(64 * WY) void k_tb2_lds(Tb2Params tp, float a1, flo
 #pragma unroll
       for (int j = 0; j < R + 2; j++) vn[j] = stencil(Bc[j + 1], Bn[j + 1], Bp[j], Bc[j + 2], Bc[j], Ar[j]);
       if (x1 >= xs && x1 < xe) {
-         float *pc = tp.C + (int64_t)x1 * plane;
+         float *pc = (float *)tp.C + (int64_t)x1 * plane;
 #pragma unroll
          for (int r = 0; r < R; r++)
             if (core_col && core_row[r]) __builtin_nontemporal_store(vn[r + 1], (vec *)(pc + offB[r + 2]));
       }
       if (x1 - 1 >= xs) {
-         float *pd = tp.D + (int64_t)(x1 - 1) * plane;
+         float *pd = (float *)tp.D + (int64_t)(x1 - 1) * plane;
 #pragma unroll
          for (int r = 0; r < R; r++) {
             const vec o = stencil(vc[r + 1], vn[r + 1], vm[r], vc[r + 2], vc[r], Bp[r + 1]);
@@ -361,9 +362,9 @@ __global__ __launch_bounds__(64 * WY) void k_tb2_lds(Tb2Params tp, float a1, flo
 // column strips z in [0, zl) and [zr, P) left over next to the temporally blocked box: one thread per 16-byte vector.
 // Out of place: u^{n-1} from u0s, u^{n+1} to u0.  Same expression order as the marching kernels (bit-identical).
 // ---------------------------------------------------------------------------------------------------------------
-struct ZStripParams {
-   const float *u1, *u0s;
-   float *u0;
+template <typename Real> struct ZStripParams {
+   const Real *u1, *u0s;
+   Real *u0;
    const uint8_t *mask;
    int64_t plane;
    int32_t Nx, Ny, Nz, P;
@@ -375,83 +376,90 @@ struct ZStripParams {
    const int32_t *zmap;
    const uint16_t *adjv;
    const int32_t *lossy;
-   float *u0b;
-   const float *u2b, *ssaf, *beta;
+   Real *u0b;
+   const Real *u2b, *ssaf, *beta;
    const int8_t *mat, *Mb;
-   const MatQuadT<float> *mq;
-   float *vh1, *gh1;
-   float lo2, sl2;
+   const MatQuadT<Real> *mq;
+   Real *vh1, *gh1;
+   Real lo2, sl2;
    int64_t Nbl;
 };
 
-__global__ __launch_bounds__(256) void k_air_zstrip(ZStripParams zp, float a1, float a2, float l, int xchunk) {
+template <typename Real>
+__global__ __launch_bounds__(256) void k_air_zstrip(ZStripParams<Real> zp, Real a1, Real a2, Real l, int xchunk) {
    // thread = one 16-byte vector of one row; it marches xchunk planes with the x neighbours in registers, so every
    // 128-byte line of u1 / u0s next to the strip is fetched once (a thread-per-cell version re-fetched the x neighbours
    // from other XCDs: 7x the compulsory bytes)
-   typedef f32x4 vec;
-   const int nl = zp.zl / 4, nr = (zp.P - zp.zr) / 4, nv = nl + nr;
+   typedef typename VecOf<Real>::type vec;
+   constexpr int V = VecOf<Real>::V;
+   const int nl = zp.zl / V, nr = (zp.P - zp.zr) / V, nv = nl + nr;
    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (t >= (int64_t)(zp.Ny - 2) * nv) return;
    const int v = (int)(t % nv);
    const int y = 1 + (int)(t / nv);
    const int xs = zp.x_begin + blockIdx.y * xchunk, xe = min(xs + xchunk, zp.x_end);
-   const int z0 = v < nl ? v * 4 : zp.zr + (v - nl) * 4;
+   const int z0 = v < nl ? v * V : zp.zr + (v - nl) * V;
    const int Nx = zp.Nx, Ny = zp.Ny, Nz = zp.Nz, P = zp.P;
    auto rowsrc = [&](int yy) { return yy == 0 ? 2 : (yy == Ny - 1 ? Ny - 3 : yy); };
    auto planesrc = [&](int xx) { return (zp.first && xx == 0) ? 2 : ((zp.last && xx == Nx - 1) ? Nx - 3 : xx); };
    const int64_t off = (int64_t)y * P + z0, offp = (int64_t)rowsrc(y + 1) * P + z0, offm = (int64_t)rowsrc(y - 1) * P + z0;
    const int zzN = Nz - 1 - z0; // position of the ghost column Nz-1 relative to this vector
    const bool yq = (y == 1 || y == Ny - 2);
-   auto centre = [&](int x, vec &c, float &lf, float &rt) { // a row of plane x with its z neighbours, ghost columns patched
-      const float *pc = zp.u1 + (int64_t)planesrc(x) * zp.plane;
+   auto centre = [&](int x, vec &c, Real &lf, Real &rt) { // a row of plane x with its z neighbours, ghost columns patched
+      const Real *pc = zp.u1 + (int64_t)planesrc(x) * zp.plane;
       c = *(const vec *)(pc + off);
-      lf = z0 > 0 ? pc[off - 1] : 0.f;
-      rt = z0 + 4 < P ? pc[off + 4] : 0.f;
-      if (z0 == 0) c[0] = c[2];
-      if (zzN == 1) c[1] = lf;
-      if (zzN == 2) c[2] = c[0];
-      if (zzN == 3) c[3] = c[1];
-      if (zzN == 4) rt = c[2];
+      lf = z0 > 0 ? pc[off - 1] : Real(0);
+      rt = z0 + V < P ? pc[off + V] : Real(0);
+      if (V == 4) { // same patches as load_own_row of k_air_cart_lean
+         if (z0 == 0) c[0] = c[2];
+         if (zzN == 1) c[1] = lf;
+         if (zzN == 2) c[2] = c[0];
+         if (zzN == 3) c[3] = c[1];
+      } else {
+         if (z0 == 0) c[0] = rt;
+         if (zzN == 1) c[1] = lf;
+      }
+      if (zzN == V) rt = c[V - 2];
    };
    vec cm, c, cp;
-   float lf, rt, lfn, rtn, dl, dr;
+   Real lf, rt, lfn, rtn, dl, dr;
    centre(xs - 1, cm, dl, dr);
    centre(xs, c, lf, rt);
    for (int x = xs; x < xe; x++) {
       centre(x + 1, cp, lfn, rtn);
-      const float *pc = zp.u1 + (int64_t)x * zp.plane;
+      const Real *pc = zp.u1 + (int64_t)x * zp.plane;
       const vec yp = *(const vec *)(pc + offp), ym = *(const vec *)(pc + offm);
       const vec old = *(const vec *)(zp.u0s + (int64_t)x * zp.plane + off);
-      const uint32_t bits = (zp.mask[((int64_t)x * zp.plane + off) >> 3] >> (off & 7)) & 0xfu;
+      const uint32_t bits = (zp.mask[((int64_t)x * zp.plane + off) >> 3] >> (off & 7)) & ((1u << V) - 1u);
       const int qxy = (((zp.first && x == 1) || (zp.last && x == Nx - 2)) ? 1 : 0) + (yq ? 1 : 0);
       vec o;
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-         const float zpv = (i == 3) ? rt : c[i < 3 ? i + 1 : 3];
-         const float zmv = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
-         float p = a1 * c[i] - old[i];
+      for (int i = 0; i < V; i++) {
+         const Real zpv = (i == V - 1) ? rt : c[i < V - 1 ? i + 1 : V - 1];
+         const Real zmv = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
+         Real p = a1 * c[i] - old[i];
          p = p + a2 * cp[i]; p = p + a2 * cm[i]; p = p + a2 * yp[i]; p = p + a2 * ym[i]; p = p + a2 * zpv; p = p + a2 * zmv;
          const int Q = qxy + ((z0 + i == 1 || z0 + i == Nz - 2) ? 1 : 0);
          if (Q > 0) { // ABC loss (cpu_engine.h:225-229), double literal of :228
-            const float lQ = l * (float)Q;
-            const float num = p + lQ * old[i];
-            p = (float)((double)num / (1.0 + (double)lQ));
+            const Real lQ = l * (Real)Q;
+            const Real num = p + lQ * old[i];
+            p = (Real)((double)num / (1.0 + (double)lQ));
          }
          if ((bits >> i) & 1u) {
             p = old[i]; // ghost / pad column, or a boundary node that the list kernel updates
-            const int32_t nb = zp.zmap ? zp.zmap[(((int64_t)x * Ny + y) * nv + v) * 4 + i] : -1;
+            const int32_t nb = zp.zmap ? zp.zmap[(((int64_t)x * Ny + y) * nv + v) * V + i] : -1;
             if (nb >= 0) { // boundary node: rigid update from the registers (k_boundary's expression), then the FD branches
                const uint32_t adj = zp.adjv[nb];
-               const float nbk[6] = {cp[i], cm[i], yp[i], ym[i], zpv, zmv};
-               const float two = 2.0f, b1 = two - zp.sl2 * (float)__popc(adj);
+               const Real nbk[6] = {cp[i], cm[i], yp[i], ym[i], zpv, zmv};
+               const Real two = 2.0, b1 = two - zp.sl2 * (Real)__popc(adj);
                p = b1 * c[i] - old[i];
 #pragma unroll
                for (int k = 0; k < 6; k++) {
-                  const float w = a2 * (float)((adj >> k) & 1u);
+                  const Real w = a2 * (Real)((adj >> k) & 1u);
                   p = p + w * nbk[k];
                }
                const int32_t li = zp.lossy[nb];
-               if (li >= 0) p = fd_node_update<float>(p, li, zp.u0b, zp.u2b, zp.ssaf, zp.mat, zp.Mb, zp.mq, zp.beta, zp.vh1, zp.gh1, zp.lo2, zp.Nbl);
+               if (li >= 0) p = fd_node_update<Real>(p, li, zp.u0b, zp.u2b, zp.ssaf, zp.mat, zp.Mb, zp.mq, zp.beta, zp.vh1, zp.gh1, zp.lo2, zp.Nbl);
             }
          }
          o[i] = p;

@@ -18,8 +18,8 @@ def scene(src, Nt=23, n=(36, 64, 280), **kw):
     return synth.shoebox(*n, Nt=Nt, Nm=2, Mb=[11, 3], src=src, rcv=rcv, **kw)
 
 
-def run(sim, variant, **kw):
-    sd = sim_data.SimData.from_sim(sim, "single", build_mask=False)
+def run(sim, variant, prec="single", **kw):
+    sd = sim_data.SimData.from_sim(sim, prec, build_mask=False)
     sd.scale_input()
     eng = engine.HipEngine(sd, air_variant=variant, timing=True, **kw)
     eng.run(0, sd.Nt)
@@ -112,3 +112,22 @@ def test_strip_kernel_can_update_its_boundary_nodes():
     for dbg in (0x2000, 0x2000 | (1 << 16)):
         out, _, tm = run(sim, 40, debug=dbg)
         assert tm["tb2_launches"] > 0 and np.array_equal(out, ref.u_out)
+
+
+@pytest.mark.parametrize("src,kw", [(None, {}), ([3, 30, 140], dict(n=(36, 72, 280), wall=6)), ([18, 8, 12], dict(n=(37, 67, 283)))],
+                         ids=["centre", "outside_wall", "odd"])
+def test_blocked_steps_in_double_precision(src, kw):
+    """fp64: 128 columns per wave (two doubles per lane), otherwise the same kernels."""
+    sim = scene(src, Nt=31, **kw)
+    ref = sim_data.SimData.from_sim(sim, "double")
+    ref.scale_input()
+    oracle.run_sim(ref)
+    assert np.abs(ref.u_out).max() > 0
+    _, base_g, _ = run(sim, 26, prec="double")
+    for variant, dbg in ((41, 0), (40, 0), (40, 0x2000)):
+        out, g, tm = run(sim, variant, prec="double", readout_chunk=8, debug=dbg)
+        assert np.array_equal(out, ref.u_out), (variant, dbg)
+        for a, b in zip(g, base_g):
+            assert np.array_equal(a[1:-1, 1:-1, 1:-1], b[1:-1, 1:-1, 1:-1]), (variant, dbg)
+        if variant == 40:
+            assert tm["tb2_launches"] > 0
