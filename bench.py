@@ -238,7 +238,8 @@ def main():
             kernel, kernel_ms = "k_tb2_reg", tm["tb2_ms_total"] / tm["tb2_launches"]
             units = 2 * tm["tb2_cells"]
         else:
-            kernel, kernel_ms, units = ("k_air_fcc" if args.fcc else "k_air_cart_lean"), air_ms_per_step, upd
+            kernel = "k_air_fcc" if args.fcc else ("k_air_cart" if tm.get("air_path") == 1 else "k_air_cart_lean")
+            kernel_ms, units = air_ms_per_step, upd
         achieved = units * bpv / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
         res = {
             "metric": "Gvoxel-updates/s", "value": round(gvox, 3), "unit": "Gvoxel-updates/s",
@@ -258,7 +259,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
                          "kernel_ms_per_launch": round(kernel_ms, 4), "voxel_updates_per_launch": int(units),
                          "bytes_per_voxel_update": bpv, "air_ms_per_step": round(air_ms_per_step, 4),
-                         "interior_voxels_per_step": upd},
+                         "interior_voxels_per_step": upd,
+                         "autotune_ms_per_step": {k: round(v, 4) for k, v in zip(("lean", "barrier_free", "blocked_pair"), tm.get("tune_ms", [0, 0, 0]))}},
         }
         # HBM bytes per air launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE in separate runs, gfx950 x2 read correction applied; tools/make_profile_summary.py)

@@ -110,6 +110,9 @@ typedef struct pf_timing {
    double  tb2_ms_total;    /* temporal blocking: sum of the two-steps-per-pass kernel's launch durations (included in air_ms_total) */
    int64_t tb2_launches;    /* kernel launches behind tb2_ms_total; 0 when the engine steps one step per pass */
    int64_t tb2_cells;       /* cells one such launch advances by two steps (average over the x ranges of the box) */
+   double  tune_ms[3];      /* creation-time measurement of the interior update of one step, ms: lean fused kernel,
+                               barrier-free kernel, temporally blocked pair / 2 (0 = not measured) */
+   int64_t air_path;        /* what the engine runs: 0 lean, 1 barrier-free (virtual ghosts), 2 blocked pairs, -1 other */
 } pf_timing;
 
 typedef struct pf_engine pf_engine;

@@ -103,6 +103,8 @@ template <typename Real> struct Engine : EngineBase {
    int32_t *segstart = nullptr;  // first boundary node of every (row, z segment) (fused rigid update)
    uint8_t *adj_dense = nullptr; // lean kernel with in-kernel rigid update: adjacency byte per padded cell
    bool lean_rigid = false;
+   Real *v1_dst = nullptr;       // autotune: destination of the barrier-free 7-point kernel (null = in place)
+   float tune_ms[3] = {0, 0, 0}; // measured at creation: lean / barrier-free / blocked pair (per step), ms
    bool v1_rigb = false;         // barrier-free 7-point kernel with the rigid update in-kernel from a cell-byte grid
    uint8_t *cellb = nullptr;     // that grid: 0 air, 0x40 skip, 0x80|adjacency at boundary nodes
    bool fused = false, fused_rigid = false, lean = false, need_fold_row = false;
@@ -467,6 +469,7 @@ template <typename Real> struct Engine : EngineBase {
          HIPCHK(hipHostMalloc((void **)&h_ring, std::max<int64_t>(Nr * ring_depth, 1) * sizeof(Real), hipHostMallocDefault));
       }
       { int rc = init_tb2(); if (rc) return rc; }
+      { int rc = autotune(); if (rc) return rc; }
       // hipGraph replay of the step loop (six steps per graph): measured on MI355X / ROCm 7.2 it does not beat plain
       // launches even on launch-bound grids (234x154x85: 0.0503 vs 0.0473 ms/step, 256^3: 0.0951 vs 0.0921) -- the gaps
       // between dependent kernels are the same inside a graph, and the counter-tick node adds one -- so it is opt-in
@@ -488,7 +491,7 @@ template <typename Real> struct Engine : EngineBase {
    int init_tb2() {
       tb2 = tb2_geom = tb2_slab = false;
       const bool single = op.slab_first && op.slab_last;
-      if (fcc || !lean || lean_rigid || op.energy) return PF_OK;
+      if (fcc || !(lean || vg) || lean_rigid || v1_rigb || op.energy || (op.debug & 0x4000)) return PF_OK; // 0x4000: single steps only
       if (!(vbase == 0 || vbase == 40 || vbase == 41) || op.numerics != PF_NUM_CPU_EXACT || !use_dpp) return PF_OK;
       if (Nb > 0 && !boundary_fused()) return PF_OK;
       int64_t dmax = 0; // depth of the deepest boundary node below the nearest grid face (slab faces towards a neighbour are no faces)
@@ -522,7 +525,9 @@ template <typename Real> struct Engine : EngineBase {
       if (vbase == 40 && vol == 0) return set_err(PF_ERR_ARG, "air_variant 40 (temporal blocking) requested but the scene has no boundary-free box");
       // auto: the shell costs grow with the perimeter of the y-z cross-section, the gain with its area -- measured on
       // MI355X: 512^2 planes -4.5 %, 768^2 +9 %, 1024^2 +13 %; and two extra grids must be worth it
-      if (vbase == 0 && ((double)vol < 0.6 * (double)(Nx * Ny * Nz) || tby1 - tby0 < 600 || tbz1 - tbz0 < 600)) return PF_OK;
+      // (single-domain engines then time a blocked pair against the single-step kernels at creation: autotune())
+      if (vbase == 0 && ((double)vol < 0.6 * (double)(Nx * Ny * Nz) || tby1 - tby0 < 300 || tbz1 - tbz0 < 300)) return PF_OK;
+      if (vbase == 0 && !single && (tby1 - tby0 < 600 || tbz1 - tbz0 < 600)) return PF_OK;
       tb2_geom = true;
       if (!single) return PF_OK; // slab engines wait for pf_engine_set_spares (all four grids must be the caller's)
       int rc;
@@ -561,6 +566,67 @@ template <typename Real> struct Engine : EngineBase {
       if (!tb2_geom || (op.slab_first && op.slab_last)) return 1; // not an error: this engine keeps stepping singly
       bufC = (Real *)g2; bufD = (Real *)g3;
       tb2_slab = true;
+      return PF_OK;
+   }
+   // ---- which interior path?  Measured, not guessed: at creation the candidates run three times each on the real grids,
+   // writing to scratch (the state is not touched): lean fused kernel, barrier-free kernel with virtual ghosts, and --
+   // where a box exists -- a temporally blocked pair incl. its shell.  The boundary pass and the I/O are common to all.
+   // (7-point only; explicit air_variant requests and debug 0x8000 skip it.)  Sizes decide in ways no static rule
+   // caught: 1024^3 fp32 pair 411 > lean 377 > barrier-free 364 Gvox/s, 896^3 barrier-free 362 > pair 335 > lean 303.
+   int autotune() {
+      if (vbase != 0 || fcc || op.energy || (op.debug & 0x8000) || !use_dpp || !(lean || vg) || v1_rigb || lean_rigid) return PF_OK;
+      if (Nx * Ny * Nz < ((int64_t)1 << 22)) return PF_OK; // tiny grids: launch-bound either way
+      Real *scr = bufC;
+      bool own = false;
+      int rc;
+      if (!scr) { if ((rc = dzalloc(&scr, npad))) return rc; own = true; }
+      hipEvent_t e0, e1;
+      HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+      HIPCHK(hipDeviceSynchronize());
+      auto timed = [&](auto &&fn) -> float {
+         fn();
+         hipEventRecord(e0, s_main);
+         for (int i = 0; i < 3; i++) fn();
+         hipEventRecord(e1, s_main);
+         hipEventSynchronize(e1);
+         float ms = 0;
+         hipEventElapsedTime(&ms, e0, e1);
+         return ms / 3;
+      };
+      const bool lean0 = lean, vg0 = vg;
+      Real *U0 = u0, *U1 = u1;
+      lean = true; vg = false; u0_src = U0; u0 = scr;
+      tune_ms[0] = timed([&] { launch_air_lean(s_main, 1, (int)Nx - 1); });
+      u0 = U0; u0_src = nullptr;
+      lean = false; vg = true; v1_dst = scr;
+      tune_ms[1] = timed([&] { launch_air_march(s_main, 1, (int)Nx - 1); });
+      v1_dst = nullptr;
+      lean = lean0; vg = vg0;
+      if (hipGetLastError() != hipSuccess) { lean = lean0; vg = vg0; }
+      else if (tune_ms[1] < 0.97f * tune_ms[0]) { lean = false; vg = true; }
+      else if (tune_ms[0] < 0.97f * tune_ms[1]) { lean = true; vg = false; }
+      if (tb2) {
+         tune_ms[2] = 0.5f * timed([&] {
+            launch_tb2(s_main, U0, U1, bufC, bufD);
+            u0_src = U0; u1 = U1; u0 = bufC; launch_shell(s_main);
+            u0_src = U1; u1 = bufC; u0 = bufD; launch_shell(s_main);
+            u0_src = nullptr; u0 = U0; u1 = U1;
+         });
+         if (!(tune_ms[2] < 0.97f * std::min(tune_ms[0], tune_ms[1]))) { // not worth it: drop the pair path and its two grids
+            tb2 = false;
+            for (Real *g : {bufC, bufD}) { own_list.erase(std::remove(own_list.begin(), own_list.end(), g), own_list.end()); hipFree(g); }
+            if (scr == bufC) scr = nullptr;
+            bufC = bufD = nullptr;
+            if (zs_map) { hipFree(zs_map); zs_map = nullptr; }
+            if (zs_rest) { hipFree(zs_rest); zs_rest = nullptr; }
+         } else {
+            HIPCHK(hipMemsetAsync(bufC, 0, npad * sizeof(Real), s_main));
+            HIPCHK(hipMemsetAsync(bufD, 0, npad * sizeof(Real), s_main));
+         }
+      }
+      HIPCHK(hipDeviceSynchronize());
+      hipEventDestroy(e0); hipEventDestroy(e1);
+      if (own && scr) hipFree(scr);
       return PF_OK;
    }
    void launch_tb2(hipStream_t s, const Real *A, const Real *B, Real *C, Real *D) {
@@ -760,6 +826,10 @@ template <typename Real> struct Engine : EngineBase {
       dim3 g(total), b(64 * WY * WZ);
       const bool fma = op.numerics == PF_NUM_FMA;
       if constexpr (R == 4 && WY == 4 && WZ == 1) {
+         if (v1_dst && vg && !fcc) { // autotune: the same kernel writing to a scratch grid
+            hipLaunchKernelGGL((pf::k_air_cart<Real, R, WY, WZ, false, true, true, false, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l, sl2, v1_dst);
+            return;
+         }
          if (v1_rigb && vg && !fcc) { // 7-point, virtual ghosts, rigid update in-kernel from the cell-byte grid
             if (fma) hipLaunchKernelGGL((pf::k_air_cart<Real, R, WY, WZ, true, true, true, false, LW, true>), g, b, 0, s, u1, u0, cellb, a1, a2, ap, l, sl2);
             else hipLaunchKernelGGL((pf::k_air_cart<Real, R, WY, WZ, false, true, true, false, LW, true>), g, b, 0, s, u1, u0, cellb, a1, a2, ap, l, sl2);
@@ -1282,6 +1352,8 @@ template <typename Real> struct Engine : EngineBase {
    int timing(pf_timing *t, int reset) override {
       int rc = harvest();
       if (rc) return rc;
+      for (int i = 0; i < 3; i++) tm.tune_ms[i] = tune_ms[i];
+      tm.air_path = (tb2 || tb2_slab) ? 2 : (lean ? 0 : (vg ? 1 : -1));
       if (t) *t = tm;
       if (reset) tm = pf_timing{};
       return PF_OK;

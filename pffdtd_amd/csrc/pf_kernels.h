@@ -112,7 +112,8 @@ struct AirParams {
 template <typename Real, int R, int WY, int WZ, bool FMA, bool DPP, bool VG = false, bool ABCK = false, int LW = 64, bool RIGB = false>
 __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restrict__ u1, Real *__restrict__ u0,
                                                           const uint8_t *__restrict__ mask, Real a1, Real a2,
-                                                          AirParams ap, Real labc, Real sl2 = Real(0)) {
+                                                          AirParams ap, Real labc, Real sl2 = Real(0),
+                                                          Real *u0_dst = nullptr) { // u0_dst: write there instead of in place
    typedef typename VecOf<Real>::type vec;
    constexpr int V = VecOf<Real>::V;
    const uint32_t total = (uint32_t)ap.nzt * ap.nyt * ap.nxc;
@@ -288,7 +289,8 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
             for (int i = 0; i < V; i++)
                if ((bits >> i) & 1u) o[i] = old[r][i];
          }
-         if (active && (y0 + r <= Ny - 2)) __builtin_nontemporal_store(o, (vec *)(po + soff[r]));
+         if (active && (y0 + r <= Ny - 2))
+            __builtin_nontemporal_store(o, (vec *)((u0_dst ? u0_dst + (int64_t)x * plane : po) + soff[r]));
       }
 #pragma unroll
       for (int r = 0; r < R; r++) {

@@ -27,7 +27,8 @@ class PfOpts(ctypes.Structure):
 class PfTiming(ctypes.Structure):
     _fields_ = [("air_ms_total", ctypes.c_double), ("air_launches", ctypes.c_int64),
                 ("step_ms_total", ctypes.c_double), ("steps", ctypes.c_int64),
-                ("tb2_ms_total", ctypes.c_double), ("tb2_launches", ctypes.c_int64), ("tb2_cells", ctypes.c_int64)]
+                ("tb2_ms_total", ctypes.c_double), ("tb2_launches", ctypes.c_int64), ("tb2_cells", ctypes.c_int64),
+                ("tune_ms", ctypes.c_double * 3), ("air_path", ctypes.c_int64)]
 
 
 class PfError(RuntimeError):
@@ -200,7 +201,8 @@ class HipEngine:
         t = PfTiming()
         _check(lib().pf_engine_timing(self._h, ctypes.byref(t), int(reset)))
         return {"air_ms_total": t.air_ms_total, "air_launches": t.air_launches, "step_ms_total": t.step_ms_total,
-                "steps": t.steps, "tb2_ms_total": t.tb2_ms_total, "tb2_launches": t.tb2_launches, "tb2_cells": t.tb2_cells}
+                "steps": t.steps, "tb2_ms_total": t.tb2_ms_total, "tb2_launches": t.tb2_launches, "tb2_cells": t.tb2_cells,
+                "tune_ms": list(t.tune_ms), "air_path": t.air_path}
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
