@@ -104,6 +104,7 @@ template <typename Real> struct Engine : EngineBase {
    uint8_t *adj_dense = nullptr; // lean kernel with in-kernel rigid update: adjacency byte per padded cell
    bool lean_rigid = false;
    Real *v1_dst = nullptr;       // autotune: destination of the barrier-free 7-point kernel (null = in place)
+   int lw_force = 0;             // autotune: lanes per row segment of the barrier-free kernels (0 = pick_lw's rule)
    float tune_ms[3] = {0, 0, 0}; // measured at creation: lean / barrier-free / blocked pair (per step), ms
    bool v1_rigb = false;         // barrier-free 7-point kernel with the rigid update in-kernel from a cell-byte grid
    uint8_t *cellb = nullptr;     // that grid: 0 air, 0x40 skip, 0x80|adjacency at boundary nodes
@@ -603,7 +604,21 @@ template <typename Real> struct Engine : EngineBase {
       tune_ms[0] = timed([&] { launch_air_lean(s_main, 1, (int)Nx - 1); });
       u0 = U0; u0_src = nullptr;
       lean = false; vg = true; v1_dst = scr;
-      tune_ms[1] = timed([&] { launch_air_march(s_main, 1, (int)Nx - 1); });
+      { // the barrier-free kernel, with 64 / 32 / 16 lanes per row segment where those pad the rows differently
+         constexpr int V = pf::VecOf<Real>::V;
+         int best_lw = 0;
+         int64_t seen[3] = {0, 0, 0};
+         int k = 0;
+         for (int lw : {64, 32, 16}) {
+            const int64_t w = cdiv(P, (int64_t)lw * V) * lw * V;
+            if (k > 0 && w == seen[k - 1]) continue; // same padded width as the wider segment: the wider one wins anyway
+            seen[k++] = w;
+            lw_force = lw;
+            const float t = timed([&] { launch_air_march(s_main, 1, (int)Nx - 1); });
+            if (best_lw == 0 || t < 0.98f * tune_ms[1]) { tune_ms[1] = t; best_lw = lw; }
+         }
+         lw_force = best_lw;
+      }
       v1_dst = nullptr;
       lean = lean0; vg = vg0;
       if (hipGetLastError() != hipSuccess) { lean = lean0; vg = vg0; }
@@ -790,6 +805,7 @@ template <typename Real> struct Engine : EngineBase {
    int pick_lw() const {
       constexpr int V = pf::VecOf<Real>::V;
       if (op.debug & 0x300) return (op.debug & 0x100) ? 32 : 16; // tuning override
+      if (lw_force) return lw_force;                             // measured at creation (autotune)
       // narrower segments cost extra edge-column loads (two per segment and row; the 13-point kernel needs them on every
       // row of all three planes): worth it only when they save >= 10 % of the padded width (7-point) / 25 % (13-point);
       // measured: Nz=309 7-pt +10 % with 16 lanes, Nz=850 13-pt -4 % with 32 lanes
