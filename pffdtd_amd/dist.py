@@ -142,8 +142,12 @@ def gather_outputs(sd, loc, info, group=None):
 def make_hip_runner(sd, rank, world, device, group=None, balance=True, **engine_kw):
     import os
     loc, info = slab_mod.split(sd, world, rank, balance=balance)
-    # temporally blocked step pairs in slab engines: measured on MI355X (1024^3, per-rank cost model) +2 % at 2 and 4
-    # ranks, -2..0 % at 8 (thin slabs: the extra launches eat the gain), so opt-in: PFFDTD_SLAB_PAIRS=1
-    engine_kw.setdefault("pairs", os.environ.get("PFFDTD_SLAB_PAIRS", "0") == "1")
+    # temporally blocked step pairs in slab engines (four state grids per rank): measured on MI355X (1024^3, per-rank cost
+    # model with an RCCL self-exchange) +14 % at 2 ranks (715 -> 817 Gvox/s), +10 % at 4 (1406 -> 1553), +0.4..2 % at 8 --
+    # thin slabs leave little box per launch, and the box kernel of a pair must wait for the previous step's exchange.
+    # Default: on for slabs of at least 192 planes; PFFDTD_SLAB_PAIRS=1 / 0 forces it on / off.  (The engine itself
+    # declines when the scene has no boundary-free box: pf_engine_set_spares returns 1 and it keeps stepping singly.)
+    env = os.environ.get("PFFDTD_SLAB_PAIRS", "")
+    engine_kw.setdefault("pairs", env == "1" or (env != "0" and loc.Nx - 2 >= 192))
     st = HipSlabStepper(loc, info, device, **engine_kw)
     return SlabRunner(st, info, group), loc, info
