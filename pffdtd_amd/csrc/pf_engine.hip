@@ -507,6 +507,11 @@ template <typename Real> struct Engine : EngineBase {
       // of the split-phase step (they need the neighbour's data between the two steps of a pair)
       tbx0 = op.slab_first ? m : 2; tbx1 = op.slab_last ? (int)Nx - m : (int)Nx - 2;
       tby0 = m; tby1 = (int)Ny - m; tbz0 = mz; tbz1 = (int)((Nz - mz) / 4 * 4);
+      { // a last z tile with only a sliver of core columns costs a whole workgroup per (row tile, x chunk) and re-reads
+         // lines the right column strip streams anyway: leave up to two 128-byte lines of columns to the strip instead
+         const int WC = 62 * pf::VecOf<Real>::V, nz = tbz1 - tbz0, rem = nz % WC;
+         if (!(op.debug & 0x10000000) && nz > WC && rem > 0 && rem * (int)sizeof(Real) <= 256) tbz1 -= rem;
+      }
       if (vbase == 41) tbx1 = tbx0; // driver test: everything goes through the out-of-place single-step path
       tb_xr.clear();
       if (tbx1 - tbx0 >= 16 && tby1 - tby0 >= 48 && tbz1 - tbz0 >= 62 * pf::VecOf<Real>::V) {
