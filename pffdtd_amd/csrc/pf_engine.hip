@@ -128,6 +128,8 @@ template <typename Real> struct Engine : EngineBase {
    std::vector<int64_t> out_row; // sorted receiver slot -> caller row
    // plane ranges of the sorted lists: lo = first owned plane (ix==1), hi = last owned plane (ix==Nx-2)
    Range bn_lo, bn_mid, bn_hi, bnl_lo, bnl_mid, bnl_hi, bna_lo, bna_mid, bna_hi, in_lo, in_mid, in_hi;
+   // the same lists cut for the split-phase pairs, whose edge stream owns two planes per side: planes 1-2 / 3..Nx-4 / Nx-3..Nx-2
+   Range bn_lo2, bn_mid2, bn_hi2, bnl_lo2, bnl_mid2, bnl_hi2, in_lo2, in_mid2, in_hi2;
    hipStream_t s_main = nullptr, s_edge = nullptr;
    hipEvent_t ev_pre = nullptr, ev_edge = nullptr, ev_main = nullptr;
    bool in_step = false;
@@ -144,7 +146,6 @@ template <typename Real> struct Engine : EngineBase {
    int pair_phase = 0;                                    // 1: between the two steps of a split-phase pair
    bool pair_now = false;                                 // the step in flight is half of a pair
    Real *pA = nullptr, *pB = nullptr;                     // u^{n-1}, u^n of the pair in flight
-   hipEvent_t ev_xchg = nullptr;                          // edge stream after the exchange of the latest step
    Real *bufC = nullptr, *bufD = nullptr;                 // the two extra state grids of the out-of-place pair
    int tbx0 = 0, tbx1 = 0, tby0 = 0, tby1 = 0, tbz0 = 0, tbz1 = 0; // box of cells k_tb2_reg produces
    std::vector<std::pair<int, int>> tb_xr;                // its x ranges (planes next to a source are cut out)
@@ -182,7 +183,6 @@ template <typename Real> struct Engine : EngineBase {
       if (ev_pre) hipEventDestroy(ev_pre);
       if (ev_edge) hipEventDestroy(ev_edge);
       if (ev_main) hipEventDestroy(ev_main);
-      if (ev_xchg) hipEventDestroy(ev_xchg);
       if (gexec) hipGraphExecDestroy(gexec);
       if (d_ctr) hipFree(d_ctr);
       if (s_main) hipStreamDestroy(s_main);
@@ -208,10 +208,11 @@ template <typename Real> struct Engine : EngineBase {
    }
 
    // split a sorted padded-index list into the ranges of plane 1 / planes 2..Nx-3 / plane Nx-2
-   void plane_ranges(const std::vector<int64_t> &idx, Range &lo, Range &mid, Range &hi) const {
+   void plane_ranges(const std::vector<int64_t> &idx, Range &lo, Range &mid, Range &hi, int w = 1) const {
       const int64_t n = (int64_t)idx.size();
       auto first_ge = [&](int64_t px) { return (int64_t)(std::lower_bound(idx.begin(), idx.end(), px * plane) - idx.begin()); };
-      const int64_t b1 = first_ge(1), b2 = first_ge(2), b3 = first_ge(Nx - 2), b4 = first_ge(Nx - 1);
+      if (w == 2 && Nx < 8) { lo = mid = hi = {0, 0}; return; } // (pairs need far thicker slabs anyway)
+      const int64_t b1 = first_ge(1), b2 = first_ge(1 + w), b3 = first_ge(Nx - 1 - w), b4 = first_ge(Nx - 1);
       lo = {b1, std::min(b2, b4)};
       if (Nx - 2 > 1) { mid = {b2, std::max(b2, b3)}; hi = {std::max(b2, b3), b4}; }
       else { mid = {b2, b2}; hi = {b2, b2}; }
@@ -284,7 +285,6 @@ template <typename Real> struct Engine : EngineBase {
       HIPCHK(hipEventCreateWithFlags(&ev_pre, hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&ev_edge, hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&ev_xchg, hipEventDisableTiming));
       use_dpp = check_dpp(s_main) == 1;
 
       // ---- state grids ----
@@ -334,6 +334,7 @@ template <typename Real> struct Engine : EngineBase {
          if ((rc = upload(&d_bn, idx.data(), Nb))) return rc;
          if ((rc = upload(&d_adj, adj.data(), Nb))) return rc;
          plane_ranges(idx, bn_lo, bn_mid, bn_hi);
+         plane_ranges(idx, bn_lo2, bn_mid2, bn_hi2, 2);
          // which interior path? 0 = auto; 1-3 unfused marching kernels; 9 naive; 10-14 generic fused kernel
          // (virtual ghosts + ABC + rigid in-kernel); 20-24 lean fused 7-point kernel (virtual ghosts + ABC)
          vbase = op.air_variant & 63;
@@ -415,6 +416,7 @@ template <typename Real> struct Engine : EngineBase {
          if ((rc = upload(&d_ssaf, ssaf.data(), Nbl))) return rc;
          if ((rc = upload(&d_mat, mat.data(), Nbl))) return rc;
          plane_ranges(idx, bnl_lo, bnl_mid, bnl_hi);
+         plane_ranges(idx, bnl_lo2, bnl_mid2, bnl_hi2, 2);
          for (int i = 0; i < 3; i++) if ((rc = dzalloc(&ub[i], Nbl))) return rc;
          if ((rc = dzalloc(&vh1, Nbl * PF_MMB))) return rc;
          if ((rc = dzalloc(&gh1, Nbl * PF_MMB))) return rc;
@@ -458,6 +460,7 @@ template <typename Real> struct Engine : EngineBase {
          if ((rc = upload(&d_in, idx.data(), Ns))) return rc;
          if ((rc = upload(&d_insig, sig.data(), Ns * Nt))) return rc;
          plane_ranges(idx, in_lo, in_mid, in_hi);
+         plane_ranges(idx, in_lo2, in_mid2, in_hi2, 2);
       }
       { // receivers
          auto perm = sorted_perm(sd.out_ixyz, Nr, idx);
@@ -503,9 +506,10 @@ template <typename Real> struct Engine : EngineBase {
          dmax = std::max(dmax, d);
       }
       const int m = (int)std::max<int64_t>(dmax + 2, 3), mz = (m + 3) / 4 * 4;
-      // towards a neighbouring slab the box stops two planes short of the ghost plane: plane 1 / Nx-2 are the edge planes
-      // of the split-phase step (they need the neighbour's data between the two steps of a pair)
-      tbx0 = op.slab_first ? m : 2; tbx1 = op.slab_last ? (int)Nx - m : (int)Nx - 2;
+      // towards a neighbouring slab the box stops three planes short of the ghost plane: planes 1-2 / Nx-3..Nx-2 are the
+      // edge planes of a split-phase pair (plane 1 needs the neighbour's data between the two steps; with plane 2 on the
+      // edge stream as well the box kernel never reads a ghost plane, so the main stream never waits for an exchange)
+      tbx0 = op.slab_first ? m : 3; tbx1 = op.slab_last ? (int)Nx - m : (int)Nx - 3;
       tby0 = m; tby1 = (int)Ny - m; tbz0 = mz; tbz1 = (int)((Nz - mz) / 4 * 4);
       { // a last z tile with only a sliver of core columns costs a whole workgroup per (row tile, x chunk) and re-reads
          // lines the right column strip streams anyway: leave up to two 128-byte lines of columns to the strip instead
@@ -1226,30 +1230,29 @@ template <typename Real> struct Engine : EngineBase {
       // Slab engines with all four grids at hand step in temporally blocked pairs that span two split-phase steps:
       // phase 0 (step n): edge planes n -> n+1 on the edge stream; box n -> n+1, n+2 plus the shell n -> n+1 on the
       // main stream; phase 1 (step n+1): edge planes and shell n+1 -> n+2.  The exchanges in between are the usual ones.
-      if (tb2_slab && (pair_phase == 1 || (n + 1 < Nt && ring_fill + 2 <= ring_depth && xh - xl >= 4))) {
+      if (tb2_slab && (pair_phase == 1 || (n + 1 < Nt && ring_fill + 2 <= ring_depth && xh - xl >= 8))) {
          const bool first_half = pair_phase == 0;
          if (first_half) { pA = u0; pB = u1; u0_src = pA; u1 = pB; u0 = bufC; }
          fold_x0 = 0; fold_x1 = 0; // (7-point only: no fold row)
-         launch_air(s_edge, xl, xl + 1);
-         launch_air(s_edge, xh, xh + 1);
-         launch_rigid(s_edge, bn_lo); launch_rigid(s_edge, bn_hi);
-         launch_fd(s_edge, bnl_lo); launch_fd(s_edge, bnl_hi);
-         launch_io(s_edge, n, false, in_lo); launch_io(s_edge, n, false, in_hi);
+         launch_air(s_edge, xl, xl + 2);
+         launch_air(s_edge, xh - 1, xh + 1);
+         launch_rigid(s_edge, bn_lo2); launch_rigid(s_edge, bn_hi2);
+         launch_fd(s_edge, bnl_lo2); launch_fd(s_edge, bnl_hi2);
+         launch_io(s_edge, n, false, in_lo2); launch_io(s_edge, n, false, in_hi2);
          HIPCHK(hipEventRecord(ev_edge, s_edge));
          std::pair<hipEvent_t, hipEvent_t> eva{}, evt{};
          auto get_ev = [&]() { std::pair<hipEvent_t, hipEvent_t> e{}; if (!ev_pool.empty()) { e = ev_pool.back(); ev_pool.pop_back(); } else { hipEventCreate(&e.first); hipEventCreate(&e.second); } return e; };
          if (op.timing) { eva = get_ev(); hipEventRecord(eva.first, s_main); }
          if (first_half) {
-            HIPCHK(hipStreamWaitEvent(s_main, ev_xchg, 0)); // the box kernel reads the ghost planes of u^n (level-1 values of plane 1)
             if (op.timing) { evt = get_ev(); hipEventRecord(evt.first, s_main); }
             launch_tb2(s_main, pA, pB, bufC, bufD);
             if (op.timing) { hipEventRecord(evt.second, s_main); tb2_ev.push_back(evt); }
          }
-         launch_shell(s_main, xl + 1, xh);
+         launch_shell(s_main, xl + 2, xh - 1);
          if (op.timing) { hipEventRecord(eva.second, s_main); air_ev.push_back(eva); }
-         launch_rigid(s_main, bn_mid);
-         launch_fd(s_main, bnl_mid);
-         launch_io(s_main, n, true, in_mid);
+         launch_rigid(s_main, bn_mid2);
+         launch_fd(s_main, bnl_mid2);
+         launch_io(s_main, n, true, in_mid2);
          HIPCHK(hipGetLastError());
          in_step = true;
          pair_now = true;
@@ -1297,7 +1300,6 @@ template <typename Real> struct Engine : EngineBase {
       // the edge *compute* only (ev_edge, recorded in step_begin before the exchange was issued) -- the exchange
       // itself stays off the main stream's critical path and only orders the edge stream.
       HIPCHK(hipEventRecord(ev_main, s_main));
-      HIPCHK(hipEventRecord(ev_xchg, s_edge)); // everything the caller queued on the edge stream for this step's exchange
       HIPCHK(hipStreamWaitEvent(s_edge, ev_main, 0));
       HIPCHK(hipStreamWaitEvent(s_main, ev_edge, 0));
       in_step = false;

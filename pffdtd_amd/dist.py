@@ -143,11 +143,11 @@ def make_hip_runner(sd, rank, world, device, group=None, balance=True, **engine_
     import os
     loc, info = slab_mod.split(sd, world, rank, balance=balance)
     # temporally blocked step pairs in slab engines (four state grids per rank): measured on MI355X (1024^3, per-rank cost
-    # model with an RCCL self-exchange) +14 % at 2 ranks (715 -> 817 Gvox/s), +10 % at 4 (1406 -> 1553), +0.4..2 % at 8 --
-    # thin slabs leave little box per launch, and the box kernel of a pair must wait for the previous step's exchange.
-    # Default: on for slabs of at least 192 planes; PFFDTD_SLAB_PAIRS=1 / 0 forces it on / off.  (The engine itself
-    # declines when the scene has no boundary-free box: pf_engine_set_spares returns 1 and it keeps stepping singly.)
+    # model with an RCCL self-exchange, old / new on the same box) +3..14 % at 2 ranks, +5..10 % at 4, +7 % on the interior
+    # slabs of 8 ranks (136 planes) and +0..2 % on its end slabs.  Default: on for slabs of at least 96 planes;
+    # PFFDTD_SLAB_PAIRS=1 / 0 forces it on / off.  (The engine itself declines when the scene has no boundary-free box
+    # or the y-z cross-section is small: pf_engine_set_spares returns 1 and it keeps stepping singly.)
     env = os.environ.get("PFFDTD_SLAB_PAIRS", "")
-    engine_kw.setdefault("pairs", env == "1" or (env != "0" and loc.Nx - 2 >= 192))
+    engine_kw.setdefault("pairs", env == "1" or (env != "0" and loc.Nx - 2 >= 96))
     st = HipSlabStepper(loc, info, device, **engine_kw)
     return SlabRunner(st, info, group), loc, info
