@@ -146,7 +146,8 @@ int  pf_engine_step_end(pf_engine *e, int64_t n);
 /* Slab engines created on caller-owned grids (pf_opts.ext_u0/ext_u1): hand over two more grids of the same size, so
  * that the engine may advance in temporally blocked pairs (two split-phase steps per pair, the state then cycles
  * through the four grids: pf_engine_halo_ptrs always names the grid being written).  Returns 0 when pairs are on,
- * 1 when this engine keeps stepping singly (scene without a boundary-free box, fp64, 13-point, ...); other values
+ * 1 when this engine keeps stepping singly (scene without a boundary-free box, small y-z cross-section, 13-point,
+ * single-domain engine, ...); other values
  * are pf_status errors.  No counterpart in the reference. */
 int  pf_engine_set_spares(pf_engine *e, void *grid2, void *grid3);
 void *pf_engine_stream(pf_engine *e, int32_t which); /* 0 main, 1 edge: hipStream_t */

@@ -72,13 +72,17 @@ def test_single_rank_runner_matches():
 
 
 @pytest.mark.parametrize("G,Nt", [(2, 21), (3, 18)])
-@pytest.mark.parametrize("src", [None, [70, 30, 150]], ids=["centre", "off_centre"])
+@pytest.mark.parametrize("src", [None, [70, 30, 150], [49, 30, 150], [45, 30, 150], [30, 33, 141]],
+                         ids=["centre", "off_centre", "second_edge_plane", "second_last_edge_plane", "third_cut"])
 def test_virtual_slabs_with_blocked_pairs(G, Nt, src):
     """Slab engines that own four grids step in temporally blocked pairs spanning two split-phase steps (air_variant 40
     forces it on this small cross-section); odd step counts end with a single step."""
     from pffdtd_amd import sim_data, synth
     n = (96, 64, 280)
-    rcv = [[50, 30, 140], [7, 8, 9], [88, 55, 260]] + ([[src[0] - 4, src[1] + 2, src[2] - 3]] if src else [])
+    # (in a pair the edge stream owns two planes per side: sources / receivers in local planes 2 and Nx-3 of a slab --
+    # global 46 / 49 with the cut at 48, 30..33 / 62..65 with cuts at 32 and 64 -- go through its two-plane lists)
+    rcv = [[50, 30, 140], [7, 8, 9], [88, 55, 260], [46, 20, 100], [49, 40, 200], [33, 12, 40], [62, 50, 77]] + \
+        ([[src[0] - 4, src[1] + 2, src[2] - 3]] if src else [])
     sim = synth.shoebox(*n, Nt=Nt, Nm=2, Mb=[11, 3], src=src, rcv=rcv)
     ref = sim_data.SimData.from_sim(sim, "single")
     ref.scale_input()
