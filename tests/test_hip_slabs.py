@@ -77,6 +77,14 @@ def test_single_rank_runner_matches():
 def test_virtual_slabs_with_blocked_pairs(G, Nt, src):
     """Slab engines that own four grids step in temporally blocked pairs spanning two split-phase steps (air_variant 40
     forces it on this small cross-section); odd step counts end with a single step."""
+    _run_blocked_pairs(G, Nt, src, "single")
+
+
+def test_virtual_slabs_with_blocked_pairs_fp64():
+    _run_blocked_pairs(2, 15, [49, 30, 150], "double")
+
+
+def _run_blocked_pairs(G, Nt, src, prec):
     from pffdtd_amd import sim_data, synth
     n = (96, 64, 280)
     # (in a pair the edge stream owns two planes per side: sources / receivers in local planes 2 and Nx-3 of a slab --
@@ -84,10 +92,10 @@ def test_virtual_slabs_with_blocked_pairs(G, Nt, src):
     rcv = [[50, 30, 140], [7, 8, 9], [88, 55, 260], [46, 20, 100], [49, 40, 200], [33, 12, 40], [62, 50, 77]] + \
         ([[src[0] - 4, src[1] + 2, src[2] - 3]] if src else [])
     sim = synth.shoebox(*n, Nt=Nt, Nm=2, Mb=[11, 3], src=src, rcv=rcv)
-    ref = sim_data.SimData.from_sim(sim, "single")
+    ref = sim_data.SimData.from_sim(sim, prec)
     ref.scale_input()
     oracle.run_sim(ref)
-    sd = sim_data.SimData.from_sim(sim, "single", build_mask=False)
+    sd = sim_data.SimData.from_sim(sim, prec, build_mask=False)
     sd.scale_input()
     parts = [slab.split(sd, G, r) for r in range(G)]
     st = [pdist.HipSlabStepper(loc, info, 0, pairs=True, air_variant=40, timing=True) for loc, info in parts]
