@@ -148,6 +148,9 @@ template <typename Real> struct Engine : EngineBase {
    Real *pA = nullptr, *pB = nullptr;                     // u^{n-1}, u^n of the pair in flight
    Real *bufC = nullptr, *bufD = nullptr;                 // the two extra state grids of the out-of-place pair
    int tbx0 = 0, tbx1 = 0, tby0 = 0, tby1 = 0, tbz0 = 0, tbz1 = 0; // box of cells k_tb2_reg produces
+   // planes per x chunk of k_tb2_reg: 12-20 are equally fast, 24 is 1 % and 48 is 6 % slower although longer chunks
+   // re-read fewer prologue planes (1024^3, tools/tb2_probe.py); PFFDTD_TB2_CHUNK overrides for such sweeps
+   int tb2_chunk = 16;
    std::vector<std::pair<int, int>> tb_xr;                // its x ranges (planes next to a source are cut out)
    const Real *u0_src = nullptr;                          // out-of-place single-step launches read u^{n-1} here
    int lean_yt0 = 0, lean_nyt = -1;                       // row-strip launches of the lean kernel (-1: all tiles)
@@ -494,6 +497,7 @@ template <typename Real> struct Engine : EngineBase {
    // off and nothing changes.  air_variant 0 (auto) and 40 enable it, 41 = same driver with the box disabled (tests).
    int init_tb2() {
       tb2 = tb2_geom = tb2_slab = false;
+      if (const char *ev = getenv("PFFDTD_TB2_CHUNK")) tb2_chunk = std::min(std::max(atoi(ev), 4), 256);
       const bool single = op.slab_first && op.slab_last;
       if (fcc || !(lean || vg) || lean_rigid || v1_rigb || op.energy || (op.debug & 0x4000)) return PF_OK; // 0x4000: single steps only
       if (!(vbase == 0 || vbase == 40 || vbase == 41) || op.numerics != PF_NUM_CPU_EXACT || !use_dpp) return PF_OK;
@@ -666,7 +670,7 @@ template <typename Real> struct Engine : EngineBase {
          tp.x_begin = r.first; tp.x_end = r.second;
          tp.y_begin = tby0; tp.y_end = tby1; tp.z_begin = tbz0; tp.z_end = tbz1;
          const int np = r.second - r.first;
-         tp.chunk = (int)cdiv(np, std::max<int64_t>(cdiv(np, 24), 1)); // ~24-plane chunks, even split (tools/tb2_probe.py)
+         tp.chunk = (int)cdiv(np, std::max<int64_t>(cdiv(np, tb2_chunk), 1)); // ~16-plane chunks, even split (tools/tb2_probe.py)
          tp.nxc = (int)cdiv(np, tp.chunk);
          tp.nzt = (int)cdiv(tbz1 - tbz0, WC);
          tp.nyt = (int)cdiv(tby1 - tby0, 12);
