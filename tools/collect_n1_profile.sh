@@ -12,6 +12,7 @@ timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o p --output-
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -o p --output-format csv -- python $R/bench.py --steps 8 --warmup 4 --no-cpu-baseline > $O/write.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats0 -o s --output-format csv -- python $R/bench.py --steps 8 --warmup 4 --no-cpu-baseline > $O/stats0.log 2>&1
 (cd $R && python tools/make_profile_summary.py $TAG $O/stats0 $O/fetch $O/write > /dev/null)
+sleep ${COOL_S:-45}  # the box loses 2-3 % once warm: let it idle before the timed run
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/stats -o s --output-format csv -- python $R/bench.py --steps 50 --warmup 5 > $O/stats.log 2>&1
 grep '^{"metric"' $O/stats.log | tail -1 > $O/bench.json
 (cd $R && python tools/make_profile_summary.py $TAG $O/stats $O/fetch $O/write $O/bench.json && cp $O/bench.json profiles/$TAG.json && mkdir -p gpurun_out/profiles_new && cp profiles/$TAG* gpurun_out/profiles_new/)
