@@ -269,7 +269,9 @@ def main():
                 and tfile.exists()):
             try:
                 ks = json.load(open(tfile))["kernels"]
-                hit = [v for k, v in ks.items() if kernel in k]
+                # (several instantiations may share the name -- the 8-row strip variant of the lean kernel: the
+                # whole-grid launches are the ones with the most bytes)
+                hit = sorted((v for k, v in ks.items() if kernel + "<" in k), key=lambda v: -v["total_bytes"])
                 if hit:
                     res["roofline"]["traffic"] = round(hit[0]["total_bytes"] / 1e9, 3)
                     res["roofline"]["traffic_unit"] = "GB per launch (PMC, profiles/r01_bench_n1_hbm_traffic.json)"

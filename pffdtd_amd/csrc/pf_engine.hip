@@ -644,7 +644,7 @@ template <typename Real> struct Engine : EngineBase {
             u0_src = U1; u1 = bufC; u0 = bufD; launch_shell(s_main);
             u0_src = nullptr; u0 = U0; u1 = U1;
          });
-         if (!(tune_ms[2] < 0.97f * std::min(tune_ms[0], tune_ms[1]))) { // not worth it: drop the pair path and its two grids
+         if (!(tune_ms[2] < 0.99f * std::min(tune_ms[0], tune_ms[1]))) { // not worth it: drop the pair path and its two grids
             tb2 = false;
             for (Real *g : {bufC, bufD}) { own_list.erase(std::remove(own_list.begin(), own_list.end(), g), own_list.end()); hipFree(g); }
             if (scr == bufC) scr = nullptr;
