@@ -116,6 +116,10 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
 
+    # RCCL's intra-node transport shares device memory between the ranks: this pool's host driver only supports dmabuf
+    # IPC (without the switch hipIpcGetMemHandle fails); normally exported already, set here as well so that a bare
+    # environment cannot break the multi-GPU run
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     from pffdtd_amd import engine
     if not torch.cuda.is_available() or engine.device_count() == 0:
