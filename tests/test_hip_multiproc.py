@@ -60,3 +60,26 @@ def test_multiprocess_hip_slabs(world, name, prec):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert np.array_equal(out, ref)
+
+
+def test_bench_two_ranks_control_flow():
+    """bench.py as the driver launches it for N>1 (torch.distributed.run, one process per rank), here with both ranks
+    on GPU 0 and gloo-staged planes (PFFDTD_BENCH_BACKEND=gloo): one JSON line from rank 0 with the contract's keys."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, PFFDTD_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", str(root / "bench.py"), "--gpus", "2", "--size", "320", "--steps", "6", "--warmup", "3",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(root))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 6 and res["warmup"] == 3 and res["value"] > 0
+    assert res["metric"] == "Gvoxel-updates/s" and res["scaling"] == "strong" and res["roofline"]["bound"] == "hbm"
