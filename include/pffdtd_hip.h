@@ -95,8 +95,11 @@ typedef struct pf_opts {
    int32_t x_global0;     /* global ix of this grid's plane 0 (slabs): only its parity matters, for the FCC
                              checkerboard form (fcc_flag 1) whose existing nodes have even ix+iy+iz */
    int32_t debug;         /* tuning switches, 0 in production: 0x100 / 0x200 force 32- / 16-lane row segments in the
-                             barrier-free kernels, 0x400 forces 64; 0x800 in-kernel rigid update from a cell-byte grid; 0x2000 column-strip kernel also updates
-                             the boundary nodes inside its strips; bits 16-23 its x chunk */
+                             barrier-free kernels, 0x400 forces 64; 0x800 in-kernel rigid update from a cell-byte grid;
+                             0x2000 column-strip kernel also updates the boundary nodes inside its strips; 0x4000 single
+                             steps only (no temporally blocked pairs); 0x8000 no creation-time measurement (static
+                             rules pick the interior kernel); bits 16-23 x chunk of the column-strip kernel;
+                             0x10000000 keep a sliver z tile in the blocked kernel */
    int32_t energy;        /* 1 = keep what the energy diagnostic needs (explicit Laplacian grid, unfused kernel
                              sequence); then use pf_engine_energy_cfg + pf_engine_run_energy */
    int32_t reserved[5];
