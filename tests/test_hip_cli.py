@@ -46,3 +46,22 @@ def test_sim_fdtd_cli_with_energy(tmp_path):
     assert len(bal) == 5 and max(abs(b) for b in bal) < 1e-12
     # energy mode runs the unfused kernels in the reference order: receivers are still the C-engine bits
     assert np.array_equal(h5io.read(tmp_path / "sim_outs.h5", "u_out"), _expected(tmp_path, "double", False))
+
+
+@pytest.mark.parametrize("gpus,name,prec", [(2, "cart_outside", "single"), (3, "fcc2_outside", "double")])
+def test_fdtd_main_cli_multi_gpu(tmp_path, gpus, name, prec):
+    """`--gpus N`: the command re-launches itself as N ranks (torch.distributed.run), Z-slabs, plane exchange, rank 0
+    writes sim_outs.h5.  Here all ranks share GPU 0 and the planes go through gloo (PFFDTD_BACKEND=gloo); the folder's
+    lists are left unsorted on purpose (the reference's multi-GPU engine would refuse them, gpu_engine.h:688)."""
+    import os
+    sim = cases.make_sim(name)
+    synth.write_folder(sim, tmp_path)
+    env = {**os.environ, "PYTHONPATH": str(ROOT), "PFFDTD_BACKEND": "gloo"}
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "pffdtd_amd.fdtd_main", "--precision", prec, "--gpus", str(gpus),
+                        "--master_port", "29653"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    for line in (f"--{gpus} GPUs", "Air update:", "Combined (total):", "RAW OUTPUTS", "wrote output dataset"):
+        assert line in r.stdout, r.stdout[-2000:]
+    assert np.array_equal(h5io.read(tmp_path / "sim_outs.h5", "u_out"), _expected(tmp_path, prec, True))
