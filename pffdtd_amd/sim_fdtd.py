@@ -137,6 +137,8 @@ def main():
     p.add_argument("--nthreads", type=int, default=None, help="ignored (kept for CLI compatibility)")
     p.add_argument("--energy", action="store_true", help="do energy calc")
     p.add_argument("--plot", action="store_true", help="not supported (visualisation is out of scope)")
+    p.add_argument("--json_model", type=str, default=None, help="ignored (only the reference's --plot uses it)")
+    p.add_argument("--draw_backend", type=str, default="mayavi", help="ignored (only the reference's --plot uses it)")
     p.add_argument("--abc", action="store_true", help="unused, as in the reference")
     p.add_argument("--precision", default="double", choices=["double", "single"])
     p.add_argument("--gpu", type=int, default=0)
