@@ -119,6 +119,8 @@ def main():
     p.add_argument("--N_order_lowpass", type=int, default=8)
     p.add_argument("--symmetric_lowpass", action="store_true")
     p.add_argument("--save_wav", action="store_true")
+    p.add_argument("--plot", action="store_true", help="ignored (plotting is out of scope)")
+    p.add_argument("--plot_raw", action="store_true", help="ignored (plotting is out of scope)")
     p.add_argument("--air_abs_filter", type=str, default="none", help="stokes, modal, OLA, or none")
     a = p.parse_args()
     po = ProcessOutputs(a.data_dir)
