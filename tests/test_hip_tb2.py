@@ -75,7 +75,8 @@ def test_rooms_without_a_box_keep_the_single_step_path():
         run(sim, 40)
 
 
-@pytest.mark.parametrize("n,wall", [((37, 67, 283), 3), ((41, 75, 291), 5), ((34, 62, 270), 4)], ids=["odd", "deep_walls", "tight"])
+@pytest.mark.parametrize("n,wall", [((37, 67, 283), 3), ((41, 75, 291), 5), ((34, 62, 270), 4), ((36, 64, 325), 3), ((36, 64, 571), 3)],
+                         ids=["odd", "deep_walls", "tight", "sliver_60_columns", "two_tiles_and_sliver"])
 def test_blocked_steps_on_awkward_sizes(n, wall):
     """Row counts that are not multiples of the strip tile height, column counts that are not multiples of 4, pitch
     padding next to the right column strip, wall depths that move the box."""
@@ -114,8 +115,9 @@ def test_strip_kernel_can_update_its_boundary_nodes():
         assert tm["tb2_launches"] > 0 and np.array_equal(out, ref.u_out)
 
 
-@pytest.mark.parametrize("src,kw", [(None, {}), ([3, 30, 140], dict(n=(36, 72, 280), wall=6)), ([18, 8, 12], dict(n=(37, 67, 283)))],
-                         ids=["centre", "outside_wall", "odd"])
+@pytest.mark.parametrize("src,kw", [(None, {}), ([3, 30, 140], dict(n=(36, 72, 280), wall=6)), ([18, 8, 12], dict(n=(37, 67, 283))),
+                                    (None, dict(n=(36, 64, 294)))],
+                         ids=["centre", "outside_wall", "odd", "sliver_30_columns"])
 def test_blocked_steps_in_double_precision(src, kw):
     """fp64: 128 columns per wave (two doubles per lane), otherwise the same kernels."""
     sim = scene(src, Nt=31, **kw)
