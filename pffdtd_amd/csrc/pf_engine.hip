@@ -210,6 +210,14 @@ template <typename Real> struct Engine : EngineBase {
       return PF_OK;
    }
 
+   // optional memory (temporal-blocking spares, autotune scratch): null instead of an error when the device is full
+   template <typename T> T *try_dzalloc(int64_t n) {
+      T *p = nullptr;
+      const size_t bytes = std::max<int64_t>(n, 1) * sizeof(T);
+      if (hipMalloc((void **)&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+      if (hipMemset(p, 0, bytes) != hipSuccess) { (void)hipGetLastError(); hipFree(p); return nullptr; }
+      return p;
+   }
    // split a sorted padded-index list into the ranges of plane 1 / planes 2..Nx-3 / plane Nx-2
    void plane_ranges(const std::vector<int64_t> &idx, Range &lo, Range &mid, Range &hi, int w = 1) const {
       const int64_t n = (int64_t)idx.size();
@@ -545,8 +553,14 @@ template <typename Real> struct Engine : EngineBase {
       tb2_geom = true;
       if (!single) return PF_OK; // slab engines wait for pf_engine_set_spares (all four grids must be the caller's)
       int rc;
-      if ((rc = dzalloc(&bufC, npad))) return rc;
-      if ((rc = dzalloc(&bufD, npad))) return rc;
+      bufC = try_dzalloc<Real>(npad);
+      bufD = bufC ? try_dzalloc<Real>(npad) : nullptr;
+      if (!bufD) { // no room for two more grids (state > ~45 % of the device memory): keep stepping singly
+         if (bufC) hipFree(bufC);
+         bufC = bufD = nullptr;
+         tb2_geom = false;
+         return PF_OK;
+      }
       own_list.push_back(bufC); own_list.push_back(bufD);
       tb2 = true;
       // Experiment (debug 0x2000, off by default): boundary nodes inside the column strips move from the list kernel to
@@ -593,7 +607,7 @@ template <typename Real> struct Engine : EngineBase {
       Real *scr = bufC;
       bool own = false;
       int rc;
-      if (!scr) { if ((rc = dzalloc(&scr, npad))) return rc; own = true; }
+      if (!scr) { scr = try_dzalloc<Real>(npad); if (!scr) return PF_OK; own = true; } // no room to measure: the static rules stand
       hipEvent_t e0, e1;
       HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
       HIPCHK(hipDeviceSynchronize());

@@ -3,6 +3,7 @@ a box exists -- blocked pairs on the real grids.  Whatever it picks, the run mus
 the measurement itself (which launches every candidate into scratch) must leave the state untouched."""
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before the engine library: the first libamdhip64 loaded serves both, and torch wants its own)
 
 import oracle
 from pffdtd_amd import engine, sim_data, synth
@@ -36,4 +37,37 @@ def test_autotuned_engine_equals_oracle(n, prec):
     assert eng.timing()["tune_ms"][0] == 0
     eng.run(0, Nt)
     eng.close()
+    assert np.array_equal(sd.u_out, ref.u_out)
+
+
+def test_engine_survives_a_full_device():
+    """The two spare grids of the blocked pairs and the scratch grid of the measurement are optional: with the device
+    nearly full the engine must still come up (stepping singly) and produce the oracle's bits."""
+    n, Nt = (160, 616, 616), 8
+    sim = synth.shoebox(*n, Nt=Nt, Nm=2, Mb=[11, 3], rcv=[[83, 308, 306], [6, 7, 8]])
+    ref = sim_data.SimData.from_sim(sim, "single")
+    ref.scale_input()
+    oracle.run_sim(ref)
+    assert np.abs(ref.u_out).max() > 0
+    sd = sim_data.SimData.from_sim(sim, "single", build_mask=False)
+    sd.scale_input()
+    eng = engine.HipEngine(sd, timing=True)          # plenty of memory: the box qualifies for pairs (may or may not win)
+    eng.run(0, Nt)
+    eng.close()
+    assert np.array_equal(sd.u_out, ref.u_out)
+    sd.u_out[:] = 0
+    grid_bytes = engine.grid_pitch(n[2], 4) * n[1] * n[0] * 4
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    keep = int(3.4 * grid_bytes)                      # room for the state (2 grids) + lists + one more grid, not two
+    hog = torch.empty(max(free - keep, 1), dtype=torch.uint8, device="cuda")
+    try:
+        eng = engine.HipEngine(sd, timing=True)
+        eng.run(0, Nt)
+        tm = eng.timing()
+        eng.close()
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    assert tm["tb2_launches"] == 0
     assert np.array_equal(sd.u_out, ref.u_out)
