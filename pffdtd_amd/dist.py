@@ -35,10 +35,14 @@ class HipSlabStepper:
         # then cycles through all four); engines that cannot use them say so and the grids are dropped again.
         self.paired = False
         if info.G > 1 and pairs:
-            with torch.cuda.device(self.device):
-                spare = [torch.zeros((loc.Nx, self.plane), dtype=self.tdtype, device=self.device) for _ in range(2)]
-                torch.cuda.synchronize()
-            if self.eng.set_spares(spare[0].data_ptr(), spare[1].data_ptr()):
+            try:
+                with torch.cuda.device(self.device):
+                    spare = [torch.zeros((loc.Nx, self.plane), dtype=self.tdtype, device=self.device) for _ in range(2)]
+                    torch.cuda.synchronize()
+            except torch.OutOfMemoryError:  # no room for two more grids: single steps
+                spare = None
+                torch.cuda.empty_cache()
+            if spare is not None and self.eng.set_spares(spare[0].data_ptr(), spare[1].data_ptr()):
                 self.grids += spare
                 self.paired = True
         self._by_ptr = {g.data_ptr(): g for g in self.grids}
