@@ -51,6 +51,18 @@ def test_linearity_and_causality_at_512(scene):
     assert not far[:, :38].any() and np.abs(out1[0:8, :12]).max() > 0
 
 
+def test_fcc_kernel_families_agree_beyond_2p32_cells():
+    """The same for the 13-point folded-FCC kernels (auto = barrier-free with in-kernel ABC, unfused, virtual-ghost, naive)
+    on a stored grid of 4224 x 1024 x 1024."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tools" / "big_grid_check.py"), "--fcc", "4224", "1024", "1024", "8"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "big-grid check OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 def test_kernel_families_agree_beyond_2p32_cells():
     """4224 x 1024 x 1024 = 1.03 x 2^32 cells (35 GB of state, source and receivers at linear indices beyond 2^32):
     blocked pairs, lean single steps, barrier-free and unfused kernels leave identical bits in every cell

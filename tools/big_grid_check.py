@@ -12,14 +12,23 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from pffdtd_amd import engine, sim_data, synth  # noqa: E402
 
-n = [int(v) for v in sys.argv[1:4]] if len(sys.argv) >= 4 else [2112, 1024, 1024]
-Nt = int(sys.argv[4]) if len(sys.argv) > 4 else 12
+fcc = "--fcc" in sys.argv  # 13-point, folded: the sizes are the STORED grid
+argv = [a for a in sys.argv if a != "--fcc"]
+n = [int(v) for v in argv[1:4]] if len(argv) >= 4 else [2112, 1024, 1024]
+Nt = int(argv[4]) if len(argv) > 4 else 12
 t0 = time.time()
 c = [v // 2 for v in n]
 src = [n[0] - 40, c[1], c[2]]  # linear indices of the source / these receivers lie beyond 2^32
 rcv = [[n[0] - 37, c[1], c[2] - 2], [n[0] - 9, n[1] - 10, n[2] - 11], [c[0] + 3, c[1], c[2] - 2], [6, 7, 8]]
-sim = synth.shoebox(*n, Nt=Nt, Nm=2, Mb=[11, 3], src=src, rcv=rcv)
+if fcc:
+    sim = synth.shoebox(n[0], 2 * (n[1] - 1), n[2], Nt=Nt, fcc=True, Nm=2, Mb=[11, 3], src=[src[0], c[1], c[2] + (src[0] + c[1] + c[2]) % 2],
+                        rcv=[[r[0], r[1] // 2 + 8, r[2] + (r[0] + r[1] // 2 + 8 + r[2]) % 2] for r in rcv])
+    synth.fold_fcc(sim)
+    synth.sort_sim(sim)
+else:
+    sim = synth.shoebox(*n, Nt=Nt, Nm=2, Mb=[11, 3], src=src, rcv=rcv)
 sd = sim_data.SimData.from_sim(sim, "single", build_mask=False)
+assert [sd.Nx, sd.Ny, sd.Nz] == n, (sd.Nx, sd.Ny, sd.Nz)
 sd.scale_input()
 print(f"scene {n} = {np.prod(n)/2**32:.2f} x 2^32 cells, Nb={sd.Nb}, built in {time.time()-t0:.1f}s", flush=True)
 P = engine.grid_pitch(n[2], 4)
@@ -29,7 +38,7 @@ gen.manual_seed(11)
 init = [(torch.rand(shape, generator=gen, device="cuda") * 2 - 1) * 1e-3 for _ in range(2)]
 g = [torch.empty(shape, dtype=torch.float32, device="cuda") for _ in range(2)]
 ref_out, ref_g = None, None
-for v in (40, 0, 25, 4, 2):  # 40 = blocked pairs forced, 0 = whatever the creation-time measurement picks
+for v in ((0, 2, 5, 9) if fcc else (40, 0, 25, 4, 2)):  # 40 = blocked pairs forced, 0 = what the engine picks, 9 = naive
     for a, b in zip(g, init):
         a.copy_(b)
     sd.u_out[:] = 0
