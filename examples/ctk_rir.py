@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""From absorption data and a scene export to room impulse responses, entirely through this package on one MI355X:
+"""From a scene export to room impulse responses, entirely through this package on one MI355X:
 
-    materials.fit_to_Sabs_oct_11  ->  sim_setup (device voxelizer, GPU prep)  ->  HIP engine  ->  process_outputs
+    wall-impedance tables (shipped DEF fits)  ->  sim_setup (device voxelizer, GPU prep)  ->  HIP engine  ->  process_outputs
 
-The same chain as the reference's  build_mats.py -> test_script_CTK_cart_gpu.py -> fdtd_main_gpu_single.x ->
+The same chain as the reference's  test_script_CTK_cart_gpu.py -> fdtd_main_gpu_single.x ->
 fdtd.process_outputs , here on the CTK church export at a reduced bandwidth so it finishes in seconds
 (--fmax 1400 --duration 3.0 is the reference's full configuration: 894x579x309 grid, 76 460 steps, about a minute).
 
@@ -14,11 +14,10 @@ import sys
 import time
 from pathlib import Path
 
-import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-from pffdtd_amd import engine, materials, scenes, sim_data  # noqa: E402
+from pffdtd_amd import engine, scenes, sim_data  # noqa: E402
 from pffdtd_amd.process_outputs import ProcessOutputs  # noqa: E402
 from pffdtd_amd.sim_setup import sim_setup  # noqa: E402
 
@@ -35,10 +34,7 @@ def main(argv=None):
     a = ap.parse_args(argv)
     out = Path(a.out)
     t0 = time.perf_counter()
-    mats = out / "materials"  # 1. wall impedances from Sabine octave-band coefficients
-    mats.mkdir(parents=True, exist_ok=True)
-    for f in sorted(set(scenes.CTK_MATS.values())):
-        materials.fit_to_Sabs_oct_11(np.array(materials.SABINE_OCT_11[f[:-3]]), mats / f)
+    mats = scenes.write_materials(out / "materials")  # 1. wall impedances: the reference's fitted DEF tables (data files)
     t1 = time.perf_counter()
     folder = out / "sim"  # 2. grid, sources/receivers, voxelization, GPU prep
     sim_setup(**scenes.setup_kwargs("ctk_cart_gpu", folder, mats, save_folder_gpu=folder, compress=0, fmax=a.fmax, PPW=a.ppw,

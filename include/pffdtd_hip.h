@@ -169,18 +169,6 @@ int  pf_engine_timing(pf_engine *e, pf_timing *t, int32_t reset);
 int  pf_engine_energy_cfg(pf_engine *e, double h, double c, double Ts, const double *DEF);
 int  pf_engine_run_energy(pf_engine *e, int64_t n0, int64_t nsteps, double *H_tot, double *E_lost, double *E_in);
 
-/* ---- calibration (tools/membench.py): time `reps` launches of a streaming kernel over two float grids of
- * Nx*Ny*P elements; kind 0 = linear stream, 1 = the marching tile pattern (R rows/lane, WY waves, prefetch PF planes).
- * Returns the average milliseconds per launch (<0 on error). */
-double pf_membench(void *u0, void *u1, int64_t Nx, int64_t Ny, int64_t Nz, int32_t kind, int32_t R, int32_t WY,
-                   int32_t PF, int32_t chunk, int32_t swizzle, int32_t reps);
-
-/* ---- research probe (tools/tb2_probe.py): two fused leap-frog steps of the pure 7-point air update on the box
- * [m, N-m)^3 of float grids A=u^{n-1}, B=u^n -> C=u^{n+1}, D=u^{n+2} (padded layout, pf_grid_pitch).  Not used by the
- * engine.  Returns the average milliseconds per launch (<0 on error). */
-double pf_tb2_probe(const void *A, const void *B, void *C, void *D, int64_t Nx, int64_t Ny, int64_t Nz, double a1, double a2,
-                    int32_t margin, int32_t tye, int32_t chunk, int32_t reps);
-
 #ifdef __cplusplus
 }
 #endif

@@ -31,20 +31,73 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value"]
+# numerics are stated per kernel with explicit fma where wanted, hence -ffp-contract=off
+
+
+def _deps(src):
+    """Headers a translation unit depends on (read from its #include "..." lines, one level of nesting is enough here)."""
+    seen, todo = set(), [src]
+    while todo:
+        f = todo.pop()
+        for line in f.read_text().splitlines():
+            if line.startswith('#include "'):
+                name = line.split('"')[1]
+                for d in (CSRC, ROOT / "include"):
+                    if (d / name).exists() and (d / name) not in seen:
+                        seen.add(d / name)
+                        todo.append(d / name)
+    return [src] + sorted(seen)
+
+
 def build_hip(force=False, verbose=False):
-    """libpffdtd_hip.so: HIP kernels + C ABI, gfx950 only."""
+    """libpffdtd_hip.so: HIP kernels + C ABI, gfx950 only.  One object per .hip file (csrc/_obj/), relinked when any changed."""
     out = PKG / "libpffdtd_hip.so"
-    srcs = sorted(CSRC.glob("*.hip")) + sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.inc")) + \
-        [ROOT / "include" / "pffdtd_hip.h"]
-    if force or _newer(out, srcs):
-        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-ffp-contract=off", "-Wno-unused-value",  # numerics are stated per kernel with explicit fma where wanted
-               "-I", str(ROOT / "include"), "-I", str(CSRC)] + \
-            [str(s) for s in sorted(CSRC.glob("*.hip"))] + ["-o", str(out)]
-        log = _run(cmd)
+    objdir = CSRC / "_obj"
+    objdir.mkdir(exist_ok=True)
+    objs, relink = [], force or not out.exists()
+    procs = []
+    for src in sorted(CSRC.glob("*.hip")):
+        obj = objdir / (src.stem + ".o")
+        objs.append(obj)
+        if force or _newer(obj, _deps(src)):
+            cmd = [hipcc(), *HIP_FLAGS, "-c", "-I", str(ROOT / "include"), "-I", str(CSRC), str(src), "-o", str(obj)]
+            procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+            relink = True
+    for cmd, p in procs:  # the translation units compile side by side
+        log = p.communicate()[0]
+        if p.returncode != 0:
+            raise RuntimeError("build failed: " + " ".join(cmd) + "\n" + log)
         if verbose:
             print(log)
+    if relink or _newer(out, objs):
+        _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [str(o) for o in objs] + ["-o", str(out)])
     return out
+
+
+def build_probe(force=False):
+    """tools/libpf_probe.so: calibration / research probes (tools/membench.py, tools/tb2_probe.py); not a product library."""
+    tdir = ROOT / "tools"
+    out = tdir / "libpf_probe.so"
+    srcs = sorted((tdir / "csrc").glob("*")) + sorted(CSRC.glob("*.h"))
+    if force or _newer(out, srcs):
+        _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+              "-Wno-unused-value", "-I", str(tdir / "csrc"), "-I", str(CSRC), "-I", str(ROOT / "include"),
+              str(tdir / "csrc" / "pf_probe.hip"), "-o", str(out)])
+    return out
+
+
+def load_probe():
+    """ctypes handle of tools/libpf_probe.so with its two entry points typed."""
+    import ctypes
+    L = ctypes.CDLL(str(build_probe()))
+    vp, i32, i64, d = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+    L.pf_probe_last_error.restype = ctypes.c_char_p
+    L.pf_tb2_probe.restype = d
+    L.pf_tb2_probe.argtypes = [vp, vp, vp, vp, i64, i64, i64, d, d, i32, i32, i32, i32]
+    L.pf_membench.restype = d
+    L.pf_membench.argtypes = [vp, vp, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32]
+    return L
 
 
 def build_h5(force=False):

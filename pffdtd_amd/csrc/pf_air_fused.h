@@ -1078,89 +1078,4 @@ __global__ __launch_bounds__(64 * WY) void k_air_fcc_lean(LeanParams fp, Real a1
    }
 }
 
-// ---- calibration kernels (tools/membench.py): the marching access pattern with the stencil taken out -----------
-// u0[cell] += u1[cell] over the interior, tiles and x-chunks exactly like k_air_cart_lean (R rows x 16 B per lane,
-// WY waves in y); PF = how many planes ahead the loads are issued.  Tells the access pattern's own ceiling apart
-// from what the stencil kernels lose on top of it.
-template <typename Real, int R, int WY, int PF, int MODE = 0, int WZ = 1>
-__global__ __launch_bounds__(64 * WY * WZ) void k_march_stream(const Real *__restrict__ u1, Real *__restrict__ u0, LeanParams fp) {
-   typedef typename VecOf<Real>::type vec;
-   constexpr int V = VecOf<Real>::V;
-   const uint32_t total = (uint32_t)fp.nzt * fp.nyt * fp.nxc;
-   uint32_t b = blockIdx.x;
-   if (fp.swizzle) b = xcd_swizzle(b, total);
-   const int zt = b % fp.nzt, yt = (b / fp.nzt) % fp.nyt, xc = b / (fp.nzt * fp.nyt);
-   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-   const int w = wv / WZ, wz = wv % WZ;
-   const int z0 = ((zt * WZ + wz) * 64 + lane) * V;
-   if (z0 >= fp.P) return;
-   const int y0 = 1 + (yt * WY + w) * R;
-   const int xs = fp.x_begin + xc * fp.chunk, xe = min(xs + fp.chunk, fp.x_end);
-   uint32_t so[R];
-   bool valid[R];
-#pragma unroll
-   for (int r = 0; r < R; r++) {
-      so[r] = (uint32_t)min(y0 + r, fp.Ny - 1) * (uint32_t)fp.P + (uint32_t)z0;
-      valid[r] = (y0 + r <= fp.Ny - 2);
-   }
-   vec a[PF + 1][R], o[PF + 1][R];
-#pragma unroll
-   for (int k = 0; k < PF; k++)
-#pragma unroll
-      for (int r = 0; r < R; r++) {
-         const int x = min(xs + k, xe - 1);
-         a[k][r] = (MODE & 1) ? __builtin_nontemporal_load((const vec *)(u1 + (int64_t)x * fp.plane + so[r])) : *(const vec *)(u1 + (int64_t)x * fp.plane + so[r]);
-         o[k][r] = (MODE & 2) ? __builtin_nontemporal_load((const vec *)(u0 + (int64_t)x * fp.plane + so[r])) : *(const vec *)(u0 + (int64_t)x * fp.plane + so[r]);
-      }
-   for (int x = xs; x < xe; x++) {
-      const int xl = min(x + PF, xe - 1);
-#pragma unroll
-      for (int r = 0; r < R; r++) {
-         a[PF][r] = (MODE & 1) ? __builtin_nontemporal_load((const vec *)(u1 + (int64_t)xl * fp.plane + so[r])) : *(const vec *)(u1 + (int64_t)xl * fp.plane + so[r]);
-         o[PF][r] = (MODE & 2) ? __builtin_nontemporal_load((const vec *)(u0 + (int64_t)xl * fp.plane + so[r])) : *(const vec *)(u0 + (int64_t)xl * fp.plane + so[r]);
-      }
-#pragma unroll
-      for (int r = 0; r < R; r++)
-         if (valid[r]) {
-            const vec res = a[0][r] + o[0][r];
-            if (MODE & 4) __builtin_nontemporal_store(res, (vec *)(u0 + (int64_t)x * fp.plane + so[r]));
-            else *(vec *)(u0 + (int64_t)x * fp.plane + so[r]) = res;
-         }
-#pragma unroll
-      for (int k = 0; k < PF; k++)
-#pragma unroll
-         for (int r = 0; r < R; r++) { a[k][r] = a[k + 1][r]; o[k][r] = o[k + 1][r]; }
-   }
-}
-// plain linear stream over the same bytes: u0[i] += u1[i], 16 B per lane.
-// MODE bit0: nontemporal loads, bit1: nontemporal stores, bit2: one-shot (no grid-stride loop), UNR vectors per thread
-template <typename Real, int MODE, int UNR>
-__global__ void k_linear_stream(const Real *__restrict__ u1, Real *__restrict__ u0, int64_t nvec) {
-   typedef typename VecOf<Real>::type vec;
-   const int64_t stride = (MODE & 4) ? 0 : (int64_t)gridDim.x * blockDim.x * UNR;
-   // MODE bits 3..: log2(number of interleaved streams): block b works on stream b%S, position b/S
-   const int S = 1 << (MODE >> 3);
-   const int64_t blk = (S == 1) ? (int64_t)blockIdx.x : (int64_t)(blockIdx.x % S) * (gridDim.x / S) + blockIdx.x / S;
-   for (int64_t i0 = blk * blockDim.x * UNR + threadIdx.x; i0 < nvec; i0 += stride) {
-      vec a[UNR], o[UNR];
-#pragma unroll
-      for (int k = 0; k < UNR; k++) {
-         const int64_t i = i0 + (int64_t)k * blockDim.x;
-         if (i < nvec) {
-            a[k] = (MODE & 1) ? __builtin_nontemporal_load((const vec *)u1 + i) : ((const vec *)u1)[i];
-            o[k] = (MODE & 1) ? __builtin_nontemporal_load((const vec *)u0 + i) : ((const vec *)u0)[i];
-         }
-      }
-#pragma unroll
-      for (int k = 0; k < UNR; k++) {
-         const int64_t i = i0 + (int64_t)k * blockDim.x;
-         if (i < nvec) {
-            const vec r = a[k] + o[k];
-            if (MODE & 2) __builtin_nontemporal_store(r, (vec *)u0 + i); else ((vec *)u0)[i] = r;
-         }
-      }
-      if (MODE & 4) break;
-   }
-}
-
 } // namespace pf

@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <unistd.h>
 #include "hdf5.h"
 
 enum { PF_H5_F64 = 0, PF_H5_F32 = 1, PF_H5_I64 = 2, PF_H5_I8 = 3, PF_H5_BOOL = 4, PF_H5_U8 = 5, PF_H5_I32 = 6 };
@@ -56,6 +57,34 @@ int pf_h5_info(const char *path, const char *name, int *ndims, int64_t *dims, in
    return 0;
 }
 
+/* names of the root group's datasets, '\n'-separated, into buf (cap bytes); returns the count or -1 */
+struct list_ctx { char *buf; size_t cap, len; int n, overflow; };
+static herr_t list_cb(hid_t g, const char *name, const H5L_info_t *info, void *op) {
+   (void)info;
+   struct list_ctx *c = (struct list_ctx *)op;
+   H5O_info_t oi;
+   if (H5Oget_info_by_name(g, name, &oi, H5P_DEFAULT) < 0 || oi.type != H5O_TYPE_DATASET) return 0;
+   size_t l = strlen(name);
+   if (c->len + l + 2 > c->cap) { c->overflow = 1; return 0; }
+   memcpy(c->buf + c->len, name, l);
+   c->len += l;
+   c->buf[c->len++] = '\n';
+   c->buf[c->len] = 0;
+   c->n++;
+   return 0;
+}
+int pf_h5_list(const char *path, char *buf, int64_t cap) {
+   quiet();
+   hid_t f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
+   if (f < 0) return fail("cannot open file", path, NULL);
+   struct list_ctx c = {buf, (size_t)cap, 0, 0, 0};
+   if (cap > 0) buf[0] = 0;
+   H5Literate(f, H5_INDEX_NAME, H5_ITER_INC, NULL, list_cb, &c);
+   H5Fclose(f);
+   if (c.overflow) return fail("dataset list does not fit the buffer", path, NULL);
+   return c.n;
+}
+
 int pf_h5_exists(const char *path, const char *name) {
    quiet();
    hid_t f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
@@ -100,9 +129,13 @@ int pf_h5_write(const char *path, const char *name, int code, int ndims, const i
    hid_t mt = memtype(code);
    if (mt < 0) return fail("bad type code", name, NULL);
    hid_t f = -1;
-   if (mode == 1) f = H5Fopen(path, H5F_ACC_RDWR, H5P_DEFAULT);
-   if (f < 0) f = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
-   if (f < 0) return fail("cannot create file", path, NULL);
+   if (mode == 1 && access(path, F_OK) == 0) { /* append to an existing file: never fall back to truncating it */
+      f = H5Fopen(path, H5F_ACC_RDWR, H5P_DEFAULT);
+      if (f < 0) return fail("cannot open existing file for update (locked, unreadable or not HDF5)", path, NULL);
+   } else {
+      f = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
+      if (f < 0) return fail("cannot create file", path, NULL);
+   }
    if (H5Lexists(f, name, H5P_DEFAULT) > 0) H5Ldelete(f, name, H5P_DEFAULT);
    hsize_t hd[8];
    int64_t total = 1;

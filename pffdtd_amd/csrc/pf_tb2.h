@@ -1,15 +1,8 @@
-// pf_tb2.h -- temporal blocking.  k_tb2_reg + k_air_zstrip are on the product path (Engine::step_pair, 7-point fp32
-// scenes with a large boundary-free box); k_tb2_proto is the earlier LDS-based research prototype
-// (driven only by tools/tb2_probe.py):
-// two leap-frog steps of the pure 7-point air update per pass (temporal blocking), to measure what the interior
-// kernel could gain from halving its HBM traffic per step.  Out of place: reads A = u^{n-1}, B = u^n, writes
-// C = u^{n+1}, D = u^{n+2}.  No mask / ABC / boundary nodes: valid for cells at least 3 away from anything special.
-//
-// Tiling: a workgroup owns TYE rows x 256 columns (one wave-width of float4) and marches x.  Stage 1 computes
-// T = u^{n+1} of plane x+1 on rows 1..TYE-2 of the tile (all 256 columns; the outermost column of each side is
-// garbage and never used), stage 2 computes u^{n+2} of plane x on rows 2..TYE-3, columns 4..251.  Tiles therefore
-// overlap by 4 rows and 8 columns: no edge loads, no cross-workgroup exchange.  u^n planes x..x+2 and u^{n+1} planes
-// x-1..x+1 live in LDS rings; every stencil operand is an LDS read.
+// pf_tb2.h -- temporal blocking: k_tb2_reg (two leap-frog steps of the pure 7-point air update per pass over a
+// boundary-free region) and k_air_zstrip (single-step update of the thin column strips beside it).  Both are on the
+// product path (Engine::step_pair).  Out of place: reads A = u^{n-1}, B = u^n, writes C = u^{n+1}, D = u^{n+2}.
+// No mask / ABC / boundary nodes: valid for cells at least 3 away from anything special.
+// (The earlier LDS-based research prototypes live in tools/csrc/pf_probe_kernels.h, outside the product library.)
 #pragma once
 #include "pf_kernels.h"
 
@@ -26,96 +19,6 @@ struct Tb2Params {
    int32_t y_end, z_end;          // one past the last core row / column (0: Ny - y_begin / Nz - z_begin)
    int32_t band;                  // 1: XCD k (blocks k, k+8, ...) works on a contiguous band of y-z tiles of every x chunk
 };
-
-template <int TYE, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void k_tb2_proto(Tb2Params tp, float a1, float a2) {
-   typedef f32x4 vec;
-   constexpr int W = 256;
-   constexpr int LROW = W + 8; // 4 pad floats each side so that column -1 / W reads stay in the row
-   __shared__ __attribute__((aligned(16))) float Bs[3][TYE][LROW];
-   __shared__ __attribute__((aligned(16))) float Ts[3][TYE][LROW];
-   const uint32_t b = blockIdx.x;
-   const int zt = b % tp.nzt, yt = (b / tp.nzt) % tp.nyt, xc = b / (tp.nzt * tp.nyt);
-   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-   const int ze0 = tp.z_begin - 4 + zt * (W - 8);      // first column of the extended tile
-   const int ye0 = tp.y_begin - 2 + yt * (TYE - 4);    // first row of the extended tile
-   const int xs = tp.x_begin + xc * tp.chunk, xe = min(xs + tp.chunk, tp.x_end);
-   const int P = tp.P;
-   const int64_t plane = tp.plane;
-   const int zc = min(max(ze0 + lane * 4, 0), P - 4);  // clamped load column (tiles at the grid edge)
-   auto grow = [&](int r) { return (int64_t)min(max(ye0 + r, 0), tp.Ny - 1) * P + zc; };
-
-   auto fill_B = [&](int x, int slot) { // u^n plane x, all TYE rows of the tile
-      const float *pl = (const float *)tp.B + (int64_t)x * plane;
-      for (int r = w; r < TYE; r += WAVES) *(vec *)&Bs[slot][r][4 + lane * 4] = *(const vec *)(pl + grow(r));
-   };
-   auto stage1 = [&](int x, bool write_c) { // T(plane x) from B planes x-1, x, x+1 (slots (x-1)%3 ...) and A plane x; rows 1..TYE-2
-      const float *pa = (const float *)tp.A + (int64_t)x * plane;
-      float *pc = (float *)tp.C + (int64_t)x * plane;
-      float(*Bm)[LROW] = Bs[(x + 2) % 3], (*Bc)[LROW] = Bs[x % 3], (*Bp)[LROW] = Bs[(x + 1) % 3];
-      for (int r = 1 + w; r <= TYE - 2; r += WAVES) {
-         const int col = 4 + lane * 4;
-         const vec c = *(const vec *)&Bc[r][col];
-         const vec yp = *(const vec *)&Bc[r + 1][col], ym = *(const vec *)&Bc[r - 1][col];
-         const vec xp = *(const vec *)&Bp[r][col], xm = *(const vec *)&Bm[r][col];
-         const float lf = Bc[r][col - 1], rt = Bc[r][col + 4];
-         const vec old = *(const vec *)(pa + grow(r));
-         vec o;
-#pragma unroll
-         for (int i = 0; i < 4; i++) {
-            const float zp = (i == 3) ? rt : c[i < 3 ? i + 1 : 3];
-            const float zm = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
-            float p = a1 * c[i] - old[i];
-            p = p + a2 * xp[i]; p = p + a2 * xm[i]; p = p + a2 * yp[i]; p = p + a2 * ym[i]; p = p + a2 * zp; p = p + a2 * zm;
-            o[i] = p;
-         }
-         *(vec *)&Ts[x % 3][r][col] = o;
-         // core cells of this tile own the C (u^{n+1}) output
-         const bool core_row = (r >= 2 && r <= TYE - 3) && (ye0 + r >= tp.y_begin) && (ye0 + r < tp.Ny - tp.y_begin);
-         const bool core_col = (lane >= 1 && lane <= 62) && (ze0 + lane * 4 + 3 < tp.Nz - tp.z_begin);
-         if (write_c && core_row && core_col) __builtin_nontemporal_store(o, (vec *)(pc + grow(r)));
-      }
-   };
-   auto stage2 = [&](int x) { // D(plane x) from T planes x-1, x, x+1 and B plane x; rows 2..TYE-3, lanes 1..62
-      float *pd = (float *)tp.D + (int64_t)x * plane;
-      float(*Tm)[LROW] = Ts[(x + 2) % 3], (*Tc)[LROW] = Ts[x % 3], (*Tp)[LROW] = Ts[(x + 1) % 3];
-      float(*Bc)[LROW] = Bs[x % 3];
-      for (int r = 2 + w; r <= TYE - 3; r += WAVES) {
-         const int col = 4 + lane * 4;
-         const vec c = *(const vec *)&Tc[r][col];
-         const vec yp = *(const vec *)&Tc[r + 1][col], ym = *(const vec *)&Tc[r - 1][col];
-         const vec xp = *(const vec *)&Tp[r][col], xm = *(const vec *)&Tm[r][col];
-         const float lf = Tc[r][col - 1], rt = Tc[r][col + 4];
-         const vec old = *(const vec *)&Bc[r][col];
-         vec o;
-#pragma unroll
-         for (int i = 0; i < 4; i++) {
-            const float zp = (i == 3) ? rt : c[i < 3 ? i + 1 : 3];
-            const float zm = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
-            float p = a1 * c[i] - old[i];
-            p = p + a2 * xp[i]; p = p + a2 * xm[i]; p = p + a2 * yp[i]; p = p + a2 * ym[i]; p = p + a2 * zp; p = p + a2 * zm;
-            o[i] = p;
-         }
-         const bool ok_row = (ye0 + r >= tp.y_begin) && (ye0 + r < tp.Ny - tp.y_begin);
-         if (ok_row && lane >= 1 && lane <= 62 && ze0 + lane * 4 + 3 < tp.Nz - tp.z_begin) __builtin_nontemporal_store(o, (vec *)(pd + grow(r)));
-      }
-   };
-   // D planes [xs, xe) need T planes xs-1 .. xe, which need B planes xs-2 .. xe+1
-   fill_B(xs - 2, (xs - 2) % 3);
-   fill_B(xs - 1, (xs - 1) % 3);
-   fill_B(xs, xs % 3);
-   __syncthreads();
-   stage1(xs - 1, false);
-   __syncthreads();
-   for (int x = xs; x <= xe; x++) {
-      fill_B(x + 1, (x + 1) % 3);    // overwrites the slot of plane x-2 (no longer needed)
-      __syncthreads();
-      stage1(x, x < xe);              // T(x) -> Ts[x%3]; this chunk owns C planes [xs, xe)
-      __syncthreads();
-      if (x - 1 >= xs) stage2(x - 1); // D(x-1) from T x-2, x-1, x and B x-1
-      __syncthreads();
-   }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_tb2_reg -- the same two-steps-per-pass scheme with every operand in registers (no LDS, no barriers).
@@ -223,137 +126,6 @@ __global__ __launch_bounds__(64 * WY) void k_tb2_reg(Tb2Params tp, Real a1, Real
       for (int j = 0; j < R + 2; j++) { vc[j] = vn[j]; Bp[j] = Bc[j + 1]; Ar[j] = Arn[j]; }
 #pragma unroll
       for (int i = 0; i < R + 4; i++) { Bc[i] = Bn[i]; Bn[i] = Bnn[i]; }
-   }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// k_tb2_lds -- k_tb2_reg with the y-halo rows of u^n and u^{n-1} exchanged between the waves of a workgroup through
-// LDS instead of being re-read through L1: a wave loads its own R rows of a plane from global memory (the top / bottom
-// wave of the workgroup also the two rows beyond it), and one iteration later -- when the plane is first needed with
-// halos -- publishes them to a double-buffered LDS tile, one barrier, and picks up its neighbours' rows.
-// Global row loads per workgroup and plane: WY*R+4 (u^n) + WY*R+2 (u^{n-1}) instead of WY*(2R+6).
-// ---------------------------------------------------------------------------------------------------------------
-template <int R, int WY>
-__global__ __launch_bounds__(64 * WY) void k_tb2_lds(Tb2Params tp, float a1, float a2) {
-   typedef f32x4 vec;
-   __shared__ __attribute__((aligned(16))) float sB[2][WY * R][256];
-   __shared__ __attribute__((aligned(16))) float sA[2][WY * R][256];
-   const uint32_t b = blockIdx.x;
-   const int zt = b % tp.nzt, yt = (b / tp.nzt) % tp.nyt, xc = b / (tp.nzt * tp.nyt);
-   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-   const int ze0 = tp.z_begin - 4 + zt * 248;
-   const int yo = tp.y_begin + (yt * WY + w) * R;
-   const int xs = tp.x_begin + xc * tp.chunk, xe = min(xs + tp.chunk, tp.x_end);
-   const int P = tp.P;
-   const int64_t plane = tp.plane;
-   const int zc = min(max(ze0 + lane * 4, 0), P - 4);
-   int64_t offB[R + 4];
-#pragma unroll
-   for (int i = 0; i < R + 4; i++) offB[i] = (int64_t)min(max(yo - 2 + i, 0), tp.Ny - 1) * P + zc;
-   const int z_end = tp.z_end ? tp.z_end : tp.Nz - tp.z_begin, y_end = tp.y_end ? tp.y_end : tp.Ny - tp.y_begin;
-   const bool core_col = (lane >= 1 && lane <= 62) && (ze0 + lane * 4 + 3 < z_end);
-   bool core_row[R];
-#pragma unroll
-   for (int r = 0; r < R; r++) core_row[r] = (yo + r < y_end);
-   const bool top = (w == 0), bot = (w == WY - 1);
-
-   // own rows (+ the rows beyond the workgroup for its first / last wave) of a plane from global memory
-   auto loadB_own = [&](int x, vec *d) {
-      const float *pl = (const float *)tp.B + (int64_t)x * plane;
-#pragma unroll
-      for (int r = 0; r < R; r++) d[r + 2] = *(const vec *)(pl + offB[r + 2]);
-      if (top) { d[0] = *(const vec *)(pl + offB[0]); d[1] = *(const vec *)(pl + offB[1]); }
-      if (bot) { d[R + 2] = *(const vec *)(pl + offB[R + 2]); d[R + 3] = *(const vec *)(pl + offB[R + 3]); }
-   };
-   auto loadA_own = [&](int x, vec *d) { // d: rows yo-1 .. yo+R
-      const float *pl = (const float *)tp.A + (int64_t)x * plane;
-#pragma unroll
-      for (int r = 0; r < R; r++) d[r + 1] = *(const vec *)(pl + offB[r + 2]);
-      if (top) d[0] = *(const vec *)(pl + offB[1]);
-      if (bot) d[R + 1] = *(const vec *)(pl + offB[R + 2]);
-   };
-   // halo rows of the planes held in Bv (R+4 rows) and Av (R+2 rows) from the neighbouring waves
-   auto exchange = [&](int slot, vec *Bv, vec *Av) {
-#pragma unroll
-      for (int r = 0; r < R; r++) {
-         *(vec *)&sB[slot][w * R + r][lane * 4] = Bv[r + 2];
-         *(vec *)&sA[slot][w * R + r][lane * 4] = Av[r + 1];
-      }
-      __syncthreads();
-      if (!top) {
-         Bv[0] = *(const vec *)&sB[slot][w * R - 2][lane * 4];
-         Bv[1] = *(const vec *)&sB[slot][w * R - 1][lane * 4];
-         Av[0] = *(const vec *)&sA[slot][w * R - 1][lane * 4];
-      }
-      if (!bot) {
-         Bv[R + 2] = *(const vec *)&sB[slot][w * R + R][lane * 4];
-         Bv[R + 3] = *(const vec *)&sB[slot][w * R + R + 1][lane * 4];
-         Av[R + 1] = *(const vec *)&sA[slot][w * R + R][lane * 4];
-      }
-   };
-   auto stencil = [&](const vec &c, const vec &xp, const vec &xm, const vec &yp, const vec &ym, const vec &old) {
-      const float lf = lane_from_lower<true>(c[3]);
-      const float rt = lane_from_upper<true>(c[0]);
-      vec o;
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-         const float zp = (i == 3) ? rt : c[i < 3 ? i + 1 : 3];
-         const float zm = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
-         float p = a1 * c[i] - old[i];
-         p = p + a2 * xp[i]; p = p + a2 * xm[i]; p = p + a2 * yp[i]; p = p + a2 * ym[i]; p = p + a2 * zp; p = p + a2 * zm;
-         o[i] = p;
-      }
-      return o;
-   };
-
-   vec Bp[R + 2], Bc[R + 4], Bn[R + 4], Bnn[R + 4], Ar[R + 2], Arn[R + 2];
-   vec vm[R], vc[R + 2], vn[R + 2];
-   {  // prologue: planes xs-2 (rows R+2 needed), xs-1, xs of u^n and xs-1 of u^{n-1}, halos through the same exchange
-      vec t[R + 4], ta[R + 2];
-      loadB_own(xs - 2, t);
-      loadA_own(xs - 1, ta);
-      exchange(0, t, ta);
-#pragma unroll
-      for (int j = 0; j < R + 2; j++) { Bp[j] = t[j + 1]; Ar[j] = ta[j]; }
-      loadB_own(xs - 1, Bc);
-      loadA_own(xs - 1, ta);
-      exchange(1, Bc, ta);
-      loadB_own(xs, Bn);       // its halos arrive at the top of the first iteration, together with Arn's
-      loadA_own(xs, Arn);      // (u^{n-1} plane xs: used from the second iteration on)
-   }
-#pragma unroll
-   for (int r = 0; r < R; r++) vm[r] = vec{0, 0, 0, 0};
-#pragma unroll
-   for (int j = 0; j < R + 2; j++) vc[j] = vec{0, 0, 0, 0};
-   int it = 0;
-   for (int x1 = xs - 1; x1 <= xe; x1++, it++) {
-      // Bn = u^n plane x1+1 and Arn = u^{n-1} plane x1+1 arrived during the previous turn: complete them with halos
-      exchange(it & 1, Bn, Arn);
-      if (x1 < xe) loadB_own(x1 + 2, Bnn);
-      // stage 1: u^{n+1}(x1) on rows yo-1 .. yo+R
-#pragma unroll
-      for (int j = 0; j < R + 2; j++) vn[j] = stencil(Bc[j + 1], Bn[j + 1], Bp[j], Bc[j + 2], Bc[j], Ar[j]);
-      if (x1 >= xs && x1 < xe) {
-         float *pc = (float *)tp.C + (int64_t)x1 * plane;
-#pragma unroll
-         for (int r = 0; r < R; r++)
-            if (core_col && core_row[r]) __builtin_nontemporal_store(vn[r + 1], (vec *)(pc + offB[r + 2]));
-      }
-      if (x1 - 1 >= xs) {
-         float *pd = (float *)tp.D + (int64_t)(x1 - 1) * plane;
-#pragma unroll
-         for (int r = 0; r < R; r++) {
-            const vec o = stencil(vc[r + 1], vn[r + 1], vm[r], vc[r + 2], vc[r], Bp[r + 1]);
-            if (core_col && core_row[r]) __builtin_nontemporal_store(o, (vec *)(pd + offB[r + 2]));
-         }
-      }
-#pragma unroll
-      for (int r = 0; r < R; r++) vm[r] = vc[r + 1];
-#pragma unroll
-      for (int j = 0; j < R + 2; j++) { vc[j] = vn[j]; Bp[j] = Bc[j + 1]; Ar[j] = Arn[j]; }
-#pragma unroll
-      for (int i = 0; i < R + 4; i++) { Bc[i] = Bn[i]; Bn[i] = Bnn[i]; }
-      if (x1 + 1 < xe) loadA_own(x1 + 2, Arn);
    }
 }
 

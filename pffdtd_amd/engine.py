@@ -39,7 +39,7 @@ EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_grid_bytes", "p
            "pf_run_sim", "pf_engine_create", "pf_engine_destroy", "pf_engine_run", "pf_engine_step_begin",
            "pf_engine_halo_ptrs", "pf_engine_step_end", "pf_engine_set_spares", "pf_engine_stream", "pf_engine_sync",
            "pf_engine_flush_outputs", "pf_engine_get_grid", "pf_engine_set_grid", "pf_engine_timing",
-           "pf_engine_energy_cfg", "pf_engine_run_energy", "pf_membench", "pf_tb2_probe"]
+           "pf_engine_energy_cfg", "pf_engine_run_energy"]
 
 
 def lib_path():
@@ -83,10 +83,6 @@ def lib():
         dp = ctypes.POINTER(ctypes.c_double)
         L.pf_engine_energy_cfg.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, dp]
         L.pf_engine_run_energy.argtypes = [vp, i64, i64, dp, dp, dp]
-        L.pf_tb2_probe.restype = ctypes.c_double
-        L.pf_tb2_probe.argtypes = [vp, vp, vp, vp, i64, i64, i64, ctypes.c_double, ctypes.c_double, i32, i32, i32, i32]
-        L.pf_membench.restype = ctypes.c_double
-        L.pf_membench.argtypes = [vp, vp, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32]
         _LIB = L
     return _LIB
 

@@ -33,6 +33,7 @@ def _lib():
         L.pf_h5_read.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]
         L.pf_h5_write.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int,
                                   ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.pf_h5_list.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int64]
         _LIB = L
     return _LIB
 
@@ -51,6 +52,15 @@ def _err():
 
 def exists(path, name):
     return bool(_lib().pf_h5_exists(os.fsencode(str(path)), name.encode()))
+
+
+def list_datasets(path):
+    """Names of the datasets in the file's root group (sorted by name)."""
+    buf = ctypes.create_string_buffer(1 << 16)
+    n = _lib().pf_h5_list(os.fsencode(str(path)), buf, len(buf))
+    if n < 0:
+        raise IOError(_err())
+    return [s for s in buf.value.decode().split("\n") if s]
 
 
 def read(path, name, dtype=None):

@@ -115,7 +115,7 @@ def main():
     p.add_argument("--resample_Fs", type=float, default=48e3)
     p.add_argument("--fcut_lowcut", type=float, default=10.0)
     p.add_argument("--fcut_lowpass", type=float, default=0.0)
-    p.add_argument("--N_order_lowcut", type=int, default=4)
+    p.add_argument("--N_order_lowcut", type=int, default=8)  # process_outputs.py:320
     p.add_argument("--N_order_lowpass", type=int, default=8)
     p.add_argument("--symmetric_lowpass", action="store_true")
     p.add_argument("--save_wav", action="store_true")
@@ -125,10 +125,10 @@ def main():
     a = p.parse_args()
     po = ProcessOutputs(a.data_dir)
     po.initial_process(fcut=a.fcut_lowcut, N_order=a.N_order_lowcut)
+    if a.resample_Fs:  # the reference resamples first and low-passes at the new rate (process_outputs.py:330-334)
+        po.resample(a.resample_Fs)
     if a.fcut_lowpass > 0:
         po.apply_lowpass(fcut=a.fcut_lowpass, N_order=a.N_order_lowpass, symmetric=a.symmetric_lowpass)
-    if a.resample_Fs:
-        po.resample(a.resample_Fs)
     flt = a.air_abs_filter.lower()  # process_outputs.py:338-343
     if flt == "modal":
         po.apply_modal_filter()

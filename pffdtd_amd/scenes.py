@@ -6,7 +6,7 @@
     test_script_MV_fcc_viz.py    -> mv_fcc_viz     small FCC run for visualisation
 
 The model exports and wall-impedance fits are data files of the reference (data/models, data/materials); copies
-travel with the tests as fixtures (tests/golden/models, tests/golden/materials_DEF.npz, see make_golden_materials.py).
+ship with the package (pffdtd_amd/data/models, pffdtd_amd/data/materials_DEF.npz; tests/golden/make_golden_materials.py made them).
 """
 from pathlib import Path
 
@@ -31,19 +31,19 @@ CONFIGS = {
                        duration=0.1, Tc=20, rh=50, fcc_flag=True, PPW=5.6, fmax=1000.0),
 }
 
-FIXTURES = Path(__file__).resolve().parent.parent / "tests" / "golden"
+DATA = Path(__file__).resolve().parent / "data"
 MODEL_FILES = {"CTK": "CTK_Church_model_export.json", "MV": "MV_model_export.json.gz"}
 
 
 def model_path(model, models_dir=None):
-    return Path(models_dir or FIXTURES / "models") / MODEL_FILES[model]
+    return Path(models_dir or DATA / "models") / MODEL_FILES[model]
 
 
 def write_materials(folder, npz=None):
     """Materialise the wall-impedance fits (DEF [Mb,3]) as <folder>/<name>.h5, the layout `SimMats.package` reads."""
     folder = Path(folder)
     folder.mkdir(parents=True, exist_ok=True)
-    z = np.load(npz or FIXTURES / "materials_DEF.npz")
+    z = np.load(npz or DATA / "materials_DEF.npz")
     for name in z.files:
         h5io.write(folder / name, "DEF", z[name], append=False)
     return folder

@@ -263,8 +263,7 @@ def fold_fcc(sim):
     v["adj_bn"] = adj
     c["in_ixyz"] = fold_idx(c["in_ixyz"])[0].astype(np.int64)
     c["out_ixyz"] = fold_idx(c["out_ixyz"])[0].astype(np.int64)
-    v["Ny"] = np.int64(Nyh)
-    v["yv"] = v["yv"][:Nyh]
+    v["Ny"] = np.int64(Nyh)  # (yv stays as it is, like fold_fcc_sim_data, rotate_sim_data.py:191-262: it is only read for plotting)
     k["fcc_flag"] = np.int8(2)
     return sim
 
@@ -303,6 +302,12 @@ def read_folder(data_dir):
         for n in opt.get(f, []):
             if h5io.exists(p, n):
                 sim[f][n] = h5io.read(p, n)
+        for n in h5io.list_datasets(p):  # everything else travels along unchanged (the reference edits the files in
+            if n not in sim[f]:          # place, rotate_sim_data.py:104-130: e.g. vox_out::h written by VoxScene.save)
+                try:
+                    sim[f][n] = h5io.read(p, n)
+                except TypeError:
+                    pass                 # a dataset class this shim cannot carry (strings): left behind
     p = data_dir / "sim_mats.h5"
     for i in range(int(sim["sim_mats"]["Nmat"])):
         sim["sim_mats"][f"mat_{i:02d}_DEF"] = h5io.read(p, f"mat_{i:02d}_DEF")

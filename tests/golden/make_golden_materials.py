@@ -10,12 +10,13 @@ from pathlib import Path
 import numpy as np
 
 HERE = Path(__file__).resolve().parent
+DATA = HERE.parent.parent / "pffdtd_amd" / "data"
 sys.path.insert(0, str(HERE.parent.parent))
 from pffdtd_amd import h5io  # noqa: E402
 
 REF = Path("/root/reference/data")
-np.savez_compressed(HERE / "materials_DEF.npz", **{f.name: h5io.read(f, "DEF") for f in sorted((REF / "materials").glob("*.h5"))})
+np.savez_compressed(DATA / "materials_DEF.npz", **{f.name: h5io.read(f, "DEF") for f in sorted((REF / "materials").glob("*.h5"))})
 with open(REF / "models/Musikverein_ConcertHall/model_export.json", "rb") as src, \
-        gzip.GzipFile(HERE / "models" / "MV_model_export.json.gz", "wb", mtime=0) as dst:
+        gzip.GzipFile(DATA / "models" / "MV_model_export.json.gz", "wb", mtime=0) as dst:
     shutil.copyfileobj(src, dst)
 print("wrote materials_DEF.npz and models/MV_model_export.json.gz")

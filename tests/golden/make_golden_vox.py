@@ -3,7 +3,7 @@
 tests/test_voxelizer.py.  Runs in the build container only: the reference modules are imported from
 /root/reference behind test-only shims (identity numba.jit, an in-memory h5py, memory_profiler stub).
 
-Scenes: the CTK church export (a data file of the reference's own test scripts, copied to tests/golden/models/)
+Scenes: the CTK church export (a data file of the reference's own test scripts, copied to pffdtd_amd/data/models/)
 at coarse grid spacings, Cartesian and FCC, plain and rotated; plus the full BASELINE cfg1 resolution (h=0.0915 m).
 Stored per case: grid shape, bn_ixyz (sorted), adj_bn packed to uint16, mat_bn, saf_bn, tidx/ndist-independent.
 """
@@ -16,6 +16,7 @@ from pathlib import Path
 import numpy as np
 
 HERE = Path(__file__).resolve().parent
+DATA = HERE.parent.parent / "pffdtd_amd" / "data"
 REF = Path("/root/reference")
 np.float = float
 np.bool8 = np.bool_
@@ -60,7 +61,7 @@ from voxelizer.vox_grid import VoxGrid  # noqa: E402
 from voxelizer.vox_scene import VoxScene  # noqa: E402
 
 MODEL = REF / "data/models/CTK_Church/model_export.json"
-dst = HERE / "models" / "CTK_Church_model_export.json"
+dst = DATA / "models" / "CTK_Church_model_export.json"
 if not dst.exists():
     shutil.copyfile(MODEL, dst)
 
@@ -78,7 +79,7 @@ CASES = [  # tag, h, fcc, az_el, Nh
     ("mv_fcc_viz_digest", 343.2 / (1000.0 * 5.6), True, [0.0, 0.0], None),
 ]
 MV_MODEL = REF / "data/models/Musikverein_ConcertHall/model_export.json"
-OPEN_MODEL = HERE / "models" / "open_scene.json"  # make_open_scene.py: _RIGID triangles, open top, custom bounds
+OPEN_MODEL = DATA / "models" / "open_scene.json"  # make_open_scene.py: _RIGID triangles, open top, custom bounds
 OPEN_BOUNDS = (np.array([-0.4, -0.4, -0.3]), np.array([4.5, 3.7, 3.4]))
 CASES += [("open_cart_h10", 0.10, False, [0.0, 0.0], None), ("open_fcc_h12", 0.12, True, [20.0, 0.0], None)]
 only = sys.argv[1:]

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Writes tests/golden/models/open_scene.json: a small hand-made export in the reference's JSON schema that exercises
+"""Writes pffdtd_amd/data/models/open_scene.json: a small hand-made export in the reference's JSON schema that exercises
 what the CTK / Musikverein exports do not: unmarked `_RIGID` triangles (sidedness 0 -> material -1), an open scene
 (no ceiling; custom bmin/bmax), a free-standing two-sided panel, a tilted one-sided reflector."""
 import json
 from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
+DATA = HERE.parent.parent / "pffdtd_amd" / "data"
 
 
 def quad(p0, p1, p2, p3):
@@ -33,5 +34,5 @@ scene = {"mats_hash": {"_RIGID": mat([floor], 0, [255, 255, 255]), "Brick": mat(
          "sources": [{"xyz": [0.7, 0.8, 1.1], "name": "S1"}, {"xyz": [3.2, 2.4, 0.9], "name": "S2"}],
          "receivers": [{"xyz": [2.9, 1.1, 0.8], "name": "R1"}, {"xyz": [0.6, 2.6, 1.5], "name": "R2"}],
          "export_datetime": "hand-made"}
-(HERE / "models" / "open_scene.json").write_text(json.dumps(scene))
+(DATA / "models" / "open_scene.json").write_text(json.dumps(scene))
 print("wrote models/open_scene.json")

@@ -96,3 +96,22 @@ def test_process_outputs_matches_reference(diff, tmp_path):
     assert abs(po.Fs_f - 48e3) < 1e-6 and po.r_out_f.shape == (2, 768)
     po.save_h5()
     assert h5io.read(tmp_path / "sim_outs_processed.h5", "r_out_f").shape == (2, 768)
+
+
+@pytest.mark.parametrize("tag", ["cart_zxy", "cart_yxz", "fcc_zyx", "fcc_xzy", "fcc_sorted_dims"])
+def test_gpu_prep_matches_reference_rotate_sim_data(tag):
+    """rotate -> fold -> sort against the reference's own rotate_sim_data.py functions run on the same un-prepared folder
+    (tests/golden/prep_reference_*.npz, made by make_golden_prep.py): every dataset they touch, bit for bit."""
+    import prep_cases
+    g = np.load(Path(__file__).resolve().parent / "golden" / f"prep_reference_{tag}.npz")
+    sim = prep_cases.make(tag)
+    synth.rotate_sim(sim)
+    if int(sim["sim_consts"]["fcc_flag"]) == 1:
+        synth.fold_fcc(sim)
+    synth.sort_sim(sim)
+    for key in g.files:
+        f, k = key.split("/")
+        got = np.asarray(sim[f][k])
+        if k == "adj_bn":
+            got = np.packbits(got.astype(bool), axis=1, bitorder="little")
+        assert got.shape == g[key].shape and np.array_equal(got, g[key]), key

@@ -9,6 +9,7 @@ import pytest
 from pffdtd_amd import h5io, scenes
 
 GOLD = Path(__file__).resolve().parent / "golden"
+DATA = Path(__file__).resolve().parent.parent / "pffdtd_amd" / "data"
 CASES = {
     "ctk_cart": ("ctk_cart_viz", dict(duration=0.02, PPW=6.0, fmax=250.0)),
     "ctk_fcc": ("ctk_cart_gpu", dict(source_num=2, duration=0.02, fcc_flag=True, PPW=6.0, fmax=350.0)),
@@ -19,7 +20,7 @@ CASES = {
 def test_scene_configs_name_the_reference_test_scripts():
     assert set(scenes.CONFIGS) == {"ctk_cart_viz", "ctk_cart_gpu", "mv_fcc_gpu", "mv_fcc_viz"}
     assert scenes.model_path("CTK").exists() and scenes.model_path("MV").exists()
-    z = np.load(GOLD / "materials_DEF.npz")
+    z = np.load(DATA / "materials_DEF.npz")
     for cfg in scenes.CONFIGS.values():
         assert set(cfg["mat_files_dict"].values()) <= set(z.files)
 

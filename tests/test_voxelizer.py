@@ -17,14 +17,15 @@ from pffdtd_amd import h5io, setup_io
 from pffdtd_amd.room_geo import RoomGeo, tris_precompute
 
 GOLD = Path(__file__).resolve().parent / "golden"
-MODELS = {"ctk": GOLD / "models" / "CTK_Church_model_export.json", "mv": GOLD / "models" / "MV_model_export.json.gz"}
+DATA = Path(__file__).resolve().parent.parent / "pffdtd_amd" / "data"
+MODELS = {"ctk": DATA / "models" / "CTK_Church_model_export.json", "mv": DATA / "models" / "MV_model_export.json.gz"}
 SMALL = ["ctk_cart_h40", "ctk_fcc_h40", "ctk_cart_h25_rot", "ctk_fcc_h30_rot"]
 MV = ["mv_fcc_h20", "mv_cart_h25"]  # Musikverein export: 32k triangles (rows of chairs)
 # hand-made export (tests/golden/make_open_scene.py): unmarked _RIGID triangles, open top with custom bounds, two-sided
 # panel, tilted one-sided reflector; goldens from the reference voxelizer like the others
 OPEN = ["open_cart_h10", "open_fcc_h12"]
 OPEN_BOUNDS = (np.array([-0.4, -0.4, -0.3]), np.array([4.5, 3.7, 3.4]))
-MODELS["open"] = GOLD / "models" / "open_scene.json"
+MODELS["open"] = DATA / "models" / "open_scene.json"
 
 
 def scene(tag):

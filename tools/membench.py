@@ -7,10 +7,10 @@ from pathlib import Path
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-from pffdtd_amd import engine  # noqa: E402
+from pffdtd_amd import build  # noqa: E402
 
 print = functools.partial(print, flush=True)
-L = engine.lib()
+L = build.load_probe()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 a = torch.rand((n, n * n), device="cuda") * 1e-3
 b = torch.rand((n, n * n), device="cuda") * 1e-3

@@ -15,7 +15,8 @@ from pffdtd_amd import engine, sim_data, synth  # noqa: E402
 print = functools.partial(print, flush=True)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 m = 8
-L = engine.lib()
+from pffdtd_amd import build  # noqa: E402
+L = build.load_probe()
 sim = synth.shoebox(n, n, n, Nt=8, box=False, lossy=False)
 sd = sim_data.SimData.from_sim(sim, "single", build_mask=False)
 sd.scale_input()
@@ -44,7 +45,7 @@ for tye in [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "2
     for chunk in [int(v) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else "16,32,64".split(","))]:
         ms = L.pf_tb2_probe(g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), g[3].data_ptr(), n, n, n, float(sd.a1), float(sd.a2), m, tye, chunk, 5)
         if ms < 0:
-            print("probe failed:", L.pf_last_error().decode()); continue
+            print("probe failed:", L.pf_probe_last_error().decode()); continue
         C = g[2].view(n, n, P)[m:n - m, m:n - m, m:n - m]
         D = g[3].view(n, n, P)[m:n - m, m:n - m, m:n - m]
         okC = bool(torch.equal(C, ref_n1[m:n - m, m:n - m, m:n - m]))
