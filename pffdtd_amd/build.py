@@ -122,6 +122,8 @@ def build_oracle(force=False):
     _run(["make", "-C", str(ROOT / "oracle"), "oracle"])
     if Path("/root/reference/c_cuda/fdtd_main.c").exists():
         _run(["make", "-C", str(ROOT / "oracle"), "ref"])
+        if (PKG / "libpffdtd_hip.so").exists():  # the reference's fdtd_main.c bound to the HIP library
+            _run(["make", "-C", str(ROOT / "oracle"), "hipbind"])
     return ROOT / "oracle" / "libpf_oracle.so"
 
 
