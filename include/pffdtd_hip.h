@@ -102,8 +102,14 @@ typedef struct pf_opts {
                              0x10000000 keep a sliver z tile in the blocked kernel */
    int32_t energy;        /* 1 = keep what the energy diagnostic needs (explicit Laplacian grid, unfused kernel
                              sequence); then use pf_engine_energy_cfg + pf_engine_run_energy */
-   int32_t reserved[5];
+   int32_t multi_flags;   /* pf_run_sim_devices only: PF_MULTI_* */
+   int32_t reserved[4];
 } pf_opts;
+
+#define PF_MULTI_EVEN_SPLIT  1 /* the reference's Nx/G planes per slab (gpu_engine.h:532-550) instead of the cost-balanced cut */
+#define PF_MULTI_ONE_THREAD  2 /* one host thread drives every slab (the reference's arrangement) instead of one thread per slab */
+#define PF_MULTI_NO_PAIRS    4 /* never step slabs in temporally blocked pairs */
+#define PF_MULTI_FORCE_PAIRS 8 /* ask every slab engine for pairs regardless of its thickness (tests) */
 
 typedef struct pf_timing {
    double  air_ms_total;    /* sum of HIP-event durations of the air kernel launches */
@@ -130,8 +136,17 @@ int64_t     pf_grid_pitch(int64_t Nz, int32_t real_bytes);
 void        pf_opts_default(pf_opts *o);
 
 /* ---- the reference seam: double run_sim(struct SimData*) ---- */
-/* Runs all sd->Nt steps on device 0, fills sd->u_out, returns elapsed seconds (<0 on error). */
+/* Runs all sd->Nt steps, fills sd->u_out (engine row order), returns elapsed seconds (<0 on error; pf_last_error()).
+ * Like the reference's GPU engine (gpu_engine.h:680-682) it spreads the grid over EVERY visible device as a chain of
+ * Z-slabs along Nx (environment: PFFDTD_NGPUS=n limits it to the first n devices, PFFDTD_DEVICES=0,1,... names the chain). */
 double      pf_run_sim(pf_simdata *sd);
+/* The same on an explicit chain: slab g on device devices[g]; an id may repeat ("virtual slabs": the whole multi-device
+ * code path on one GPU).  One host thread per slab, split-phase steps, ghost planes pulled from the neighbours with
+ * peer copies on the edge stream while the interior planes run (replaces gpu_engine.h:516-662,739-823,993-1145).
+ * base: options common to all slabs (numerics, air_variant, readout_chunk, debug, multi_flags); NULL = defaults. */
+double      pf_run_sim_devices(pf_simdata *sd, int32_t nslabs, const int32_t *devices, const pf_opts *base);
+/* The owned plane ranges such a run uses: cuts[0..nslabs], slab g owns global planes [cuts[g], cuts[g+1]). */
+int         pf_slab_partition(const pf_simdata *sd, int32_t nslabs, int32_t even_split, int64_t *cuts);
 
 /* ---- engine object (what run_sim does inside, exposed for the Python host, slabs and tests) ---- */
 int  pf_engine_create(const pf_simdata *sd, const pf_opts *opts, pf_engine **out);

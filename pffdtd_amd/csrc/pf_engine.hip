@@ -1514,20 +1514,4 @@ int pf_engine_run_energy(pf_engine *e, int64_t n0, int64_t nsteps, double *H_tot
    return e->impl->run_energy(n0, nsteps, H_tot, E_lost, E_in);
 }
 
-// double run_sim(struct SimData *sd): cpu_engine.h:52 / gpu_engine.h:665
-double pf_run_sim(pf_simdata *sd) {
-   pf_engine *e = nullptr;
-   pf_opts o;
-   pf_opts_default(&o);
-   if (pf_engine_create(sd, &o, &e) != PF_OK) return -1.0;
-   auto t0 = std::chrono::steady_clock::now();
-   int rc = pf_engine_run(e, 0, sd->Nt);
-   if (rc == PF_OK) rc = pf_engine_sync(e);
-   double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-   std::string keep = g_err;
-   pf_engine_destroy(e);
-   if (rc != PF_OK) { g_err = keep; return -1.0; }
-   return el;
-}
-
 } // extern "C"

@@ -3,6 +3,9 @@
 There is no CPU fallback: if the HIP library is missing or no GPU is visible, construction raises.
 """
 import ctypes
+import importlib.util
+import os
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -21,7 +24,7 @@ class PfOpts(ctypes.Structure):
                 ("slab_last", ctypes.c_int32), ("readout_chunk", ctypes.c_int32), ("air_variant", ctypes.c_int32),
                 ("air_chunk", ctypes.c_int32), ("timing", ctypes.c_int32), ("ext_u0", ctypes.c_void_p),
                 ("ext_u1", ctypes.c_void_p), ("x_global0", ctypes.c_int32), ("debug", ctypes.c_int32),
-                ("energy", ctypes.c_int32), ("reserved", ctypes.c_int32 * 5)]
+                ("energy", ctypes.c_int32), ("multi_flags", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4)]
 
 
 class PfTiming(ctypes.Structure):
@@ -39,7 +42,31 @@ EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_grid_bytes", "p
            "pf_run_sim", "pf_engine_create", "pf_engine_destroy", "pf_engine_run", "pf_engine_step_begin",
            "pf_engine_halo_ptrs", "pf_engine_step_end", "pf_engine_set_spares", "pf_engine_stream", "pf_engine_sync",
            "pf_engine_flush_outputs", "pf_engine_get_grid", "pf_engine_set_grid", "pf_engine_timing",
-           "pf_engine_energy_cfg", "pf_engine_run_energy"]
+           "pf_engine_energy_cfg", "pf_engine_run_energy", "pf_run_sim_devices", "pf_slab_partition"]
+
+
+PF_MULTI_EVEN_SPLIT, PF_MULTI_ONE_THREAD, PF_MULTI_NO_PAIRS, PF_MULTI_FORCE_PAIRS = 1, 2, 4, 8
+
+
+def _preload_torch_hip():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7 (same soname as /opt/rocm's).  The copy loaded first serves
+    the whole process, and torch only finds its GPUs through its own.  So that the order of `import torch` and the first
+    engine call does not matter, load torch's copy (without importing torch) before libpffdtd_hip.so pulls in the system
+    one.  PFFDTD_SYSTEM_HIP=1 keeps the system runtime (engine-only hosts that never import torch)."""
+    if "torch" in sys.modules or os.environ.get("PFFDTD_SYSTEM_HIP") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    p = Path(spec.submodule_search_locations[0]) / "lib" / "libamdhip64.so"
+    if p.exists():
+        try:
+            ctypes.CDLL(str(p), mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def lib_path():
@@ -53,6 +80,7 @@ def lib():
         p = lib_path()
         if not p.exists():
             raise PfError(f"{p} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _preload_torch_hip()
         L = ctypes.CDLL(str(p))
         vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
         L.pf_last_error.restype = ctypes.c_char_p
@@ -83,6 +111,10 @@ def lib():
         dp = ctypes.POINTER(ctypes.c_double)
         L.pf_engine_energy_cfg.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, dp]
         L.pf_engine_run_energy.argtypes = [vp, i64, i64, dp, dp, dp]
+        L.pf_run_sim_devices.restype = ctypes.c_double
+        L.pf_run_sim_devices.argtypes = [ctypes.POINTER(PfSimData), i32, ctypes.POINTER(i32), ctypes.POINTER(PfOpts)]
+        L.pf_slab_partition.argtypes = [ctypes.POINTER(PfSimData), i32, i32, ctypes.POINTER(i64)]
+        L.pf_engine_set_spares.argtypes = [vp, vp, vp]
         _LIB = L
     return _LIB
 
@@ -107,6 +139,31 @@ def run_sim(sd):
     if el < 0:
         raise PfError(f"pf_run_sim failed: {lib().pf_last_error().decode()}")
     return el
+
+
+def run_sim_devices(sd, devices, multi_flags=0, **opts):
+    """pf_run_sim_devices: run_sim on a chain of Z-slabs, slab g on HIP device devices[g] (ids may repeat = virtual
+    slabs on one GPU).  opts: numerics, air_variant, readout_chunk, debug.  Fills sd.u_out, returns seconds."""
+    L = lib()
+    s = sd.as_struct()
+    o = PfOpts()
+    L.pf_opts_default(ctypes.byref(o))
+    for k, v in opts.items():
+        setattr(o, k, int(v))
+    o.multi_flags = int(multi_flags)
+    devs = (ctypes.c_int32 * len(devices))(*[int(d) for d in devices])
+    el = L.pf_run_sim_devices(ctypes.byref(s), len(devices), devs, ctypes.byref(o))
+    if el < 0:
+        raise PfError(f"pf_run_sim_devices failed: {L.pf_last_error().decode()}")
+    return el
+
+
+def slab_partition(sd, nslabs, even=False):
+    """Owned plane ranges [(x0, x1)] of pf_run_sim_devices' slabs."""
+    s = sd.as_struct()
+    cuts = (ctypes.c_int64 * (nslabs + 1))()
+    _check(lib().pf_slab_partition(ctypes.byref(s), int(nslabs), int(bool(even)), cuts))
+    return [(int(cuts[g]), int(cuts[g + 1])) for g in range(nslabs)]
 
 
 class HipEngine:
@@ -150,10 +207,7 @@ class HipEngine:
 
     def set_spares(self, ptr2, ptr3):
         """Two more caller-owned state grids: lets a slab engine step in temporally blocked pairs.  -> True if it will."""
-        L = lib()
-        L.pf_engine_set_spares.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-        L.pf_engine_set_spares.restype = ctypes.c_int
-        rc = L.pf_engine_set_spares(self._h, ctypes.c_void_p(ptr2), ctypes.c_void_p(ptr3))
+        rc = lib().pf_engine_set_spares(self._h, ctypes.c_void_p(ptr2), ctypes.c_void_p(ptr3))
         if rc not in (0, 1):
             _check(rc)
         return rc == 0

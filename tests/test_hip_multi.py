@@ -1,0 +1,105 @@
+"""GPU: multi-device run_sim behind the C seam (pf_run_sim_devices / pf_run_sim, csrc/pf_multi.hip): a chain of Z-slabs,
+one host thread per slab, ghost planes pulled from the neighbours with device copies on the edge stream.  A device id may
+repeat, so the whole path -- slab cut in C, threads, barrier, events, copies, pairs -- runs on ONE GPU here; results must
+be the single-domain CPU oracle's, bit for bit (the reference's counterpart: gpu_engine.h:516-662,739-823,993-1145)."""
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import cases
+import oracle
+from pffdtd_amd import engine, h5io, sim_data, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _ref(name, prec, **kw):
+    sd = cases.make_sd(name, prec, **kw)
+    oracle.run_sim(sd)
+    assert np.abs(sd.u_out).max() > 0
+    return sd.u_out.copy()
+
+
+@pytest.mark.parametrize("name,prec", [("cart_outside", "single"), ("cart_mb11", "double"), ("fcc2_outside", "single"),
+                                       ("fcc1_outside", "double"), ("cart_wall2", "single"), ("fcc2_mb11", "double")])
+@pytest.mark.parametrize("G", [2, 3])
+def test_virtual_slabs_through_the_c_seam(name, prec, G):
+    want = _ref(name, prec)
+    sd = cases.make_sd(name, prec)
+    el = engine.run_sim_devices(sd, [0] * G)
+    assert el > 0 and np.array_equal(sd.u_out, want)
+
+
+@pytest.mark.parametrize("flags", [engine.PF_MULTI_EVEN_SPLIT, engine.PF_MULTI_ONE_THREAD,
+                                   engine.PF_MULTI_EVEN_SPLIT | engine.PF_MULTI_ONE_THREAD | engine.PF_MULTI_NO_PAIRS])
+def test_split_rule_and_host_threading_do_not_change_the_bits(flags):
+    want = _ref("cart_outside", "single")
+    sd = cases.make_sd("cart_outside", "single")
+    engine.run_sim_devices(sd, [0, 0, 0, 0], multi_flags=flags)
+    assert np.array_equal(sd.u_out, want)
+
+
+def test_unsorted_lists_and_ring_flushes():
+    """lists in arbitrary order (the reference's multi-GPU engine refuses them, gpu_engine.h:688) and a receiver ring
+    much shorter than the run, so every slab flushes several times in mid-run"""
+    want = _ref("cart_outside", "double")
+    sd = cases.make_sd("cart_outside", "double")
+    rng = np.random.default_rng(5)
+    p = rng.permutation(sd.Nb)
+    sd.bn_ixyz, sd.adj_bn, sd.K_bn = sd.bn_ixyz[p].copy(), sd.adj_bn[p].copy(), sd.K_bn[p].copy()
+    engine.run_sim_devices(sd, [0, 0, 0], readout_chunk=7)
+    assert np.array_equal(sd.u_out, want)
+
+
+@pytest.mark.parametrize("prec", ["single", "double"])
+def test_slabs_in_temporally_blocked_pairs(prec):
+    """a box room wide enough for the two-steps-per-pass kernel, pairs forced in every slab (air_variant 40)"""
+    kw = dict(Nx=44, Ny=70, Nz=276, Nt=31, wall=3, Nm=1, Mb=3, src=[21, 30, 100], rcv=[[8, 9, 10], [36, 60, 250], [22, 35, 140]])
+    sim = synth.shoebox(**kw)
+    sd = sim_data.SimData.from_sim(sim, prec)
+    sd.scale_input()
+    oracle.run_sim(sd)
+    want = sd.u_out.copy()
+    assert np.abs(want).max() > 0
+    for devs in ([0, 0], [0, 0, 0]):
+        sd2 = sim_data.SimData.from_sim(synth.shoebox(**kw), prec)
+        sd2.scale_input()
+        engine.run_sim_devices(sd2, devs, multi_flags=engine.PF_MULTI_FORCE_PAIRS, air_variant=40)
+        assert np.array_equal(sd2.u_out, want), devs
+
+
+def test_run_sim_uses_the_device_chain_named_in_the_environment(tmp_path):
+    """pf_run_sim (the seam itself) with PFFDTD_DEVICES=0,0,0 -- through the reference's own driver when it was built"""
+    want = _ref("fcc2_lossy", "double")
+    code = ("import sys; sys.path[:0] = [%r, %r]; import numpy as np, cases; from pffdtd_amd import engine; "
+            "sd = cases.make_sd('fcc2_lossy', 'double'); engine.run_sim(sd); np.save(%r, sd.u_out)"
+            % (str(ROOT), str(ROOT / "tests"), str(tmp_path / "u.npy")))
+    r = subprocess.run([os.sys.executable, "-c", code], env={**os.environ, "PFFDTD_DEVICES": "0,0,0", "PFFDTD_VERBOSE": "1"},
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "3 slabs" in r.stderr
+    assert np.array_equal(np.load(tmp_path / "u.npy"), want)
+    exe = ROOT / "oracle" / "_ref" / "fdtd_main_hip_single.x"
+    if exe.exists():
+        sim = synth.sort_sim(cases.make_sim("cart_outside"))
+        synth.write_folder(sim, tmp_path / "f")
+        r = subprocess.run([str(exe)], cwd=tmp_path / "f", env={**os.environ, "PFFDTD_DEVICES": "0,0", "PFFDTD_VERBOSE": "1"},
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "2 slabs" in r.stderr, (r.stdout[-800:], r.stderr[-800:])
+        ref = sim_data.SimData.from_folder(tmp_path / "f", "single")
+        ref.scale_input()
+        oracle.run_sim(ref)
+        ref.rescale_output()
+        assert np.array_equal(h5io.read(tmp_path / "f" / "sim_outs.h5", "u_out"), ref.u_out[ref.out_reorder, :])
+
+
+def test_errors_surface_through_the_seam():
+    sd = cases.make_sd("cart_rigid", "single")
+    with pytest.raises(engine.PfError, match="out of range"):
+        engine.run_sim_devices(sd, [0, 99])
+    with pytest.raises(engine.PfError):
+        engine.run_sim_devices(sd, [0] * int(sd.Nx))  # more slabs than planes (gpu_engine.h:682)

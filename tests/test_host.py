@@ -170,3 +170,14 @@ def test_weighted_partition_covers_and_balances():
         loc, info = slab.split(sd, 3, r, balance=True)
         seen += loc.Nb
     assert seen == sd.Nb
+
+
+@pytest.mark.parametrize("name", ["cart_lossy", "cart_outside", "fcc2_outside", "cart_mb11"])
+def test_c_seam_slab_partition_matches_python(name):
+    """pf_slab_partition (the cut pf_run_sim_devices uses; no device needed) == pffdtd_amd.slab's two rules."""
+    sd = cases.make_sd(name, "single")
+    for G in (1, 2, 3, 5):
+        assert engine.slab_partition(sd, G, even=True) == slab.partition(sd.Nx, G)
+        assert engine.slab_partition(sd, G, even=False) == slab.partition_weighted(sd, G)
+    with pytest.raises(engine.PfError):
+        engine.slab_partition(sd, sd.Nx)  # gpu_engine.h:682
