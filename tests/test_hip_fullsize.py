@@ -77,3 +77,27 @@ def test_kernel_families_agree_beyond_2p32_cells():
     import re
     m = re.search(r"variant 40: .* blocked launches (\d+)", r.stdout)
     assert m and int(m.group(1)) > 0, r.stdout[-1500:]  # the blocked pairs really ran
+
+
+def _tool(args, timeout=1500):
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    return subprocess.run([sys.executable, str(root / "tools" / args[0])] + args[1:], capture_output=True, text=True, timeout=timeout)
+
+
+def test_fp64_fcc_kernel_families_agree_at_1536_cubed():
+    """BASELINE configs[4] on one GPU: folded FCC fp64, stored grid 1536^3 = 0.84 x 2^32 cells, 58 GB of state -- the
+    64-bit index arithmetic of the fp64 13-point kernels (pitch 1536, 2.36e6-element planes, offsets beyond 2^31 BYTES
+    from plane 114 on, beyond 2^32 bytes from plane 228 on): the families agree on every cell."""
+    r = _tool(["big_grid_check.py", "--fcc", "--double", "1536", "1536", "1536", "6"])
+    assert r.returncode == 0 and "big-grid check OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.parametrize("name", ["ctk_cart_gpu", "mv_fcc_gpu"])
+def test_reference_configurations_at_full_size(name):
+    """BASELINE configs[1] (CTK 894x579x309, 7-point) and configs[2] (Musikverein 2852x552x850 folded, 13-point) built from
+    the reference's scene exports on this box: kernel families agree on every cell and receiver."""
+    r = _tool(["config_family_check.py", name, "10"])
+    assert r.returncode == 0 and "config family check OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]

@@ -58,7 +58,7 @@ def test_unsorted_lists_and_ring_flushes():
 @pytest.mark.parametrize("prec", ["single", "double"])
 def test_slabs_in_temporally_blocked_pairs(prec):
     """a box room wide enough for the two-steps-per-pass kernel, pairs forced in every slab (air_variant 40)"""
-    kw = dict(Nx=44, Ny=70, Nz=276, Nt=31, wall=3, Nm=1, Mb=3, src=[21, 30, 100], rcv=[[8, 9, 10], [36, 60, 250], [22, 35, 140]])
+    kw = dict(Nx=100, Ny=70, Nz=276, Nt=45, wall=3, Nm=1, Mb=3, src=[47, 30, 100], rcv=[[30, 25, 96], [66, 36, 110], [48, 35, 104], [47, 4, 101]])
     sim = synth.shoebox(**kw)
     sd = sim_data.SimData.from_sim(sim, prec)
     sd.scale_input()

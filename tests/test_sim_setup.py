@@ -62,3 +62,27 @@ def test_setup_to_engine_end_to_end(tmp_path):
         engine.run_sim(sd)
         assert np.abs(ref.u_out).max() > 0
         assert np.array_equal(sd.u_out, ref.u_out), prec
+
+
+@pytest.mark.gpu
+def test_musikverein_fcc_setup_to_engine_against_the_oracle(tmp_path):
+    """BASELINE configs[2] geometry (python/test_script_MV_fcc_gpu.py:30-38 at a coarse fmax): Musikverein export ->
+    sim_setup on the device (13-point FCC, 5 materials x 11 branches) -> fold + sort -> HIP engine, fp32 and fp64,
+    bit for bit against the CPU oracle on the same folder, run long enough that the wave reaches every receiver."""
+    import oracle
+    from pffdtd_amd import engine, sim_data
+    from pffdtd_amd.sim_setup import sim_setup
+    mats = scenes.write_materials(tmp_path / "materials")
+    folder, gpu = tmp_path / "sim", tmp_path / "gpu"
+    sim_setup(**scenes.setup_kwargs("mv_fcc_gpu", folder, mats, save_folder_gpu=gpu, compress=0, duration=0.12, PPW=5.0, fmax=420.0))
+    for prec in ("single", "double"):
+        sd = sim_data.SimData.from_folder(gpu, prec)
+        assert sd.fcc_flag == 2 and sd.Nx >= sd.Ny >= sd.Nz and sd.Nm == 5 and (np.asarray(sd.Mb) == 11).all()
+        sd.scale_input()
+        ref = sim_data.SimData.from_folder(gpu, prec)
+        ref.scale_input()
+        oracle.run_sim(ref)
+        engine.run_sim(sd)
+        heard = np.abs(ref.u_out).max(axis=1) > 0
+        assert heard.all(), f"{(~heard).sum()} of {heard.size} receiver nodes silent after {sd.Nt} steps"
+        assert np.array_equal(sd.u_out, ref.u_out), prec

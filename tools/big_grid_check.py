@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Grids beyond 2^32 cells: the interior-kernel families (blocked pairs, lean single steps, barrier-free, unfused) must
 agree bit for bit on EVERY cell and on the receivers (the oracle is too slow there).  The fields start from seeded random
-data, so every cell is live from step 0.   usage: tools/big_grid_check.py [Nx Ny Nz] [Nt]"""
+data, so every cell is live from step 0.   usage: tools/big_grid_check.py [--fcc] [--double] [Nx Ny Nz] [Nt]"""
 import sys
 import time
 from pathlib import Path
@@ -13,7 +13,8 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from pffdtd_amd import engine, sim_data, synth  # noqa: E402
 
 fcc = "--fcc" in sys.argv  # 13-point, folded: the sizes are the STORED grid
-argv = [a for a in sys.argv if a != "--fcc"]
+prec = "double" if "--double" in sys.argv else "single"
+argv = [a for a in sys.argv if a not in ("--fcc", "--double")]
 n = [int(v) for v in argv[1:4]] if len(argv) >= 4 else [2112, 1024, 1024]
 Nt = int(argv[4]) if len(argv) > 4 else 12
 t0 = time.time()
@@ -27,16 +28,18 @@ if fcc:
     synth.sort_sim(sim)
 else:
     sim = synth.shoebox(*n, Nt=Nt, Nm=2, Mb=[11, 3], src=src, rcv=rcv)
-sd = sim_data.SimData.from_sim(sim, "single", build_mask=False)
+sd = sim_data.SimData.from_sim(sim, prec, build_mask=False)
 assert [sd.Nx, sd.Ny, sd.Nz] == n, (sd.Nx, sd.Ny, sd.Nz)
 sd.scale_input()
-print(f"scene {n} = {np.prod(n)/2**32:.2f} x 2^32 cells, Nb={sd.Nb}, built in {time.time()-t0:.1f}s", flush=True)
-P = engine.grid_pitch(n[2], 4)
+print(f"scene {n} {prec} = {np.prod(n)/2**32:.2f} x 2^32 cells, Nb={sd.Nb}, built in {time.time()-t0:.1f}s", flush=True)
+rb = 4 if prec == "single" else 8
+tdt = torch.float32 if rb == 4 else torch.float64
+P = engine.grid_pitch(n[2], rb)
 shape = (n[0], n[1] * P)
 gen = torch.Generator(device="cuda")
 gen.manual_seed(11)
-init = [(torch.rand(shape, generator=gen, device="cuda") * 2 - 1) * 1e-3 for _ in range(2)]
-g = [torch.empty(shape, dtype=torch.float32, device="cuda") for _ in range(2)]
+init = [((torch.rand(shape, generator=gen, device="cuda", dtype=tdt) * 2 - 1) * 1e-3) for _ in range(2)]
+g = [torch.empty(shape, dtype=tdt, device="cuda") for _ in range(2)]
 ref_out, ref_g = None, None
 for v in ((0, 2, 5, 9) if fcc else (40, 0, 25, 4, 2)):  # 40 = blocked pairs forced, 0 = what the engine picks, 9 = naive
     for a, b in zip(g, init):
