@@ -96,7 +96,7 @@ typedef struct pf_opts {
                              checkerboard form (fcc_flag 1) whose existing nodes have even ix+iy+iz */
    int32_t debug;         /* tuning switches, 0 in production: 0x100 / 0x200 force 32- / 16-lane row segments in the
                              barrier-free kernels, 0x400 forces 64; 0x800 in-kernel rigid update from a cell-byte grid;
-                             0x2000 column-strip kernel also updates the boundary nodes inside its strips; 0x4000 single
+                             0x2000 column-strip kernel does rigid update AND branch ODEs of the boundary nodes inside its strips (default: rigid only, ODEs in a dense pass), 0x20000000: neither (list kernel visits every node); 0x4000 single
                              steps only (no temporally blocked pairs); 0x8000 no creation-time measurement (static
                              rules pick the interior kernel); bits 16-23 x chunk of the column-strip kernel;
                              0x10000000 keep a sliver z tile in the blocked kernel */

@@ -51,6 +51,8 @@ namespace {
 inline int64_t round_up(int64_t a, int64_t m) { return (a + m - 1) / m * m; }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// z pitch: rows start on 128-byte lines.  (Measured and dropped: one extra line on pitches that are a multiple of 4 KiB,
+// to spread a column's rows over more memory channels -- every kernel got slower, lean 2.31 -> 2.53 ms, 13-point 2.45 -> 2.58.)
 int64_t grid_pitch(int64_t Nz, int32_t real_bytes) { return round_up(Nz, 128 / real_bytes); }
 
 // DPP wave-shift semantics verified once per process on the device
@@ -158,6 +160,10 @@ template <typename Real> struct Engine : EngineBase {
    // the list kernel the floor / ceiling nodes of a box room cost half of the whole boundary pass)
    int32_t *zs_map = nullptr, *zs_rest = nullptr;         // strip cell -> boundary list position; the other nodes
    int64_t zs_nrest = 0;
+   int zs_mode = 0;                                       // 0: list kernel does them; 1: strip kernel, rigid + FD inline (debug 0x2000);
+                                                          // 2: strip kernel does the rigid update, k_fd_sel the branch ODEs (default)
+   int32_t *zs_fd = nullptr;                              // mode 2: the lossy nodes (indices into the lossy arrays) inside the strips
+   int64_t zs_nfd = 0;
    const int32_t *bnd_sel = nullptr;                      // launch_boundary visits bnd_sel[range] when set
    // energy diagnostic (pf_energy.h)
    Real *Lu = nullptr, *vh_old = nullptr, *u2in = nullptr;
@@ -176,7 +182,7 @@ template <typename Real> struct Engine : EngineBase {
       auto F = [](void *p) { if (p) hipFree(p); };
       for (Real *g : own_list) F(g); // state grids this engine allocated (u0/u1 unless external, the temporal-blocking spares)
       own_list.clear();
-      F(d_lossy); F(mask); F(mask_bn); F(cellb); F(zs_map); F(zs_rest); F(segstart); F(adj_dense); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
+      F(d_lossy); F(mask); F(mask_bn); F(cellb); F(zs_map); F(zs_rest); F(zs_fd); F(segstart); F(adj_dense); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
       F(d_beta); F(d_insig); F(d_mq); F(ub[0]); F(ub[1]); F(ub[2]); F(u2ba); F(vh1); F(gh1); F(ring);
       if (h_ring) hipHostFree(h_ring);
       for (auto &p : air_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -563,11 +569,15 @@ template <typename Real> struct Engine : EngineBase {
       }
       own_list.push_back(bufC); own_list.push_back(bufD);
       tb2 = true;
-      // Experiment (debug 0x2000, off by default): boundary nodes inside the column strips move from the list kernel to
-      // k_air_zstrip, which streams their lines anyway (in k_boundary the floor / ceiling nodes of a box room cost half of
-      // the pass: 0.30 of 0.63 ms at 1024^3).  Bit-identical, but slower: the FD branches run on the few lanes per wave
-      // that hold a node (2.92 vs 2.59 ms per step), so the list kernel keeps them.
-      if (Nb > 0 && !tb_xr.empty() && (op.debug & 0x2000)) {
+      // Boundary nodes inside the column strips are updated by k_air_zstrip, which streams their lines anyway and holds
+      // their six neighbours in registers (in k_boundary the floor / ceiling nodes of a box room -- stride-P neighbours,
+      // one 128-byte line of u1 and of u0 per two nodes -- cost half of the pass: 0.30 of 0.63 ms at 1024^3).  The strip
+      // kernel does the RIGID update only and leaves the result in u0b[li]; the branch ODEs of the lossy ones follow in
+      // k_fd_sel, dense over the compact arrays (mode 2).  Doing the ODEs inside the strip kernel as well (mode 1, debug
+      // 0x2000) is bit-identical but slower: they run on the few lanes per wave that hold a node (2.92 vs 2.59 ms per step).
+      // debug 0x20000000: mode 0, the list kernel visits every boundary node (the round-1 arrangement).
+      zs_mode = (op.debug & 0x2000) ? 1 : ((op.debug & 0x20000000) ? 0 : 2);
+      if (Nb > 0 && !tb_xr.empty() && zs_mode > 0 && Nbl < ((int64_t)1 << 31)) {
          const int xb = tb_xr.front().first, xe = tb_xr.back().second;
          constexpr int V = pf::VecOf<Real>::V;
          const int nl = tbz0 / V, nv = nl + (int)(P - tbz1) / V;
@@ -585,7 +595,16 @@ template <typename Real> struct Engine : EngineBase {
          zs_nrest = (int64_t)rest.size();
          if ((rc = upload(&zs_map, zm.data(), (int64_t)zm.size()))) return rc;
          if ((rc = upload(&zs_rest, rest.data(), zs_nrest))) return rc;
-      }
+         if (zs_mode == 2) {
+            std::vector<int32_t> hl(Nb), fd;
+            HIPCHK(hipMemcpy(hl.data(), d_lossy, Nb * sizeof(int32_t), hipMemcpyDeviceToHost));
+            std::vector<uint8_t> in_rest(Nb, 0);
+            for (int32_t nb : rest) in_rest[nb] = 1;
+            for (int64_t nb = 0; nb < Nb; nb++) if (!in_rest[nb] && hl[nb] >= 0) fd.push_back(hl[nb]);
+            zs_nfd = (int64_t)fd.size();
+            if ((rc = upload(&zs_fd, fd.data(), zs_nfd))) return rc;
+         }
+      } else zs_mode = 0;
       return PF_OK;
    }
    int set_spares(void *g2, void *g3) override {
@@ -665,6 +684,8 @@ template <typename Real> struct Engine : EngineBase {
             bufC = bufD = nullptr;
             if (zs_map) { hipFree(zs_map); zs_map = nullptr; }
             if (zs_rest) { hipFree(zs_rest); zs_rest = nullptr; }
+            if (zs_fd) { hipFree(zs_fd); zs_fd = nullptr; }
+            zs_mode = 0;
          } else {
             HIPCHK(hipMemsetAsync(bufC, 0, npad * sizeof(Real), s_main));
             HIPCHK(hipMemsetAsync(bufD, 0, npad * sizeof(Real), s_main));
@@ -718,7 +739,7 @@ template <typename Real> struct Engine : EngineBase {
             zp.zmap = zs_map; zp.adjv = d_adj; zp.lossy = d_lossy; zp.u0b = ub[0]; zp.u2b = ub[2];
             zp.ssaf = d_ssaf; zp.beta = d_beta; zp.mat = d_mat; zp.Mb = d_Mb;
             zp.mq = d_mq; zp.vh1 = vh1; zp.gh1 = gh1;
-            zp.lo2 = lo2; zp.sl2 = sl2; zp.Nbl = Nbl;
+            zp.lo2 = lo2; zp.sl2 = sl2; zp.Nbl = Nbl; zp.fd_split = zs_mode == 2 ? 1 : 0;
          }
          const int64_t nthreads = (int64_t)(zp.zl / V + (P - zp.zr) / V) * (Ny - 2);
          const int xchunk = (op.debug >> 16) & 0xff ? (op.debug >> 16) & 0xff : 16;
@@ -744,6 +765,7 @@ template <typename Real> struct Engine : EngineBase {
       launch_shell(s);
       if (op.timing) { hipEventRecord(eva.second, s); air_ev.push_back(eva); eva = get_ev(); }
       launch_rigid(s, bnd);
+      launch_fd_sel(s);
       launch_fd(s, {0, Nbl});
       launch_io(s, n, true, {0, Ns});
       { Real *t = ub[2]; ub[2] = ub[1]; ub[1] = ub[0]; ub[0] = t; }
@@ -754,6 +776,7 @@ template <typename Real> struct Engine : EngineBase {
       launch_shell(s);
       if (op.timing) { hipEventRecord(eva.second, s); air_ev.push_back(eva); }
       launch_rigid(s, bnd);
+      launch_fd_sel(s);
       bnd_sel = nullptr;
       launch_fd(s, {0, Nbl});
       launch_io(s, n + 1, true, {0, Ns});
@@ -1066,6 +1089,12 @@ template <typename Real> struct Engine : EngineBase {
       if (boundary_fused()) return; // done by launch_boundary
       if (r.e > r.b)
          hipLaunchKernelGGL(pf::k_fd_boundary<Real>, dim3((unsigned)cdiv(r.e - r.b, 128)), dim3(128), 0, s, u0, d_bnl, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq, d_beta, vh1, gh1, lo2, Nbl, r.b, r.e);
+   }
+   // branch ODEs of the lossy nodes whose rigid update the column-strip kernel has just done (zs_mode 2)
+   void launch_fd_sel(hipStream_t s) {
+      if (zs_mode != 2 || !bnd_sel || zs_nfd <= 0) return;
+      hipLaunchKernelGGL(pf::k_fd_sel<Real>, dim3((unsigned)cdiv(zs_nfd, 128)), dim3(128), 0, s, u0, d_bnl, zs_fd, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq,
+                         d_beta, vh1, gh1, lo2, Nbl, zs_nfd);
    }
    // receivers on/off + a range of the (sorted) source list
    void launch_io(hipStream_t s, int64_t n, bool receivers, Range src, const int64_t *ctr = nullptr) {

@@ -696,6 +696,21 @@ __device__ __forceinline__ Real fd_node_update(Real p, int32_t li, Real *__restr
    return u;
 }
 
+// ---- FD update of a selection of lossy nodes whose rigid update has been done elsewhere (k_air_zstrip, which holds the
+// six neighbours of its boundary nodes in registers): the rigid result waits in u0b[li]; the final value goes back to
+// u0b[li] and to the grid.  Dense over the compact arrays: no gathers from the grid, one scattered store per node.
+template <typename Real>
+__global__ void k_fd_sel(Real *u0, const int64_t *__restrict__ idx_l, const int32_t *__restrict__ sel, Real *__restrict__ u0b,
+                         const Real *__restrict__ u2b, const Real *__restrict__ ssaf, const int8_t *__restrict__ mat,
+                         const int8_t *__restrict__ Mb, const MatQuadT<Real> *__restrict__ mq, const Real *__restrict__ beta,
+                         Real *__restrict__ vh1, Real *__restrict__ gh1, Real lo2, int64_t Nbl, int64_t n) {
+   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (t >= n) return;
+   const int32_t li = sel[t];
+   const Real p = u0b[li];
+   u0[idx_l[li]] = fd_node_update<Real>(p, li, u0b, u2b, ssaf, mat, Mb, mq, beta, vh1, gh1, lo2, Nbl);
+}
+
 // ---- fused boundary pass: rigid update of every boundary node + FD update of the lossy ones in one visit ----------
 // (cpu_engine.h:234-287 then :290-301,363-405 for the same node: identical arithmetic, the gather / scatter of u0
 // between the two is a register).  lossy[nb] = index into the lossy-node arrays, or -1 for a rigid node; lossy

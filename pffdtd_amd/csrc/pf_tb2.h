@@ -155,6 +155,8 @@ template <typename Real> struct ZStripParams {
    Real *vh1, *gh1;
    Real lo2, sl2;
    int64_t Nbl;
+   int32_t fd_split;         // 1: lossy nodes get their RIGID update here (value left in u0b[li] and in the grid); the
+                             // branch ODEs follow in k_fd_sel, dense over the compact lossy arrays
 };
 
 template <typename Real>
@@ -231,7 +233,10 @@ __global__ __launch_bounds__(256) void k_air_zstrip(ZStripParams<Real> zp, Real 
                   p = p + w * nbk[k];
                }
                const int32_t li = zp.lossy[nb];
-               if (li >= 0) p = fd_node_update<Real>(p, li, zp.u0b, zp.u2b, zp.ssaf, zp.mat, zp.Mb, zp.mq, zp.beta, zp.vh1, zp.gh1, zp.lo2, zp.Nbl);
+               if (li >= 0) {
+                  if (zp.fd_split) zp.u0b[li] = p;
+                  else p = fd_node_update<Real>(p, li, zp.u0b, zp.u2b, zp.ssaf, zp.mat, zp.Mb, zp.mq, zp.beta, zp.vh1, zp.gh1, zp.lo2, zp.Nbl);
+               }
             }
          }
          o[i] = p;

@@ -103,16 +103,17 @@ def test_blocked_steps_long_run():
     assert np.array_equal(out, ref.u_out)
 
 
-def test_strip_kernel_can_update_its_boundary_nodes():
-    """debug 0x2000: the column-strip kernel also does the rigid + FD update of the boundary nodes inside its strips
-    (an experiment that stays off by default: slower).  Same bits."""
+def test_strip_kernel_boundary_modes_give_the_same_bits():
+    """Boundary nodes inside the column strips: by default the strip kernel does their rigid update and k_fd_sel the branch
+    ODEs (dense); debug 0x2000 = both inside the strip kernel; 0x20000000 = neither (the list kernel visits every node, the
+    round-1 arrangement).  Same bits as the oracle in all three, with a source in a corner so that every wall is live."""
     sim = scene([18, 8, 12], Nt=18)
     ref = sim_data.SimData.from_sim(sim, "single")
     ref.scale_input()
     oracle.run_sim(ref)
-    for dbg in (0x2000, 0x2000 | (1 << 16)):
+    for dbg in (0, 1 << 16, 0x2000, 0x2000 | (1 << 16), 0x20000000):
         out, _, tm = run(sim, 40, debug=dbg)
-        assert tm["tb2_launches"] > 0 and np.array_equal(out, ref.u_out)
+        assert tm["tb2_launches"] > 0 and np.array_equal(out, ref.u_out), hex(dbg)
 
 
 @pytest.mark.parametrize("src,kw", [(None, {}), ([3, 30, 140], dict(n=(36, 72, 280), wall=6)), ([18, 8, 12], dict(n=(37, 67, 283))),
@@ -126,7 +127,7 @@ def test_blocked_steps_in_double_precision(src, kw):
     oracle.run_sim(ref)
     assert np.abs(ref.u_out).max() > 0
     _, base_g, _ = run(sim, 26, prec="double")
-    for variant, dbg in ((41, 0), (40, 0), (40, 0x2000)):
+    for variant, dbg in ((41, 0), (40, 0), (40, 0x2000), (40, 0x20000000)):
         out, g, tm = run(sim, variant, prec="double", readout_chunk=8, debug=dbg)
         assert np.array_equal(out, ref.u_out), (variant, dbg)
         for a, b in zip(g, base_g):
