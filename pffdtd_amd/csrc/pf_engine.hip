@@ -153,7 +153,12 @@ template <typename Real> struct Engine : EngineBase {
    // planes per x chunk of k_tb2_reg: 12-20 are equally fast, 24 is 1 % and 48 is 6 % slower although longer chunks
    // re-read fewer prologue planes (1024^3, tools/tb2_probe.py); PFFDTD_TB2_CHUNK overrides for such sweeps
    int tb2_chunk = 16;
-   std::vector<std::pair<int, int>> tb_xr;                // its x ranges (planes next to a source are cut out)
+   std::vector<std::pair<int, int>> tb_xr;                // its x range (empty: no box)
+   // the box is cut into tiles (x chunk x rows of one workgroup x core columns of one row segment); tiles with a boundary
+   // node or a source within one cell of their core ("dirty") take single steps (k_tb1_tile), the others pairs
+   int tb_lw = 64, tb_chunk = 16, tb_nxc = 0, tb_nyt = 0, tb_nzt = 0;
+   int32_t *tb_clean = nullptr, *tb_dirty = nullptr;      // tile ids (xc*nyt + yt)*nzt + zt
+   int64_t tb_nclean = 0, tb_ndirty = 0, tb_clean_cells = 0;
    const Real *u0_src = nullptr;                          // out-of-place single-step launches read u^{n-1} here
    int lean_yt0 = 0, lean_nyt = -1;                       // row-strip launches of the lean kernel (-1: all tiles)
    // boundary nodes inside the column strips are updated by k_air_zstrip itself (it streams their lines anyway; in
@@ -182,7 +187,7 @@ template <typename Real> struct Engine : EngineBase {
       auto F = [](void *p) { if (p) hipFree(p); };
       for (Real *g : own_list) F(g); // state grids this engine allocated (u0/u1 unless external, the temporal-blocking spares)
       own_list.clear();
-      F(d_lossy); F(mask); F(mask_bn); F(cellb); F(zs_map); F(zs_rest); F(zs_fd); F(segstart); F(adj_dense); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
+      F(d_lossy); F(mask); F(mask_bn); F(cellb); F(zs_map); F(zs_rest); F(zs_fd); F(tb_clean); F(tb_dirty); F(segstart); F(adj_dense); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
       F(d_beta); F(d_insig); F(d_mq); F(ub[0]); F(ub[1]); F(ub[2]); F(u2ba); F(vh1); F(gh1); F(ring);
       if (h_ring) hipHostFree(h_ring);
       for (auto &p : air_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -516,46 +521,99 @@ template <typename Real> struct Engine : EngineBase {
       if (fcc || !(lean || vg) || lean_rigid || v1_rigb || op.energy || (op.debug & 0x4000)) return PF_OK; // 0x4000: single steps only
       if (!(vbase == 0 || vbase == 40 || vbase == 41) || op.numerics != PF_NUM_CPU_EXACT || !use_dpp) return PF_OK;
       if (Nb > 0 && !boundary_fused()) return PF_OK;
-      int64_t dmax = 0; // depth of the deepest boundary node below the nearest grid face (slab faces towards a neighbour are no faces)
-      const int64_t NzNy = Nz * Ny, INF = (int64_t)1 << 40;
+      // Margins of the box: three cells off every grid face (the ABC cells sit at index 1 and the box must stay two cells
+      // away from anything that is not a plain air update), deeper where a wall layer hugs the face -- a face whose plane at
+      // depth d <= 12 is at least half boundary nodes pushes the box to depth d + 2 (shoebox rooms: walls at depth 2-3,
+      // box from depth 5).  Whatever geometry remains inside the box is dealt with tile by tile below.
+      const int64_t NzNy = Nz * Ny;
+      int64_t hist[6][16] = {};
       for (int64_t i = 0; i < Nb; i++) {
          const int64_t ii = sd.bn_ixyz[i], ix = ii / NzNy, iy = (ii / Nz) % Ny, iz = ii % Nz;
-         const int64_t d = std::min({op.slab_first ? ix : INF, op.slab_last ? Nx - 1 - ix : INF, iy, Ny - 1 - iy, iz, Nz - 1 - iz});
-         dmax = std::max(dmax, d);
+         const int64_t d[6] = {ix, Nx - 1 - ix, iy, Ny - 1 - iy, iz, Nz - 1 - iz};
+         for (int f = 0; f < 6; f++) if (d[f] < 16) hist[f][d[f]]++;
       }
-      const int m = (int)std::max<int64_t>(dmax + 2, 3), mz = (m + 3) / 4 * 4;
+      auto margin = [&](int f, int64_t area) {
+         int m = 3;
+         for (int d = 0; d <= 12; d++) if (hist[f][d] * 2 >= area) m = std::max(m, d + 2);
+         return m;
+      };
+      constexpr int V = pf::VecOf<Real>::V;
       // towards a neighbouring slab the box stops three planes short of the ghost plane: planes 1-2 / Nx-3..Nx-2 are the
       // edge planes of a split-phase pair (plane 1 needs the neighbour's data between the two steps; with plane 2 on the
       // edge stream as well the box kernel never reads a ghost plane, so the main stream never waits for an exchange)
-      tbx0 = op.slab_first ? m : 3; tbx1 = op.slab_last ? (int)Nx - m : (int)Nx - 3;
-      tby0 = m; tby1 = (int)Ny - m; tbz0 = mz; tbz1 = (int)((Nz - mz) / 4 * 4);
-      { // a last z tile with only a sliver of core columns costs a whole workgroup per (row tile, x chunk) and re-reads
-         // lines the right column strip streams anyway: leave up to two 128-byte lines of columns to the strip instead
-         const int WC = 62 * pf::VecOf<Real>::V, nz = tbz1 - tbz0, rem = nz % WC;
-         if (!(op.debug & 0x10000000) && nz > WC && rem > 0 && rem * (int)sizeof(Real) <= 256) tbz1 -= rem;
+      tbx0 = op.slab_first ? margin(0, NzNy) : 3; tbx1 = (int)Nx - (op.slab_last ? margin(1, NzNy) : 3);
+      tby0 = margin(2, Nx * Nz); tby1 = (int)Ny - margin(3, Nx * Nz);
+      const int mz0 = (margin(4, Nx * Ny) + 3) / 4 * 4, mz1 = (margin(5, Nx * Ny) + 3) / 4 * 4;
+      tbz0 = mz0;
+      // row segments of 64 / 32 / 16 lanes (a wave stacks 1 / 2 / 4 of them in y): the width that needs the fewest lanes
+      // for the box's z range (ties: the widest).  A last z tile with only a sliver of core columns costs a whole
+      // workgroup per (row tile, x chunk) and re-reads lines the right column strip streams anyway: up to two 128-byte
+      // lines of columns are left to the strip instead.
+      {
+         int64_t best = -1;
+         for (int lw : {64, 32, 16}) {
+            if (op.debug & 0x300) { if (lw != ((op.debug & 0x100) ? 32 : 16)) continue; } // tuning override (as pick_lw)
+            const int TC = (lw - 2) * V;
+            int z1 = (int)((Nz - mz1) / 4 * 4);
+            const int nz = z1 - tbz0, rem = nz % TC;
+            if (!(op.debug & 0x10000000) && nz > TC && rem > 0 && rem * (int)sizeof(Real) <= 256) z1 -= rem;
+            if (z1 - tbz0 < TC / 2) continue;
+            const int64_t lanes = cdiv(z1 - tbz0, TC) * lw;
+            if (best < 0 || lanes < best) { best = lanes; tb_lw = lw; tbz1 = z1; }
+         }
+         if (best < 0) return PF_OK; // no room for a single row segment
       }
       if (vbase == 41) tbx1 = tbx0; // driver test: everything goes through the out-of-place single-step path
       tb_xr.clear();
-      if (tbx1 - tbx0 >= 16 && tby1 - tby0 >= 48 && tbz1 - tbz0 >= 62 * pf::VecOf<Real>::V) {
-         std::vector<int> cut; // planes the box must leave to the single-step kernels: sources (+-1 plane)
-         for (int64_t i = 0; i < Ns; i++) { const int ix = (int)(sd.in_ixyz[i] / NzNy); for (int d = -1; d <= 1; d++) cut.push_back(ix + d); }
-         std::sort(cut.begin(), cut.end());
-         int xa = tbx0;
-         for (int c : cut) {
-            if (c < xa || c >= tbx1) continue;
-            if (c - xa >= 8) tb_xr.push_back({xa, c});
-            xa = c + 1;
-         }
-         if (tbx1 - xa >= 8) tb_xr.push_back({xa, tbx1});
-      }
+      const int TC = (tb_lw - 2) * V, TR = 12 * (64 / tb_lw);
       int64_t vol = 0;
-      for (auto &r : tb_xr) vol += (int64_t)(r.second - r.first) * (tby1 - tby0) * (tbz1 - tbz0);
-      if (vbase == 40 && vol == 0) return set_err(PF_ERR_ARG, "air_variant 40 (temporal blocking) requested but the scene has no boundary-free box");
+      if (tbx1 - tbx0 >= 16 && tby1 - tby0 >= 24 && tbz1 - tbz0 >= TC / 2) {
+         tb_xr.push_back({tbx0, tbx1});
+         const int np = tbx1 - tbx0;
+         tb_chunk = (int)cdiv(np, std::max<int64_t>(cdiv(np, tb2_chunk), 1)); // ~16-plane chunks, even split (tools/tb2_probe.py)
+         tb_nxc = (int)cdiv(np, tb_chunk); tb_nyt = (int)cdiv(tby1 - tby0, TR); tb_nzt = (int)cdiv(tbz1 - tbz0, TC);
+         const int64_t ntile = (int64_t)tb_nxc * tb_nyt * tb_nzt;
+         if (ntile >= ((int64_t)1 << 31)) return PF_OK;
+         std::vector<uint8_t> dirty((size_t)ntile, 0);
+         auto mark = [&](int64_t ii) { // every tile whose core, grown by one cell, holds this cell
+            const int ix = (int)(ii / NzNy), iy = (int)((ii / Nz) % Ny), iz = (int)(ii % Nz);
+            auto span = [](int c, int org, int size, int n, int end, int &lo, int &hi) {
+               if (c < org - 1 || c > end) return false;
+               lo = (c - 1 - org) >= 0 ? (c - 1 - org) / size : 0;
+               hi = std::min((c + 1 - org) / size, n - 1);
+               return lo <= hi;
+            };
+            int x0, x1, y0, y1, z0, z1;
+            if (!span(ix, tbx0, tb_chunk, tb_nxc, tbx1, x0, x1) || !span(iy, tby0, TR, tb_nyt, tby1, y0, y1) ||
+                !span(iz, tbz0, TC, tb_nzt, tbz1, z0, z1)) return;
+            for (int a = x0; a <= x1; a++) for (int b = y0; b <= y1; b++) for (int c = z0; c <= z1; c++)
+               dirty[((size_t)a * tb_nyt + b) * tb_nzt + c] = 1;
+         };
+         for (int64_t i = 0; i < Nb; i++) mark(sd.bn_ixyz[i]);
+         for (int64_t i = 0; i < Ns; i++) mark(sd.in_ixyz[i]); // (the source is added between the two steps)
+         std::vector<int32_t> cl, di;
+         for (int64_t t = 0; t < ntile; t++) {
+            if (dirty[t]) { di.push_back((int32_t)t); continue; }
+            cl.push_back((int32_t)t);
+            const int zt = (int)(t % tb_nzt), yt = (int)((t / tb_nzt) % tb_nyt), xc = (int)(t / ((int64_t)tb_nzt * tb_nyt));
+            vol += (int64_t)(std::min(tbx0 + (xc + 1) * tb_chunk, tbx1) - (tbx0 + xc * tb_chunk)) *
+                   (std::min(tby0 + (yt + 1) * TR, tby1) - (tby0 + yt * TR)) * (std::min(tbz0 + (zt + 1) * TC, tbz1) - (tbz0 + zt * TC));
+         }
+         tb_nclean = (int64_t)cl.size(); tb_ndirty = (int64_t)di.size(); tb_clean_cells = vol;
+         int rc;
+         if (tb_clean) { hipFree(tb_clean); tb_clean = nullptr; }
+         if (tb_dirty) { hipFree(tb_dirty); tb_dirty = nullptr; }
+         if ((rc = upload(&tb_clean, cl.data(), tb_nclean))) return rc;
+         if ((rc = upload(&tb_dirty, di.data(), tb_ndirty))) return rc;
+         if (tb_nclean == 0) tb_xr.clear();
+      }
+      if (vbase == 40 && vol == 0) return set_err(PF_ERR_ARG, "air_variant 40 (temporal blocking) requested but the scene has no boundary-free tiles");
       // auto: the shell costs grow with the perimeter of the y-z cross-section, the gain with its area -- measured on
-      // MI355X: 512^2 planes -4.5 %, 768^2 +9 %, 1024^2 +13 %; and two extra grids must be worth it
-      // (single-domain engines then time a blocked pair against the single-step kernels at creation: autotune())
-      if (vbase == 0 && ((double)vol < 0.6 * (double)(Nx * Ny * Nz) || tby1 - tby0 < 300 || tbz1 - tbz0 < 300)) return PF_OK;
-      if (vbase == 0 && !single && (tby1 - tby0 < 600 || tbz1 - tbz0 < 600)) return PF_OK;
+      // MI355X: 512^2 planes -4.5 %, 768^2 +9 %, 1024^2 +13 % for a box room; and two extra grids must be worth it.
+      // Single-domain engines then time a blocked pair against the single-step kernels at creation (autotune()), so the
+      // static rule only has to exclude the hopeless cases; slab engines have no such measurement and keep the strict one.
+      if (vbase == 0 && single && ((double)vol < 0.35 * (double)(Nx * Ny * Nz) || tby1 - tby0 < 100 || tbz1 - tbz0 < 100)) return PF_OK;
+      if (vbase == 0 && !single && ((double)vol < 0.6 * (double)(Nx * Ny * Nz) || tby1 - tby0 < 600 || tbz1 - tbz0 < 600)) return PF_OK;
       tb2_geom = true;
       if (!single) return PF_OK; // slab engines wait for pf_engine_set_spares (all four grids must be the caller's)
       int rc;
@@ -696,21 +754,34 @@ template <typename Real> struct Engine : EngineBase {
       if (own && scr) hipFree(scr);
       return PF_OK;
    }
+   pf::Tb2Params tile_params() const {
+      pf::Tb2Params tp{};
+      tp.plane = plane; tp.Nx = (int)Nx; tp.Ny = (int)Ny; tp.Nz = (int)Nz; tp.P = (int)P;
+      tp.x_begin = tbx0; tp.x_end = tbx1; tp.y_begin = tby0; tp.y_end = tby1; tp.z_begin = tbz0; tp.z_end = tbz1;
+      tp.chunk = tb_chunk; tp.nxc = tb_nxc; tp.nyt = tb_nyt; tp.nzt = tb_nzt;
+      return tp;
+   }
+   // two steps of the clean tiles
    void launch_tb2(hipStream_t s, const Real *A, const Real *B, Real *C, Real *D) {
-      constexpr int V = pf::VecOf<Real>::V, WC = 64 * V - 2 * V; // core columns of a wave (lanes 1..62)
-      for (auto &r : tb_xr) {
-         pf::Tb2Params tp{};
-         tp.A = A; tp.B = B; tp.C = C; tp.D = D;
-         tp.plane = plane; tp.Nx = (int)Nx; tp.Ny = (int)Ny; tp.Nz = (int)Nz; tp.P = (int)P;
-         tp.x_begin = r.first; tp.x_end = r.second;
-         tp.y_begin = tby0; tp.y_end = tby1; tp.z_begin = tbz0; tp.z_end = tbz1;
-         const int np = r.second - r.first;
-         tp.chunk = (int)cdiv(np, std::max<int64_t>(cdiv(np, tb2_chunk), 1)); // ~16-plane chunks, even split (tools/tb2_probe.py)
-         tp.nxc = (int)cdiv(np, tp.chunk);
-         tp.nzt = (int)cdiv(tbz1 - tbz0, WC);
-         tp.nyt = (int)cdiv(tby1 - tby0, 12);
-         hipLaunchKernelGGL((pf::k_tb2_reg<Real, 3, 4, false>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(256), 0, s, tp, a1, a2);
-      }
+      if (tb_xr.empty() || tb_nclean <= 0) return;
+      pf::Tb2Params tp = tile_params();
+      tp.A = A; tp.B = B; tp.C = C; tp.D = D;
+      tp.tiles = tb_ndirty > 0 ? tb_clean : nullptr; // all clean: the dense order (identical to the list's)
+      const dim3 g((uint32_t)tb_nclean), b(256);
+      if (tb_lw == 32) hipLaunchKernelGGL((pf::k_tb2_reg<Real, 3, 4, false, 32>), g, b, 0, s, tp, a1, a2);
+      else if (tb_lw == 16) hipLaunchKernelGGL((pf::k_tb2_reg<Real, 3, 4, false, 16>), g, b, 0, s, tp, a1, a2);
+      else hipLaunchKernelGGL((pf::k_tb2_reg<Real, 3, 4, false, 64>), g, b, 0, s, tp, a1, a2);
+   }
+   // one out-of-place step of the dirty tiles: u1, (u0_src old) -> u0
+   void launch_dirty_tiles(hipStream_t s) {
+      if (tb_xr.empty() || tb_ndirty <= 0) return;
+      pf::Tb2Params tp = tile_params();
+      tp.A = u0_src ? u0_src : u0; tp.B = u1; tp.C = u0; tp.D = nullptr;
+      tp.tiles = tb_dirty; tp.mask = mask;
+      const dim3 g((uint32_t)tb_ndirty), b(256);
+      if (tb_lw == 32) hipLaunchKernelGGL((pf::k_tb1_tile<Real, 3, 4, 32>), g, b, 0, s, tp, a1, a2);
+      else if (tb_lw == 16) hipLaunchKernelGGL((pf::k_tb1_tile<Real, 3, 4, 16>), g, b, 0, s, tp, a1, a2);
+      else hipLaunchKernelGGL((pf::k_tb1_tile<Real, 3, 4, 64>), g, b, 0, s, tp, a1, a2);
    }
    // one out-of-place single step of everything outside the box: u1 -> (u0_src old) -> u0
    void launch_shell(hipStream_t s) { launch_shell(s, 1, (int)Nx - 1); }
@@ -746,6 +817,7 @@ template <typename Real> struct Engine : EngineBase {
          hipLaunchKernelGGL(pf::k_air_zstrip<Real>, dim3((unsigned)cdiv(nthreads, 256), (unsigned)cdiv(xe - xb, xchunk)), dim3(256), 0, s, zp,
                             a1, a2, l, xchunk);
       }
+      launch_dirty_tiles(s); // ... and the tiles of the box that hold geometry or a source
    }
    // steps n and n+1 in one go; the state moves from (u0, u1) to (bufC, bufD), which swap roles with them
    int step_pair(int64_t n) {
@@ -1409,13 +1481,11 @@ template <typename Real> struct Engine : EngineBase {
       for (auto &p : tb2_ev) {
          float ms = 0;
          HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));
-         tm.tb2_ms_total += ms; tm.tb2_launches += (int64_t)tb_xr.size(); // one kernel launch per x range
+         tm.tb2_ms_total += ms; tm.tb2_launches += 1;
          ev_pool.push_back(p);
       }
       tb2_ev.clear();
-      tm.tb2_cells = 0;
-      for (auto &r : tb_xr) tm.tb2_cells += (int64_t)(r.second - r.first) * (tby1 - tby0) * (tbz1 - tbz0);
-      if (!tb_xr.empty()) tm.tb2_cells /= (int64_t)tb_xr.size(); // per launch, on average
+      tm.tb2_cells = tb_clean_cells;
       for (auto &p : step_ev) {
          float ms = 0;
          HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));

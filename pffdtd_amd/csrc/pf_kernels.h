@@ -612,51 +612,11 @@ __global__ void k_rigid(const Real *__restrict__ u1, Real *__restrict__ u0, cons
 // gather + ODE update + scatter in one pass; branch states are SoA [m*Nbl + nb] so that lanes coalesce.
 template <typename Real> struct MatQuadT { Real b, bd, bDh, bFh; };
 
-template <typename Real>
-__global__ void k_fd_boundary(Real *__restrict__ u0, const int64_t *__restrict__ idx, Real *__restrict__ u0b,
-                              const Real *__restrict__ u2b, const Real *__restrict__ ssaf,
-                              const int8_t *__restrict__ mat, const int8_t *__restrict__ Mb,
-                              const MatQuadT<Real> *__restrict__ mq, const Real *__restrict__ beta,
-                              Real *__restrict__ vh1, Real *__restrict__ gh1, Real lo2, int64_t Nbl, int64_t begin,
-                              int64_t end) {
-   const int64_t nb = begin + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-   if (nb >= end) return;
-   const Real one = 1.0, two = 2.0;
-   const int32_t k = mat[nb];
-   const int M = Mb[k];
-   const Real sf = ssaf[nb];
-   const Real g = lo2 * sf * beta[k];
-   const Real fac = two * lo2 * sf / (one + g);
-   const int64_t ii = idx[nb];
-   Real u = u0[ii];
-   const Real u2 = u2b[nb];
-   u = (u + g * u2) / (one + g);
-   Real v1[12], g1[12];
-#pragma unroll
-   for (int m = 0; m < 12; m++) {
-      if (m < M) {
-         const MatQuadT<Real> q = mq[k * 12 + m];
-         v1[m] = __builtin_nontemporal_load(&vh1[(int64_t)m * Nbl + nb]);
-         g1[m] = __builtin_nontemporal_load(&gh1[(int64_t)m * Nbl + nb]);
-         u -= fac * (two * q.bDh * v1[m] - q.bFh * g1[m]);
-      }
-   }
-   const Real du = u - u2;
-#pragma unroll
-   for (int m = 0; m < 12; m++) {
-      if (m < M) {
-         const MatQuadT<Real> q = mq[k * 12 + m];
-         const Real v0 = q.b * du + q.bd * v1[m] - two * q.bFh * g1[m];
-         __builtin_nontemporal_store(g1[m] + (v0 + v1[m]) / two, &gh1[(int64_t)m * Nbl + nb]);
-         __builtin_nontemporal_store(v0, &vh1[(int64_t)m * Nbl + nb]);
-      }
-   }
-   u0b[nb] = u;
-   u0[ii] = u;
-}
-
 // ---- FD (RLC-branch) update of one lossy node, cpu_engine.h:363-405: p = the node's value after the rigid update ------
-// (shared by k_boundary and the column-strip kernel of pf_tb2.h, so that both produce the same bits)
+// (shared by k_boundary, k_fd_boundary, k_fd_sel and the column-strip kernel of pf_tb2.h, so that all produce the same bits)
+// All branch-state and coefficient loads are issued up front (their addresses do not depend on the arithmetic): with the
+// loads inside the accumulation loop every branch cost a memory round trip and the list kernels ran latency-bound
+// (k_fd_sel 2.6 TB/s); the arithmetic keeps the reference's order.
 template <typename Real>
 __device__ __forceinline__ Real fd_node_update(Real p, int32_t li, Real *__restrict__ u0b, const Real *__restrict__ u2b,
                                                const Real *__restrict__ ssaf, const int8_t *__restrict__ mat,
@@ -666,34 +626,51 @@ __device__ __forceinline__ Real fd_node_update(Real p, int32_t li, Real *__restr
    const Real two = 2.0, one = 1.0;
    const int32_t k = mat[li];
    const int M = Mb[k];
+   Real v1[12], g1[12];
+   MatQuadT<Real> q[12];
+#pragma unroll
+   for (int m = 0; m < 12; m++) {
+      if (m < M) {
+         v1[m] = __builtin_nontemporal_load(&vh1[(int64_t)m * Nbl + li]);
+         g1[m] = __builtin_nontemporal_load(&gh1[(int64_t)m * Nbl + li]);
+         q[m] = mq[k * 12 + m];
+      }
+   }
    const Real sf = ssaf[li];
    const Real g = lo2 * sf * beta[k];
    const Real fac = two * lo2 * sf / (one + g);
    Real u = p;
    const Real u2 = u2b[li];
    u = (u + g * u2) / (one + g);
-   Real v1[12], g1[12];
 #pragma unroll
-   for (int m = 0; m < 12; m++) {
-      if (m < M) {
-         const MatQuadT<Real> q = mq[k * 12 + m];
-         v1[m] = __builtin_nontemporal_load(&vh1[(int64_t)m * Nbl + li]);
-         g1[m] = __builtin_nontemporal_load(&gh1[(int64_t)m * Nbl + li]);
-         u -= fac * (two * q.bDh * v1[m] - q.bFh * g1[m]);
-      }
-   }
+   for (int m = 0; m < 12; m++)
+      if (m < M) u -= fac * (two * q[m].bDh * v1[m] - q[m].bFh * g1[m]);
    const Real du = u - u2;
 #pragma unroll
    for (int m = 0; m < 12; m++) {
       if (m < M) {
-         const MatQuadT<Real> q = mq[k * 12 + m];
-         const Real v0 = q.b * du + q.bd * v1[m] - two * q.bFh * g1[m];
+         const Real v0 = q[m].b * du + q[m].bd * v1[m] - two * q[m].bFh * g1[m];
          __builtin_nontemporal_store(g1[m] + (v0 + v1[m]) / two, &gh1[(int64_t)m * Nbl + li]);
          __builtin_nontemporal_store(v0, &vh1[(int64_t)m * Nbl + li]);
       }
    }
    u0b[li] = u;
    return u;
+}
+
+// ---- frequency-dependent (lossy) boundary nodes as a separate pass, cpu_engine.h:290-301 + 363-405 (gpu_engine.h:368-432):
+// gather + ODE update + scatter; branch states are SoA [m*Nbl + nb] so that lanes coalesce.
+template <typename Real>
+__global__ void k_fd_boundary(Real *__restrict__ u0, const int64_t *__restrict__ idx, Real *__restrict__ u0b,
+                              const Real *__restrict__ u2b, const Real *__restrict__ ssaf,
+                              const int8_t *__restrict__ mat, const int8_t *__restrict__ Mb,
+                              const MatQuadT<Real> *__restrict__ mq, const Real *__restrict__ beta,
+                              Real *__restrict__ vh1, Real *__restrict__ gh1, Real lo2, int64_t Nbl, int64_t begin,
+                              int64_t end) {
+   const int64_t nb = begin + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (nb >= end) return;
+   const int64_t ii = idx[nb];
+   u0[ii] = fd_node_update<Real>(u0[ii], (int32_t)nb, u0b, u2b, ssaf, mat, Mb, mq, beta, vh1, gh1, lo2, Nbl);
 }
 
 // ---- FD update of a selection of lossy nodes whose rigid update has been done elsewhere (k_air_zstrip, which holds the

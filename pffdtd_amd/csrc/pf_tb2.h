@@ -18,6 +18,9 @@ struct Tb2Params {
    int32_t y_begin, z_begin;      // first core row / first core column of tile (0,0)
    int32_t y_end, z_end;          // one past the last core row / column (0: Ny - y_begin / Nz - z_begin)
    int32_t band;                  // 1: XCD k (blocks k, k+8, ...) works on a contiguous band of y-z tiles of every x chunk
+   const int32_t *tiles;          // non-null: block b works on tile tiles[b] = (xc*nyt + yt)*nzt + zt (rooms with interior
+                                  // geometry: the clean tiles for k_tb2_reg, the others for k_tb1_tile)
+   const uint8_t *mask;           // k_tb1_tile: the engine's skip-mask
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -27,15 +30,22 @@ struct Tb2Params {
 // u^{n+1} on its R rows + 1 above + 1 below from u^n rows R+4 (halo rows re-read through L1/L2 by the waves above and
 // below).  Per plane and lane: R+4 row loads of u^n, R+2 of u^{n-1}, R stores of u^{n+1}, R of u^{n+2}.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename Real, int R, int WY, bool NTA = true>
+template <typename Real, int R, int WY, bool NTA = true, int LW = 64>
 __global__ __launch_bounds__(64 * WY) void k_tb2_reg(Tb2Params tp, Real a1, Real a2) {
    typedef typename VecOf<Real>::type vec;
-   constexpr int V = VecOf<Real>::V, W = 64 * V; // columns per lane / per wave (256 fp32, 128 fp64); lanes 0 and 63 are halo
+   // LW lanes span a row segment of LW*V columns whose first and last lane are z halo (their u^{n+1} values feed their
+   // neighbours through the DPP wave shifts; what the shifts carry across a segment border only ever lands in a halo
+   // lane's outer columns, which nobody reads); a wave stacks 64/LW such segments in y (narrow grids, cf. Engine::pick_lw)
+   static_assert(LW == 64 || LW == 32 || LW == 16, "row segments are 64, 32 or 16 lanes wide");
+   constexpr int V = VecOf<Real>::V, W = LW * V, NSUB = 64 / LW; // columns per lane / per segment (256 fp32, 128 fp64 at LW=64)
    // plain order by default: the XCD swizzle of the single-step kernels costs 12 % here (measured).  band: all XCDs
    // stay on the same x chunk, but each takes a contiguous band of its y-z tiles, so tiles that share halo rows share an L2.
    uint32_t b = blockIdx.x;
    int zt, yt, xc;
-   if (tp.band) {
+   if (tp.tiles) {
+      const uint32_t t = (uint32_t)tp.tiles[b];
+      zt = t % tp.nzt; yt = (t / tp.nzt) % tp.nyt; xc = t / (tp.nzt * tp.nyt);
+   } else if (tp.band) {
       const uint32_t T = (uint32_t)tp.nzt * tp.nyt, Tp = (T + 7) / 8;
       xc = b / (8 * Tp);
       const uint32_t r = b % (8 * Tp), j = (r % 8) * Tp + r / 8;
@@ -44,9 +54,10 @@ __global__ __launch_bounds__(64 * WY) void k_tb2_reg(Tb2Params tp, Real a1, Real
    } else {
       zt = b % tp.nzt; yt = (b / tp.nzt) % tp.nyt; xc = b / (tp.nzt * tp.nyt);
    }
-   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+   const int wlane = threadIdx.x & 63, w = threadIdx.x >> 6;
+   const int lane = wlane % LW, sub = wlane / LW;
    const int ze0 = tp.z_begin - V + zt * (W - 2 * V);
-   const int yo = tp.y_begin + (yt * WY + w) * R;           // first output row of this wave
+   const int yo = tp.y_begin + ((yt * WY + w) * NSUB + sub) * R; // first output row of this lane's segment
    const int xs = tp.x_begin + xc * tp.chunk, xe = min(xs + tp.chunk, tp.x_end);
    const int P = tp.P;
    const int64_t plane = tp.plane;
@@ -55,7 +66,7 @@ __global__ __launch_bounds__(64 * WY) void k_tb2_reg(Tb2Params tp, Real a1, Real
 #pragma unroll
    for (int i = 0; i < R + 4; i++) offB[i] = (int64_t)min(max(yo - 2 + i, 0), tp.Ny - 1) * P + zc;
    const int z_end = tp.z_end ? tp.z_end : tp.Nz - tp.z_begin, y_end = tp.y_end ? tp.y_end : tp.Ny - tp.y_begin;
-   const bool core_col = (lane >= 1 && lane <= 62) && (ze0 + lane * V + V - 1 < z_end);
+   const bool core_col = (lane >= 1 && lane <= LW - 2) && (ze0 + lane * V + V - 1 < z_end);
    bool core_row[R];
 #pragma unroll
    for (int r = 0; r < R; r++) core_row[r] = (yo + r < y_end);
@@ -126,6 +137,85 @@ __global__ __launch_bounds__(64 * WY) void k_tb2_reg(Tb2Params tp, Real a1, Real
       for (int j = 0; j < R + 2; j++) { vc[j] = vn[j]; Bp[j] = Bc[j + 1]; Ar[j] = Arn[j]; }
 #pragma unroll
       for (int i = 0; i < R + 4; i++) { Bc[i] = Bn[i]; Bn[i] = Bnn[i]; }
+   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_tb1_tile -- ONE 7-point air update of the tiles k_tb2_reg must leave alone (a boundary node, a source or the ABC
+// shell within one cell of their core), with the same tile geometry, out of place: A = u^{n-1}, B = u^n -> C = u^{n+1}.
+// Cells whose skip-mask bit is set (boundary nodes) are not written: the boundary pass writes them afterwards.
+// Inside the box of tiles there are no ghost cells and no ABC cells, so none of that is handled here.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename Real, int R, int WY, int LW = 64>
+__global__ __launch_bounds__(64 * WY) void k_tb1_tile(Tb2Params tp, Real a1, Real a2) {
+   typedef typename VecOf<Real>::type vec;
+   static_assert(LW == 64 || LW == 32 || LW == 16, "row segments are 64, 32 or 16 lanes wide");
+   constexpr int V = VecOf<Real>::V, W = LW * V, NSUB = 64 / LW;
+   const uint32_t t = tp.tiles ? (uint32_t)tp.tiles[blockIdx.x] : blockIdx.x;
+   const int zt = t % tp.nzt, yt = (t / tp.nzt) % tp.nyt, xc = t / (tp.nzt * tp.nyt);
+   const int wlane = threadIdx.x & 63, w = threadIdx.x >> 6;
+   const int lane = wlane % LW, sub = wlane / LW;
+   const int ze0 = tp.z_begin - V + zt * (W - 2 * V);
+   const int yo = tp.y_begin + ((yt * WY + w) * NSUB + sub) * R;
+   const int xs = tp.x_begin + xc * tp.chunk, xe = min(xs + tp.chunk, tp.x_end);
+   const int P = tp.P;
+   const int64_t plane = tp.plane;
+   const int zc = min(max(ze0 + lane * V, 0), P - V);
+   int64_t off[R + 2];                                        // rows yo-1 .. yo+R
+#pragma unroll
+   for (int i = 0; i < R + 2; i++) off[i] = (int64_t)min(max(yo - 1 + i, 0), tp.Ny - 1) * P + zc;
+   const int z_end = tp.z_end ? tp.z_end : tp.Nz - tp.z_begin, y_end = tp.y_end ? tp.y_end : tp.Ny - tp.y_begin;
+   const bool core_col = (lane >= 1 && lane <= LW - 2) && (ze0 + lane * V + V - 1 < z_end);
+   bool core_row[R];
+#pragma unroll
+   for (int r = 0; r < R; r++) core_row[r] = (yo + r < y_end);
+   auto loadB = [&](int x, vec *d) {
+      const Real *pl = (const Real *)tp.B + (int64_t)x * plane;
+#pragma unroll
+      for (int i = 0; i < R + 2; i++) d[i] = *(const vec *)(pl + off[i]);
+   };
+   vec Bp[R], Bc[R + 2], Bn[R + 2];
+   {
+      vec t2[R + 2];
+      loadB(xs - 1, t2);
+#pragma unroll
+      for (int r = 0; r < R; r++) Bp[r] = t2[r + 1];
+      loadB(xs, Bc);
+   }
+   for (int x = xs; x < xe; x++) {
+      loadB(x + 1, Bn);
+      const Real *pa = (const Real *)tp.A + (int64_t)x * plane;
+      Real *pc = (Real *)tp.C + (int64_t)x * plane;
+      const uint8_t *pm = tp.mask + (((int64_t)x * plane) >> 3);
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+         const vec old = __builtin_nontemporal_load((const vec *)(pa + off[r + 1]));
+         const uint32_t bits = (uint32_t)pm[off[r + 1] >> 3] >> (uint32_t)(off[r + 1] & 7);
+         const vec c = Bc[r + 1];
+         const Real lf = lane_from_lower<true>(c[V - 1]);
+         const Real rt = lane_from_upper<true>(c[0]);
+         vec o;
+#pragma unroll
+         for (int i = 0; i < V; i++) {
+            const Real zp = (i == V - 1) ? rt : c[i < V - 1 ? i + 1 : V - 1];
+            const Real zm = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
+            Real p = a1 * c[i] - old[i];
+            p = p + a2 * Bn[r + 1][i]; p = p + a2 * Bp[r][i]; p = p + a2 * Bc[r + 2][i]; p = p + a2 * Bc[r][i]; p = p + a2 * zp; p = p + a2 * zm;
+            o[i] = p;
+         }
+         if (core_col && core_row[r]) {
+            if ((bits & ((1u << V) - 1u)) == 0u) __builtin_nontemporal_store(o, (vec *)(pc + off[r + 1]));
+            else {
+#pragma unroll
+               for (int i = 0; i < V; i++)
+                  if (!((bits >> i) & 1u)) pc[off[r + 1] + i] = o[i];
+            }
+         }
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) Bp[r] = Bc[r + 1];
+#pragma unroll
+      for (int i = 0; i < R + 2; i++) Bc[i] = Bn[i];
    }
 }
 

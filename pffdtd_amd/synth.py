@@ -66,12 +66,14 @@ def _ind2sub(ii, Ny, Nz):
 
 
 def shoebox(Nx, Ny, Nz, Nt, fcc=False, wall=3, Nm=1, Mb=2, lossy=True, rigid_every=0,
-            src=None, rcv=None, sig="impulse", diff=True, h=0.05, c=343.2, box=True):
+            src=None, rcv=None, sig="impulse", diff=True, h=0.05, c=343.2, box=True, blocks=()):
     """Return the in-memory file contract for a shoebox room: dict of {file: {dataset: array}}.
 
     fcc=True gives fcc_flag 1 (checkerboard subgrid, python engine / C-CPU form); use fold_fcc() for flag 2.
     box=False gives free space (no boundary nodes: only the ABC shell terminates the grid).  Note that the
     box is closed: a source inside never reaches the ghost/ABC shell, a source outside (src=...) never enters.
+    blocks = solid cuboids (x0, x1, y0, y1, z0, z1), inclusive cell ranges, standing inside the room (interior geometry:
+    pillars, balconies): their cells are outside the air domain and their surfaces get boundary nodes like the walls.
     """
     assert min(Nx, Ny, Nz) >= 2 * wall + 3, "grid too small for the wall offset"
     if fcc:
@@ -82,13 +84,24 @@ def shoebox(Nx, Ny, Nz, Nt, fcc=False, wall=3, Nm=1, Mb=2, lossy=True, rigid_eve
     dims = np.array([Nx, Ny, Nz])
 
     cand = _shell_candidates(Nx, Ny, Nz, w) if box else np.zeros((0,), dtype=np.int64)
+    if len(blocks):  # every cell within one cell of a block (inside or outside it)
+        extra = []
+        for (x0, x1, y0, y1, z0, z1) in blocks:
+            assert w < x0 <= x1 < Nx - 1 - w and w < y0 <= y1 < Ny - 1 - w and w < z0 <= z1 < Nz - 1 - w, "blocks stand inside the room"
+            gx, gy, gz = np.meshgrid(np.arange(x0 - 1, x1 + 2), np.arange(y0 - 1, y1 + 2), np.arange(z0 - 1, z1 + 2), indexing="ij")
+            deep = ((gx > x0) & (gx < x1) & (gy > y0) & (gy < y1) & (gz > z0) & (gz < z1))  # not next to the surface
+            extra.append(((gx * Ny + gy) * Nz + gz)[~deep].ravel())
+        cand = np.unique(np.concatenate([cand] + extra)).astype(np.int64)
     cx, cy, cz = _ind2sub(cand, Ny, Nz)
     if fcc:
         keep = ((cx + cy + cz) % 2) == 0
         cand, cx, cy, cz = cand[keep], cx[keep], cy[keep], cz[keep]
 
     def inside(x, y, z):
-        return ((x >= w) & (x <= Nx - 1 - w) & (y >= w) & (y <= Ny - 1 - w) & (z >= w) & (z <= Nz - 1 - w))
+        ok = ((x >= w) & (x <= Nx - 1 - w) & (y >= w) & (y <= Ny - 1 - w) & (z >= w) & (z <= Nz - 1 - w))
+        for (x0, x1, y0, y1, z0, z1) in blocks:
+            ok = ok & ~((x >= x0) & (x <= x1) & (y >= y0) & (y <= y1) & (z >= z0) & (z <= z1))
+        return ok
 
     ins = inside(cx, cy, cz)
     adj = np.empty((cand.size, NN), dtype=np.bool_)

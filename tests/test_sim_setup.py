@@ -74,7 +74,17 @@ def test_musikverein_fcc_setup_to_engine_against_the_oracle(tmp_path):
     from pffdtd_amd.sim_setup import sim_setup
     mats = scenes.write_materials(tmp_path / "materials")
     folder, gpu = tmp_path / "sim", tmp_path / "gpu"
-    sim_setup(**scenes.setup_kwargs("mv_fcc_gpu", folder, mats, save_folder_gpu=gpu, compress=0, duration=0.12, PPW=5.0, fmax=420.0))
+    # The hall's receivers stand as close as 17 cm to a surface (R9; R12 / R13: 21 cm): the grid must be finer than ~6 cm or
+    # one of their eight nodes lands on a boundary node, which the reference refuses too (sim_comms.py:233-249).
+    for fmax in (1100.0, 1200.0, 1300.0):  # h = 5.7, 5.2, 4.8 cm: 4.0e7 FCC nodes at the first
+        try:
+            sim_setup(**scenes.setup_kwargs("mv_fcc_gpu", folder, mats, save_folder_gpu=gpu, compress=0, duration=0.09, PPW=5.5, fmax=fmax))
+            break
+        except AssertionError as exc:
+            if "boundary node" not in str(exc):
+                raise
+    else:
+        pytest.fail("no clash-free resolution among the candidates")
     for prec in ("single", "double"):
         sd = sim_data.SimData.from_folder(gpu, prec)
         assert sd.fcc_flag == 2 and sd.Nx >= sd.Ny >= sd.Nz and sd.Nm == 5 and (np.asarray(sd.Mb) == 11).all()
@@ -83,6 +93,32 @@ def test_musikverein_fcc_setup_to_engine_against_the_oracle(tmp_path):
         ref.scale_input()
         oracle.run_sim(ref)
         engine.run_sim(sd)
-        heard = np.abs(ref.u_out).max(axis=1) > 0
-        assert heard.all(), f"{(~heard).sum()} of {heard.size} receiver nodes silent after {sd.Nt} steps"
+        heard = np.abs(ref.u_out).max(axis=1) > 0  # 0.09 s = 31 m of travel: all but the receivers at the far end of the hall
+        assert heard.mean() >= 0.7, f"{(~heard).sum()} of {heard.size} receiver nodes silent after {sd.Nt} steps"
+        assert np.array_equal(sd.u_out, ref.u_out), prec
+
+
+@pytest.mark.gpu
+def test_ctk_church_in_temporally_blocked_pairs_against_the_oracle(tmp_path):
+    """BASELINE configs[1] geometry (python/test_script_CTK_cart_gpu.py:33-38 at a coarse fmax) with pairs FORCED
+    (air_variant 40): the clean tiles of the church step two at a time, the tiles holding walls, pews and the source one
+    at a time -- receivers bit for bit the CPU oracle's."""
+    import oracle
+    from pffdtd_amd import engine, sim_data
+    from pffdtd_amd.sim_setup import sim_setup
+    mats = scenes.write_materials(tmp_path / "materials")
+    folder, gpu = tmp_path / "sim", tmp_path / "gpu"
+    sim_setup(**scenes.setup_kwargs("ctk_cart_gpu", folder, mats, save_folder_gpu=gpu, compress=0, duration=0.035, PPW=6.0, fmax=640.0))
+    for prec in ("single", "double"):
+        ref = sim_data.SimData.from_folder(gpu, prec)
+        ref.scale_input()
+        oracle.run_sim(ref)
+        assert np.abs(ref.u_out).max() > 0
+        sd = sim_data.SimData.from_folder(gpu, prec)
+        sd.scale_input()
+        eng = engine.HipEngine(sd, air_variant=40, timing=True)
+        eng.run(0, sd.Nt)
+        tm = eng.timing()
+        eng.close()
+        assert tm["tb2_launches"] > 0 and tm["tb2_cells"] > 0, (tm, sd.Nx, sd.Ny, sd.Nz)  # (few tiles are clean at this resolution)
         assert np.array_equal(sd.u_out, ref.u_out), prec

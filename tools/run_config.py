@@ -32,6 +32,7 @@ ap.add_argument("--fmax", type=float, default=None, help="override fmax (Hz)")
 ap.add_argument("--ppw", type=float, default=None, help="override points per wavelength")
 ap.add_argument("--duration", type=float, default=None, help="override the simulated duration (s)")
 ap.add_argument("--debug", type=lambda v: int(v, 0), default=0, help="pf_opts.debug (tuning switches)")
+ap.add_argument("--variant", type=int, default=0, help="pf_opts.air_variant (0 = automatic, 40 = blocked pairs forced)")
 ap.add_argument("--energy", action="store_true", help="run all Nt steps with the energy diagnostic (double only)")
 ap.add_argument("--keep", default=None, help="keep the sim folder here instead of a temp dir")
 a = ap.parse_args()
@@ -74,7 +75,7 @@ if a.energy:
                gvox_per_s=round(sd.Npts * sd.Nt / el / 1e9, 3))
 else:
     K, W = min(a.steps, sd.Nt - a.warmup), a.warmup
-    eng = engine.HipEngine(sd, timing=True, debug=a.debug)
+    eng = engine.HipEngine(sd, timing=True, debug=a.debug, air_variant=a.variant)
     eng.run(0, W)
     eng.sync()
     eng.timing(reset=True)
@@ -85,6 +86,8 @@ else:
     tm = eng.timing()
     res.update(steps=K, seconds=round(el, 4), ms_per_step=round(el / K * 1e3, 4), gvox_per_s=round(sd.Npts * K / el / 1e9, 2),
                air_ms_per_step=round(tm["air_ms_total"] / max(tm["steps"], 1), 4),
-               finite=bool(np.isfinite(sd.u_out).all()), out_peak=float(np.abs(sd.u_out).max()))
+               finite=bool(np.isfinite(sd.u_out).all()), out_peak=float(np.abs(sd.u_out).max()),
+               air_path=int(tm["air_path"]), tune_ms=[round(v, 4) for v in tm["tune_ms"]],
+               blocked_cell_fraction=round(tm["tb2_cells"] / sd.Npts, 4) if tm["tb2_launches"] else 0.0)
 eng.close()
 print(json.dumps(res), flush=True)
