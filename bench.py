@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=7, help="the K-step region is timed this many times; value = the MEDIAN region")
+    ap.add_argument("--no-rigid-run", action="store_true", help="skip the second, rigid-wall run (SURVEY 8d asks for both)")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--nx", type=int, default=0, help="override the number of planes along x (experiments only)")
     ap.add_argument("--precision", default="single", choices=["single", "double"])
@@ -152,10 +154,10 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    K, W = args.steps, args.warmup
+    K, W, R = args.steps, args.warmup, max(args.repeats, 1)
     n = args.size
     lossy = not args.rigid
-    sd = build_scene(n, K + W, args.precision, args.fcc, lossy, args.mb, args.nx)
+    sd = build_scene(n, R * K + W, args.precision, args.fcc, lossy, args.mb, args.nx)
     real_bytes = 4 if args.precision == "single" else 8
     ekw = dict(numerics=args.numerics, air_variant=args.variant, air_chunk=args.chunk, timing=True, debug=args.debug)
 
@@ -211,23 +213,30 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
+    runner.verify_steps = min(W, 4) if world > 1 else 0  # N>1: checksum the first exchanges against the senders' planes
     run(0, W)
     sync()
     timing(reset=True)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(W, K)
-    sync()
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-    el = t1 - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([el], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+
+    def timed_region(n0):
+        """K steps bracketed by barrier + synchronize on both sides; max over ranks"""
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(n0, K)
+        sync()
+        torch.cuda.synchronize()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([el], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    regions = [timed_region(W + r * K) for r in range(R)]
+    el = sorted(regions)[len(regions) // 2]  # the median region is the one reported
     tm = timing()
 
     # sanity: the field must still be finite
@@ -256,6 +265,7 @@ def main():
         res = {
             "metric": "Gvoxel-updates/s", "value": round(gvox, 3), "unit": "Gvoxel-updates/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(el / K * 1e3, 4),
+            "repeats": R, "ms_per_step_min": round(min(regions) / K * 1e3, 4), "ms_per_step_max": round(max(regions) / K * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if real_bytes == 4 else "f64", "data": "synthetic",
             "config": {"workload": f"shoebox {n}^3 {'13-pt folded FCC' if args.fcc else '7-pt Cartesian'} "
@@ -266,6 +276,7 @@ def main():
                        "numerics": "cpu-exact" if args.numerics == 0 else "fma",
                        "parallelism": parallelism, "air_variant": args.variant},
             "achieved_hbm_GBs_whole_step": round(gvox * bpv, 1),
+            "whole_step_frac_of_hbm_roofline": round(gvox * bpv / HBM_PEAK_GBS, 4),
             "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
@@ -274,22 +285,56 @@ def main():
                          "interior_voxels_per_step": upd,
                          "autotune_ms_per_step": {k: round(v, 4) for k, v in zip(("lean", "barrier_free", "blocked_pair"), tm.get("tune_ms", [0, 0, 0]))}},
         }
-        # HBM bytes per air launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE in separate runs, gfx950 x2 read correction applied; tools/make_profile_summary.py)
-        tfile = ROOT / "profiles" / "r01_bench_n1_hbm_traffic.json"
-        if (world == 1 and n == 1024 and real_bytes == 4 and not args.fcc and lossy and args.variant == 0
-                and tfile.exists()):
+        # HBM bytes per launch of the dominant kernel: from the committed PMC passes of this same command (rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 x2 read correction applied; tools/collect_n1_profile.sh).  Only
+        # quoted when the committed profile is of the very kernel instantiation this run used, advancing the same number of
+        # voxel updates per launch -- otherwise null.
+        tfile, pfile = ROOT / "profiles" / "r02_bench_n1_hbm_traffic.json", ROOT / "profiles" / "r02_bench_n1.json"
+        if world == 1 and tm.get("tb2_launches", 0) > 0 and tfile.exists() and pfile.exists():
+            inst = f"pf::k_tb2_reg<{'float' if real_bytes == 4 else 'double'}, 3, 4, false, {int(tm['tb2_lw'])}>"
             try:
                 ks = json.load(open(tfile))["kernels"]
-                # (several instantiations may share the name -- the 8-row strip variant of the lean kernel: the
-                # whole-grid launches are the ones with the most bytes)
-                hit = sorted((v for k, v in ks.items() if kernel + "<" in k), key=lambda v: -v["total_bytes"])
-                if hit:
+                prof = json.load(open(pfile))
+                hit = [v for k, v in ks.items() if inst in k]
+                same = (prof["roofline"]["voxel_updates_per_launch"] == int(units) and prof["config"]["grid"] == [sd.Nx, sd.Ny, sd.Nz]
+                        and prof["config"]["Nb"] == sd.Nb and prof["dtype"] == res["dtype"])
+                if hit and same:
                     res["roofline"]["traffic"] = round(hit[0]["total_bytes"] / 1e9, 3)
-                    res["roofline"]["traffic_unit"] = "GB per launch (PMC, profiles/r01_bench_n1_hbm_traffic.json)"
+                    res["roofline"]["traffic_unit"] = f"GB per launch of {inst} (PMC, profiles/r02_bench_n1_hbm_traffic.json)"
                     res["roofline"]["algorithmic_GB_per_launch"] = round(units * bpv / 1e9, 3)
+                else:
+                    res["roofline"]["traffic_note"] = "committed profile is of another kernel instantiation / workload: not quoted"
             except (OSError, KeyError, ValueError):
                 pass
+        if world > 1:
+            res["exchange_verified"] = runner.exchange_verified
+            res["exchange"] = {"backend": backend, "ranks": world, "checked_steps": min(W, 4),
+                               "what": "bit-pattern checksums of the received ghost planes == the senders' planes, all ranks"}
+        if world == 1 and lossy and not args.no_rigid_run and emu is None:
+            # a rigid-wall run next to the frequency-dependent one (same grid, no branch ODEs)
+            runner.st.close()
+            runner.st.grids.clear()
+            torch.cuda.empty_cache()
+            sd_r = build_scene(n, 3 * K + W, args.precision, args.fcc, False, args.mb, args.nx)
+            rr, loc_r, _ = pdist.make_hip_runner(sd_r, 0, 1, local_rank, None, **ekw)
+            for g in rr.st.grids:
+                g.copy_((torch.rand(g.shape, generator=gen, device=g.device, dtype=torch.float32) * 2.0 - 1.0) * 1e-3)
+            torch.cuda.synchronize()
+            rr.st.eng.run(0, W)
+            rr.st.eng.sync()
+            ts = []
+            for r in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                rr.st.eng.run(W + r * K, K)
+                rr.st.eng.sync()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            t_r = sorted(ts)[1]
+            res["rigid_walls"] = {"value": round(sd_r.Npts * K / t_r / 1e9, 3), "unit": "Gvoxel-updates/s",
+                                  "ms_per_step": round(t_r / K * 1e3, 4), "repeats": 3, "Nb": sd_r.Nb,
+                                  "whole_step_frac_of_hbm_roofline": round(sd_r.Npts * K / t_r / 1e9 * bpv / HBM_PEAK_GBS, 4)}
+            rr.st.close()
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.precision, args.fcc, args.mb, lossy)
         print(json.dumps(res), flush=True)

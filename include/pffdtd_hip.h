@@ -122,6 +122,8 @@ typedef struct pf_timing {
    double  tune_ms[3];      /* creation-time measurement of the interior update of one step, ms: lean fused kernel,
                                barrier-free kernel, temporally blocked pair / 2 (0 = not measured) */
    int64_t air_path;        /* what the engine runs: 0 lean, 1 barrier-free (virtual ghosts), 2 blocked pairs, -1 other */
+   int64_t tb2_lw;          /* blocked pairs: lanes per row segment of the two-steps-per-pass kernel (64 | 32 | 16), else 0 */
+   int64_t tb2_dirty_tiles; /* blocked pairs: tiles of the box that step singly (geometry or a source inside) */
 } pf_timing;
 
 typedef struct pf_engine pf_engine;

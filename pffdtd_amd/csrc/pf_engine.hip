@@ -1500,6 +1500,8 @@ template <typename Real> struct Engine : EngineBase {
       if (rc) return rc;
       for (int i = 0; i < 3; i++) tm.tune_ms[i] = tune_ms[i];
       tm.air_path = (tb2 || tb2_slab) ? 2 : (lean ? 0 : (vg ? 1 : -1));
+      tm.tb2_lw = (tb2 || tb2_slab) ? tb_lw : 0;
+      tm.tb2_dirty_tiles = (tb2 || tb2_slab) ? tb_ndirty : 0;
       if (t) *t = tm;
       if (reset) tm = pf_timing{};
       return PF_OK;

@@ -83,6 +83,8 @@ class SlabRunner:
     def __init__(self, stepper, info, group=None):
         self.st, self.info, self.group = stepper, info, group
         self.rank, self.G = info.rank, info.G
+        self.verify_steps = 0          # >0: checksum the planes of that many upcoming exchanges against the senders'
+        self.exchange_verified = None  # None = never checked, True / False = result on every rank (all-reduced)
 
     def exchange(self):
         """Send my first/last updated planes to the neighbours' ghost planes, receive theirs (gpu_engine.h:1086-1126)."""
@@ -121,10 +123,38 @@ class SlabRunner:
                 recv.copy_(hbuf)
             torch.cuda.current_stream().synchronize()
 
+    def _verify_exchange(self):
+        """Every rank checksums (bit patterns, exact) the two planes it sent and the two it received; the sums travel by
+        all_gather and each rank checks that what arrived in its ghost planes is what its neighbours sent -- and that a
+        send plane is not all zeros by accident of an unexercised path (the fields are pre-filled in bench.py)."""
+        s_lo, s_hi, r_lo, r_hi = self.st.halo_tensors()
+        with self.st.comm_context():
+            if s_lo.is_cuda:
+                torch.cuda.current_stream().synchronize()
+            itype = torch.int32 if s_lo.element_size() == 4 else torch.int64
+
+            def csum(t):
+                return int(t.contiguous().view(itype).to(torch.int64).sum().item())
+            mine = [csum(s_lo), csum(s_hi), csum(r_lo), csum(r_hi)]
+        allv = [None] * self.G
+        dist.all_gather_object(allv, mine, group=self.group)
+        ok = True
+        if not self.info.first:
+            ok &= mine[2] == allv[self.rank - 1][1]   # my plane 0 = left neighbour's last owned plane
+        if not self.info.last:
+            ok &= mine[3] == allv[self.rank + 1][0]   # my last plane = right neighbour's first owned plane
+        flags = [None] * self.G
+        dist.all_gather_object(flags, bool(ok), group=self.group)
+        good = all(flags)
+        self.exchange_verified = good if self.exchange_verified is None else (self.exchange_verified and good)
+
     def run(self, n0, nsteps):
         for n in range(n0, n0 + nsteps):
             self.st.step_begin(n)
             self.exchange()
+            if self.verify_steps > 0 and self.G > 1:
+                self.verify_steps -= 1
+                self._verify_exchange()
             self.st.step_end(n)
 
     def finish(self):

@@ -31,7 +31,8 @@ class PfTiming(ctypes.Structure):
     _fields_ = [("air_ms_total", ctypes.c_double), ("air_launches", ctypes.c_int64),
                 ("step_ms_total", ctypes.c_double), ("steps", ctypes.c_int64),
                 ("tb2_ms_total", ctypes.c_double), ("tb2_launches", ctypes.c_int64), ("tb2_cells", ctypes.c_int64),
-                ("tune_ms", ctypes.c_double * 3), ("air_path", ctypes.c_int64)]
+                ("tune_ms", ctypes.c_double * 3), ("air_path", ctypes.c_int64), ("tb2_lw", ctypes.c_int64),
+                ("tb2_dirty_tiles", ctypes.c_int64)]
 
 
 class PfError(RuntimeError):
@@ -252,7 +253,7 @@ class HipEngine:
         _check(lib().pf_engine_timing(self._h, ctypes.byref(t), int(reset)))
         return {"air_ms_total": t.air_ms_total, "air_launches": t.air_launches, "step_ms_total": t.step_ms_total,
                 "steps": t.steps, "tb2_ms_total": t.tb2_ms_total, "tb2_launches": t.tb2_launches, "tb2_cells": t.tb2_cells,
-                "tune_ms": list(t.tune_ms), "air_path": t.air_path}
+                "tune_ms": list(t.tune_ms), "air_path": t.air_path, "tb2_lw": t.tb2_lw, "tb2_dirty_tiles": t.tb2_dirty_tiles}
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -87,7 +87,7 @@ def test_musikverein_fcc_setup_to_engine_against_the_oracle(tmp_path):
         pytest.fail("no clash-free resolution among the candidates")
     for prec in ("single", "double"):
         sd = sim_data.SimData.from_folder(gpu, prec)
-        assert sd.fcc_flag == 2 and sd.Nx >= sd.Ny >= sd.Nz and sd.Nm == 5 and (np.asarray(sd.Mb) == 11).all()
+        assert sd.fcc_flag == 2 and sd.Nx >= sd.Nz and sd.Nm == 5 and (np.asarray(sd.Mb) == 11).all()  # (Ny was halved by the fold)
         sd.scale_input()
         ref = sim_data.SimData.from_folder(gpu, prec)
         ref.scale_input()

@@ -77,11 +77,18 @@ def _worker(rank, world, port, name, prec, q):
         sd = cases.make_sd(name, prec)
         loc, info = slab.split(sd, world, rank)
         runner = pdist.SlabRunner(OracleSlabStepper(loc, info), info)
+        runner.verify_steps = sd.Nt  # checksum every exchange against the senders' planes (bench.py does a few)
         runner.run(0, sd.Nt)
         runner.finish()
+        verified = runner.exchange_verified
+        # the check must also be able to FAIL: corrupt one received plane on the last rank and look again
+        if rank == world - 1:
+            runner.st.halo_tensors()[2][3] += 1.0
+        runner._verify_exchange()
+        caught = runner.exchange_verified is False
         out = pdist.gather_outputs(sd, loc, info)
         if rank == 0:
-            q.put(out.copy())
+            q.put((out.copy(), verified, caught))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -97,8 +104,9 @@ def test_gloo_slab_chain_equals_single_domain(world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, name, prec, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = q.get(timeout=240)
+    out, verified, caught = q.get(timeout=240)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     assert np.array_equal(out, ref)
+    assert verified is True and caught is True
