@@ -256,7 +256,7 @@ def main():
         if tm.get("tb2_launches", 0) > 0:
             # temporal blocking: the dominant kernel advances `tb2_cells` cells by TWO steps per launch; its algorithmic
             # bytes are therefore 2 x 12.125 B per cell and launch (SURVEY 8d's per-update figure x the updates it performs)
-            kernel, kernel_ms = "k_tb2_reg", tm["tb2_ms_total"] / tm["tb2_launches"]
+            kernel, kernel_ms = ("k_tb2_fcc" if args.fcc else "k_tb2_reg"), tm["tb2_ms_total"] / tm["tb2_launches"]
             units = 2 * tm["tb2_cells"]
         else:
             kernel = "k_air_fcc" if args.fcc else ("k_air_cart" if tm.get("air_path") == 1 else "k_air_cart_lean")
@@ -291,7 +291,8 @@ def main():
         # voxel updates per launch -- otherwise null.
         tfile, pfile = ROOT / "profiles" / "r02_bench_n1_hbm_traffic.json", ROOT / "profiles" / "r02_bench_n1.json"
         if world == 1 and tm.get("tb2_launches", 0) > 0 and tfile.exists() and pfile.exists():
-            inst = f"pf::k_tb2_reg<{'float' if real_bytes == 4 else 'double'}, 3, 4, false, {int(tm['tb2_lw'])}>"
+            inst = (f"pf::k_tb2_fcc<{'float' if real_bytes == 4 else 'double'}, 2, 4, {int(tm['tb2_lw'])}>" if args.fcc else
+                    f"pf::k_tb2_reg<{'float' if real_bytes == 4 else 'double'}, 3, 4, false, {int(tm['tb2_lw'])}>")
             try:
                 ks = json.load(open(tfile))["kernels"]
                 prof = json.load(open(pfile))

@@ -159,6 +159,11 @@ template <typename Real> struct Engine : EngineBase {
    int tb_lw = 64, tb_chunk = 16, tb_nxc = 0, tb_nyt = 0, tb_nzt = 0;
    int32_t *tb_clean = nullptr, *tb_dirty = nullptr;      // tile ids (xc*nyt + yt)*nzt + zt
    int64_t tb_nclean = 0, tb_ndirty = 0, tb_clean_cells = 0;
+   // 13-point pairs (folded FCC): whatever of the box is not a clean tile's core is stepped by k_air_fcc over its own tiles
+   // (256 columns x 16 rows x the same x chunks), listed here
+   int32_t *sh_tiles = nullptr;
+   int64_t sh_ntiles = 0;
+   int sh_nyt = 0, sh_nzt = 0;
    const Real *u0_src = nullptr;                          // out-of-place single-step launches read u^{n-1} here
    int lean_yt0 = 0, lean_nyt = -1;                       // row-strip launches of the lean kernel (-1: all tiles)
    // boundary nodes inside the column strips are updated by k_air_zstrip itself (it streams their lines anyway; in
@@ -187,7 +192,7 @@ template <typename Real> struct Engine : EngineBase {
       auto F = [](void *p) { if (p) hipFree(p); };
       for (Real *g : own_list) F(g); // state grids this engine allocated (u0/u1 unless external, the temporal-blocking spares)
       own_list.clear();
-      F(d_lossy); F(mask); F(mask_bn); F(cellb); F(zs_map); F(zs_rest); F(zs_fd); F(tb_clean); F(tb_dirty); F(segstart); F(adj_dense); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
+      F(d_lossy); F(mask); F(mask_bn); F(cellb); F(zs_map); F(zs_rest); F(zs_fd); F(tb_clean); F(tb_dirty); F(sh_tiles); F(segstart); F(adj_dense); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
       F(d_beta); F(d_insig); F(d_mq); F(ub[0]); F(ub[1]); F(ub[2]); F(u2ba); F(vh1); F(gh1); F(ring);
       if (h_ring) hipHostFree(h_ring);
       for (auto &p : air_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -375,6 +380,7 @@ template <typename Real> struct Engine : EngineBase {
          }
          else if (vbase == 7 || vbase == 8) { abck = true; if (!ok) return set_err(PF_ERR_ARG, "air_variant %d (in-kernel ABC) requested but its preconditions do not hold", op.air_variant); }
          else if (vbase >= 4 && vbase <= 6) { vg = true; if (!ok) return set_err(PF_ERR_ARG, "air_variant %d (virtual ghost shell) requested but its preconditions do not hold", op.air_variant); }
+         else if (fcc && (vbase == 40 || vbase == 41)) { abck = true; if (!ok) return set_err(PF_ERR_ARG, "air_variant %d (blocked pairs) requested but the fused-path preconditions do not hold", op.air_variant); }
          else if (vbase >= 20) { lean = true; fused = false; }
          else if (vbase >= 10) { fused = true; lean = false; }
          if ((lean || fused) && !ok)
@@ -518,7 +524,10 @@ template <typename Real> struct Engine : EngineBase {
       tb2 = tb2_geom = tb2_slab = false;
       if (const char *ev = getenv("PFFDTD_TB2_CHUNK")) tb2_chunk = std::min(std::max(atoi(ev), 4), 256);
       const bool single = op.slab_first && op.slab_last;
-      if (fcc || !(lean || vg) || lean_rigid || v1_rigb || op.energy || (op.debug & 0x4000)) return PF_OK; // 0x4000: single steps only
+      if (lean_rigid || v1_rigb || op.energy || (op.debug & 0x4000)) return PF_OK; // 0x4000: single steps only
+      // 7-point: the fused single-step kernels carry the shell; 13-point: folded grids on one device, with the flips in
+      // memory and the ABC loss in the interior kernel (the automatic 13-point arrangement)
+      if (fcc ? !(fold && abck && single) : !(lean || vg)) return PF_OK;
       if (!(vbase == 0 || vbase == 40 || vbase == 41) || op.numerics != PF_NUM_CPU_EXACT || !use_dpp) return PF_OK;
       if (Nb > 0 && !boundary_fused()) return PF_OK;
       // Margins of the box: three cells off every grid face (the ABC cells sit at index 1 and the box must stay two cells
@@ -565,7 +574,7 @@ template <typename Real> struct Engine : EngineBase {
       }
       if (vbase == 41) tbx1 = tbx0; // driver test: everything goes through the out-of-place single-step path
       tb_xr.clear();
-      const int TC = (tb_lw - 2) * V, TR = 12 * (64 / tb_lw);
+      const int TC = (tb_lw - 2) * V, TR = (fcc ? 8 : 12) * (64 / tb_lw); // rows of a workgroup: 4 waves x R = 3 (7-point) | 2 (13-point)
       int64_t vol = 0;
       if (tbx1 - tbx0 >= 16 && tby1 - tby0 >= 24 && tbz1 - tbz0 >= TC / 2) {
          tb_xr.push_back({tbx0, tbx1});
@@ -606,13 +615,36 @@ template <typename Real> struct Engine : EngineBase {
          if ((rc = upload(&tb_clean, cl.data(), tb_nclean))) return rc;
          if ((rc = upload(&tb_dirty, di.data(), tb_ndirty))) return rc;
          if (tb_nclean == 0) tb_xr.clear();
+         if (fcc && !tb_xr.empty()) {
+            // the single-step kernel's own tiling of the box's planes: 256 (fp64: 128) columns x 16 rows x the same x
+            // chunks; a tile is needed unless every interior cell of it between the column strips lies in a clean core
+            sh_nzt = (int)cdiv(P, 64 * V); sh_nyt = (int)cdiv(Ny - 2, 16);
+            std::vector<int32_t> sh;
+            for (int xc = 0; xc < tb_nxc; xc++)
+               for (int yt = 0; yt < sh_nyt; yt++)
+                  for (int zt = 0; zt < sh_nzt; zt++) {
+                     const int ya = 1 + yt * 16, yb = std::min(ya + 16, (int)Ny - 1);
+                     const int za = std::max(zt * 64 * V, tbz0), zb = std::min((zt + 1) * 64 * V, tbz1);
+                     if (za >= zb) continue; // only column-strip cells: k_zstrip_fcc
+                     bool need = ya < tby0 || yb > tby1;
+                     if (!need) {
+                        const int t0y = (ya - tby0) / TR, t1y = (yb - 1 - tby0) / TR, t0z = (za - tbz0) / TC, t1z = (zb - 1 - tbz0) / TC;
+                        for (int a = t0y; a <= t1y && !need; a++)
+                           for (int c = t0z; c <= t1z && !need; c++) need = dirty[((size_t)xc * tb_nyt + a) * tb_nzt + c] != 0;
+                     }
+                     if (need) sh.push_back((int32_t)(((int64_t)xc * sh_nyt + yt) * sh_nzt + zt));
+                  }
+            sh_ntiles = (int64_t)sh.size();
+            if (sh_tiles) { hipFree(sh_tiles); sh_tiles = nullptr; }
+            if ((rc = upload(&sh_tiles, sh.data(), sh_ntiles))) return rc;
+         }
       }
       if (vbase == 40 && vol == 0) return set_err(PF_ERR_ARG, "air_variant 40 (temporal blocking) requested but the scene has no boundary-free tiles");
       // auto: the shell costs grow with the perimeter of the y-z cross-section, the gain with its area -- measured on
       // MI355X: 512^2 planes -4.5 %, 768^2 +9 %, 1024^2 +13 % for a box room; and two extra grids must be worth it.
       // Single-domain engines then time a blocked pair against the single-step kernels at creation (autotune()), so the
       // static rule only has to exclude the hopeless cases; slab engines have no such measurement and keep the strict one.
-      if (vbase == 0 && single && ((double)vol < 0.35 * (double)(Nx * Ny * Nz) || tby1 - tby0 < 100 || tbz1 - tbz0 < 100)) return PF_OK;
+      if (vbase == 0 && single && ((double)vol < (fcc ? 0.5 : 0.35) * (double)(Nx * Ny * Nz) || tby1 - tby0 < 100 || tbz1 - tbz0 < 100)) return PF_OK;
       if (vbase == 0 && !single && ((double)vol < 0.6 * (double)(Nx * Ny * Nz) || tby1 - tby0 < 600 || tbz1 - tbz0 < 600)) return PF_OK;
       tb2_geom = true;
       if (!single) return PF_OK; // slab engines wait for pf_engine_set_spares (all four grids must be the caller's)
@@ -634,7 +666,7 @@ template <typename Real> struct Engine : EngineBase {
       // k_fd_sel, dense over the compact arrays (mode 2).  Doing the ODEs inside the strip kernel as well (mode 1, debug
       // 0x2000) is bit-identical but slower: they run on the few lanes per wave that hold a node (2.92 vs 2.59 ms per step).
       // debug 0x20000000: mode 0, the list kernel visits every boundary node (the round-1 arrangement).
-      zs_mode = (op.debug & 0x2000) ? 1 : ((op.debug & 0x20000000) ? 0 : 2);
+      zs_mode = fcc ? 0 : ((op.debug & 0x2000) ? 1 : ((op.debug & 0x20000000) ? 0 : 2));
       if (Nb > 0 && !tb_xr.empty() && zs_mode > 0 && Nbl < ((int64_t)1 << 31)) {
          const int xb = tb_xr.front().first, xe = tb_xr.back().second;
          constexpr int V = pf::VecOf<Real>::V;
@@ -678,7 +710,47 @@ template <typename Real> struct Engine : EngineBase {
    // where a box exists -- a temporally blocked pair incl. its shell.  The boundary pass and the I/O are common to all.
    // (7-point only; explicit air_variant requests and debug 0x8000 skip it.)  Sizes decide in ways no static rule
    // caught: 1024^3 fp32 pair 411 > lean 377 > barrier-free 364 Gvox/s, 896^3 barrier-free 362 > pair 335 > lean 303.
+   // 13-point: one in-place-equivalent single step (written to scratch) against half a blocked pair with its shell
+   int autotune_fcc() {
+      if (!tb2 || vbase != 0 || (op.debug & 0x8000)) return PF_OK;
+      hipEvent_t e0, e1;
+      HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+      HIPCHK(hipDeviceSynchronize());
+      auto timed = [&](auto &&fn) -> float {
+         fn();
+         hipEventRecord(e0, s_main);
+         for (int i = 0; i < 3; i++) fn();
+         hipEventRecord(e1, s_main);
+         hipEventSynchronize(e1);
+         float ms = 0;
+         hipEventElapsedTime(&ms, e0, e1);
+         return ms / 3;
+      };
+      Real *U0 = u0, *U1 = u1;
+      u0_src = U0; u0 = bufC;
+      for (int i = 0; i < 8 && (double)i * (double)(Nx * Ny * Nz) < 8.0e9; i++) launch_air_march(s_main, 1, (int)Nx - 1); // clocks up
+      HIPCHK(hipStreamSynchronize(s_main));
+      tune_ms[1] = timed([&] { launch_flips(s_main); launch_air_march(s_main, 1, (int)Nx - 1); });
+      tune_ms[2] = 0.5f * timed([&] {
+         launch_tb2(s_main, U0, U1, bufC, bufD);
+         u0_src = U0; u1 = U1; u0 = bufC; launch_shell(s_main);
+         u0_src = U1; u1 = bufC; u0 = bufD; launch_shell(s_main);
+      });
+      u0_src = nullptr; u0 = U0; u1 = U1;
+      if (!(tune_ms[2] < 0.99f * tune_ms[1])) { // not worth it: drop the pair path and its two grids
+         tb2 = false;
+         for (Real *g : {bufC, bufD}) { own_list.erase(std::remove(own_list.begin(), own_list.end(), g), own_list.end()); hipFree(g); }
+         bufC = bufD = nullptr;
+      } else {
+         HIPCHK(hipMemsetAsync(bufC, 0, npad * sizeof(Real), s_main));
+         HIPCHK(hipMemsetAsync(bufD, 0, npad * sizeof(Real), s_main));
+      }
+      HIPCHK(hipDeviceSynchronize());
+      hipEventDestroy(e0); hipEventDestroy(e1);
+      return PF_OK;
+   }
    int autotune() {
+      if (fcc) return autotune_fcc();
       if (vbase != 0 || fcc || op.energy || (op.debug & 0x8000) || !use_dpp || !(lean || vg) || v1_rigb || lean_rigid) return PF_OK;
       if (Nx * Ny * Nz < ((int64_t)1 << 22)) return PF_OK; // tiny grids: launch-bound either way
       Real *scr = bufC;
@@ -768,6 +840,7 @@ template <typename Real> struct Engine : EngineBase {
       tp.A = A; tp.B = B; tp.C = C; tp.D = D;
       tp.tiles = tb_ndirty > 0 ? tb_clean : nullptr; // all clean: the dense order (identical to the list's)
       const dim3 g((uint32_t)tb_nclean), b(256);
+      if (fcc) { pf::launch_tb2_fcc<Real>(s, tp, a1, a2, tb_lw, (uint32_t)tb_nclean); return; }
       if (tb_lw == 32) hipLaunchKernelGGL((pf::k_tb2_reg<Real, 3, 4, false, 32>), g, b, 0, s, tp, a1, a2);
       else if (tb_lw == 16) hipLaunchKernelGGL((pf::k_tb2_reg<Real, 3, 4, false, 16>), g, b, 0, s, tp, a1, a2);
       else hipLaunchKernelGGL((pf::k_tb2_reg<Real, 3, 4, false, 64>), g, b, 0, s, tp, a1, a2);
@@ -785,7 +858,35 @@ template <typename Real> struct Engine : EngineBase {
    }
    // one out-of-place single step of everything outside the box: u1 -> (u0_src old) -> u0
    void launch_shell(hipStream_t s) { launch_shell(s, 1, (int)Nx - 1); }
+   // 13-point: ghost flips of u1 in memory, then x slabs (whole planes), column strips, and the single-step tiles of the box
+   void launch_shell_fcc(hipStream_t s) {
+      launch_flips(s);
+      if (tb_xr.empty()) { launch_air_march(s, 1, (int)Nx - 1); return; }
+      if (tbx0 > 1) launch_air_march(s, 1, tbx0);
+      if (tbx1 < Nx - 1) launch_air_march(s, tbx1, (int)Nx - 1);
+      constexpr int V = pf::VecOf<Real>::V;
+      {
+         pf::ZStripParams<Real> zp{};
+         zp.u1 = u1; zp.u0s = u0_src ? u0_src : u0; zp.u0 = u0; zp.mask = mask;
+         zp.plane = plane; zp.Nx = (int)Nx; zp.Ny = (int)Ny; zp.Nz = (int)Nz; zp.P = (int)P;
+         zp.x_begin = tbx0; zp.x_end = tbx1; zp.zl = tbz0; zp.zr = tbz1; zp.first = op.slab_first; zp.last = op.slab_last;
+         const int64_t nthreads = (int64_t)(zp.zl / V + (P - zp.zr) / V) * (Ny - 2);
+         const int xchunk = 16;
+         hipLaunchKernelGGL(pf::k_zstrip_fcc<Real>, dim3((unsigned)cdiv(nthreads, 256), (unsigned)cdiv(tbx1 - tbx0, xchunk)), dim3(256), 0, s, zp,
+                            a1, a2, l, xchunk, fold ? 1 : 0);
+      }
+      if (sh_ntiles > 0) {
+         pf::AirParams ap;
+         ap.Ny = Ny; ap.P = P; ap.plane = plane;
+         ap.x_begin = tbx0; ap.x_end = tbx1; ap.chunk = tb_chunk; ap.nxc = tb_nxc; ap.nzt = sh_nzt; ap.nyt = sh_nyt;
+         ap.swizzle = 0;
+         ap.Nx = (int)Nx; ap.Nz = (int)Nz; ap.first = op.slab_first; ap.last = op.slab_last; ap.fold = fold ? 1 : 0;
+         hipLaunchKernelGGL((pf::k_air_fcc<Real, 4, 4, 1, false, true, false, true, 64>), dim3((uint32_t)sh_ntiles), dim3(256), 0, s, u1, u0, mask, a1, a2,
+                            ap, l, u0_src, sh_tiles);
+      }
+   }
    void launch_shell(hipStream_t s, int xlo, int xhi) { // planes [xlo, xhi) (the box lies inside)
+      if (fcc) { launch_shell_fcc(s); return; }
       int xa = xlo;
       for (auto &r : tb_xr) { // x slabs: everything before / between / after the box's plane ranges, full planes
          if (r.first > xa) launch_air_lean(s, xa, r.first);
@@ -981,6 +1082,12 @@ template <typename Real> struct Engine : EngineBase {
 #define PF_LAUNCH(K, FMA, DPP) do { if (vg) hipLaunchKernelGGL((K<Real, R, WY, WZ, FMA, DPP, true, false, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l); \
                                     else if (abck) hipLaunchKernelGGL((K<Real, R, WY, WZ, FMA, DPP, false, true, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l); \
                                     else hipLaunchKernelGGL((K<Real, R, WY, WZ, FMA, DPP, false, false, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l); } while (0)
+      if constexpr (R == 4 && WY == 4 && WZ == 1) {
+         if (fcc && abck && use_dpp && !fma && u0_src) { // out of place (shell of a temporally blocked pair, creation-time measurement)
+            hipLaunchKernelGGL((pf::k_air_fcc<Real, R, WY, WZ, false, true, false, true, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l, u0_src, (const int32_t *)nullptr);
+            return;
+         }
+      }
       if constexpr (LW == 64) {
          if (fcc) {
             if (fma) { if (use_dpp) PF_LAUNCH(pf::k_air_fcc, true, true); else PF_LAUNCH(pf::k_air_fcc, true, false); }

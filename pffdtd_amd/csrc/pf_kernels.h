@@ -56,7 +56,7 @@ template <bool DPP> __device__ __forceinline__ double lane_from_upper(double v) 
 
 // self-test kernel for the two DPP controls (run once per process; the engine falls back to ds_bpermute
 // shuffles if the semantics are not the expected ones)
-__global__ void k_dpp_selftest(int *out) {
+static __global__ void k_dpp_selftest(int *out) {
    int lane = threadIdx.x & 63;
    int a = dpp_from_lower(lane + 100);
    int b = dpp_from_upper(lane + 100);
@@ -311,14 +311,18 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
 // columns from the edge lanes.
 // =============================================================================================================
 template <typename Real, int R, int WY, int WZ, bool FMA, bool DPP, bool VG = false, bool ABCK = false, int LW = 64>
-__global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict__ u1, Real *__restrict__ u0,
+__global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict__ u1, Real *u0,
                                                          const uint8_t *__restrict__ mask, Real a1, Real a2,
-                                                         AirParams ap, Real labc) {
+                                                         AirParams ap, Real labc, const Real *u0_src = nullptr,
+                                                         const int32_t *__restrict__ tiles = nullptr) {
+   // u0_src: read u^{n-1} there instead of from u0 (out of place: the shell of a temporally blocked pair);
+   // tiles: block b works on tile tiles[b] = (xc*nyt + yt)*nzt + zt instead of walking the whole range
    typedef typename VecOf<Real>::type vec;
    constexpr int V = VecOf<Real>::V;
    const uint32_t total = (uint32_t)ap.nzt * ap.nyt * ap.nxc;
    uint32_t b = blockIdx.x;
-   if (ap.swizzle) b = xcd_swizzle(b, total);
+   if (tiles) b = (uint32_t)tiles[b];
+   else if (ap.swizzle) b = xcd_swizzle(b, total);
    const int zt = b % ap.nzt;
    const int yt = (b / ap.nzt) % ap.nyt;
    const int xc = b / (ap.nzt * ap.nyt);
@@ -409,9 +413,10 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict
          nxtR[j] = need_r ? pn[roff[j] + V] : Real(0);
          patch(nxt[j], nxtL[j]);
       }
+      const Real *pold = u0_src ? u0_src + (int64_t)x * plane : po;
 #pragma unroll
       for (int r = 0; r < R; r++) {
-         old[r] = __builtin_nontemporal_load((const vec *)(po + soff[r]));
+         old[r] = __builtin_nontemporal_load((const vec *)(pold + soff[r]));
          mb[r] = pmk[soff[r] >> 3];
       }
       const bool qx = (VG || ABCK) && ((ap.first && x == 1) || (ap.last && x == ap.Nx - 2));
@@ -493,7 +498,7 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict
 
 // Naive one-thread-per-cell air kernels: debugging reference variant (air_variant 9), same arithmetic.
 template <typename Real, bool FCC, bool FMA>
-__global__ void k_air_naive(const Real *__restrict__ u1, Real *__restrict__ u0, const uint8_t *__restrict__ mask,
+static __global__ void k_air_naive(const Real *__restrict__ u1, Real *__restrict__ u0, const uint8_t *__restrict__ mask,
                             Real a1, Real a2, int64_t Ny, int64_t Nz, int64_t P, int64_t plane, int32_t x_begin,
                             int32_t x_end) {
    const int64_t iz = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -530,7 +535,7 @@ __global__ void k_air_naive(const Real *__restrict__ u1, Real *__restrict__ u0, 
 // ---- ghost-shell maintenance (cpu_engine.h:135-172; gpu_engine.h:277-285,435-494) ---------------------------
 // z faces: one thread per (x,y) row
 template <typename Real>
-__global__ void k_flip_z(Real *__restrict__ u1, int64_t nrows, int64_t P, int64_t Nz) {
+static __global__ void k_flip_z(Real *__restrict__ u1, int64_t nrows, int64_t P, int64_t Nz) {
    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (r >= nrows) return;
    Real *row = u1 + r * P;
@@ -540,7 +545,7 @@ __global__ void k_flip_z(Real *__restrict__ u1, int64_t nrows, int64_t P, int64_
 // y faces (+ the folded-FCC ghost row, which the reference copies before the flips: done by the caller's order)
 // mode bit0: row0 <- row2 ; bit1: row Ny-1 <- row Ny-3 ; bit2: row Ny-1 <- row Ny-2 (fold)
 template <typename Real>
-__global__ void k_flip_y(Real *__restrict__ u1, int64_t Nx, int64_t Ny, int64_t P, int64_t Nz, int mode) {
+static __global__ void k_flip_y(Real *__restrict__ u1, int64_t Nx, int64_t Ny, int64_t P, int64_t Nz, int mode) {
    const int64_t iz = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    const int64_t ix = blockIdx.y;
    if (iz >= Nz || ix >= Nx) return;
@@ -551,7 +556,7 @@ __global__ void k_flip_y(Real *__restrict__ u1, int64_t Nx, int64_t Ny, int64_t 
 }
 // x faces: plane 0 <- plane 2 (first slab), plane Nx-1 <- plane Nx-3 (last slab)
 template <typename Real>
-__global__ void k_flip_x(Real *__restrict__ u1, int64_t Nx, int64_t plane, int first, int last) {
+static __global__ void k_flip_x(Real *__restrict__ u1, int64_t Nx, int64_t plane, int first, int last) {
    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (i >= plane) return;
    if (first) u1[i] = u1[2 * plane + i];
@@ -560,13 +565,13 @@ __global__ void k_flip_x(Real *__restrict__ u1, int64_t Nx, int64_t plane, int f
 
 // ---- ABC (first-order Engquist-Majda), cpu_engine.h:131-134 (save) and :225-229 (loss) ----------------------
 template <typename Real>
-__global__ void k_abc_save(const Real *__restrict__ u0, const int64_t *__restrict__ idx, Real *__restrict__ u2ba,
+static __global__ void k_abc_save(const Real *__restrict__ u0, const int64_t *__restrict__ idx, Real *__restrict__ u2ba,
                            int64_t n) {
    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (i < n) u2ba[i] = u0[idx[i]];
 }
 template <typename Real>
-__global__ void k_abc_loss(Real *__restrict__ u0, const int64_t *__restrict__ idx, const int8_t *__restrict__ Q,
+static __global__ void k_abc_loss(Real *__restrict__ u0, const int64_t *__restrict__ idx, const int8_t *__restrict__ Q,
                            const Real *__restrict__ u2ba, Real l, int64_t begin, int64_t end) {
    const int64_t i = begin + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (i >= end) return;
@@ -580,7 +585,7 @@ __global__ void k_abc_loss(Real *__restrict__ u0, const int64_t *__restrict__ id
 
 // ---- rigid boundary nodes, cpu_engine.h:234-287 (gpu_engine.h:288-348) --------------------------------------
 template <typename Real, bool FCC, bool FMA>
-__global__ void k_rigid(const Real *__restrict__ u1, Real *__restrict__ u0, const int64_t *__restrict__ idx,
+static __global__ void k_rigid(const Real *__restrict__ u1, Real *__restrict__ u0, const int64_t *__restrict__ idx,
                         const uint16_t *__restrict__ adjv, Real a2, Real sl2, int64_t P, int64_t plane,
                         int64_t begin, int64_t end) {
    const int64_t nb = begin + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -661,7 +666,7 @@ __device__ __forceinline__ Real fd_node_update(Real p, int32_t li, Real *__restr
 // ---- frequency-dependent (lossy) boundary nodes as a separate pass, cpu_engine.h:290-301 + 363-405 (gpu_engine.h:368-432):
 // gather + ODE update + scatter; branch states are SoA [m*Nbl + nb] so that lanes coalesce.
 template <typename Real>
-__global__ void k_fd_boundary(Real *__restrict__ u0, const int64_t *__restrict__ idx, Real *__restrict__ u0b,
+static __global__ void k_fd_boundary(Real *__restrict__ u0, const int64_t *__restrict__ idx, Real *__restrict__ u0b,
                               const Real *__restrict__ u2b, const Real *__restrict__ ssaf,
                               const int8_t *__restrict__ mat, const int8_t *__restrict__ Mb,
                               const MatQuadT<Real> *__restrict__ mq, const Real *__restrict__ beta,
@@ -677,7 +682,7 @@ __global__ void k_fd_boundary(Real *__restrict__ u0, const int64_t *__restrict__
 // six neighbours of its boundary nodes in registers): the rigid result waits in u0b[li]; the final value goes back to
 // u0b[li] and to the grid.  Dense over the compact arrays: no gathers from the grid, one scattered store per node.
 template <typename Real>
-__global__ void k_fd_sel(Real *u0, const int64_t *__restrict__ idx_l, const int32_t *__restrict__ sel, Real *__restrict__ u0b,
+static __global__ void k_fd_sel(Real *u0, const int64_t *__restrict__ idx_l, const int32_t *__restrict__ sel, Real *__restrict__ u0b,
                          const Real *__restrict__ u2b, const Real *__restrict__ ssaf, const int8_t *__restrict__ mat,
                          const int8_t *__restrict__ Mb, const MatQuadT<Real> *__restrict__ mq, const Real *__restrict__ beta,
                          Real *__restrict__ vh1, Real *__restrict__ gh1, Real lo2, int64_t Nbl, int64_t n) {
@@ -695,7 +700,7 @@ __global__ void k_fd_sel(Real *u0, const int64_t *__restrict__ idx_l, const int3
 // sel != null: visit the nodes sel[begin..end) instead of begin..end (temporal blocking leaves the column-strip nodes
 // to k_air_zstrip).
 template <typename Real, bool FCC, bool FMA>
-__global__ void k_boundary(const Real *__restrict__ u1, Real *u0, const int64_t *__restrict__ idx,
+static __global__ void k_boundary(const Real *__restrict__ u1, Real *u0, const int64_t *__restrict__ idx,
                            const uint16_t *__restrict__ adjv, const int32_t *__restrict__ lossy, Real a2, Real sl2,
                            int64_t P, int64_t plane, Real *__restrict__ u0b, const Real *__restrict__ u2b,
                            const Real *__restrict__ ssaf, const int8_t *__restrict__ mat, const int8_t *__restrict__ Mb,
@@ -731,12 +736,12 @@ __global__ void k_boundary(const Real *__restrict__ u1, Real *u0, const int64_t 
 }
 
 // device-side step counters of the graph-replayed loop: ctr[0] = step index, ctr[1] = receiver ring column
-__global__ void k_ctr_set(int64_t *ctr, int64_t n, int64_t col) { ctr[0] = n; ctr[1] = col; }
-__global__ void k_ctr_tick(int64_t *ctr) { ctr[0]++; ctr[1]++; }
+static __global__ void k_ctr_set(int64_t *ctr, int64_t n, int64_t col) { ctr[0] = n; ctr[1] = col; }
+static __global__ void k_ctr_tick(int64_t *ctr) { ctr[0]++; ctr[1]++; }
 
 // one byte per padded cell for the RIGB kernels: 0x40 at ghost z columns and pad columns (never updated), 0 elsewhere;
 // boundary nodes are then stamped with 0x80 | adjacency bits (k_adj_dense_set)
-__global__ void k_cellbytes_init(uint8_t *__restrict__ cb, int64_t nrows, int64_t P, int64_t Nz) {
+static __global__ void k_cellbytes_init(uint8_t *__restrict__ cb, int64_t nrows, int64_t P, int64_t Nz) {
    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (i >= nrows * P) return;
    const int64_t z = i % P;
@@ -747,7 +752,7 @@ __global__ void k_cellbytes_init(uint8_t *__restrict__ cb, int64_t nrows, int64_
 // one launch: threads [0,Nr) gather into the ring column, thread Nr (alone) applies all sources in list order
 // (the reference loop is serial, so duplicate source nodes accumulate in order).
 template <typename Real>
-__global__ void k_io(const Real *__restrict__ u1, Real *__restrict__ u0, const int64_t *__restrict__ out_idx,
+static __global__ void k_io(const Real *__restrict__ u1, Real *__restrict__ u0, const int64_t *__restrict__ out_idx,
                      Real *__restrict__ ring, int64_t Nr, int64_t ring_col, int64_t ring_depth,
                      const int64_t *__restrict__ in_idx, const Real *__restrict__ in_sigs, int64_t Ns, int64_t Nt,
                      int64_t n, const int64_t *__restrict__ ctr = nullptr) {
@@ -762,7 +767,7 @@ __global__ void k_io(const Real *__restrict__ u1, Real *__restrict__ u0, const i
 
 // build the engine's skip-mask rows for ghost z columns / pad / odd parity (boundary-node bits are OR-ed in
 // afterwards by k_mask_set)
-__global__ void k_mask_init(uint8_t *__restrict__ mask, int64_t Nx, int64_t Ny, int64_t P, int64_t Nz, int parity) {
+static __global__ void k_mask_init(uint8_t *__restrict__ mask, int64_t Nx, int64_t Ny, int64_t P, int64_t Nz, int parity) {
    // one thread per mask byte of a row; blockIdx.y = row (ix*Ny + iy): no 64-bit divisions per bit
    const int64_t bcol = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; // byte within the row
    const int64_t row = blockIdx.y + (int64_t)blockIdx.z * 65535;
@@ -778,7 +783,7 @@ __global__ void k_mask_init(uint8_t *__restrict__ mask, int64_t Nx, int64_t Ny, 
    }
    mask[row * (P / 8) + bcol] = (uint8_t)m;
 }
-__global__ void k_mask_set(uint8_t *__restrict__ mask, const int64_t *__restrict__ idx, int64_t n) {
+static __global__ void k_mask_set(uint8_t *__restrict__ mask, const int64_t *__restrict__ idx, int64_t n) {
    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (i >= n) return;
    const int64_t jj = idx[i];

@@ -141,6 +141,135 @@ __global__ __launch_bounds__(64 * WY) void k_tb2_reg(Tb2Params tp, Real a1, Real
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// k_tb2_fcc -- the two-steps-per-pass scheme for the 13-point FCC stencil on the folded grid (cpu_engine.h:195-223;
+// neighbour / accumulation order (+x+y)(-x-y)(+y+z)(-y-z)(+x+z)(-x-z)(+x-y)(-x+y)(+y-z)(-y+z)(+x-z)(-x+z) as k_air_fcc).
+// Same tiling as k_tb2_reg; every neighbour lies on a diagonal, so all three u^n planes of a turn need their rows above and
+// below (R+4 rows each) and all three u^{n+1} planes R+2 rows.  R = 2: 44 16-byte vectors of state per lane.
+// The z +-1 neighbours of a row are the row itself shifted by one column: in-lane for three of four columns, one DPP
+// wave shift for the fourth.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename Real, int R, int WY, int LW = 64>
+__global__ __launch_bounds__(64 * WY) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tb2_fcc(Tb2Params tp, Real a1, Real a2_) {
+   typedef typename VecOf<Real>::type vec;
+   static_assert(LW == 64 || LW == 32 || LW == 16, "row segments are 64, 32 or 16 lanes wide");
+   constexpr int V = VecOf<Real>::V, W = LW * V, NSUB = 64 / LW;
+   const uint32_t t = tp.tiles ? (uint32_t)tp.tiles[blockIdx.x] : blockIdx.x;
+   const int zt = t % tp.nzt, yt = (t / tp.nzt) % tp.nyt, xc = t / (tp.nzt * tp.nyt);
+   const int wlane = threadIdx.x & 63, w = threadIdx.x >> 6;
+   const int lane = wlane % LW, sub = wlane / LW;
+   const int ze0 = tp.z_begin - V + zt * (W - 2 * V);
+   const int yo = tp.y_begin + ((yt * WY + w) * NSUB + sub) * R;
+   const int xs = tp.x_begin + xc * tp.chunk, xe = min(xs + tp.chunk, tp.x_end);
+   const int P = tp.P;
+   const int64_t plane = tp.plane;
+   const int zc = min(max(ze0 + lane * V, 0), P - V);
+   uint32_t offB[R + 4];                                      // rows yo-2 .. yo+R+1 (a plane holds < 2^31 elements)
+#pragma unroll
+   for (int i = 0; i < R + 4; i++) offB[i] = (uint32_t)min(max(yo - 2 + i, 0), tp.Ny - 1) * (uint32_t)P + (uint32_t)zc;
+   const int z_end = tp.z_end ? tp.z_end : tp.Nz - tp.z_begin, y_end = tp.y_end ? tp.y_end : tp.Ny - tp.y_begin;
+   const bool core_col = (lane >= 1 && lane <= LW - 2) && (ze0 + lane * V + V - 1 < z_end);
+   bool core_row[R];
+#pragma unroll
+   for (int r = 0; r < R; r++) core_row[r] = (yo + r < y_end);
+
+   auto loadB = [&](int x, vec *d) {
+      const Real *pl = (const Real *)tp.B + (int64_t)x * plane;
+#pragma unroll
+      for (int i = 0; i < R + 4; i++) d[i] = *(const vec *)(pl + offB[i]);
+   };
+   auto loadA = [&](int x, vec *d) { // rows yo-1 .. yo+R
+      const Real *pl = (const Real *)tp.A + (int64_t)x * plane;
+#pragma unroll
+      for (int j = 0; j < R + 2; j++) d[j] = __builtin_nontemporal_load((const vec *)(pl + offB[j + 1]));
+   };
+   // c: the row itself (plane x); cU / cD: rows y+1 / y-1 of plane x; n*: plane x+1, p*: plane x-1 (U, C, D = rows y+1, y, y-1)
+   auto stencil = [&](const vec &c, const vec &old, const vec &cU, const vec &cD, const vec &nU, const vec &nC, const vec &nD,
+                      const vec &pU, const vec &pC, const vec &pD) {
+      const Real cUm = lane_from_lower<true>(cU[V - 1]), cUp = lane_from_upper<true>(cU[0]);
+      const Real cDm = lane_from_lower<true>(cD[V - 1]), cDp = lane_from_upper<true>(cD[0]);
+      const Real nCm = lane_from_lower<true>(nC[V - 1]), nCp = lane_from_upper<true>(nC[0]);
+      const Real pCm = lane_from_lower<true>(pC[V - 1]), pCp = lane_from_upper<true>(pC[0]);
+      // every row multiplies with its own, opaque copy of a2: otherwise the compiler shares the products a2 * u between
+      // the rows that use the same cell, keeps them all alive and spills (348 registers wanted, 256 to be had)
+      Real a2 = a2_;
+      asm volatile("" : "+s"(a2));
+      vec o;
+#pragma unroll
+      for (int i = 0; i < V; i++) {
+         const int im = i > 0 ? i - 1 : 0, ip = i < V - 1 ? i + 1 : V - 1;
+         Real p = a1 * c[i] - old[i];
+         p = p + a2 * nU[i];                               // +x+y
+         p = p + a2 * pD[i];                               // -x-y
+         p = p + a2 * ((i == V - 1) ? cUp : cU[ip]);       // +y+z
+         p = p + a2 * ((i == 0) ? cDm : cD[im]);           // -y-z
+         p = p + a2 * ((i == V - 1) ? nCp : nC[ip]);       // +x+z
+         p = p + a2 * ((i == 0) ? pCm : pC[im]);           // -x-z
+         p = p + a2 * nD[i];                               // +x-y
+         p = p + a2 * pU[i];                               // -x+y
+         p = p + a2 * ((i == 0) ? cUm : cU[im]);           // +y-z
+         p = p + a2 * ((i == V - 1) ? cDp : cD[ip]);       // -y+z
+         p = p + a2 * ((i == 0) ? nCm : nC[im]);           // +x-z
+         p = p + a2 * ((i == V - 1) ? pCp : pC[ip]);       // -x+z
+         o[i] = p;
+      }
+      return o;
+   };
+
+   // Three u^n plane buffers and three u^{n+1} plane buffers whose roles (x-1, x, x+1) rotate with the turn; the x loop is
+   // unrolled by three so that the rotation is a renaming, not register moves (a first version with a fourth "prefetch"
+   // buffer and moves spilled and ran 2.7x slower than the single-step kernel).  The plane x1+2 is loaded into the buffer
+   // of plane x1-1 as soon as stage 1 is done with it (its R centre rows -- the old values of stage 2 -- are set aside),
+   // stage 2 and the other wave of the SIMD cover the latency.
+   vec b0[R + 4], b1[R + 4], b2[R + 4], Ar[R + 2], Bold[R];
+   vec v0[R + 2], v1[R + 2], v2[R + 2];
+   loadB(xs - 2, b0);
+   loadB(xs - 1, b1);
+   loadB(xs, b2);
+   loadA(xs - 1, Ar);
+#pragma unroll
+   for (int j = 0; j < R + 2; j++) { v0[j] = vec{}; v1[j] = vec{}; }
+   // one turn: x1 = plane of the u^{n+1} values computed; Pm / Pc / Pn = u^n planes x1-1 / x1 / x1+1; Vm / Vc = u^{n+1}
+   // planes x1-2 / x1-1, Vn receives plane x1
+   auto turn = [&](int x1, vec(&Pm)[R + 4], vec(&Pc)[R + 4], vec(&Pn)[R + 4], vec(&Vm)[R + 2], vec(&Vc)[R + 2], vec(&Vn)[R + 2]) {
+      // stage 1: u^{n+1}(x1) on rows yo-1 .. yo+R
+#pragma unroll
+      for (int j = 0; j < R + 2; j++) {
+         Vn[j] = stencil(Pc[j + 1], Ar[j], Pc[j + 2], Pc[j], Pn[j + 2], Pn[j + 1], Pn[j], Pm[j + 2], Pm[j + 1], Pm[j]);
+         __builtin_amdgcn_sched_barrier(0); // row by row: interleaving the rows for ILP costs more registers than there are
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) Bold[r] = Pm[r + 2];
+      if (x1 < xe) { loadB(x1 + 2, Pm); loadA(x1 + 1, Ar); }
+      if (x1 >= xs && x1 < xe) {
+         Real *pc = (Real *)tp.C + (int64_t)x1 * plane;
+#pragma unroll
+         for (int r = 0; r < R; r++)
+            if (core_col && core_row[r]) __builtin_nontemporal_store(Vn[r + 1], (vec *)(pc + offB[r + 2]));
+      }
+      // stage 2: u^{n+2}(x1-1) from u^{n+1} planes x1-2, x1-1, x1; its old value is u^n(x1-1)
+      if (x1 - 1 >= xs) {
+         Real *pd = (Real *)tp.D + (int64_t)(x1 - 1) * plane;
+#pragma unroll
+         for (int r = 0; r < R; r++) {
+            const vec o = stencil(Vc[r + 1], Bold[r], Vc[r + 2], Vc[r], Vn[r + 2], Vn[r + 1], Vn[r], Vm[r + 2], Vm[r + 1], Vm[r]);
+            if (core_col && core_row[r]) __builtin_nontemporal_store(o, (vec *)(pd + offB[r + 2]));
+            __builtin_amdgcn_sched_barrier(0);
+         }
+      }
+   };
+   for (int x1 = xs - 1; x1 <= xe; x1 += 3) {
+      turn(x1, b0, b1, b2, v0, v1, v2);
+      if (x1 + 1 > xe) break;
+      turn(x1 + 1, b1, b2, b0, v1, v2, v0);
+      if (x1 + 2 > xe) break;
+      turn(x1 + 2, b2, b0, b1, v2, v0, v1);
+   }
+}
+
+// host-side launcher, defined (and the kernel instantiated) in pf_tb2_fcc.hip, which is built with its own flags
+template <typename Real> void launch_tb2_fcc(hipStream_t s, const Tb2Params &tp, Real a1, Real a2, int lw, uint32_t nblocks);
+
+// ---------------------------------------------------------------------------------------------------------------
 // k_tb1_tile -- ONE 7-point air update of the tiles k_tb2_reg must leave alone (a boundary node, a source or the ABC
 // shell within one cell of their core), with the same tile geometry, out of place: A = u^{n-1}, B = u^n -> C = u^{n+1}.
 // Cells whose skip-mask bit is set (boundary nodes) are not written: the boundary pass writes them afterwards.
@@ -333,6 +462,80 @@ __global__ __launch_bounds__(256) void k_air_zstrip(ZStripParams<Real> zp, Real 
       }
       *(vec *)(zp.u0 + (int64_t)x * zp.plane + off) = o;
       cm = c; c = cp; lf = lfn; rt = rtn;
+   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_zstrip_fcc -- 13-point counterpart of k_air_zstrip for the folded FCC grid: single-step update (+ ABC loss) of the thin
+// column strips z in [0, zl) and [zr, P) beside the temporally blocked box, out of place (u^{n-1} from u0s, u^{n+1} to
+// u0).  The ghost shell of u1 is in memory here (the 13-point path keeps the flip kernels), so rows y-1 .. y+1 and the
+// columns next to a vector are simply loaded.  Boundary nodes keep their old value (the list kernel writes them).
+// Same accumulation order as k_air_fcc (bit-identical).
+// ---------------------------------------------------------------------------------------------------------------
+template <typename Real>
+__global__ __launch_bounds__(256) void k_zstrip_fcc(ZStripParams<Real> zp, Real a1, Real a2, Real l, int xchunk, int fold) {
+   typedef typename VecOf<Real>::type vec;
+   constexpr int V = VecOf<Real>::V;
+   const int nl = zp.zl / V, nr = (zp.P - zp.zr) / V, nv = nl + nr;
+   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (t >= (int64_t)(zp.Ny - 2) * nv) return;
+   const int v = (int)(t % nv);
+   const int y = 1 + (int)(t / nv);
+   const int xs = zp.x_begin + blockIdx.y * xchunk, xe = min(xs + xchunk, zp.x_end);
+   const int z0 = v < nl ? v * V : zp.zr + (v - nl) * V;
+   const int Nx = zp.Nx, Ny = zp.Ny, Nz = zp.Nz, P = zp.P;
+   const int64_t off = (int64_t)y * P + z0;
+   struct Row { vec c; Real lf, rt; };
+   auto load_row = [&](const Real *pl, int64_t o) {
+      Row r;
+      r.c = *(const vec *)(pl + o);
+      r.lf = z0 > 0 ? pl[o - 1] : Real(0);
+      r.rt = z0 + V < P ? pl[o + V] : Real(0);
+      return r;
+   };
+   auto load_plane = [&](int x, Row *d) { // rows y-1, y, y+1
+      const Real *pl = zp.u1 + (int64_t)x * zp.plane;
+      d[0] = load_row(pl, off - P); d[1] = load_row(pl, off); d[2] = load_row(pl, off + P);
+   };
+   auto lo = [&](const Row &r, int i) { return i == 0 ? r.lf : r.c[i > 0 ? i - 1 : 0]; };
+   auto hi = [&](const Row &r, int i) { return i == V - 1 ? r.rt : r.c[i < V - 1 ? i + 1 : V - 1]; };
+   const int qy = (y == 1 || (!fold && y == Ny - 2)) ? 1 : 0;
+   Row pm[3], pc[3], pn[3];
+   load_plane(xs - 1, pm);
+   load_plane(xs, pc);
+   for (int x = xs; x < xe; x++) {
+      load_plane(x + 1, pn);
+      const vec old = *(const vec *)(zp.u0s + (int64_t)x * zp.plane + off);
+      const uint32_t bits = (zp.mask[((int64_t)x * zp.plane + off) >> 3] >> (off & 7)) & ((1u << V) - 1u);
+      const int qxy = (((zp.first && x == 1) || (zp.last && x == Nx - 2)) ? 1 : 0) + qy;
+      vec o;
+#pragma unroll
+      for (int i = 0; i < V; i++) {
+         Real p = a1 * pc[1].c[i] - old[i];
+         p = p + a2 * pn[2].c[i];      // +x+y
+         p = p + a2 * pm[0].c[i];      // -x-y
+         p = p + a2 * hi(pc[2], i);    // +y+z
+         p = p + a2 * lo(pc[0], i);    // -y-z
+         p = p + a2 * hi(pn[1], i);    // +x+z
+         p = p + a2 * lo(pm[1], i);    // -x-z
+         p = p + a2 * pn[0].c[i];      // +x-y
+         p = p + a2 * pm[2].c[i];      // -x+y
+         p = p + a2 * lo(pc[2], i);    // +y-z
+         p = p + a2 * hi(pc[0], i);    // -y+z
+         p = p + a2 * lo(pn[1], i);    // +x-z
+         p = p + a2 * hi(pm[1], i);    // -x+z
+         const int Q = qxy + ((z0 + i == 1 || z0 + i == Nz - 2) ? 1 : 0);
+         if (Q > 0) { // ABC loss (cpu_engine.h:225-229), double literal of :228
+            const Real lQ = l * (Real)Q;
+            const Real num = p + lQ * old[i];
+            p = (Real)((double)num / (1.0 + (double)lQ));
+         }
+         if ((bits >> i) & 1u) p = old[i]; // ghost / pad column or a boundary node
+         o[i] = p;
+      }
+      *(vec *)(zp.u0 + (int64_t)x * zp.plane + off) = o;
+#pragma unroll
+      for (int r = 0; r < 3; r++) { pm[r] = pc[r]; pc[r] = pn[r]; }
    }
 }
 

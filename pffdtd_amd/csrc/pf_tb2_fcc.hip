@@ -1,0 +1,20 @@
+// pf_tb2_fcc.hip -- the 13-point two-steps-per-pass kernel (k_tb2_fcc, pf_tb2.h) in a translation unit of its own, built
+// with -fno-slp-vectorize (pffdtd_amd/build.py): with the SLP vectoriser on, the compiler pairs the fp32 operations into
+// v_pk_mul_f32 / v_pk_add_f32, whose aligned operand pairs cost ~200 register moves per plane and push the kernel from
+// 244 registers to 348 (spills at two waves per SIMD).  The other kernels are memory-bound and keep the default flags.
+#include <hip/hip_runtime.h>
+
+#include "pf_tb2.h"
+
+namespace pf {
+
+template <typename Real> void launch_tb2_fcc(hipStream_t s, const Tb2Params &tp, Real a1, Real a2, int lw, uint32_t nblocks) {
+   const dim3 g(nblocks), b(256);
+   if (lw == 32) hipLaunchKernelGGL((k_tb2_fcc<Real, 2, 4, 32>), g, b, 0, s, tp, a1, a2);
+   else if (lw == 16) hipLaunchKernelGGL((k_tb2_fcc<Real, 2, 4, 16>), g, b, 0, s, tp, a1, a2);
+   else hipLaunchKernelGGL((k_tb2_fcc<Real, 2, 4, 64>), g, b, 0, s, tp, a1, a2);
+}
+template void launch_tb2_fcc<float>(hipStream_t, const Tb2Params &, float, float, int, uint32_t);
+template void launch_tb2_fcc<double>(hipStream_t, const Tb2Params &, double, double, int, uint32_t);
+
+} // namespace pf

@@ -162,3 +162,51 @@ def test_blocked_steps_in_double_precision(src, kw):
             assert np.array_equal(a[1:-1, 1:-1, 1:-1], b[1:-1, 1:-1, 1:-1]), (variant, dbg)
         if variant == 40:
             assert tm["tb2_launches"] > 0
+
+
+def fcc_scene(n=(36, 70, 280), Nt=25, src=None, blocks=(), wall=3, rcv=None):
+    """folded FCC room with a stored grid of n (unfolded Ny = 2 (n[1] - 1)); receivers near the source"""
+    Nyu = 2 * (n[1] - 1)
+    src = src or [n[0] // 2, n[1] // 2, n[2] // 2]
+    src = [src[0], src[1], src[2] + (sum(src) % 2)]  # an existing (even) node of the subgrid
+    rcv = rcv or [[src[0] + dx, src[1] + dy, src[2] + dz + ((dx + dy + dz) % 2)] for dx, dy, dz in ((2, 3, -4), (-5, 2, 6), (3, -6, 9), (-2, -3, -8))]
+    sim = synth.shoebox(n[0], Nyu, n[2], Nt=Nt, fcc=True, Nm=2, Mb=[11, 3], src=src, rcv=rcv, blocks=blocks, wall=wall)
+    synth.fold_fcc(sim)
+    synth.sort_sim(sim)
+    return sim
+
+
+@pytest.mark.parametrize("prec", ["single", "double"])
+@pytest.mark.parametrize("dbg", [0, 0x100, 0x200], ids=["lw64", "lw32", "lw16"])
+@pytest.mark.parametrize("blocks", [(), ((12, 17, 20, 40, 60, 130), (22, 24, 8, 12, 150, 260))], ids=["box", "blocks"])
+def test_fcc_blocked_pairs_match_single_steps_and_oracle(prec, dbg, blocks):
+    """13-point folded FCC: k_tb2_fcc over the clean tiles, k_air_fcc tiles / k_zstrip_fcc / whole-plane slabs around them,
+    ghost flips in memory -- receivers equal the oracle's, whole fields the single-step engine's."""
+    sim = fcc_scene(blocks=blocks, src=[19, 45, 138] if blocks else None)
+    ref = sim_data.SimData.from_sim(sim, prec)
+    ref.scale_input()
+    oracle.run_sim(ref)
+    assert np.abs(ref.u_out).max() > 0
+    base_out, base_g, tm0 = run(sim, 0, prec=prec, debug=0x4000)   # single steps
+    assert tm0["tb2_launches"] == 0 and np.array_equal(base_out, ref.u_out)
+    for chunk in (0, 6):
+        out, g, tm = run(sim, 40, prec=prec, readout_chunk=chunk, debug=dbg)
+        assert tm["tb2_launches"] > 0 and tm["tb2_cells"] > 0, tm
+        assert np.array_equal(out, ref.u_out), chunk
+        for a, b in zip(g, base_g):
+            assert np.array_equal(a[1:-1, 1:-1, 1:-1], b[1:-1, 1:-1, 1:-1]), chunk
+
+
+def test_fcc_blocked_pairs_with_live_abc_and_odd_sizes():
+    """source outside the room (the wave runs into the ABC shell and the ghost flips on every face), sizes that are no
+    multiples of the tile dimensions"""
+    sim = fcc_scene(n=(38, 67, 286), Nt=31, src=[3, 30, 140], wall=7, rcv=[[2, 33, 137], [4, 25, 151], [3, 30, 128], [33, 4, 200]])
+    ref = sim_data.SimData.from_sim(sim, "single")
+    ref.scale_input()
+    oracle.run_sim(ref)
+    assert np.abs(ref.u_out).max() > 0
+    out, g, tm = run(sim, 40)
+    assert tm["tb2_launches"] > 0 and np.array_equal(out, ref.u_out)
+    _, base_g, _ = run(sim, 0, debug=0x4000)
+    for a, b in zip(g, base_g):
+        assert np.array_equal(a[1:-1, 1:-1, 1:-1], b[1:-1, 1:-1, 1:-1])
