@@ -290,14 +290,15 @@ def main():
         # quoted when the committed profile is of the very kernel instantiation this run used, advancing the same number of
         # voxel updates per launch -- otherwise null.
         tfile, pfile = ROOT / "profiles" / "r02_bench_n1_hbm_traffic.json", ROOT / "profiles" / "r02_bench_n1.json"
-        if world == 1 and tm.get("tb2_launches", 0) > 0 and tfile.exists() and pfile.exists():
+        if world == 1 and tm.get("tb2_launches", 0) > 0 and tfile.exists():
             inst = (f"pf::k_tb2_fcc<{'float' if real_bytes == 4 else 'double'}, 2, 4, {int(tm['tb2_lw'])}>" if args.fcc else
                     f"pf::k_tb2_reg<{'float' if real_bytes == 4 else 'double'}, 3, 4, false, {int(tm['tb2_lw'])}>")
             try:
                 ks = json.load(open(tfile))["kernels"]
-                prof = json.load(open(pfile))
+                # (pfile absent = the profile collection itself, tools/collect_n1_profile.sh: the passes just taken are of this build)
+                prof = json.load(open(pfile)) if pfile.exists() else None
                 hit = [v for k, v in ks.items() if inst in k]
-                same = (prof["roofline"]["voxel_updates_per_launch"] == int(units) and prof["config"]["grid"] == [sd.Nx, sd.Ny, sd.Nz]
+                same = prof is None or (prof["roofline"]["voxel_updates_per_launch"] == int(units) and prof["config"]["grid"] == [sd.Nx, sd.Ny, sd.Nz]
                         and prof["config"]["Nb"] == sd.Nb and prof["dtype"] == res["dtype"])
                 if hit and same:
                     res["roofline"]["traffic"] = round(hit[0]["total_bytes"] / 1e9, 3)

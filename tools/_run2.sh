@@ -1,12 +1,10 @@
 set -x
-python -m pytest tests/test_hip_tb2.py -x -q --tb=short -k fcc 2>&1 | tail -5
+bash tools/collect_n1_profile.sh r02_bench_n1 2>&1 | tail -2
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/p3 -o s --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --fcc --steps 12 --warmup 4 --repeats 1 --no-cpu-baseline --no-rigid-run --variant 40 2>&1 | grep '"metric"' | cut -c1-200
-cd $GRAFT_REPO_ROOT; python - <<'PY'
-import csv, glob
-for f in glob.glob("gpurun_out/p3/*kernel_stats.csv"):
-    for r in csv.DictReader(open(f)):
-        if "pf::" in r["Name"]: print(r["Name"][:90], r["Calls"], round(float(r["AverageNs"])/1e3,1))
-PY
-python bench.py --fcc --precision double --size 768 --steps 12 --warmup 4 --repeats 1 --no-cpu-baseline --no-rigid-run --variant 40 2>&1 | grep '"metric"' | cut -c1-250
-python bench.py --fcc --precision double --size 768 --steps 12 --warmup 4 --repeats 1 --no-cpu-baseline --no-rigid-run --debug 0x4000 2>&1 | grep '"metric"' | cut -c1-250
+R=$GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/p_ctk -o s --output-format csv -- python $R/tools/run_config.py ctk_cart_gpu --steps 400 2>&1 | grep '"config"' > $R/gpurun_out/ctk.json
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/p_mv -o s --output-format csv -- python $R/tools/run_config.py mv_fcc_gpu --steps 200 2>&1 | grep '"config"' > $R/gpurun_out/mv.json
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/p_fcc -o s --output-format csv -- python $R/bench.py --fcc --steps 30 --warmup 6 --repeats 3 --no-cpu-baseline --no-rigid-run 2>&1 | grep '"metric"' > $R/gpurun_out/fcc.json
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/p_fcc40 -o s --output-format csv -- python $R/bench.py --fcc --steps 30 --warmup 6 --repeats 3 --no-cpu-baseline --no-rigid-run --variant 40 2>&1 | grep '"metric"' > $R/gpurun_out/fcc40.json
+python $R/tools/run_config.py ctk_cart_viz --precision double --energy 2>&1 | grep '"config"' > $R/gpurun_out/ctk_viz.json
+cat $R/gpurun_out/ctk.json $R/gpurun_out/mv.json $R/gpurun_out/ctk_viz.json | cut -c1-400

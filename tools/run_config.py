@@ -19,6 +19,7 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
+import torch  # noqa: E402,F401  (before the engine library: see INTEGRATION.md 3)
 from pffdtd_amd import engine, scenes, sim_data  # noqa: E402
 from pffdtd_amd.sim_setup import sim_setup  # noqa: E402
 
@@ -75,7 +76,18 @@ if a.energy:
                gvox_per_s=round(sd.Npts * sd.Nt / el / 1e9, 3))
 else:
     K, W = min(a.steps, sd.Nt - a.warmup), a.warmup
-    eng = engine.HipEngine(sd, timing=True, debug=a.debug, air_variant=a.variant)
+    # state grids owned here and pre-filled with seeded noise of the magnitude of a running simulation: every cell is live
+    # from step 0 (receivers included -- the source's own wave needs thousands of steps to reach them at this resolution),
+    # and the clocks see the data activity of a real run (all-zero fields clock higher)
+    import torch
+    rb = 4 if a.precision == "single" else 8
+    P = engine.grid_pitch(sd.Nz, rb)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(7)
+    grids = [((torch.rand((sd.Nx, sd.Ny * P), generator=gen, device="cuda", dtype=torch.float32 if rb == 4 else torch.float64) * 2 - 1) * 1e-3)
+             for _ in range(2)]
+    torch.cuda.synchronize()
+    eng = engine.HipEngine(sd, timing=True, debug=a.debug, air_variant=a.variant, ext_u0=grids[0].data_ptr(), ext_u1=grids[1].data_ptr())
     eng.run(0, W)
     eng.sync()
     eng.timing(reset=True)
