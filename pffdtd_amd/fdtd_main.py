@@ -12,6 +12,10 @@ gpu_engine.h:516-662), steps it with the split-phase engine and exchanges one pl
 rank 0 gathers the receiver rows and writes `sim_outs.h5`.  Unlike the reference (gpu_engine.h:688) the lists need
 not be sorted: the slabs are cut by plane tests and every engine sorts its own lists.
 It can also be started under `python -m torch.distributed.run --nproc-per-node N -m pffdtd_amd.fdtd_main ...` directly.
+
+`--devices 0,1,2,3` is the in-process alternative, closest to the reference binary: ONE process, the C library's own
+multi-device `run_sim` (pf_run_sim_devices, csrc/pf_multi.hip: one host thread per slab, ghost planes pulled with peer
+copies), no torch and no RCCL involved; a device id may repeat (several slabs on one GPU).
 """
 import argparse
 import os
@@ -52,6 +56,19 @@ def run_single(a):
     tm = eng.timing()
     eng.close()
     _summary(sd, tm, el)
+    _finish(sd, a.data_dir)
+
+
+def run_devices(a, devices):
+    """`--devices`: the C seam's multi-device run_sim in this process"""
+    print(f"--Date and time: {time.ctime()}")
+    sd = sim_data.SimData.from_folder(Path(a.data_dir), a.precision, build_mask=False)
+    sd.scale_input()
+    print(f"--{len(devices)} slabs on devices {devices}: planes {engine.slab_partition(sd, len(devices))}")
+    t0 = time.perf_counter()
+    engine.run_sim_devices(sd, devices)
+    el = time.perf_counter() - t0
+    print(f"Combined (total): {el:.6f}s, {sd.Npts * sd.Nt / 1e6 / el:.2f} Mvox/s")  # incl. engine creation on every device
     _finish(sd, a.data_dir)
 
 
@@ -109,8 +126,11 @@ def main():
     p.add_argument("--gpu", type=int, default=0, help="device of a single-GPU run")
     p.add_argument("--gpus", type=int, default=1, help="number of GPUs (one process each, Z-slabs)")
     p.add_argument("--master_port", type=int, default=29541)
+    p.add_argument("--devices", default="", help="comma-separated device chain for the in-process multi-device run, e.g. 0,1,2,3")
     a = p.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.devices:
+        return run_devices(a, [int(v) for v in a.devices.split(",")])
     if world > 1:
         if a.gpus not in (1, world):
             raise SystemExit(f"--gpus {a.gpus} != WORLD_SIZE {world}")

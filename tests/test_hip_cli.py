@@ -65,3 +65,15 @@ def test_fdtd_main_cli_multi_gpu(tmp_path, gpus, name, prec):
     for line in (f"--{gpus} GPUs", "Air update:", "Combined (total):", "RAW OUTPUTS", "wrote output dataset"):
         assert line in r.stdout, r.stdout[-2000:]
     assert np.array_equal(h5io.read(tmp_path / "sim_outs.h5", "u_out"), _expected(tmp_path, prec, True))
+
+
+def test_fdtd_main_cli_in_process_device_chain(tmp_path):
+    """`--devices 0,0,0`: one process, the C library's multi-device run_sim (three slabs on GPU 0), unsorted lists"""
+    import os
+    sim = cases.make_sim("cart_outside")
+    synth.write_folder(sim, tmp_path)
+    r = subprocess.run([sys.executable, "-m", "pffdtd_amd.fdtd_main", "--precision", "double", "--devices", "0,0,0"], cwd=tmp_path,
+                       env={**os.environ, "PYTHONPATH": str(ROOT)}, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "3 slabs" in r.stdout and "wrote output dataset" in r.stdout
+    assert np.array_equal(h5io.read(tmp_path / "sim_outs.h5", "u_out"), _expected(tmp_path, "double", True))
