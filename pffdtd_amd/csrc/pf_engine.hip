@@ -162,6 +162,7 @@ template <typename Real> struct Engine : EngineBase {
    // 13-point pairs (folded FCC): whatever of the box is not a clean tile's core is stepped by k_air_fcc over its own tiles
    // (256 columns x 16 rows x the same x chunks), listed here
    int32_t *sh_tiles = nullptr;
+   int fcc_wt = 8; // waves per workgroup of k_tb2_fcc_x (two of them halo providers); 0: the register-only k_tb2_fcc
    int64_t sh_ntiles = 0;
    int sh_nyt = 0, sh_nzt = 0;
    const Real *u0_src = nullptr;                          // out-of-place single-step launches read u^{n-1} here
@@ -574,12 +575,16 @@ template <typename Real> struct Engine : EngineBase {
       }
       if (vbase == 41) tbx1 = tbx0; // driver test: everything goes through the out-of-place single-step path
       tb_xr.clear();
-      const int TC = (tb_lw - 2) * V, TR = (fcc ? 8 : 12) * (64 / tb_lw); // rows of a workgroup: 4 waves x R = 3 (7-point) | 2 (13-point)
+      // rows of a workgroup: 4 waves x R = 3 (7-point); 13-point: 6 inner waves x R = 2 with 64-lane segments (k_tb2_fcc_x), else 4 x 2
+      if (const char *ev = getenv("PFFDTD_FCC_WT")) { const int v = atoi(ev); if (v == 6 || v == 8 || v == 0) fcc_wt = v; }
+      const int TC = (tb_lw - 2) * V, TR = fcc ? ((tb_lw == 64 && fcc_wt) ? 2 * (fcc_wt - 2) : 8 * (64 / tb_lw)) : 12 * (64 / tb_lw);
       int64_t vol = 0;
       if (tbx1 - tbx0 >= 16 && tby1 - tby0 >= 24 && tbz1 - tbz0 >= TC / 2) {
          tb_xr.push_back({tbx0, tbx1});
          const int np = tbx1 - tbx0;
-         tb_chunk = (int)cdiv(np, std::max<int64_t>(cdiv(np, tb2_chunk), 1)); // ~16-plane chunks, even split (tools/tb2_probe.py)
+         // ~16-plane chunks, even split (tools/tb2_probe.py); 13-point: ~24 (3.93 vs 4.07 ms per launch at 1024^3, 32-48 the same)
+         const int want_chunk = (fcc && !getenv("PFFDTD_TB2_CHUNK")) ? 24 : tb2_chunk;
+         tb_chunk = (int)cdiv(np, std::max<int64_t>(cdiv(np, want_chunk), 1));
          tb_nxc = (int)cdiv(np, tb_chunk); tb_nyt = (int)cdiv(tby1 - tby0, TR); tb_nzt = (int)cdiv(tbz1 - tbz0, TC);
          const int64_t ntile = (int64_t)tb_nxc * tb_nyt * tb_nzt;
          if (ntile >= ((int64_t)1 << 31)) return PF_OK;
@@ -840,7 +845,12 @@ template <typename Real> struct Engine : EngineBase {
       tp.A = A; tp.B = B; tp.C = C; tp.D = D;
       tp.tiles = tb_ndirty > 0 ? tb_clean : nullptr; // all clean: the dense order (identical to the list's)
       const dim3 g((uint32_t)tb_nclean), b(256);
-      if (fcc) { pf::launch_tb2_fcc<Real>(s, tp, a1, a2, tb_lw, (uint32_t)tb_nclean); return; }
+      if (fcc) {
+         if (tb_lw == 64 && fcc_wt == 8) hipLaunchKernelGGL((pf::k_tb2_fcc_x<Real, 2, 8>), g, dim3(512), 0, s, tp, a1, a2);      // 12-row tiles
+         else if (tb_lw == 64 && fcc_wt == 6) hipLaunchKernelGGL((pf::k_tb2_fcc_x<Real, 2, 6>), g, dim3(384), 0, s, tp, a1, a2); // 8-row tiles
+         else pf::launch_tb2_fcc<Real>(s, tp, a1, a2, tb_lw, (uint32_t)tb_nclean, fcc_wt);
+         return;
+      }
       if (tb_lw == 32) hipLaunchKernelGGL((pf::k_tb2_reg<Real, 3, 4, false, 32>), g, b, 0, s, tp, a1, a2);
       else if (tb_lw == 16) hipLaunchKernelGGL((pf::k_tb2_reg<Real, 3, 4, false, 16>), g, b, 0, s, tp, a1, a2);
       else hipLaunchKernelGGL((pf::k_tb2_reg<Real, 3, 4, false, 64>), g, b, 0, s, tp, a1, a2);

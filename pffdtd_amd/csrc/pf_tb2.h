@@ -266,8 +266,141 @@ __global__ __launch_bounds__(64 * WY) __attribute__((amdgpu_waves_per_eu(2, 2)))
    }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_tb2_fcc_x -- k_tb2_fcc with the u^{n+1} halo rows EXCHANGED between the waves of a workgroup through LDS instead of
+// recomputed.  The 13-point kernel is VALU-bound in the bit-exact mode, and with R = 2 the recomputation doubles stage 1
+// (4 row updates for 2 useful).  Here a workgroup is WT waves stacked in y, each computing stage 1 on its own R rows only;
+// the first and the last wave are pure halo providers (no stage 2, no stores), the WT-2 waves between them own the tile's
+// (WT-2)*R rows.  Per plane: every wave publishes its R new u^{n+1} rows to a double-buffered LDS tile, one barrier, the
+// inner waves pick up the row above and the row below.  Row updates per plane and workgroup: WT*R + (WT-2)*R for
+// (WT-2)*R*2 useful (WT = 8: 1.17x instead of 1.5x), u^n rows loaded per wave R+2 instead of R+4, u^{n-1} rows R instead
+// of R+2, and 28 instead of 40 vectors of state per lane.  64-lane row segments only.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename Real, int R, int WT>
+__global__ __launch_bounds__(64 * WT) void k_tb2_fcc_x(Tb2Params tp, Real a1, Real a2_) {
+   typedef typename VecOf<Real>::type vec;
+   constexpr int V = VecOf<Real>::V, W = 64 * V;
+   __shared__ __attribute__((aligned(16))) Real sV[2][WT * R][W];
+   const uint32_t t = tp.tiles ? (uint32_t)tp.tiles[blockIdx.x] : blockIdx.x;
+   const int zt = t % tp.nzt, yt = (t / tp.nzt) % tp.nyt, xc = t / (tp.nzt * tp.nyt);
+   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+   const bool inner = w >= 1 && w <= WT - 2;
+   const int ze0 = tp.z_begin - V + zt * (W - 2 * V);
+   const int yo = tp.y_begin + (yt * (WT - 2) + (w - 1)) * R;   // first own row of this wave (wave 0: the R rows above the tile)
+   const int xs = tp.x_begin + xc * tp.chunk, xe = min(xs + tp.chunk, tp.x_end);
+   const int P = tp.P;
+   const int64_t plane = tp.plane;
+   const int zc = min(max(ze0 + lane * V, 0), P - V);
+   uint32_t offB[R + 2];                                      // rows yo-1 .. yo+R
+#pragma unroll
+   for (int i = 0; i < R + 2; i++) offB[i] = (uint32_t)min(max(yo - 1 + i, 0), tp.Ny - 1) * (uint32_t)P + (uint32_t)zc;
+   const int z_end = tp.z_end ? tp.z_end : tp.Nz - tp.z_begin, y_end = tp.y_end ? tp.y_end : tp.Ny - tp.y_begin;
+   const bool core_col = inner && (lane >= 1 && lane <= 62) && (ze0 + lane * V + V - 1 < z_end);
+   bool core_row[R];
+#pragma unroll
+   for (int r = 0; r < R; r++) core_row[r] = (yo + r < y_end);
+
+   auto loadB = [&](int x, vec *d) {
+      const Real *pl = (const Real *)tp.B + (int64_t)x * plane;
+#pragma unroll
+      for (int i = 0; i < R + 2; i++) d[i] = *(const vec *)(pl + offB[i]);
+   };
+   auto loadA = [&](int x, vec *d) { // rows yo .. yo+R-1
+      const Real *pl = (const Real *)tp.A + (int64_t)x * plane;
+#pragma unroll
+      for (int j = 0; j < R; j++) d[j] = __builtin_nontemporal_load((const vec *)(pl + offB[j + 1]));
+   };
+   auto stencil = [&](const vec &c, const vec &old, const vec &cU, const vec &cD, const vec &nU, const vec &nC, const vec &nD,
+                      const vec &pU, const vec &pC, const vec &pD) {
+      const Real cUm = lane_from_lower<true>(cU[V - 1]), cUp = lane_from_upper<true>(cU[0]);
+      const Real cDm = lane_from_lower<true>(cD[V - 1]), cDp = lane_from_upper<true>(cD[0]);
+      const Real nCm = lane_from_lower<true>(nC[V - 1]), nCp = lane_from_upper<true>(nC[0]);
+      const Real pCm = lane_from_lower<true>(pC[V - 1]), pCp = lane_from_upper<true>(pC[0]);
+      Real a2 = a2_; // opaque per row, as in k_tb2_fcc
+      asm volatile("" : "+s"(a2));
+      vec o;
+#pragma unroll
+      for (int i = 0; i < V; i++) {
+         const int im = i > 0 ? i - 1 : 0, ip = i < V - 1 ? i + 1 : V - 1;
+         Real p = a1 * c[i] - old[i];
+         p = p + a2 * nU[i];                               // +x+y
+         p = p + a2 * pD[i];                               // -x-y
+         p = p + a2 * ((i == V - 1) ? cUp : cU[ip]);       // +y+z
+         p = p + a2 * ((i == 0) ? cDm : cD[im]);           // -y-z
+         p = p + a2 * ((i == V - 1) ? nCp : nC[ip]);       // +x+z
+         p = p + a2 * ((i == 0) ? pCm : pC[im]);           // -x-z
+         p = p + a2 * nD[i];                               // +x-y
+         p = p + a2 * pU[i];                               // -x+y
+         p = p + a2 * ((i == 0) ? cUm : cU[im]);           // +y-z
+         p = p + a2 * ((i == V - 1) ? cDp : cD[ip]);       // -y+z
+         p = p + a2 * ((i == 0) ? nCm : nC[im]);           // +x-z
+         p = p + a2 * ((i == V - 1) ? pCp : pC[ip]);       // -x+z
+         o[i] = p;
+      }
+      return o;
+   };
+   // Four u^n plane buffers: x1-1, x1, x1+1 and the plane x1+2 still in flight -- with one barrier per plane and one
+   // workgroup per CU there is nobody to hide a load issued in the same turn it is needed, so planes are requested two
+   // turns ahead (x1+3 goes into the buffer of x1-1 as soon as stage 1 is done with it); likewise two u^{n-1} buffers.
+   // The x loop is unrolled by four so that these roles are renamings; the three u^{n+1} planes rotate by moves.
+   vec b0[R + 2], b1[R + 2], b2[R + 2], b3[R + 2], A0[R], A1[R], Bold[R];
+   vec Vm[R + 2], Vc[R + 2], Vn[R + 2];
+   loadB(xs - 2, b0);
+   loadB(xs - 1, b1);
+   loadB(xs, b2);
+   loadB(min(xs + 1, xe + 1), b3);
+   loadA(xs - 1, A0);
+   loadA(xs, A1);
+#pragma unroll
+   for (int j = 0; j < R + 2; j++) { Vm[j] = vec{}; Vc[j] = vec{}; }
+   auto turn = [&](int x1, vec(&Pm)[R + 2], vec(&Pc)[R + 2], vec(&Pn)[R + 2], vec(&Ac)[R]) {
+      const int buf = (x1 - xs + 1) & 1;
+      // stage 1: u^{n+1}(x1) on the wave's own rows yo .. yo+R-1, published to the workgroup
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+         Vn[j + 1] = stencil(Pc[j + 1], Ac[j], Pc[j + 2], Pc[j], Pn[j + 2], Pn[j + 1], Pn[j], Pm[j + 2], Pm[j + 1], Pm[j]);
+         *(vec *)&sV[buf][w * R + j][lane * V] = Vn[j + 1];
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) Bold[r] = Pm[r + 1];
+      if (x1 + 3 <= xe + 1) loadB(x1 + 3, Pm);
+      if (x1 + 2 <= xe) loadA(x1 + 2, Ac);
+      __syncthreads();
+      if (inner) {
+         Vn[0] = *(const vec *)&sV[buf][w * R - 1][lane * V];
+         Vn[R + 1] = *(const vec *)&sV[buf][w * R + R][lane * V];
+      }
+      if (x1 >= xs && x1 < xe) {
+         Real *pc = (Real *)tp.C + (int64_t)x1 * plane;
+#pragma unroll
+         for (int r = 0; r < R; r++)
+            if (core_col && core_row[r]) __builtin_nontemporal_store(Vn[r + 1], (vec *)(pc + offB[r + 1]));
+      }
+      // stage 2 (inner waves): u^{n+2}(x1-1) from u^{n+1} planes x1-2, x1-1, x1; its old value is u^n(x1-1)
+      if (inner && x1 - 1 >= xs) {
+         Real *pd = (Real *)tp.D + (int64_t)(x1 - 1) * plane;
+#pragma unroll
+         for (int r = 0; r < R; r++) {
+            const vec o = stencil(Vc[r + 1], Bold[r], Vc[r + 2], Vc[r], Vn[r + 2], Vn[r + 1], Vn[r], Vm[r + 2], Vm[r + 1], Vm[r]);
+            if (core_col && core_row[r]) __builtin_nontemporal_store(o, (vec *)(pd + offB[r + 1]));
+         }
+      }
+#pragma unroll
+      for (int j = 0; j < R + 2; j++) { Vm[j] = Vc[j]; Vc[j] = Vn[j]; }
+   };
+   for (int x1 = xs - 1; x1 <= xe; x1 += 4) {
+      turn(x1, b0, b1, b2, A0);
+      if (x1 + 1 > xe) break;
+      turn(x1 + 1, b1, b2, b3, A1);
+      if (x1 + 2 > xe) break;
+      turn(x1 + 2, b2, b3, b0, A0);
+      if (x1 + 3 > xe) break;
+      turn(x1 + 3, b3, b0, b1, A1);
+   }
+}
+
 // host-side launcher, defined (and the kernel instantiated) in pf_tb2_fcc.hip, which is built with its own flags
-template <typename Real> void launch_tb2_fcc(hipStream_t s, const Tb2Params &tp, Real a1, Real a2, int lw, uint32_t nblocks);
+template <typename Real> void launch_tb2_fcc(hipStream_t s, const Tb2Params &tp, Real a1, Real a2, int lw, uint32_t nblocks, int wt);
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_tb1_tile -- ONE 7-point air update of the tiles k_tb2_reg must leave alone (a boundary node, a source or the ABC
