@@ -1,4 +1,4 @@
-python -m pytest tests/test_hip_tb2.py tests/test_hip_parity.py -x -q --tb=short 2>&1 | tail -2
-python bench.py --fcc --precision double --size 1536 --steps 12 --warmup 4 --repeats 3 --no-cpu-baseline --no-rigid-run 2>&1 | grep '"metric"' | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('fp64 1536 auto', d['value'], d['ms_per_step'], r['kernel'], r['kernel_ms_per_launch'], r['frac'], r['autotune_ms_per_step'])"
-python bench.py --fcc --precision double --size 1536 --steps 12 --warmup 4 --repeats 3 --no-cpu-baseline --no-rigid-run --debug 0x4000 2>&1 | grep '"metric"' | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('fp64 1536 single', d['value'], d['ms_per_step'], r['kernel'], r['kernel_ms_per_launch'], r['frac'])"
-python bench.py --fcc --steps 30 --warmup 6 --repeats 3 --no-cpu-baseline --no-rigid-run 2>&1 | grep '"metric"' | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('fp32 1024 auto', d['value'], d['ms_per_step'], r['kernel'], r['kernel_ms_per_launch'], r['frac'], r['autotune_ms_per_step'])"
+for wy in 4 8 4 8; do
+PFFDTD_TB2_WY=$wy python bench.py --steps 40 --warmup 8 --repeats 3 --no-cpu-baseline --no-rigid-run 2>&1 | grep '"metric"' | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('wy $wy', d['value'], d['ms_per_step'], d['roofline']['kernel_ms_per_launch'])"
+done
+PFFDTD_TB2_WY=8 python -m pytest tests/test_hip_tb2.py -x -q -k "not fcc" 2>&1 | tail -2
