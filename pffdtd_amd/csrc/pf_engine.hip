@@ -526,9 +526,9 @@ template <typename Real> struct Engine : EngineBase {
       if (const char *ev = getenv("PFFDTD_TB2_CHUNK")) tb2_chunk = std::min(std::max(atoi(ev), 4), 256);
       const bool single = op.slab_first && op.slab_last;
       if (lean_rigid || v1_rigb || op.energy || (op.debug & 0x4000)) return PF_OK; // 0x4000: single steps only
-      // 7-point: the fused single-step kernels carry the shell; 13-point: folded grids on one device, with the flips in
-      // memory and the ABC loss in the interior kernel (the automatic 13-point arrangement)
-      if (fcc ? !(fold && abck && single) : !(lean || vg)) return PF_OK;
+      // 7-point: the fused single-step kernels carry the shell; 13-point: folded grids with the flips in memory and the ABC
+      // loss in the interior kernel (the automatic 13-point arrangement)
+      if (fcc ? !(fold && abck) : !(lean || vg)) return PF_OK;
       if (!(vbase == 0 || vbase == 40 || vbase == 41) || op.numerics != PF_NUM_CPU_EXACT || !use_dpp) return PF_OK;
       if (Nb > 0 && !boundary_fused()) return PF_OK;
       // Margins of the box: three cells off every grid face (the ABC cells sit at index 1 and the box must stay two cells
@@ -869,11 +869,11 @@ template <typename Real> struct Engine : EngineBase {
    // one out-of-place single step of everything outside the box: u1 -> (u0_src old) -> u0
    void launch_shell(hipStream_t s) { launch_shell(s, 1, (int)Nx - 1); }
    // 13-point: ghost flips of u1 in memory, then x slabs (whole planes), column strips, and the single-step tiles of the box
-   void launch_shell_fcc(hipStream_t s) {
-      launch_flips(s);
-      if (tb_xr.empty()) { launch_air_march(s, 1, (int)Nx - 1); return; }
-      if (tbx0 > 1) launch_air_march(s, 1, tbx0);
-      if (tbx1 < Nx - 1) launch_air_march(s, tbx1, (int)Nx - 1);
+   void launch_shell_fcc(hipStream_t s, int xlo, int xhi, bool flips) { // planes [xlo, xhi); flips: also the ghost shell of u1
+      if (flips) launch_flips(s);
+      if (tb_xr.empty()) { launch_air_march(s, xlo, xhi); return; }
+      if (tbx0 > xlo) launch_air_march(s, xlo, tbx0);
+      if (tbx1 < xhi) launch_air_march(s, tbx1, xhi);
       constexpr int V = pf::VecOf<Real>::V;
       {
          pf::ZStripParams<Real> zp{};
@@ -896,7 +896,7 @@ template <typename Real> struct Engine : EngineBase {
       }
    }
    void launch_shell(hipStream_t s, int xlo, int xhi) { // planes [xlo, xhi) (the box lies inside)
-      if (fcc) { launch_shell_fcc(s); return; }
+      if (fcc) { launch_shell_fcc(s, xlo, xhi, !tb2_slab); return; } // (slab engines flip on the edge stream, after the exchange)
       int xa = xlo;
       for (auto &r : tb_xr) { // x slabs: everything before / between / after the box's plane ranges, full planes
          if (r.first > xa) launch_air_lean(s, xa, r.first);
@@ -1469,11 +1469,21 @@ template <typename Real> struct Engine : EngineBase {
       if (tb2_slab && (pair_phase == 1 || (n + 1 < Nt && ring_fill + 2 <= ring_depth && xh - xl >= 8))) {
          const bool first_half = pair_phase == 0;
          if (first_half) { pA = u0; pB = u1; u0_src = pA; u1 = pB; u0 = bufC; }
-         fold_x0 = 0; fold_x1 = 0; // (7-point only: no fold row)
-         // (the lean kernel explicitly, as launch_shell does: it is the one that honours u0_src -- the barrier-free kernel
-         // an engine may have chosen for its single steps reads u^{n-1} from u0, which here is the grid being written)
-         launch_air_lean(s_edge, xl, xl + 2);
-         launch_air_lean(s_edge, xh - 1, xh + 1);
+         fold_x0 = 0; fold_x1 = 0; // (virtual-ghost modes with a fold row do not block in pairs)
+         if (fcc) {
+            // 13-point: the ghost shell of u1 lives in memory; its flips touch the whole grid, ghost planes included, so
+            // they go on the edge stream (ordered after the exchange that filled those planes) and the interior waits
+            launch_flips(s_edge);
+            HIPCHK(hipEventRecord(ev_pre, s_edge));
+            HIPCHK(hipStreamWaitEvent(s_main, ev_pre, 0));
+            launch_air_march(s_edge, xl, xl + 2);   // (k_air_fcc reads u^{n-1} from u0_src)
+            launch_air_march(s_edge, xh - 1, xh + 1);
+         } else {
+            // (the lean kernel explicitly, as launch_shell does: it is the one that honours u0_src -- the barrier-free
+            // kernel an engine may have chosen for its single steps reads u^{n-1} from u0, which here is the grid being written)
+            launch_air_lean(s_edge, xl, xl + 2);
+            launch_air_lean(s_edge, xh - 1, xh + 1);
+         }
          launch_rigid(s_edge, bn_lo2); launch_rigid(s_edge, bn_hi2);
          launch_fd(s_edge, bnl_lo2); launch_fd(s_edge, bnl_hi2);
          launch_io(s_edge, n, false, in_lo2); launch_io(s_edge, n, false, in_hi2);

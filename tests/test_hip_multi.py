@@ -103,3 +103,26 @@ def test_errors_surface_through_the_seam():
         engine.run_sim_devices(sd, [0, 99])
     with pytest.raises(engine.PfError):
         engine.run_sim_devices(sd, [0] * int(sd.Nx))  # more slabs than planes (gpu_engine.h:682)
+
+
+@pytest.mark.parametrize("prec", ["single", "double"])
+def test_fcc_slabs_in_temporally_blocked_pairs(prec):
+    """13-point folded FCC slabs with pairs forced in every slab: flips on the edge stream after the exchange, k_tb2_fcc_x over
+    the slab's clean tiles, out-of-place k_air_fcc for the edge planes -- bit for bit the single-domain oracle"""
+    kw = dict(Nx=100, Ny=138, Nz=276, Nt=41, fcc=True, wall=3, Nm=1, Mb=3, src=[47, 30, 101],
+              rcv=[[40, 25, 97], [56, 36, 110], [48, 35, 105], [47, 6, 101]])
+
+    def make():
+        sim = synth.shoebox(**kw)
+        synth.fold_fcc(sim)
+        synth.sort_sim(sim)
+        sd = sim_data.SimData.from_sim(sim, prec)
+        sd.scale_input()
+        return sd
+    ref = make()
+    oracle.run_sim(ref)
+    assert np.abs(ref.u_out).max() > 0
+    for devs in ([0, 0], [0, 0, 0]):
+        sd = make()
+        engine.run_sim_devices(sd, devs, multi_flags=engine.PF_MULTI_FORCE_PAIRS, air_variant=40)
+        assert np.array_equal(sd.u_out, ref.u_out), devs
