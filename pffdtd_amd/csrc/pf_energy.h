@@ -93,7 +93,7 @@ __global__ void k_energy_stored(const Real *__restrict__ vh1, const Real *__rest
       const int k = mat[nb];
       double s = 0.0;
       for (int m = 0; m < Mb[k]; m++) {
-         const double v = (double)vh1[(int64_t)m * Nbl + nb], g = (double)gh1[(int64_t)m * Nbl + nb];
+         const double v = (double)vh1[st_idx(m, nb)], g = (double)gh1[st_idx(m, nb)];
          const double D = DEF[(k * 12 + m) * 3 + 0], F = DEF[(k * 12 + m) * 3 + 2];
          s += (v * v) * D + ((Ts * g) * (Ts * g)) * F;
       }
@@ -136,7 +136,7 @@ __global__ void k_energy_loss(const Real *__restrict__ vh_old, const Real *__res
       const int k = mat[nb];
       double s = 0.0;
       for (int m = 0; m < Mb[k]; m++) {
-         const double v = (double)vh_old[(int64_t)m * Nbl + nb] + (double)vh_new[(int64_t)m * Nbl + nb];
+         const double v = (double)vh_old[st_idx(m, nb)] + (double)vh_new[st_idx(m, nb)];
          s += (v * v) * DEF[(k * 12 + m) * 3 + 1];
       }
       e = (double)ssaf[nb] * s;

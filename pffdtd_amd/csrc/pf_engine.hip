@@ -93,6 +93,7 @@ template <typename Real> struct Engine : EngineBase {
    pf_opts op{};
    int64_t Nx = 0, Ny = 0, Nz = 0, P = 0, plane = 0, npad = 0;
    int64_t Nb = 0, Nbl = 0, Nba = 0, Ns = 0, Nr = 0, Nt = 0;
+   int mb_max = 0; // largest branch count of the materials
    bool fcc = false, fold = false;
    bool use_dpp = true;
    Real a1, a2, sl2, lo2, l;
@@ -295,6 +296,7 @@ template <typename Real> struct Engine : EngineBase {
       if (Nt < 0 || Ns < 0 || Nr < 0 || Nb < 0 || Nbl < 0 || Nba < 0) return set_err(PF_ERR_ARG, "negative count");
       for (int k = 0; k < sd.Nm; k++)
          if (sd.Mb[k] < 0 || sd.Mb[k] > PF_MMB) return set_err(PF_ERR_ARG, "Mb[%d] out of range (MMb=%d)", k, PF_MMB);
+      for (int k = 0; k < sd.Nm; k++) mb_max = std::max(mb_max, (int)sd.Mb[k]);
       fcc = sd.fcc_flag > 0;
       fold = sd.fcc_flag == 2;
       a1 = (Real)sd.a1; a2 = (Real)sd.a2; sl2 = (Real)sd.sl2; lo2 = (Real)sd.lo2; l = (Real)sd.l;
@@ -447,8 +449,8 @@ template <typename Real> struct Engine : EngineBase {
          plane_ranges(idx, bnl_lo, bnl_mid, bnl_hi);
          plane_ranges(idx, bnl_lo2, bnl_mid2, bnl_hi2, 2);
          for (int i = 0; i < 3; i++) if ((rc = dzalloc(&ub[i], Nbl))) return rc;
-         if ((rc = dzalloc(&vh1, Nbl * PF_MMB))) return rc;
-         if ((rc = dzalloc(&gh1, Nbl * PF_MMB))) return rc;
+         if ((rc = dzalloc(&vh1, round_up(Nbl, 64) * PF_MMB))) return rc; // [node / 64][branch][node % 64], pf::st_idx
+         if ((rc = dzalloc(&gh1, round_up(Nbl, 64) * PF_MMB))) return rc;
          const int64_t nm = std::max<int64_t>(sd.Nm, 1);
          if ((rc = upload(&d_mq, (const pf::MatQuadT<Real> *)sd.mat_quads, sd.Nm ? nm * PF_MMB : 0))) return rc;
          if ((rc = upload(&d_beta, (const Real *)sd.mat_beta, sd.Nm))) return rc;
@@ -921,7 +923,7 @@ template <typename Real> struct Engine : EngineBase {
             zp.zmap = zs_map; zp.adjv = d_adj; zp.lossy = d_lossy; zp.u0b = ub[0]; zp.u2b = ub[2];
             zp.ssaf = d_ssaf; zp.beta = d_beta; zp.mat = d_mat; zp.Mb = d_Mb;
             zp.mq = d_mq; zp.vh1 = vh1; zp.gh1 = gh1;
-            zp.lo2 = lo2; zp.sl2 = sl2; zp.Nbl = Nbl; zp.fd_split = zs_mode == 2 ? 1 : 0;
+            zp.lo2 = lo2; zp.sl2 = sl2; zp.mmax = mb_max; zp.fd_split = zs_mode == 2 ? 1 : 0;
          }
          const int64_t nthreads = (int64_t)(zp.zl / V + (P - zp.zr) / V) * (Ny - 2);
          const int xchunk = (op.debug >> 16) & 0xff ? (op.debug >> 16) & 0xff : 16;
@@ -1254,7 +1256,7 @@ template <typename Real> struct Engine : EngineBase {
       launch_fold_row(s);
       dim3 g((unsigned)cdiv(r.e - r.b, 128)), b(128);
       const bool fma = op.numerics == PF_NUM_FMA;
-#define PF_BND(F, M) hipLaunchKernelGGL((pf::k_boundary<Real, F, M>), g, b, 0, s, u1, u0, d_bn, d_adj, d_lossy, a2, sl2, P, plane, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq, d_beta, vh1, gh1, lo2, Nbl, r.b, r.e, u0_src ? u0_src : (const Real *)u0, bnd_sel)
+#define PF_BND(F, M) hipLaunchKernelGGL((pf::k_boundary<Real, F, M>), g, b, 0, s, u1, u0, d_bn, d_adj, d_lossy, a2, sl2, P, plane, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq, d_beta, vh1, gh1, lo2, (int64_t)mb_max, r.b, r.e, u0_src ? u0_src : (const Real *)u0, bnd_sel)
       if (fcc) { if (fma) PF_BND(true, true); else PF_BND(true, false); }
       else { if (fma) PF_BND(false, true); else PF_BND(false, false); }
 #undef PF_BND
@@ -1277,13 +1279,13 @@ template <typename Real> struct Engine : EngineBase {
    void launch_fd(hipStream_t s, Range r) {
       if (boundary_fused()) return; // done by launch_boundary
       if (r.e > r.b)
-         hipLaunchKernelGGL(pf::k_fd_boundary<Real>, dim3((unsigned)cdiv(r.e - r.b, 128)), dim3(128), 0, s, u0, d_bnl, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq, d_beta, vh1, gh1, lo2, Nbl, r.b, r.e);
+         hipLaunchKernelGGL(pf::k_fd_boundary<Real>, dim3((unsigned)cdiv(r.e - r.b, 128)), dim3(128), 0, s, u0, d_bnl, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq, d_beta, vh1, gh1, lo2, (int64_t)mb_max, r.b, r.e);
    }
    // branch ODEs of the lossy nodes whose rigid update the column-strip kernel has just done (zs_mode 2)
    void launch_fd_sel(hipStream_t s) {
       if (zs_mode != 2 || !bnd_sel || zs_nfd <= 0) return;
       hipLaunchKernelGGL(pf::k_fd_sel<Real>, dim3((unsigned)cdiv(zs_nfd, 128)), dim3(128), 0, s, u0, d_bnl, zs_fd, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq,
-                         d_beta, vh1, gh1, lo2, Nbl, zs_nfd);
+                         d_beta, vh1, gh1, lo2, (int64_t)mb_max, zs_nfd);
    }
    // receivers on/off + a range of the (sorted) source list
    void launch_io(hipStream_t s, int64_t n, bool receivers, Range src, const int64_t *ctr = nullptr) {
@@ -1371,7 +1373,7 @@ template <typename Real> struct Engine : EngineBase {
       int rc;
       if (!Lu) {
          if ((rc = dzalloc(&Lu, npad))) return rc;
-         if ((rc = dzalloc(&vh_old, Nbl * PF_MMB))) return rc;
+         if ((rc = dzalloc(&vh_old, round_up(Nbl, 64) * PF_MMB))) return rc;
          if ((rc = dzalloc(&u2in, Ns))) return rc;
          if ((rc = dzalloc(&d_acc, (int64_t)pf::EN_NACC))) return rc;
          if ((rc = upload(&d_DEF, DEF, (int64_t)std::max<int>(sd.Nm, 1) * PF_MMB * 3))) return rc;
@@ -1397,7 +1399,7 @@ template <typename Real> struct Engine : EngineBase {
          if (Nba) hipLaunchKernelGGL(pf::k_energy_abc<Real>, g1(Nba, 256), dim3(256), 0, s, u1, u0, Lu, d_bna, d_Q, Nba, l2d, d_acc);
          if (Nbl) hipLaunchKernelGGL(pf::k_energy_stored<Real>, g1(Nbl, 256), dim3(256), 0, s, vh1, gh1, d_ssaf, d_mat, d_Mb, d_DEF, Nbl, en_Ts, d_acc);
          if (Ns) hipLaunchKernelGGL(pf::k_energy_in<Real>, g1(Ns, 64), dim3(64), 0, s, u0, u2in, d_in, d_insig, Ns, Nt, n, 0, d_acc);
-         if (Nbl) HIPCHK(hipMemcpyAsync(vh_old, vh1, sizeof(Real) * Nbl * PF_MMB, hipMemcpyDeviceToDevice, s));
+         if (Nbl) HIPCHK(hipMemcpyAsync(vh_old, vh1, sizeof(Real) * round_up(Nbl, 64) * PF_MMB, hipMemcpyDeviceToDevice, s));
          // the step itself (unfused sequence), with Lu = L(u1) taken after the ghost flips
          fold_x0 = 0; fold_x1 = (int)Nx;
          launch_pre(s);

@@ -506,7 +506,7 @@ template <typename Real> struct ZStripParams {
    const MatQuadT<Real> *mq;
    Real *vh1, *gh1;
    Real lo2, sl2;
-   int64_t Nbl;
+   int64_t mmax;             // largest branch count of the scene's materials (fd_node_update)
    int32_t fd_split;         // 1: lossy nodes get their RIGID update here (value left in u0b[li] and in the grid); the
                              // branch ODEs follow in k_fd_sel, dense over the compact lossy arrays
 };
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) void k_air_zstrip(ZStripParams<Real> zp, Real 
                const int32_t li = zp.lossy[nb];
                if (li >= 0) {
                   if (zp.fd_split) zp.u0b[li] = p;
-                  else p = fd_node_update<Real>(p, li, zp.u0b, zp.u2b, zp.ssaf, zp.mat, zp.Mb, zp.mq, zp.beta, zp.vh1, zp.gh1, zp.lo2, zp.Nbl);
+                  else p = fd_node_update<Real>(p, li, zp.u0b, zp.u2b, zp.ssaf, zp.mat, zp.Mb, zp.mq, zp.beta, zp.vh1, zp.gh1, zp.lo2, zp.mmax);
                }
             }
          }
