@@ -83,3 +83,5 @@ def test_bench_two_ranks_control_flow():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 6 and res["warmup"] == 3 and res["value"] > 0
     assert res["metric"] == "Gvoxel-updates/s" and res["scaling"] == "strong" and res["roofline"]["bound"] == "hbm"
+    # the exchange self-check ran during warm-up on both ranks and found the received ghost planes equal to the sent ones
+    assert res["exchange_verified"] is True and res["exchange"]["ranks"] == 2 and res["repeats"] >= 1
