@@ -160,6 +160,7 @@ template <typename Real> struct Engine : EngineBase {
    int tb_lw = 64, tb_chunk = 16, tb_nxc = 0, tb_nyt = 0, tb_nzt = 0;
    int32_t *tb_clean = nullptr, *tb_dirty = nullptr;      // tile ids (xc*nyt + yt)*nzt + zt
    int64_t tb_nclean = 0, tb_ndirty = 0, tb_clean_cells = 0;
+   bool tb_order_band = false;
    // 13-point pairs (folded FCC): whatever of the box is not a clean tile's core is stepped by k_air_fcc over its own tiles
    // (256 columns x 16 rows x the same x chunks), listed here
    int32_t *sh_tiles = nullptr;
@@ -615,6 +616,32 @@ template <typename Real> struct Engine : EngineBase {
             vol += (int64_t)(std::min(tbx0 + (xc + 1) * tb_chunk, tbx1) - (tbx0 + xc * tb_chunk)) *
                    (std::min(tby0 + (yt + 1) * TR, tby1) - (tby0 + yt * TR)) * (std::min(tbz0 + (zt + 1) * TC, tbz1) - (tbz0 + zt * TC));
          }
+         tb_order_band = true;
+         if (const char *ev = getenv("PFFDTD_TB2_ORDER")) tb_order_band = ev[0] != 'd'; // "dense": plain tile order
+         if (tb_order_band && !cl.empty()) {
+            // XCD-banded order: hardware places block b on XCD b % 8; each XCD gets a contiguous band of the clean tiles of
+            // every x chunk (tiles that share halo rows then share an L2), blocks b .. b+7 walking the 8 bands in step.
+            // Measured at 1024^3, alternating runs on one box: k_tb2_reg 3.258 vs 3.295 ms per launch, whole step 427.3 vs
+            // 422.2 Gvox/s; 13-point 3.94 vs 3.98 ms.  (Round 1's in-kernel band mapping of the dense grid was 6 % SLOWER:
+            // it kept all XCDs on one x chunk with a rounded-up band size; here the list is simply permuted on the host.)
+            std::vector<int32_t> out;
+            out.reserve(cl.size());
+            size_t i0 = 0;
+            const int64_t per_chunk = (int64_t)tb_nyt * tb_nzt;
+            while (i0 < cl.size()) {
+               size_t i1 = i0;
+               const int64_t xc = cl[i0] / per_chunk;
+               while (i1 < cl.size() && cl[i1] / per_chunk == xc) i1++;
+               const size_t n = i1 - i0, per = (n + 7) / 8;
+               for (size_t p2 = 0; p2 < per; p2++)
+                  for (size_t k = 0; k < 8; k++) {
+                     const size_t j = k * per + p2;
+                     if (j < n) out.push_back(cl[i0 + j]);
+                  }
+               i0 = i1;
+            }
+            cl.swap(out);
+         }
          tb_nclean = (int64_t)cl.size(); tb_ndirty = (int64_t)di.size(); tb_clean_cells = vol;
          int rc;
          if (tb_clean) { hipFree(tb_clean); tb_clean = nullptr; }
@@ -845,7 +872,7 @@ template <typename Real> struct Engine : EngineBase {
       if (tb_xr.empty() || tb_nclean <= 0) return;
       pf::Tb2Params tp = tile_params();
       tp.A = A; tp.B = B; tp.C = C; tp.D = D;
-      tp.tiles = tb_ndirty > 0 ? tb_clean : nullptr; // all clean: the dense order (identical to the list's)
+      tp.tiles = (tb_ndirty > 0 || tb_order_band) ? tb_clean : nullptr; // all clean: the dense order (identical to the list's)
       const dim3 g((uint32_t)tb_nclean), b(256);
       if (fcc) {
          if (tb_lw == 64 && fcc_wt == 8) hipLaunchKernelGGL((pf::k_tb2_fcc_x<Real, 2, 8>), g, dim3(512), 0, s, tp, a1, a2);      // 12-row tiles
