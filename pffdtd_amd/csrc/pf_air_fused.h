@@ -55,7 +55,8 @@ __global__ __launch_bounds__(64 * WY) void k_air_fused(FusedParams fp, Real a1, 
    Real *__restrict__ u0 = (Real *)fp.u0;
    const uint32_t total = (uint32_t)fp.nzt * fp.nyt * fp.nxc;
    uint32_t b = blockIdx.x;
-   if (fp.swizzle) b = xcd_swizzle(b, total);
+   if (fp.swizzle == 2) { if (!xcd_band(blockIdx.x, (uint32_t)fp.nzt * fp.nyt, (uint32_t)fp.nxc, b)) return; }
+   else if (fp.swizzle) b = xcd_swizzle(b, total);
    const int zt = b % fp.nzt;
    const int yt = (b / fp.nzt) % fp.nyt;
    const int xc = b / (fp.nzt * fp.nyt);
@@ -423,7 +424,8 @@ __global__ __launch_bounds__(64 * WY) void k_air_cart_lean(LeanParams fp, Real a
    const Real *u0s = fp.u0_src ? (const Real *)fp.u0_src : (const Real *)fp.u0;
    const uint32_t total = (uint32_t)fp.nzt * fp.nyt * fp.nxc;
    uint32_t b = blockIdx.x;
-   if (fp.swizzle) b = xcd_swizzle(b, total);
+   if (fp.swizzle == 2) { if (!xcd_band(blockIdx.x, (uint32_t)fp.nzt * fp.nyt, (uint32_t)fp.nxc, b)) return; }
+   else if (fp.swizzle) b = xcd_swizzle(b, total);
    const int zt = b % fp.nzt;
    int yt = (b / fp.nzt) % fp.nyt;
    yt = (fp.yt_split >= 0 && yt >= fp.yt_split) ? fp.yt_hi0 + (yt - fp.yt_split) : fp.yt0 + yt;
@@ -673,7 +675,8 @@ __global__ __launch_bounds__(64 * WY) void k_air_cart_lds(LeanParams fp, Real a1
    Real *__restrict__ u0 = (Real *)fp.u0;
    const uint32_t total = (uint32_t)fp.nzt * fp.nyt * fp.nxc;
    uint32_t b = blockIdx.x;
-   if (fp.swizzle) b = xcd_swizzle(b, total);
+   if (fp.swizzle == 2) { if (!xcd_band(blockIdx.x, (uint32_t)fp.nzt * fp.nyt, (uint32_t)fp.nxc, b)) return; }
+   else if (fp.swizzle) b = xcd_swizzle(b, total);
    const int zt = b % fp.nzt;
    const int yt = (b / fp.nzt) % fp.nyt;
    const int xc = b / (fp.nzt * fp.nyt);
@@ -858,7 +861,8 @@ __global__ __launch_bounds__(64 * WY) void k_air_fcc_lean(LeanParams fp, Real a1
    Real *__restrict__ u0 = (Real *)fp.u0;
    const uint32_t total = (uint32_t)fp.nzt * fp.nyt * fp.nxc;
    uint32_t b = blockIdx.x;
-   if (fp.swizzle) b = xcd_swizzle(b, total);
+   if (fp.swizzle == 2) { if (!xcd_band(blockIdx.x, (uint32_t)fp.nzt * fp.nyt, (uint32_t)fp.nxc, b)) return; }
+   else if (fp.swizzle) b = xcd_swizzle(b, total);
    const int zt = b % fp.nzt;
    const int yt = (b / fp.nzt) % fp.nyt;
    const int xc = b / (fp.nzt * fp.nyt);

@@ -634,9 +634,9 @@ template <typename Real> struct Engine : EngineBase {
                while (i1 < cl.size() && cl[i1] / per_chunk == xc) i1++;
                const size_t n = i1 - i0, per = (n + 7) / 8;
                for (size_t p2 = 0; p2 < per; p2++)
-                  for (size_t k = 0; k < 8; k++) {
-                     const size_t j = k * per + p2;
-                     if (j < n) out.push_back(cl[i0 + j]);
+                  for (size_t k = 0; k < 8; k++) { // balanced bands [k n / 8, (k+1) n / 8)
+                     const size_t j0 = k * n / 8, j1 = (k + 1) * n / 8;
+                     if (p2 < j1 - j0) out.push_back(cl[i0 + j0 + p2]);
                   }
                i0 = i1;
             }
@@ -1081,6 +1081,19 @@ template <typename Real> struct Engine : EngineBase {
       }
       return best;
    }
+   // tile order of the marching kernels: 2 = XCD-banded inside every x chunk (pf_kernels.h: xcd_band), 1 = one contiguous run
+   // of the launch per XCD (round 1), 0 = plain (air_variant | 64); PFFDTD_SWIZZLE overrides for measurements
+   // Banded wins on large planes (1024^2: k_air_fcc 2.46 -> 2.32 ms, barrier-free 7-point 2.45 -> 2.29, lean 2.33 -> 2.28;
+   // Musikverein 552 x 850: 3.60 -> 3.44), the per-XCD run on small ones, where a whole chunk of planes fits one L2 and a band
+   // is a handful of tiles (CTK church 579 x 309, 50 tiles per chunk: 0.392 vs 0.425 ms): banded from 96 tiles per chunk.
+   int swizzle_mode(int64_t tiles_per_chunk) const {
+      static const int env = [] { const char *e = getenv("PFFDTD_SWIZZLE"); return e ? atoi(e) : -1; }();
+      if (op.air_variant & 64) return 0;
+      return env >= 0 ? env : (tiles_per_chunk >= 96 ? 2 : 1);
+   }
+   static uint32_t grid_blocks(int swz, int nzt, int nyt, int nxc) {
+      return swz == 2 ? pf::xcd_band_blocks((uint32_t)nzt * nyt, (uint32_t)nxc) : (uint32_t)nzt * nyt * nxc;
+   }
    template <int R, int WY, int WZ> void launch_air_cfg(hipStream_t s, int xb, int xe) {
       if constexpr (R == 4 && WY == 4 && WZ == 1) {
          if (use_dpp && !(op.debug & 0x400)) {
@@ -1102,9 +1115,9 @@ template <typename Real> struct Engine : EngineBase {
       const int chunk = pick_chunk(nplanes, (int64_t)ap.nzt * ap.nyt, false);
       ap.chunk = chunk;
       ap.nxc = (int)cdiv(nplanes, chunk);
-      ap.swizzle = (op.air_variant & 64) ? 0 : 1;
+      ap.swizzle = swizzle_mode((int64_t)ap.nzt * ap.nyt);
       ap.Nx = (int)Nx; ap.Nz = (int)Nz; ap.first = op.slab_first; ap.last = op.slab_last; ap.fold = fold ? 1 : 0;
-      const uint32_t total = (uint32_t)ap.nzt * ap.nyt * ap.nxc;
+      const uint32_t total = grid_blocks(ap.swizzle, ap.nzt, ap.nyt, ap.nxc);
       dim3 g(total), b(64 * WY * WZ);
       const bool fma = op.numerics == PF_NUM_FMA;
       if constexpr (R == 4 && WY == 4 && WZ == 1) {
@@ -1162,11 +1175,11 @@ template <typename Real> struct Engine : EngineBase {
       const int chunk = pick_chunk(nplanes, (int64_t)fp.nzt * fp.nyt, true);
       fp.chunk = chunk;
       fp.nxc = (int)cdiv(nplanes, chunk);
-      fp.swizzle = (op.air_variant & 64) ? 0 : 1;
+      fp.swizzle = swizzle_mode((int64_t)fp.nzt * fp.nyt);
       fp.first = op.slab_first; fp.last = op.slab_last;
       fp.fold = fold ? 1 : 0; fp.parity = sd.fcc_flag == 1 ? 1 + (op.x_global0 & 1) : 0;
       fp.do_abc = 1; fp.do_rigid = (fused_rigid && Nb > 0) ? 1 : 0;
-      dim3 g((uint32_t)fp.nzt * fp.nyt * fp.nxc), b(64 * WY);
+      dim3 g(grid_blocks(fp.swizzle, fp.nzt, fp.nyt, fp.nxc)), b(64 * WY);
       const bool fma = op.numerics == PF_NUM_FMA;
       if (fcc) {
          if (fma) hipLaunchKernelGGL((pf::k_air_fused<Real, true, R, WY, true>), g, b, 0, s, fp, a1, a2, sl2, l);
@@ -1205,11 +1218,11 @@ template <typename Real> struct Engine : EngineBase {
       const int chunk = pick_chunk(nplanes, (int64_t)fp.nzt * fp.nyt, true);
       fp.chunk = chunk;
       fp.nxc = (int)cdiv(nplanes, chunk);
-      fp.swizzle = (op.air_variant & 64) ? 0 : 1;
+      fp.swizzle = swizzle_mode((int64_t)fp.nzt * fp.nyt);
       fp.first = op.slab_first; fp.last = op.slab_last;
       fp.do_abc = 1;
       fp.debug = op.debug;
-      dim3 g((uint32_t)fp.nzt * fp.nyt * fp.nxc), b(64 * WY);
+      dim3 g(grid_blocks(fp.swizzle, fp.nzt, fp.nyt, fp.nxc)), b(64 * WY);
       if (fcc) {
          if constexpr (!LDS && R <= 2) {
             if (op.numerics == PF_NUM_FMA) hipLaunchKernelGGL((pf::k_air_fcc_lean<Real, R, WY, true>), g, b, 0, s, fp, a1, a2, l, fold ? 1 : 0);
