@@ -6,17 +6,18 @@ source differentiation), optional symmetric low-pass, resampling, WAV / h5 expor
                                          --N_order_lowpass 8 --symmetric_lowpass --resample_Fs 48000 --save_wav
                                          --air_abs_filter stokes|modal|OLA]
 
-Difference from the reference: resampling uses scipy's polyphase `resample_poly` (resampy is not available here; the
-reference uses resampy 'kaiser_best').  The air-absorption filters are in pffdtd_amd/air_abs.py.
+Resampling: the reference calls resampy's `resample(..., filter='kaiser_best')`; resampy is not in this image, its
+published algorithm and filter design are restated in pffdtd_amd/resample.py (parity unpinned, see there).  The
+air-absorption filters are in pffdtd_amd/air_abs.py.
 """
 import argparse
-from fractions import Fraction
 from pathlib import Path
 
 import numpy as np
-from scipy.signal import bilinear_zpk, butter, lfilter, resample_poly, sosfilt, zpk2sos
+from scipy.signal import bilinear_zpk, butter, lfilter, sosfilt, zpk2sos
 
 from . import h5io
+from .resample import resample as resample_kaiser_best
 
 
 class ProcessOutputs:
@@ -72,10 +73,10 @@ class ProcessOutputs:
     def resample(self, Fs_f=48e3):
         if self.Fs == Fs_f:
             return
-        fr = Fraction(Fs_f / self.Fs).limit_denominator(2000)
-        self.r_out_f = resample_poly(self.r_out_f, fr.numerator, fr.denominator, axis=-1)
-        self.Fs_f = self.Fs * fr.numerator / fr.denominator
-        self.Ts_f, self.Nt_f = 1 / self.Fs_f, self.r_out_f.shape[-1]
+        self.print("resampling")
+        self.r_out_f = resample_kaiser_best(self.r_out_f, self.Fs, Fs_f, axis=-1)  # process_outputs.py:161
+        self.Fs_f = Fs_f
+        self.Ts_f, self.Nt_f = 1 / Fs_f, self.r_out_f.shape[-1]
 
     def _air(self, name, fn, **kw):
         from . import air_abs
