@@ -151,6 +151,7 @@ template <typename Real> struct Engine : EngineBase {
    Real *pA = nullptr, *pB = nullptr;                     // u^{n-1}, u^n of the pair in flight
    Real *bufC = nullptr, *bufD = nullptr;                 // the two extra state grids of the out-of-place pair
    int tbx0 = 0, tbx1 = 0, tby0 = 0, tby1 = 0, tbz0 = 0, tbz1 = 0; // box of cells k_tb2_reg produces
+   int szl = 0, szr = 0;                                  // 7-point column strips: columns [0, szl) and [szr, P)
    // planes per x chunk of k_tb2_reg: 12-20 are equally fast, 24 is 1 % and 48 is 6 % slower although longer chunks
    // re-read fewer prologue planes (1024^3, tools/tb2_probe.py); PFFDTD_TB2_CHUNK overrides for such sweeps
    int tb2_chunk = 16;
@@ -171,7 +172,10 @@ template <typename Real> struct Engine : EngineBase {
    int lean_yt0 = 0, lean_nyt = -1;                       // row-strip launches of the lean kernel (-1: all tiles)
    // boundary nodes inside the column strips are updated by k_air_zstrip itself (it streams their lines anyway; in
    // the list kernel the floor / ceiling nodes of a box room cost half of the whole boundary pass)
-   int32_t *zs_map = nullptr, *zs_rest = nullptr;         // strip cell -> boundary list position; the other nodes
+   uint32_t *zs_map = nullptr;                            // per strip vector: first node number << 4 | node bits (ZStripParams::zvec)
+   uint16_t *zs_adj = nullptr;                            // adjacency bits / lossy-list positions of the strips' nodes, in strip order
+   int32_t *zs_li = nullptr;
+   int32_t *zs_rest = nullptr;                            // the other boundary nodes (positions in the boundary list)
    int64_t zs_nrest = 0;
    int zs_mode = 0;                                       // 0: list kernel does them; 1: strip kernel, rigid + FD inline (debug 0x2000);
                                                           // 2: strip kernel does the rigid update, k_fd_sel the branch ODEs (default)
@@ -195,7 +199,7 @@ template <typename Real> struct Engine : EngineBase {
       auto F = [](void *p) { if (p) hipFree(p); };
       for (Real *g : own_list) F(g); // state grids this engine allocated (u0/u1 unless external, the temporal-blocking spares)
       own_list.clear();
-      F(d_lossy); F(mask); F(mask_bn); F(cellb); F(zs_map); F(zs_rest); F(zs_fd); F(tb_clean); F(tb_dirty); F(sh_tiles); F(segstart); F(adj_dense); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
+      F(d_lossy); F(mask); F(mask_bn); F(cellb); F(zs_map); F(zs_adj); F(zs_li); F(zs_rest); F(zs_fd); F(tb_clean); F(tb_dirty); F(sh_tiles); F(segstart); F(adj_dense); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
       F(d_beta); F(d_insig); F(d_mq); F(ub[0]); F(ub[1]); F(ub[2]); F(u2ba); F(vh1); F(gh1); F(ring);
       if (h_ring) hipHostFree(h_ring);
       for (auto &p : air_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -576,6 +580,7 @@ template <typename Real> struct Engine : EngineBase {
          }
          if (best < 0) return PF_OK; // no room for a single row segment
       }
+      szl = tbz0; szr = tbz1; // (widened to whole 128-byte lines, the overlap computed twice: slower, 2.32 -> 2.34-2.53 ms/step)
       if (vbase == 41) tbx1 = tbx0; // driver test: everything goes through the out-of-place single-step path
       tb_xr.clear();
       // rows of a workgroup: 4 waves x R = 3 (7-point); 13-point: 6 inner waves x R = 2 with 64-lane segments (k_tb2_fcc_x), else 4 x 2
@@ -704,29 +709,44 @@ template <typename Real> struct Engine : EngineBase {
       if (Nb > 0 && !tb_xr.empty() && zs_mode > 0 && Nbl < ((int64_t)1 << 31)) {
          const int xb = tb_xr.front().first, xe = tb_xr.back().second;
          constexpr int V = pf::VecOf<Real>::V;
-         const int nl = tbz0 / V, nv = nl + (int)(P - tbz1) / V;
+         const int nl = szl / V, nv = nl + (int)(P - szr) / V;
          std::vector<int64_t> hb(Nb);
          HIPCHK(hipMemcpy(hb.data(), d_bn, Nb * sizeof(int64_t), hipMemcpyDeviceToHost));
-         std::vector<int32_t> zm((size_t)(Nx * Ny * nv * V), -1), rest;
+         std::vector<int32_t> hl(Nb), rest, sli, fd;
+         std::vector<uint16_t> hadj(Nb), sadj;
+         HIPCHK(hipMemcpy(hl.data(), d_lossy, Nb * sizeof(int32_t), hipMemcpyDeviceToHost));
+         HIPCHK(hipMemcpy(hadj.data(), d_adj, Nb * sizeof(uint16_t), hipMemcpyDeviceToHost));
+         // The boundary list is sorted by cell, so its strip nodes come in strip order (x, y, z): node k of the strips is the
+         // k-th of them; a vector's record holds the number of its first node and one bit per cell with a node.
+         std::vector<uint32_t> zv((size_t)(Nx * Ny * nv), 0u);
          rest.reserve(Nb);
+         bool sorted = true;
+         int64_t prev = -1;
          for (int64_t nb = 0; nb < Nb; nb++) {
             const int64_t ix = hb[nb] / plane, rem = hb[nb] % plane, iy = rem / P, iz = rem % P;
-            const bool in_strip = ix >= xb && ix < xe && (iz < tbz0 || iz >= tbz1);
+            const bool in_strip = ix >= xb && ix < xe && (iz < szl || iz >= szr);
             if (!in_strip) { rest.push_back((int32_t)nb); continue; }
-            const int64_t v = iz < tbz0 ? iz / V : nl + (iz - tbz1) / V, i = iz < tbz0 ? iz % V : (iz - tbz1) % V;
-            zm[(size_t)(((ix * Ny + iy) * nv + v) * V + i)] = (int32_t)nb;
+            if (hb[nb] <= prev) { sorted = false; break; }
+            prev = hb[nb];
+            const int64_t v = iz < szl ? iz / V : nl + (iz - szr) / V, i = iz < szl ? iz % V : (iz - szr) % V;
+            uint32_t &rec = zv[(size_t)((ix * Ny + iy) * nv + v)];
+            if ((rec & 15u) == 0) rec = (uint32_t)sadj.size() << 4;
+            rec |= 1u << i;
+            sadj.push_back(hadj[nb]);
+            sli.push_back(hl[nb]);
+            if (hl[nb] >= 0) fd.push_back(hl[nb]);
          }
-         zs_nrest = (int64_t)rest.size();
-         if ((rc = upload(&zs_map, zm.data(), (int64_t)zm.size()))) return rc;
-         if ((rc = upload(&zs_rest, rest.data(), zs_nrest))) return rc;
-         if (zs_mode == 2) {
-            std::vector<int32_t> hl(Nb), fd;
-            HIPCHK(hipMemcpy(hl.data(), d_lossy, Nb * sizeof(int32_t), hipMemcpyDeviceToHost));
-            std::vector<uint8_t> in_rest(Nb, 0);
-            for (int32_t nb : rest) in_rest[nb] = 1;
-            for (int64_t nb = 0; nb < Nb; nb++) if (!in_rest[nb] && hl[nb] >= 0) fd.push_back(hl[nb]);
-            zs_nfd = (int64_t)fd.size();
-            if ((rc = upload(&zs_fd, fd.data(), zs_nfd))) return rc;
+         if (!sorted || sadj.size() >= ((size_t)1 << 28)) zs_mode = 0; // (the engine sorts its lists: never seen)
+         else {
+            zs_nrest = (int64_t)rest.size();
+            if ((rc = upload(&zs_map, zv.data(), (int64_t)zv.size()))) return rc;
+            if ((rc = upload(&zs_adj, sadj.data(), (int64_t)sadj.size()))) return rc;
+            if ((rc = upload(&zs_li, sli.data(), (int64_t)sli.size()))) return rc;
+            if ((rc = upload(&zs_rest, rest.data(), zs_nrest))) return rc;
+            if (zs_mode == 2) {
+               zs_nfd = (int64_t)fd.size();
+               if ((rc = upload(&zs_fd, fd.data(), zs_nfd))) return rc;
+            }
          }
       } else zs_mode = 0;
       return PF_OK;
@@ -847,6 +867,8 @@ template <typename Real> struct Engine : EngineBase {
             if (scr == bufC) scr = nullptr;
             bufC = bufD = nullptr;
             if (zs_map) { hipFree(zs_map); zs_map = nullptr; }
+            if (zs_adj) { hipFree(zs_adj); zs_adj = nullptr; }
+            if (zs_li) { hipFree(zs_li); zs_li = nullptr; }
             if (zs_rest) { hipFree(zs_rest); zs_rest = nullptr; }
             if (zs_fd) { hipFree(zs_fd); zs_fd = nullptr; }
             zs_mode = 0;
@@ -945,9 +967,9 @@ template <typename Real> struct Engine : EngineBase {
          pf::ZStripParams<Real> zp{};
          zp.u1 = u1; zp.u0s = u0_src ? u0_src : u0; zp.u0 = u0; zp.mask = mask;
          zp.plane = plane; zp.Nx = (int)Nx; zp.Ny = (int)Ny; zp.Nz = (int)Nz; zp.P = (int)P;
-         zp.x_begin = xb; zp.x_end = xe; zp.zl = tbz0; zp.zr = tbz1; zp.first = op.slab_first; zp.last = op.slab_last;
+         zp.x_begin = xb; zp.x_end = xe; zp.zl = szl; zp.zr = szr; zp.first = op.slab_first; zp.last = op.slab_last;
          if (zs_map && bnd_sel) { // (inside step_pair) the strips' boundary nodes are updated right here
-            zp.zmap = zs_map; zp.adjv = d_adj; zp.lossy = d_lossy; zp.u0b = ub[0]; zp.u2b = ub[2];
+            zp.zvec = zs_map; zp.adjv = zs_adj; zp.lossy = zs_li; zp.u0b = ub[0]; zp.u2b = ub[2];
             zp.ssaf = d_ssaf; zp.beta = d_beta; zp.mat = d_mat; zp.Mb = d_Mb;
             zp.mq = d_mq; zp.vh1 = vh1; zp.gh1 = gh1;
             zp.lo2 = lo2; zp.sl2 = sl2; zp.mmax = mb_max; zp.fd_split = zs_mode == 2 ? 1 : 0;

@@ -495,11 +495,14 @@ template <typename Real> struct ZStripParams {
    int32_t x_begin, x_end;   // planes [x_begin, x_end)
    int32_t zl, zr;           // strips [0, zl) and [zr, P), multiples of 4
    int32_t first, last;
-   // boundary nodes inside the strips (optional; zmap == null: the boundary-list kernel does them, masked cells keep
-   // their old value here): zmap[((x*Ny + y)*nv + v)*4 + i] = position in the boundary list or -1
-   const int32_t *zmap;
-   const uint16_t *adjv;
-   const int32_t *lossy;
+   // boundary nodes inside the strips (optional; zvec == null: the boundary-list kernel does them, masked cells keep
+   // their old value here).  The strips' nodes are numbered in strip order (x, y, z) and their adjacency bits / lossy-list
+   // positions are stored in that order; zvec[(x*Ny + y)*nv + v] = (number of the vector's first node << 4) | one bit per
+   // cell of the vector that holds a node: 4 bytes per 16-byte vector instead of a 128-byte line of the skip mask plus a
+   // 128-byte line of cell -> node indices per row
+   const uint32_t *zvec;
+   const uint16_t *adjv;     // [strip node]
+   const int32_t *lossy;     // [strip node] position in the lossy arrays or -1
    Real *u0b;
    const Real *u2b, *ssaf, *beta;
    const int8_t *mat, *Mb;
@@ -531,6 +534,9 @@ __global__ __launch_bounds__(256) void k_air_zstrip(ZStripParams<Real> zp, Real 
    const int64_t off = (int64_t)y * P + z0, offp = (int64_t)rowsrc(y + 1) * P + z0, offm = (int64_t)rowsrc(y - 1) * P + z0;
    const int zzN = Nz - 1 - z0; // position of the ghost column Nz-1 relative to this vector
    const bool yq = (y == 1 || y == Ny - 2);
+   uint32_t ghost = 0; // ghost / pad columns of this vector
+#pragma unroll
+   for (int i = 0; i < V; i++) ghost |= (z0 + i == 0 || z0 + i >= Nz - 1) ? (1u << i) : 0u;
    auto centre = [&](int x, vec &c, Real &lf, Real &rt) { // a row of plane x with its z neighbours, ghost columns patched
       const Real *pc = zp.u1 + (int64_t)planesrc(x) * zp.plane;
       c = *(const vec *)(pc + off);
@@ -556,7 +562,8 @@ __global__ __launch_bounds__(256) void k_air_zstrip(ZStripParams<Real> zp, Real 
       const Real *pc = zp.u1 + (int64_t)x * zp.plane;
       const vec yp = *(const vec *)(pc + offp), ym = *(const vec *)(pc + offm);
       const vec old = *(const vec *)(zp.u0s + (int64_t)x * zp.plane + off);
-      const uint32_t bits = (zp.mask[((int64_t)x * zp.plane + off) >> 3] >> (off & 7)) & ((1u << V) - 1u);
+      const uint32_t zrec = zp.zvec ? zp.zvec[((int64_t)x * Ny + y) * nv + v] : 0u;
+      const uint32_t bits = zp.zvec ? (ghost | (zrec & 15u)) : ((zp.mask[((int64_t)x * zp.plane + off) >> 3] >> (off & 7)) & ((1u << V) - 1u));
       const int qxy = (((zp.first && x == 1) || (zp.last && x == Nx - 2)) ? 1 : 0) + (yq ? 1 : 0);
       vec o;
 #pragma unroll
@@ -573,8 +580,8 @@ __global__ __launch_bounds__(256) void k_air_zstrip(ZStripParams<Real> zp, Real 
          }
          if ((bits >> i) & 1u) {
             p = old[i]; // ghost / pad column, or a boundary node that the list kernel updates
-            const int32_t nb = zp.zmap ? zp.zmap[(((int64_t)x * Ny + y) * nv + v) * V + i] : -1;
-            if (nb >= 0) { // boundary node: rigid update from the registers (k_boundary's expression), then the FD branches
+            const int32_t nb = ((zrec >> i) & 1u) ? (int32_t)((zrec >> 4) + __popc(zrec & ((1u << i) - 1u))) : -1;
+            if (nb >= 0) { // boundary node (its number in strip order): rigid update from the registers (k_boundary's expression), then the FD branches
                const uint32_t adj = zp.adjv[nb];
                const Real nbk[6] = {cp[i], cm[i], yp[i], ym[i], zpv, zmv};
                const Real two = 2.0, b1 = two - zp.sl2 * (Real)__popc(adj);
