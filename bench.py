@@ -283,7 +283,9 @@ def main():
                          "kernel_ms_per_launch": round(kernel_ms, 4), "voxel_updates_per_launch": int(units),
                          "bytes_per_voxel_update": bpv, "air_ms_per_step": round(air_ms_per_step, 4),
                          "interior_voxels_per_step": upd,
-                         "autotune_ms_per_step": {k: round(v, 4) for k, v in zip(("lean", "barrier_free", "blocked_pair"), tm.get("tune_ms", [0, 0, 0]))}},
+                         "autotune_ms_per_step": {k: round(v, 4) for k, v in zip(("lean", "barrier_free", "blocked_pair"), tm.get("tune_ms", [0, 0, 0]))},
+                         "grid_placement": {"candidates": tm.get("place_candidates", 0),
+                                            "kernel_ms_as_allocated_chosen_slowest": [round(v, 4) for v in tm.get("place_ms", [0, 0, 0])]}},
         }
         # HBM bytes per launch of the dominant kernel: from the committed PMC passes of this same command (rocprofv3 --pmc
         # FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 x2 read correction applied; tools/collect_n1_profile.sh).  Only
@@ -333,9 +335,12 @@ def main():
                 torch.cuda.synchronize()
                 ts.append(time.perf_counter() - t0)
             t_r = sorted(ts)[1]
+            tm_r = rr.st.eng.timing()
             res["rigid_walls"] = {"value": round(sd_r.Npts * K / t_r / 1e9, 3), "unit": "Gvoxel-updates/s",
                                   "ms_per_step": round(t_r / K * 1e3, 4), "repeats": 3, "Nb": sd_r.Nb,
-                                  "whole_step_frac_of_hbm_roofline": round(sd_r.Npts * K / t_r / 1e9 * bpv / HBM_PEAK_GBS, 4)}
+                                  "whole_step_frac_of_hbm_roofline": round(sd_r.Npts * K / t_r / 1e9 * bpv / HBM_PEAK_GBS, 4),
+                                  "blocked_pairs": tm_r.get("tb2_launches", 0) > 0,
+                                  "autotune_ms_per_step": {k: round(v, 4) for k, v in zip(("lean", "barrier_free", "blocked_pair"), tm_r.get("tune_ms", [0, 0, 0]))}}
             rr.st.close()
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.precision, args.fcc, args.mb, lossy)

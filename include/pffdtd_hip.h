@@ -124,6 +124,8 @@ typedef struct pf_timing {
    int64_t air_path;        /* what the engine runs: 0 lean, 1 barrier-free (virtual ghosts), 2 blocked pairs, -1 other */
    int64_t tb2_lw;          /* blocked pairs: lanes per row segment of the two-steps-per-pass kernel (64 | 32 | 16), else 0 */
    int64_t tb2_dirty_tiles; /* blocked pairs: tiles of the box that step singly (geometry or a source inside) */
+   int64_t place_candidates;/* blocked pairs: grid placements timed at creation (0: none), and the two-steps-per-pass kernel's */
+   double  place_ms[3];     /*   ms per launch on the first (as allocated), the chosen (fastest) and the slowest of them */
 } pf_timing;
 
 typedef struct pf_engine pf_engine;
@@ -170,6 +172,11 @@ int  pf_engine_step_end(pf_engine *e, int64_t n);
  * single-domain engine, ...); other values
  * are pf_status errors.  No counterpart in the reference. */
 int  pf_engine_set_spares(pf_engine *e, void *grid2, void *grid3);
+/* Device pointers of the two state grids as they stand between runs (u_prev = u^{n-1}, overwritten by the next step;
+ * u_cur = u^n), each pf_grid_bytes() long: the engine's own allocations unless pf_opts.ext_u0 / ext_u1 were given.
+ * Lets a host that left the allocation to the engine (which then also chooses WHERE the grids live, see DESIGN.md
+ * "placement") initialise or inspect the field on the device.  No counterpart in the reference. */
+int  pf_engine_state_grids(pf_engine *e, void **u_prev, void **u_cur);
 void *pf_engine_stream(pf_engine *e, int32_t which); /* 0 main, 1 edge: hipStream_t */
 int  pf_engine_sync(pf_engine *e);
 int  pf_engine_flush_outputs(pf_engine *e);          /* ring -> sd->u_out */

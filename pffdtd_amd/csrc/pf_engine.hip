@@ -77,6 +77,7 @@ struct EngineBase {
    virtual int step_begin(int64_t n) = 0;
    virtual int step_end(int64_t n) = 0;
    virtual int halo_ptrs(void **slo, void **shi, void **rlo, void **rhi, size_t *bytes) = 0;
+   virtual int state_grids(void **up, void **uc) = 0;
    virtual int sync() = 0;
    virtual int flush() = 0;
    virtual int set_spares(void *g2, void *g3) = 0;
@@ -100,6 +101,7 @@ template <typename Real> struct Engine : EngineBase {
    // device state
    Real *u0 = nullptr, *u1 = nullptr;
    bool own_grids = true;
+   std::vector<float> place_ms;                           // sample_placement: ms per launch of every candidate
    std::vector<Real *> own_list;
    uint8_t *mask = nullptr;      // skip-mask of the unfused kernels (boundary nodes + ghost z + pad + parity)
    uint8_t *mask_bn = nullptr;   // boundary nodes only (fused kernel)
@@ -509,6 +511,7 @@ template <typename Real> struct Engine : EngineBase {
          HIPCHK(hipHostMalloc((void **)&h_ring, std::max<int64_t>(Nr * ring_depth, 1) * sizeof(Real), hipHostMallocDefault));
       }
       { int rc = init_tb2(); if (rc) return rc; }
+      { int rc = sample_placement(); if (rc) return rc; }
       { int rc = autotune(); if (rc) return rc; }
       // hipGraph replay of the step loop (six steps per graph): measured on MI355X / ROCm 7.2 it does not beat plain
       // launches even on launch-bound grids (234x154x85: 0.0503 vs 0.0473 ms/step, 256^3: 0.0951 vs 0.0921) -- the gaps
@@ -800,6 +803,92 @@ template <typename Real> struct Engine : EngineBase {
          HIPCHK(hipMemsetAsync(bufD, 0, npad * sizeof(Real), s_main));
       }
       HIPCHK(hipDeviceSynchronize());
+      hipEventDestroy(e0); hipEventDestroy(e1);
+      return PF_OK;
+   }
+   // ---- where do the pair's four grids live?  The pair kernel streams four grids at once, and its speed depends on how
+   // their PHYSICAL pages fall onto the memory channels relative to each other: engines of one process, alive side by side
+   // and timed in turn, keep their own speed (1024^3: 3.07 / 3.07 / 3.79 ms per launch, round after round;
+   // tools/placement_probe.py) -- a property of the allocations, not of the clock state, and nothing a virtual address
+   // shows; nor do pairwise copy times between the grids, or any per-grid property: it is the combination that counts (a
+   // pool of 8 grids at 1024^3: 2.94 ... 4.25 ms per launch over 64 assignments, a third of them within 2 % of the best).
+   // So the engine samples: besides its own grids it allocates up to four more, times the pair kernel (both directions of
+   // the four-grid cycle) on two dozen random assignments of pool members to the roles u^{n-1}, u^n, u^{n+1}, u^{n+2},
+   // keeps the fastest and frees the rest.  A few hundred ms, once.  With caller-owned state grids (pf_opts.ext_u0 / ext_u1)
+   // only the two spares are placed, and only the forward direction is timed (the caller's grids are not written).
+   int sample_placement() {
+      if (!tb2 || tb2_slab || !bufC || !bufD || (op.debug & 0x8000) || vbase == 41) return PF_OK;
+      int extra = 4, evals = 24;
+      if (const char *ev = getenv("PFFDTD_PLACE_EXTRA")) extra = std::min(std::max(atoi(ev), 0), 12);
+      if (const char *ev = getenv("PFFDTD_PLACE_EVALS")) evals = std::min(std::max(atoi(ev), 1), 64);
+      if (extra == 0 && !own_grids) return PF_OK;
+      const bool verbose = getenv("PFFDTD_VERBOSE") && atoi(getenv("PFFDTD_VERBOSE")) > 0;
+      hipEvent_t e0, e1;
+      HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+      auto time_fwd = [&](Real *A, Real *B, Real *C, Real *D) -> float {
+         hipEventRecord(e0, s_main);
+         launch_tb2(s_main, A, B, C, D);
+         launch_tb2(s_main, A, B, C, D);
+         hipEventRecord(e1, s_main);
+         hipEventSynchronize(e1);
+         float ms = 0;
+         hipEventElapsedTime(&ms, e0, e1);
+         return ms / 2;
+      };
+      std::vector<Real *> pool;
+      if (own_grids) { pool.push_back(u0); pool.push_back(u1); }
+      pool.push_back(bufC); pool.push_back(bufD);
+      const size_t base = pool.size();
+      for (int i = 0; i < extra; i++) {
+         Real *p = try_dzalloc<Real>(npad);
+         if (!p) break; // no room for another candidate
+         pool.push_back(p);
+      }
+      for (int i = 0; i < 4; i++) launch_tb2(s_main, u0, u1, bufC, bufD); // clocks up
+      struct Cand { int a, b, c, d; float ms; };
+      std::vector<Cand> cands;
+      auto eval = [&](int a, int b, int c, int d) {
+         Real *A = own_grids ? pool[a] : u0, *B = own_grids ? pool[b] : u1, *C = pool[c], *D = pool[d];
+         float ms = time_fwd(A, B, C, D);
+         if (own_grids) ms = 0.5f * (ms + time_fwd(C, D, A, B));
+         cands.push_back({a, b, c, d, ms});
+      };
+      uint32_t rng = 0x9e3779b9u;
+      auto next = [&](uint32_t n) { rng = rng * 1664525u + 1013904223u; return (rng >> 8) % n; };
+      if (own_grids) eval(0, 1, 2, 3); else eval(-1, -1, 0, 1);
+      const int n = (int)pool.size();
+      for (int t = 1; t < evals && (n > (int)base || own_grids); t++) {
+         int idx[4];
+         const int k = own_grids ? 4 : 2;
+         for (int i = 0; i < k; i++) { // k distinct pool members, in order
+            bool dup;
+            do { idx[i] = (int)next((uint32_t)n); dup = false; for (int j = 0; j < i; j++) dup |= idx[j] == idx[i]; } while (dup);
+         }
+         if (own_grids) eval(idx[0], idx[1], idx[2], idx[3]); else eval(-1, -1, idx[0], idx[1]);
+      }
+      size_t best = 0;
+      for (size_t i = 1; i < cands.size(); i++) if (cands[i].ms < cands[best].ms) best = i;
+      place_ms.clear();
+      for (auto &c : cands) place_ms.push_back(c.ms);
+      if (verbose) {
+         fprintf(stderr, "pffdtd_hip: grid placement, %d candidates of a pool of %d:", (int)cands.size(), n);
+         for (size_t i = 0; i < cands.size(); i++) fprintf(stderr, " %.3f%s", cands[i].ms, i == best ? "*" : "");
+         fprintf(stderr, " ms per launch\n");
+      }
+      const Cand w = cands[best];
+      std::vector<Real *> keep;
+      if (own_grids) { u0 = pool[w.a]; u1 = pool[w.b]; keep.push_back(u0); keep.push_back(u1); }
+      bufC = pool[w.c]; bufD = pool[w.d];
+      keep.push_back(bufC); keep.push_back(bufD);
+      for (Real *g : pool) {
+         own_list.erase(std::remove(own_list.begin(), own_list.end(), g), own_list.end());
+         if (std::find(keep.begin(), keep.end(), g) == keep.end()) hipFree(g);
+      }
+      for (Real *g : keep) {
+         own_list.push_back(g);
+         HIPCHK(hipMemsetAsync(g, 0, npad * sizeof(Real), s_main)); // (the pair kernel wrote zeros computed from zeros; be explicit)
+      }
+      HIPCHK(hipStreamSynchronize(s_main));
       hipEventDestroy(e0); hipEventDestroy(e1);
       return PF_OK;
    }
@@ -1595,6 +1684,12 @@ template <typename Real> struct Engine : EngineBase {
       in_step = true;
       return PF_OK;
    }
+   int state_grids(void **up, void **uc) override {
+      if (in_step || pair_phase) return set_err(PF_ERR_STATE, "pf_engine_state_grids inside a step");
+      if (up) *up = u0;
+      if (uc) *uc = u1;
+      return PF_OK;
+   }
    int halo_ptrs(void **slo, void **shi, void **rlo, void **rhi, size_t *bytes) override {
       // new state is u0 until step_end rotates (gpu_engine.h:1086-1126 sends the same planes)
       if (slo) *slo = u0 + plane;
@@ -1693,6 +1788,12 @@ template <typename Real> struct Engine : EngineBase {
       tm.air_path = (tb2 || tb2_slab) ? 2 : (lean ? 0 : (vg ? 1 : -1));
       tm.tb2_lw = (tb2 || tb2_slab) ? tb_lw : 0;
       tm.tb2_dirty_tiles = (tb2 || tb2_slab) ? tb_ndirty : 0;
+      tm.place_candidates = (int64_t)place_ms.size();
+      if (!place_ms.empty()) {
+         tm.place_ms[0] = place_ms[0];
+         tm.place_ms[1] = *std::min_element(place_ms.begin(), place_ms.end());
+         tm.place_ms[2] = *std::max_element(place_ms.begin(), place_ms.end());
+      }
       if (t) *t = tm;
       if (reset) tm = pf_timing{};
       return PF_OK;
@@ -1792,6 +1893,7 @@ int pf_engine_halo_ptrs(pf_engine *e, void **send_lo, void **send_hi, void **rec
    return e->impl->halo_ptrs(send_lo, send_hi, recv_lo, recv_hi, plane_bytes);
 }
 int pf_engine_step_end(pf_engine *e, int64_t n) { PF_NEED(e); return e->impl->step_end(n); }
+int pf_engine_state_grids(pf_engine *e, void **u_prev, void **u_cur) { PF_NEED(e); return e->impl->state_grids(u_prev, u_cur); }
 int pf_engine_set_spares(pf_engine *e, void *g2, void *g3) { PF_NEED(e); return e->impl->set_spares(g2, g3); }
 void *pf_engine_stream(pf_engine *e, int32_t which) { return (e && e->impl) ? e->impl->stream(which) : nullptr; }
 int pf_engine_sync(pf_engine *e) { PF_NEED(e); return e->impl->sync(); }

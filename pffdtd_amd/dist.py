@@ -10,14 +10,25 @@ that stream only, and the interior planes run concurrently on the main stream.
 The per-slab work is behind a small `stepper` interface so that the exchange schedule itself can be
 tested on CPU with gloo (tests inject an oracle-backed stepper; the product stepper is HIP only).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 from . import slab as slab_mod
 
 
+class _DevMem:
+    """A device allocation that is not torch's, described for torch.as_tensor (CUDA array interface v2)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
 class HipSlabStepper:
-    """HIP engine of one slab with torch-owned state grids (so the halo planes are addressable as tensors)."""
+    """HIP engine of one slab whose state grids are addressable as tensors (halo planes, initial fields).  Slabs of a
+    multi-rank run: torch-owned grids handed to the engine.  A single domain: the engine allocates -- it then also chooses
+    where its four grids live (creation-time placement sampling) -- and `grids` are views of its allocations."""
 
     def __init__(self, loc, info, device, pairs=False, **engine_kw):
         from . import engine
@@ -26,11 +37,21 @@ class HipSlabStepper:
         self.tdtype = torch.float32 if loc.real_bytes == 4 else torch.float64
         P = engine.grid_pitch(loc.Nz, loc.real_bytes)
         self.plane = loc.Ny * P
-        with torch.cuda.device(self.device):
-            self.grids = [torch.zeros((loc.Nx, self.plane), dtype=self.tdtype, device=self.device) for _ in range(2)]
-            torch.cuda.synchronize()
-        self.eng = engine.HipEngine(loc, device=device, slab_first=info.first, slab_last=info.last, x_global0=info.xlo,
-                                    ext_u0=self.grids[0].data_ptr(), ext_u1=self.grids[1].data_ptr(), **engine_kw)
+        if info.G == 1 and os.environ.get("PFFDTD_TORCH_GRIDS", "") != "1":
+            self.eng = engine.HipEngine(loc, device=device, slab_first=info.first, slab_last=info.last, x_global0=info.xlo,
+                                        **engine_kw)
+            ts = "<f4" if loc.real_bytes == 4 else "<f8"
+            with torch.cuda.device(self.device):
+                self.grids = [torch.as_tensor(_DevMem(p, (loc.Nx, self.plane), ts), device=self.device)
+                              for p in self.eng.state_grids()]
+            if [g.data_ptr() for g in self.grids] != list(self.eng.state_grids()):
+                raise RuntimeError("torch copied the engine's state grids instead of wrapping them")
+        else:
+            with torch.cuda.device(self.device):
+                self.grids = [torch.zeros((loc.Nx, self.plane), dtype=self.tdtype, device=self.device) for _ in range(2)]
+                torch.cuda.synchronize()
+            self.eng = engine.HipEngine(loc, device=device, slab_first=info.first, slab_last=info.last, x_global0=info.xlo,
+                                        ext_u0=self.grids[0].data_ptr(), ext_u1=self.grids[1].data_ptr(), **engine_kw)
         # Two more grids let a slab engine with a boundary-free box advance in temporally blocked pairs (the state
         # then cycles through all four); engines that cannot use them say so and the grids are dropped again.
         self.paired = False

@@ -32,7 +32,7 @@ class PfTiming(ctypes.Structure):
                 ("step_ms_total", ctypes.c_double), ("steps", ctypes.c_int64),
                 ("tb2_ms_total", ctypes.c_double), ("tb2_launches", ctypes.c_int64), ("tb2_cells", ctypes.c_int64),
                 ("tune_ms", ctypes.c_double * 3), ("air_path", ctypes.c_int64), ("tb2_lw", ctypes.c_int64),
-                ("tb2_dirty_tiles", ctypes.c_int64)]
+                ("tb2_dirty_tiles", ctypes.c_int64), ("place_candidates", ctypes.c_int64), ("place_ms", ctypes.c_double * 3)]
 
 
 class PfError(RuntimeError):
@@ -41,7 +41,7 @@ class PfError(RuntimeError):
 
 EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_grid_bytes", "pf_grid_pitch", "pf_opts_default",
            "pf_run_sim", "pf_engine_create", "pf_engine_destroy", "pf_engine_run", "pf_engine_step_begin",
-           "pf_engine_halo_ptrs", "pf_engine_step_end", "pf_engine_set_spares", "pf_engine_stream", "pf_engine_sync",
+           "pf_engine_halo_ptrs", "pf_engine_step_end", "pf_engine_state_grids", "pf_engine_set_spares", "pf_engine_stream", "pf_engine_sync",
            "pf_engine_flush_outputs", "pf_engine_get_grid", "pf_engine_set_grid", "pf_engine_timing",
            "pf_engine_energy_cfg", "pf_engine_run_energy", "pf_run_sim_devices", "pf_slab_partition"]
 
@@ -102,6 +102,7 @@ def lib():
         L.pf_engine_step_end.argtypes = [vp, i64]
         L.pf_engine_halo_ptrs.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
                                           ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
+        L.pf_engine_state_grids.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
         L.pf_engine_stream.restype = vp
         L.pf_engine_stream.argtypes = [vp, i32]
         L.pf_engine_sync.argtypes = [vp]
@@ -206,6 +207,13 @@ class HipEngine:
                                          ctypes.byref(rhi), ctypes.byref(nb)))
         return slo.value, shi.value, rlo.value, rhi.value, nb.value
 
+    def state_grids(self):
+        """Device pointers (u^{n-1}, u^n) of the state grids between runs (pf_engine_state_grids)."""
+        vp = ctypes.c_void_p
+        up, uc = vp(), vp()
+        _check(lib().pf_engine_state_grids(self._h, ctypes.byref(up), ctypes.byref(uc)))
+        return up.value, uc.value
+
     def set_spares(self, ptr2, ptr3):
         """Two more caller-owned state grids: lets a slab engine step in temporally blocked pairs.  -> True if it will."""
         rc = lib().pf_engine_set_spares(self._h, ctypes.c_void_p(ptr2), ctypes.c_void_p(ptr3))
@@ -253,7 +261,8 @@ class HipEngine:
         _check(lib().pf_engine_timing(self._h, ctypes.byref(t), int(reset)))
         return {"air_ms_total": t.air_ms_total, "air_launches": t.air_launches, "step_ms_total": t.step_ms_total,
                 "steps": t.steps, "tb2_ms_total": t.tb2_ms_total, "tb2_launches": t.tb2_launches, "tb2_cells": t.tb2_cells,
-                "tune_ms": list(t.tune_ms), "air_path": t.air_path, "tb2_lw": t.tb2_lw, "tb2_dirty_tiles": t.tb2_dirty_tiles}
+                "tune_ms": list(t.tune_ms), "air_path": t.air_path, "tb2_lw": t.tb2_lw, "tb2_dirty_tiles": t.tb2_dirty_tiles,
+                "place_candidates": t.place_candidates, "place_ms": list(t.place_ms)}
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
