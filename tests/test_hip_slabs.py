@@ -71,6 +71,51 @@ def test_single_rank_runner_matches():
     assert np.array_equal(out, ref)
 
 
+@pytest.mark.parametrize("torch_grids", [False, True])
+def test_single_domain_stepper_grids_are_the_engines(torch_grids, monkeypatch):
+    """A single domain lets the engine allocate (and place) its state grids; `grids` are torch views of those allocations
+    (pf_engine_state_grids): an initial field written through them is the one the engine steps.  PFFDTD_TORCH_GRIDS=1 keeps
+    the torch-owned grids of the slab case; same bits either way, blocked pairs (four grids, placement sampled) included."""
+    from pffdtd_amd import engine, sim_data, synth
+    if torch_grids:
+        monkeypatch.setenv("PFFDTD_TORCH_GRIDS", "1")
+    n = (36, 64, 280)  # (the box of a blocked pair needs >= 248 columns)
+    sim = synth.shoebox(*n, Nt=23, Nm=2, Mb=[11, 3], src=None, rcv=[[21, 32, 138], [6, 7, 8], [27, 54, 200]])
+
+    def make_sd():
+        s = sim_data.SimData.from_sim(sim, "single", build_mask=False)
+        s.scale_input()
+        return s
+    sd = make_sd()
+    rng = np.random.default_rng(5)
+    P = engine.grid_pitch(sd.Nz, 4)
+    init = [(rng.standard_normal((sd.Nx, sd.Ny, P)) * 1e-3).astype(np.float32) for _ in range(2)]
+    for g in init:  # interior cells only (ghost shell and pad columns stay zero, as after any step)
+        g[0], g[-1], g[:, 0], g[:, -1], g[:, :, 0], g[:, :, sd.Nz - 1:] = 0, 0, 0, 0, 0, 0
+    outs = []
+    for variant in (20, 40):
+        sd = make_sd()
+        runner, loc, info = pdist.make_hip_runner(sd, 0, 1, 0, air_variant=variant, timing=True)
+        st = runner.st
+        ptrs = st.eng.state_grids()
+        assert ptrs[0] and ptrs[1] and ptrs[0] != ptrs[1]
+        assert [g.data_ptr() for g in st.grids] == list(ptrs)
+        for g, h in zip(st.grids, init):
+            g.copy_(torch.from_numpy(h.reshape(sd.Nx, -1)).to(g.device))
+        torch.cuda.synchronize()
+        assert np.array_equal(st.eng.get_grid(0), init[0][:, :, :sd.Nz])  # the engine sees what torch wrote
+        st.eng.run(0, sd.Nt)  # (as bench.py does for one GPU; SlabRunner.run would take the split-phase steps of a slab)
+        st.finish()
+        tm = st.eng.timing()
+        if variant == 40:
+            assert tm["tb2_launches"] > 0
+            assert tm["place_candidates"] >= (2 if not torch_grids else 1)
+            assert 0 < tm["place_ms"][1] <= tm["place_ms"][0] <= tm["place_ms"][2]
+        outs.append(pdist.gather_outputs(sd, loc, info).copy())
+        st.close()
+    assert np.abs(outs[0]).max() > 0 and np.array_equal(outs[0], outs[1])  # single steps == blocked pairs, from a noise field
+
+
 @pytest.mark.parametrize("G,Nt", [(2, 21), (3, 18)])
 @pytest.mark.parametrize("src", [None, [70, 30, 150], [49, 30, 150], [45, 30, 150], [30, 33, 141]],
                          ids=["centre", "off_centre", "second_edge_plane", "second_last_edge_plane", "third_cut"])

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Does the pair kernel's speed depend on which engine of a process it runs in?  Builds the bench scene once, then creates,
+"""(Superseded by tools/placement_probe.py, which found the cause: grid placement.)
+Does the pair kernel's speed depend on which engine of a process it runs in?  Builds the bench scene once, then creates,
 runs and destroys the engine several times in one process and prints the blocked kernel's time per launch for each."""
 import sys
 import time
