@@ -172,6 +172,14 @@ int  pf_engine_step_end(pf_engine *e, int64_t n);
  * single-domain engine, ...); other values
  * are pf_status errors.  No counterpart in the reference. */
 int  pf_engine_set_spares(pf_engine *e, void *grid2, void *grid3);
+/* The same with a choice: before its first step a slab engine is offered a pool of n >= 4 zero-filled caller-owned grids
+ * (pool[0], pool[1] may be the ext_u0 / ext_u1 it was created on).  The speed of the two-steps-per-pass kernel depends on
+ * where its four grids lie relative to each other in physical memory ("grid placement"), so the engine times
+ * assignments of pool members to its four roles and adopts the fastest: idx[0], idx[1] = the state grids from now on,
+ * idx[2], idx[3] = the spares; the caller may free the others.  An engine that keeps stepping singly (cf.
+ * pf_engine_set_spares) stays on pool[0] and pool[1] and says idx = 0, 1, -1, -1.  Returns a pf_status.  No counterpart in
+ * the reference. */
+int  pf_engine_place_grids(pf_engine *e, void *const *pool, int32_t n, int32_t idx[4]);
 /* Device pointers of the two state grids as they stand between runs (u_prev = u^{n-1}, overwritten by the next step;
  * u_cur = u^n), each pf_grid_bytes() long: the engine's own allocations unless pf_opts.ext_u0 / ext_u1 were given.
  * Lets a host that left the allocation to the engine (which then also chooses WHERE the grids live, see DESIGN.md

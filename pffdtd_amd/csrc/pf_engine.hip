@@ -81,6 +81,7 @@ struct EngineBase {
    virtual int sync() = 0;
    virtual int flush() = 0;
    virtual int set_spares(void *g2, void *g3) = 0;
+   virtual int place_grids(void *const *grids, int n, int32_t *idx) = 0;
    virtual int get_grid(int which, void *host) = 0;
    virtual int set_grid(int which, const void *host) = 0;
    virtual int timing(pf_timing *t, int reset) = 0;
@@ -816,12 +817,10 @@ template <typename Real> struct Engine : EngineBase {
    // the four-grid cycle) on two dozen random assignments of pool members to the roles u^{n-1}, u^n, u^{n+1}, u^{n+2},
    // keeps the fastest and frees the rest.  A few hundred ms, once.  With caller-owned state grids (pf_opts.ext_u0 / ext_u1)
    // only the two spares are placed, and only the forward direction is timed (the caller's grids are not written).
-   int sample_placement() {
-      if (!tb2 || tb2_slab || !bufC || !bufD || (op.debug & 0x8000) || vbase == 41) return PF_OK;
-      int extra = 4, evals = 24;
-      if (const char *ev = getenv("PFFDTD_PLACE_EXTRA")) extra = std::min(std::max(atoi(ev), 0), 12);
-      if (const char *ev = getenv("PFFDTD_PLACE_EVALS")) evals = std::min(std::max(atoi(ev), 1), 64);
-      if (extra == 0 && !own_grids) return PF_OK;
+   // the search itself: `evals` assignments of pool members to the roles (the first as given in `first`, the others drawn with
+   // a fixed-seed generator), timed with the pair kernel; fixed_ab: the state grids stay where they are (u0 / u1), only the
+   // two spares are drawn; both: the reverse direction of the four-grid cycle is timed as well (writes every member)
+   int search_placement(const std::vector<Real *> &pool, bool fixed_ab, bool both, int evals, const int first[4], int chosen[4]) {
       const bool verbose = getenv("PFFDTD_VERBOSE") && atoi(getenv("PFFDTD_VERBOSE")) > 0;
       hipEvent_t e0, e1;
       HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
@@ -835,36 +834,28 @@ template <typename Real> struct Engine : EngineBase {
          hipEventElapsedTime(&ms, e0, e1);
          return ms / 2;
       };
-      std::vector<Real *> pool;
-      if (own_grids) { pool.push_back(u0); pool.push_back(u1); }
-      pool.push_back(bufC); pool.push_back(bufD);
-      const size_t base = pool.size();
-      for (int i = 0; i < extra; i++) {
-         Real *p = try_dzalloc<Real>(npad);
-         if (!p) break; // no room for another candidate
-         pool.push_back(p);
-      }
-      for (int i = 0; i < 4; i++) launch_tb2(s_main, u0, u1, bufC, bufD); // clocks up
-      struct Cand { int a, b, c, d; float ms; };
+      auto grid = [&](int i, Real *fallback) { return i >= 0 ? pool[i] : fallback; };
+      for (int i = 0; i < 4; i++) launch_tb2(s_main, grid(first[0], u0), grid(first[1], u1), pool[first[2]], pool[first[3]]); // clocks up
+      struct Cand { int r[4]; float ms; };
       std::vector<Cand> cands;
-      auto eval = [&](int a, int b, int c, int d) {
-         Real *A = own_grids ? pool[a] : u0, *B = own_grids ? pool[b] : u1, *C = pool[c], *D = pool[d];
+      auto eval = [&](const int r[4]) {
+         Real *A = grid(r[0], u0), *B = grid(r[1], u1), *C = pool[r[2]], *D = pool[r[3]];
          float ms = time_fwd(A, B, C, D);
-         if (own_grids) ms = 0.5f * (ms + time_fwd(C, D, A, B));
-         cands.push_back({a, b, c, d, ms});
+         if (both) ms = 0.5f * (ms + time_fwd(C, D, A, B));
+         cands.push_back({{r[0], r[1], r[2], r[3]}, ms});
       };
       uint32_t rng = 0x9e3779b9u;
-      auto next = [&](uint32_t n) { rng = rng * 1664525u + 1013904223u; return (rng >> 8) % n; };
-      if (own_grids) eval(0, 1, 2, 3); else eval(-1, -1, 0, 1);
-      const int n = (int)pool.size();
-      for (int t = 1; t < evals && (n > (int)base || own_grids); t++) {
-         int idx[4];
-         const int k = own_grids ? 4 : 2;
+      auto next = [&](uint32_t m) { rng = rng * 1664525u + 1013904223u; return (rng >> 8) % m; };
+      eval(first);
+      const int n = (int)pool.size(), k = fixed_ab ? 2 : 4;
+      for (int t = 1; t < evals && n >= k && (n > k || !fixed_ab); t++) {
+         int idx[4], r[4] = {-1, -1, -1, -1};
          for (int i = 0; i < k; i++) { // k distinct pool members, in order
             bool dup;
             do { idx[i] = (int)next((uint32_t)n); dup = false; for (int j = 0; j < i; j++) dup |= idx[j] == idx[i]; } while (dup);
+            r[4 - k + i] = idx[i];
          }
-         if (own_grids) eval(idx[0], idx[1], idx[2], idx[3]); else eval(-1, -1, idx[0], idx[1]);
+         eval(r);
       }
       size_t best = 0;
       for (size_t i = 1; i < cands.size(); i++) if (cands[i].ms < cands[best].ms) best = i;
@@ -875,10 +866,35 @@ template <typename Real> struct Engine : EngineBase {
          for (size_t i = 0; i < cands.size(); i++) fprintf(stderr, " %.3f%s", cands[i].ms, i == best ? "*" : "");
          fprintf(stderr, " ms per launch\n");
       }
-      const Cand w = cands[best];
+      for (int i = 0; i < 4; i++) chosen[i] = cands[best].r[i];
+      hipEventDestroy(e0); hipEventDestroy(e1);
+      return hipGetLastError() == hipSuccess ? PF_OK : set_err(PF_ERR_HIP, "placement search: kernel launch failed");
+   }
+   int place_evals() const {
+      int evals = 24;
+      if (const char *ev = getenv("PFFDTD_PLACE_EVALS")) evals = std::min(std::max(atoi(ev), 1), 64);
+      return evals;
+   }
+   int sample_placement() {
+      if (!tb2 || tb2_slab || !bufC || !bufD || (op.debug & 0x8000) || vbase == 41) return PF_OK;
+      int extra = 4;
+      if (const char *ev = getenv("PFFDTD_PLACE_EXTRA")) extra = std::min(std::max(atoi(ev), 0), 12);
+      if (extra == 0 && !own_grids) return PF_OK;
+      std::vector<Real *> pool;
+      if (own_grids) { pool.push_back(u0); pool.push_back(u1); }
+      pool.push_back(bufC); pool.push_back(bufD);
+      for (int i = 0; i < extra; i++) {
+         Real *p = try_dzalloc<Real>(npad);
+         if (!p) break; // no room for another candidate
+         pool.push_back(p);
+      }
+      const int first_own[4] = {0, 1, 2, 3}, first_ext[4] = {-1, -1, 0, 1};
+      int w[4];
+      int rc = search_placement(pool, !own_grids, own_grids, place_evals(), own_grids ? first_own : first_ext, w);
+      if (rc) return rc;
       std::vector<Real *> keep;
-      if (own_grids) { u0 = pool[w.a]; u1 = pool[w.b]; keep.push_back(u0); keep.push_back(u1); }
-      bufC = pool[w.c]; bufD = pool[w.d];
+      if (own_grids) { u0 = pool[w[0]]; u1 = pool[w[1]]; keep.push_back(u0); keep.push_back(u1); }
+      bufC = pool[w[2]]; bufD = pool[w[3]];
       keep.push_back(bufC); keep.push_back(bufD);
       for (Real *g : pool) {
          own_list.erase(std::remove(own_list.begin(), own_list.end(), g), own_list.end());
@@ -889,7 +905,36 @@ template <typename Real> struct Engine : EngineBase {
          HIPCHK(hipMemsetAsync(g, 0, npad * sizeof(Real), s_main)); // (the pair kernel wrote zeros computed from zeros; be explicit)
       }
       HIPCHK(hipStreamSynchronize(s_main));
-      hipEventDestroy(e0); hipEventDestroy(e1);
+      return PF_OK;
+   }
+   // Slab engines (caller-owned grids): the caller offers a pool of n >= 4 zero-filled grids before the first step; the
+   // engine adopts the fastest assignment of four of them -- idx[0], idx[1]: the state grids (they replace ext_u0 / ext_u1),
+   // idx[2], idx[3]: the spares of pf_engine_set_spares, or idx = 0, 1, -1, -1 when this engine steps singly.
+   int place_grids(void *const *grids, int n, int32_t *idx) override {
+      if (in_step || pair_phase || steps_done > 0) return set_err(PF_ERR_STATE, "pf_engine_place_grids after the first step");
+      if (own_grids) return set_err(PF_ERR_STATE, "pf_engine_place_grids: this engine allocated its own grids");
+      if (!grids || !idx || n < 2) return set_err(PF_ERR_ARG, "pf_engine_place_grids: need a pool of at least two grids");
+      for (int i = 0; i < n; i++) {
+         if (!grids[i]) return set_err(PF_ERR_ARG, "pf_engine_place_grids: null grid");
+         for (int j = 0; j < i; j++) if (grids[i] == grids[j]) return set_err(PF_ERR_ARG, "pf_engine_place_grids: grid offered twice");
+      }
+      HIPCHK(hipSetDevice(op.device));
+      u0 = (Real *)grids[0]; u1 = (Real *)grids[1];
+      idx[0] = 0; idx[1] = 1; idx[2] = idx[3] = -1;
+      if (n < 4 || !tb2_geom || (op.slab_first && op.slab_last)) return PF_OK; // keeps stepping singly, on grids 0 and 1
+      std::vector<Real *> pool;
+      for (int i = 0; i < n; i++) pool.push_back((Real *)grids[i]);
+      int w[4] = {0, 1, 2, 3};
+      if (n > 4 && !(op.debug & 0x8000)) {
+         const int first[4] = {0, 1, 2, 3};
+         int rc = search_placement(pool, false, true, place_evals(), first, w);
+         if (rc) return rc;
+         for (int i = 0; i < n; i++) HIPCHK(hipMemsetAsync(pool[i], 0, npad * sizeof(Real), s_main));
+         HIPCHK(hipStreamSynchronize(s_main));
+      }
+      u0 = pool[w[0]]; u1 = pool[w[1]]; bufC = pool[w[2]]; bufD = pool[w[3]];
+      for (int i = 0; i < 4; i++) idx[i] = w[i];
+      tb2_slab = true;
       return PF_OK;
    }
    int autotune() {
@@ -1895,6 +1940,7 @@ int pf_engine_halo_ptrs(pf_engine *e, void **send_lo, void **send_hi, void **rec
 int pf_engine_step_end(pf_engine *e, int64_t n) { PF_NEED(e); return e->impl->step_end(n); }
 int pf_engine_state_grids(pf_engine *e, void **u_prev, void **u_cur) { PF_NEED(e); return e->impl->state_grids(u_prev, u_cur); }
 int pf_engine_set_spares(pf_engine *e, void *g2, void *g3) { PF_NEED(e); return e->impl->set_spares(g2, g3); }
+int pf_engine_place_grids(pf_engine *e, void *const *grids, int32_t n, int32_t *idx) { PF_NEED(e); return e->impl->place_grids(grids, n, idx); }
 void *pf_engine_stream(pf_engine *e, int32_t which) { return (e && e->impl) ? e->impl->stream(which) : nullptr; }
 int pf_engine_sync(pf_engine *e) { PF_NEED(e); return e->impl->sync(); }
 int pf_engine_flush_outputs(pf_engine *e) { PF_NEED(e); return e->impl->flush(); }

@@ -245,18 +245,25 @@ void create_slab(Shared &S, int g) {
    o.ext_u0 = S.grids[0][g]; o.ext_u1 = S.grids[1][g];
    ECHK(g, pf_engine_create(&sl.sd, &o, &S.eng[g]));
    if (want_pairs) {
-      void *p2 = nullptr, *p3 = nullptr;
-      if (hipMalloc(&p2, gb) == hipSuccess && hipMalloc(&p3, gb) == hipSuccess) {
-         MCHK(g, hipMemset(p2, 0, gb));
-         MCHK(g, hipMemset(p3, 0, gb));
-         MCHK(g, hipDeviceSynchronize());
-         const int rc = pf_engine_set_spares(S.eng[g], p2, p3);
-         if (rc == 0) { S.grids[2][g] = p2; S.grids[3][g] = p3; S.paired[g] = 1; }
-         else { hipFree(p2); hipFree(p3); if (rc != 1) { S.set_error(rc, pf_last_error()); return; } }
-      } else {
-         (void)hipGetLastError();
-         if (p2) hipFree(p2);
+      // a pool of up to eight grids: the engine keeps the four its pair kernel is fastest on (grid placement)
+      std::vector<void *> pool = {S.grids[0][g], S.grids[1][g]};
+      int extra = 6;
+      if (const char *ev = getenv("PFFDTD_PLACE_EXTRA")) extra = std::min(std::max(atoi(ev), 0), 12) + 2;
+      for (int k = 0; k < extra; k++) {
+         void *p = nullptr;
+         if (hipMalloc(&p, gb) != hipSuccess) { (void)hipGetLastError(); break; } // what fits
+         if (hipMemset(p, 0, gb) != hipSuccess) { (void)hipGetLastError(); hipFree(p); break; }
+         pool.push_back(p);
       }
+      MCHK(g, hipDeviceSynchronize());
+      int32_t idx[4] = {0, 1, -1, -1};
+      int rc = 0;
+      if (pool.size() >= 4) rc = pf_engine_place_grids(S.eng[g], pool.data(), (int32_t)pool.size(), idx);
+      if (rc != 0) { for (size_t k = 2; k < pool.size(); k++) hipFree(pool[k]); S.set_error(rc, pf_last_error()); return; }
+      for (int k = 0; k < 4; k++) S.grids[k][g] = idx[k] >= 0 ? pool[idx[k]] : nullptr;
+      for (size_t k = 0; k < pool.size(); k++)
+         if ((int)k != idx[0] && (int)k != idx[1] && (int)k != idx[2] && (int)k != idx[3]) hipFree(pool[k]);
+      S.paired[g] = idx[2] >= 0;
    }
    S.edge[g] = (hipStream_t)pf_engine_stream(S.eng[g], 1);
    for (int k = 0; k < 2; k++) MCHK(g, hipEventCreateWithFlags(&S.ev[k][g], hipEventDisableTiming));

@@ -54,18 +54,23 @@ class HipSlabStepper:
                                         ext_u0=self.grids[0].data_ptr(), ext_u1=self.grids[1].data_ptr(), **engine_kw)
         # Two more grids let a slab engine with a boundary-free box advance in temporally blocked pairs (the state
         # then cycles through all four); engines that cannot use them say so and the grids are dropped again.
+        # The pair kernel's speed depends on where its four grids lie relative to each other (grid placement):
+        # the engine is offered a pool of up to eight and keeps the four it is fastest on.
         self.paired = False
         if info.G > 1 and pairs:
+            pool = list(self.grids)
             try:
                 with torch.cuda.device(self.device):
-                    spare = [torch.zeros((loc.Nx, self.plane), dtype=self.tdtype, device=self.device) for _ in range(2)]
+                    for _ in range(int(os.environ.get("PFFDTD_PLACE_EXTRA", "4")) + 2):
+                        pool.append(torch.zeros((loc.Nx, self.plane), dtype=self.tdtype, device=self.device))
                     torch.cuda.synchronize()
-            except torch.OutOfMemoryError:  # no room for two more grids: single steps
-                spare = None
+            except torch.OutOfMemoryError:  # no room for more: what fits
                 torch.cuda.empty_cache()
-            if spare is not None and self.eng.set_spares(spare[0].data_ptr(), spare[1].data_ptr()):
-                self.grids += spare
-                self.paired = True
+            if len(pool) >= 4:
+                self.paired, idx = self.eng.place_grids([g.data_ptr() for g in pool])
+                self.grids = [pool[i] for i in idx if i >= 0]
+            del pool
+            torch.cuda.empty_cache()
         self._by_ptr = {g.data_ptr(): g for g in self.grids}
         self.edge_stream = torch.cuda.ExternalStream(self.eng.stream(1), device=self.device)
         self.main_stream = torch.cuda.ExternalStream(self.eng.stream(0), device=self.device)

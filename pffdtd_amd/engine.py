@@ -41,7 +41,7 @@ class PfError(RuntimeError):
 
 EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_grid_bytes", "pf_grid_pitch", "pf_opts_default",
            "pf_run_sim", "pf_engine_create", "pf_engine_destroy", "pf_engine_run", "pf_engine_step_begin",
-           "pf_engine_halo_ptrs", "pf_engine_step_end", "pf_engine_state_grids", "pf_engine_set_spares", "pf_engine_stream", "pf_engine_sync",
+           "pf_engine_halo_ptrs", "pf_engine_step_end", "pf_engine_state_grids", "pf_engine_place_grids", "pf_engine_set_spares", "pf_engine_stream", "pf_engine_sync",
            "pf_engine_flush_outputs", "pf_engine_get_grid", "pf_engine_set_grid", "pf_engine_timing",
            "pf_engine_energy_cfg", "pf_engine_run_energy", "pf_run_sim_devices", "pf_slab_partition"]
 
@@ -103,6 +103,7 @@ def lib():
         L.pf_engine_halo_ptrs.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
                                           ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
         L.pf_engine_state_grids.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
+        L.pf_engine_place_grids.argtypes = [vp, ctypes.POINTER(vp), i32, ctypes.POINTER(i32)]
         L.pf_engine_stream.restype = vp
         L.pf_engine_stream.argtypes = [vp, i32]
         L.pf_engine_sync.argtypes = [vp]
@@ -213,6 +214,14 @@ class HipEngine:
         up, uc = vp(), vp()
         _check(lib().pf_engine_state_grids(self._h, ctypes.byref(up), ctypes.byref(uc)))
         return up.value, uc.value
+
+    def place_grids(self, ptrs):
+        """Offer a pool of >= 4 zero-filled caller-owned grids to a slab engine (pf_engine_place_grids).  -> (paired, idx):
+        idx[0:2] = positions of the state grids in the pool, idx[2:4] = the spares (or -1 when it steps singly)."""
+        arr = (ctypes.c_void_p * len(ptrs))(*[int(p) for p in ptrs])
+        idx = (ctypes.c_int32 * 4)()
+        _check(lib().pf_engine_place_grids(self._h, arr, len(ptrs), idx))
+        return idx[2] >= 0, list(idx)
 
     def set_spares(self, ptr2, ptr3):
         """Two more caller-owned state grids: lets a slab engine step in temporally blocked pairs.  -> True if it will."""

@@ -129,6 +129,34 @@ def test_virtual_slabs_with_blocked_pairs_fp64():
     _run_blocked_pairs(2, 15, [49, 30, 150], "double")
 
 
+def test_place_grids_argument_errors():
+    from pffdtd_amd import engine, sim_data, synth
+    sim = synth.shoebox(96, 64, 280, Nt=6, Nm=2, Mb=[11, 3], src=None, rcv=[[50, 30, 140]])
+    sd = sim_data.SimData.from_sim(sim, "single", build_mask=False)
+    sd.scale_input()
+    loc, info = slab.split(sd, 2, 0)
+    P = engine.grid_pitch(loc.Nz, 4)
+    pool = [torch.zeros((loc.Nx, loc.Ny * P), dtype=torch.float32, device="cuda:0") for _ in range(5)]
+    eng = engine.HipEngine(loc, device=0, slab_first=info.first, slab_last=info.last, x_global0=info.xlo, air_variant=40,
+                           ext_u0=pool[0].data_ptr(), ext_u1=pool[1].data_ptr())
+    ptrs = [g.data_ptr() for g in pool]
+    with pytest.raises(RuntimeError, match="twice"):
+        eng.place_grids(ptrs[:3] + [ptrs[0]])
+    with pytest.raises(RuntimeError, match="at least two"):
+        eng.place_grids(ptrs[:1])
+    paired, idx = eng.place_grids(ptrs[:3])            # fewer than four: single steps on the first two
+    assert not paired and idx == [0, 1, -1, -1]
+    paired, idx = eng.place_grids(ptrs)
+    assert paired and sorted(set(idx)) == sorted(idx) and all(0 <= i < 5 for i in idx)
+    assert list(eng.state_grids()) == [ptrs[idx[0]], ptrs[idx[1]]]
+    assert all(float(g.abs().max()) == 0.0 for g in pool)  # the timing passes leave zeros
+    eng.close()
+    own = engine.HipEngine(sd, device=0, air_variant=40)  # an engine with its own grids has nothing to be offered
+    with pytest.raises(RuntimeError, match="own grids"):
+        own.place_grids(ptrs)
+    own.close()
+
+
 def _run_blocked_pairs(G, Nt, src, prec):
     from pffdtd_amd import sim_data, synth
     n = (96, 64, 280)
@@ -145,6 +173,11 @@ def _run_blocked_pairs(G, Nt, src, prec):
     parts = [slab.split(sd, G, r) for r in range(G)]
     st = [pdist.HipSlabStepper(loc, info, 0, pairs=True, air_variant=40, timing=True) for loc, info in parts]
     assert all(s.paired for s in st)
+    for s in st:  # four distinct grids chosen from the pool the engine was offered (pf_engine_place_grids), timed there
+        assert len(s.grids) == 4 and len({g.data_ptr() for g in s.grids}) == 4
+        tm = s.eng.timing()
+        assert tm["place_candidates"] >= 2 and 0 < tm["place_ms"][1] <= tm["place_ms"][0] <= tm["place_ms"][2]
+        assert list(s.eng.state_grids()) == [s.grids[0].data_ptr(), s.grids[1].data_ptr()]
     for k in range(sd.Nt):
         for s in st:
             s.step_begin(k)
