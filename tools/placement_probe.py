@@ -16,8 +16,9 @@ from pffdtd_amd import dist as pdist  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 neng = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+fcc = len(sys.argv) > 4 and sys.argv[4] == "fcc"
 K, W = 20, 4
-sd = bench.build_scene(n, (K + W) * (rounds + 1), "single", False, True, 11)
+sd = bench.build_scene(n, (K + W) * (rounds + 1), "single", fcc, True, 11)
 gen = torch.Generator(device="cuda")
 engs = []
 for r in range(neng):
