@@ -1068,7 +1068,8 @@ template <typename Real> struct Engine : EngineBase {
       pf::Tb2Params tp = tile_params();
       tp.A = u0_src ? u0_src : u0; tp.B = u1; tp.C = u0; tp.D = nullptr;
       tp.tiles = tb_dirty; tp.mask = mask;
-      const dim3 g((uint32_t)tb_ndirty), b(256);
+      tp.xsub = tb_ndirty <= 256 ? std::min(4, std::max(tb_chunk / 4, 1)) : 1; // few tiles: shorter marches, more workgroups
+      const dim3 g((uint32_t)tb_ndirty * (uint32_t)tp.xsub), b(256);
       if (tb_lw == 32) hipLaunchKernelGGL((pf::k_tb1_tile<Real, 3, 4, 32>), g, b, 0, s, tp, a1, a2);
       else if (tb_lw == 16) hipLaunchKernelGGL((pf::k_tb1_tile<Real, 3, 4, 16>), g, b, 0, s, tp, a1, a2);
       else hipLaunchKernelGGL((pf::k_tb1_tile<Real, 3, 4, 64>), g, b, 0, s, tp, a1, a2);

@@ -21,6 +21,7 @@ struct Tb2Params {
    const int32_t *tiles;          // non-null: block b works on tile tiles[b] = (xc*nyt + yt)*nzt + zt (rooms with interior
                                   // geometry: the clean tiles for k_tb2_reg, the others for k_tb1_tile)
    const uint8_t *mask;           // k_tb1_tile: the engine's skip-mask
+   int32_t xsub;                  // k_tb1_tile: > 1: that many workgroups share a tile, each marching a piece of its x chunk
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -413,13 +414,19 @@ __global__ __launch_bounds__(64 * WY) void k_tb1_tile(Tb2Params tp, Real a1, Rea
    typedef typename VecOf<Real>::type vec;
    static_assert(LW == 64 || LW == 32 || LW == 16, "row segments are 64, 32 or 16 lanes wide");
    constexpr int V = VecOf<Real>::V, W = LW * V, NSUB = 64 / LW;
-   const uint32_t t = tp.tiles ? (uint32_t)tp.tiles[blockIdx.x] : blockIdx.x;
+   // a handful of dirty tiles (the source's) is a launch of a few workgroups marching 16 planes each, all latency: xsub
+   // workgroups per tile shorten the march (each starts with its own two-plane prologue)
+   const uint32_t nsplit = tp.xsub > 1 ? (uint32_t)tp.xsub : 1u, tb = blockIdx.x / nsplit, piece = blockIdx.x % nsplit;
+   const uint32_t t = tp.tiles ? (uint32_t)tp.tiles[tb] : tb;
    const int zt = t % tp.nzt, yt = (t / tp.nzt) % tp.nyt, xc = t / (tp.nzt * tp.nyt);
    const int wlane = threadIdx.x & 63, w = threadIdx.x >> 6;
    const int lane = wlane % LW, sub = wlane / LW;
    const int ze0 = tp.z_begin - V + zt * (W - 2 * V);
    const int yo = tp.y_begin + ((yt * WY + w) * NSUB + sub) * R;
-   const int xs = tp.x_begin + xc * tp.chunk, xe = min(xs + tp.chunk, tp.x_end);
+   const int xs0 = tp.x_begin + xc * tp.chunk, xe0 = min(xs0 + tp.chunk, tp.x_end);
+   const int plen = (xe0 - xs0 + (int)nsplit - 1) / (int)nsplit;
+   const int xs = xs0 + (int)piece * plen, xe = min(xs + plen, xe0);
+   if (xs >= xe) return;
    const int P = tp.P;
    const int64_t plane = tp.plane;
    const int zc = min(max(ze0 + lane * V, 0), P - V);
