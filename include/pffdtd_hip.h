@@ -177,7 +177,7 @@ int  pf_engine_set_spares(pf_engine *e, void *grid2, void *grid3);
  * where its four grids lie relative to each other in physical memory ("grid placement"), so the engine times
  * assignments of pool members to its four roles and adopts the fastest: idx[0], idx[1] = the state grids from now on,
  * idx[2], idx[3] = the spares; the caller may free the others.  An engine that keeps stepping singly (cf.
- * pf_engine_set_spares) stays on pool[0] and pool[1] and says idx = 0, 1, -1, -1.  Returns a pf_status.  No counterpart in
+ * pf_engine_set_spares) picks the pair of the pool its single step is fastest on and says idx = i, j, -1, -1.  Returns a pf_status.  No counterpart in
  * the reference. */
 int  pf_engine_place_grids(pf_engine *e, void *const *pool, int32_t n, int32_t idx[4]);
 /* Device pointers of the two state grids as they stand between runs (u_prev = u^{n-1}, overwritten by the next step;

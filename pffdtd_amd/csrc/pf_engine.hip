@@ -514,6 +514,7 @@ template <typename Real> struct Engine : EngineBase {
       { int rc = init_tb2(); if (rc) return rc; }
       { int rc = sample_placement(); if (rc) return rc; }
       { int rc = autotune(); if (rc) return rc; }
+      if (!tb2 && op.slab_first && op.slab_last) { int rc = sample_placement_single(); if (rc) return rc; }
       // hipGraph replay of the step loop (six steps per graph): measured on MI355X / ROCm 7.2 it does not beat plain
       // launches even on launch-bound grids (234x154x85: 0.0503 vs 0.0473 ms/step, 256^3: 0.0951 vs 0.0921) -- the gaps
       // between dependent kernels are the same inside a graph, and the counter-tick node adds one -- so it is opt-in
@@ -897,6 +898,78 @@ template <typename Real> struct Engine : EngineBase {
       if (const char *ev = getenv("PFFDTD_PLACE_EVALS")) evals = std::min(std::max(atoi(ev), 1), 64);
       return evals;
    }
+   // the single-step paths stream two grids (u^n read, u^{n-1} read and overwritten): the same question with a smaller answer
+   // (Musikverein, 13-point, 1.3e9 cells: 4.36-4.61 ms per step over the pairs of a pool of six; small grids: 1-3 %);
+   // every unordered pair of the pool is timed on a whole step (both role assignments, the grids swap roles every step)
+   int search_pair(const std::vector<Real *> &pool, int &bi, int &bj) {
+      const bool verbose = getenv("PFFDTD_VERBOSE") && atoi(getenv("PFFDTD_VERBOSE")) > 0;
+      hipEvent_t e0, e1;
+      HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+      const int tsave = op.timing;
+      op.timing = 0;
+      Real *const s0 = u0, *const s1 = u1;
+      auto one_step = [&](Real *a, Real *b) { // u0 = a, u1 = b; all-zero state: every kernel writes zeros
+         u0 = a; u1 = b;
+         launch_pre(s_main);
+         launch_air(s_main, 1, (int)Nx - 1);
+         launch_abc(s_main, {0, Nba});
+         launch_rigid(s_main, {0, Nb});
+         launch_fd(s_main, {0, Nbl});
+      };
+      auto time_pair = [&](Real *a, Real *b) -> float {
+         hipEventRecord(e0, s_main);
+         one_step(a, b); one_step(b, a); one_step(a, b); one_step(b, a);
+         hipEventRecord(e1, s_main);
+         hipEventSynchronize(e1);
+         float ms = 0;
+         hipEventElapsedTime(&ms, e0, e1);
+         return ms / 4;
+      };
+      for (int i = 0; i < 6; i++) one_step(pool[0], pool[1]); // clocks up
+      const int n = (int)pool.size();
+      bi = 0; bj = 1;
+      float best = 0, worst = 0, first = 0;
+      place_ms.clear();
+      for (int i = 0; i < n; i++)
+         for (int j = i + 1; j < n; j++) {
+            const float ms = time_pair(pool[i], pool[j]);
+            place_ms.push_back(ms);
+            if (i == 0 && j == 1) first = best = worst = ms;
+            if (ms < best) { best = ms; bi = i; bj = j; }
+            worst = std::max(worst, ms);
+         }
+      op.timing = tsave;
+      u0 = s0; u1 = s1;
+      if (verbose) fprintf(stderr, "pffdtd_hip: grid placement (single steps), %d pairs of a pool of %d: as allocated %.4f, chosen %.4f, slowest %.4f ms per step\n",
+                           (int)place_ms.size(), n, first, best, worst);
+      for (int i = 0; i < n; i++) HIPCHK(hipMemsetAsync(pool[i], 0, npad * sizeof(Real), s_main)); // (zeros from zeros; be explicit)
+      HIPCHK(hipStreamSynchronize(s_main));
+      hipEventDestroy(e0); hipEventDestroy(e1);
+      return hipGetLastError() == hipSuccess ? PF_OK : set_err(PF_ERR_HIP, "placement search: kernel launch failed");
+   }
+   bool place_single_ok() const { return !(op.debug & 0x8000) && !op.energy && vbase == 0 && npad * (int64_t)sizeof(Real) >= ((int64_t)64 << 20); }
+   int sample_placement_single() {
+      if (!own_grids || !place_single_ok()) return PF_OK;
+      int extra = 4;
+      if (const char *ev = getenv("PFFDTD_PLACE_EXTRA")) extra = std::min(std::max(atoi(ev), 0), 12);
+      if (extra == 0) return PF_OK;
+      std::vector<Real *> pool = {u0, u1};
+      for (int i = 0; i < extra; i++) {
+         Real *p = try_dzalloc<Real>(npad);
+         if (!p) break;
+         pool.push_back(p);
+      }
+      int bi, bj;
+      int rc = search_pair(pool, bi, bj);
+      if (rc) return rc;
+      u0 = pool[bi]; u1 = pool[bj];
+      for (int i = 0; i < (int)pool.size(); i++) {
+         own_list.erase(std::remove(own_list.begin(), own_list.end(), pool[i]), own_list.end());
+         if (i != bi && i != bj) hipFree(pool[i]);
+      }
+      own_list.push_back(u0); own_list.push_back(u1);
+      return PF_OK;
+   }
    int sample_placement() {
       if (!tb2 || tb2_slab || !bufC || !bufD || (op.debug & 0x8000) || vbase == 41) return PF_OK;
       int extra = 4;
@@ -943,7 +1016,18 @@ template <typename Real> struct Engine : EngineBase {
       HIPCHK(hipSetDevice(op.device));
       u0 = (Real *)grids[0]; u1 = (Real *)grids[1];
       idx[0] = 0; idx[1] = 1; idx[2] = idx[3] = -1;
-      if (n < 4 || !tb2_geom || (op.slab_first && op.slab_last)) return PF_OK; // keeps stepping singly, on grids 0 and 1
+      if (n < 4 || !tb2_geom || (op.slab_first && op.slab_last)) { // keeps stepping singly: on the fastest pair of the pool
+         if (n > 2 && place_single_ok()) {
+            std::vector<Real *> pool;
+            for (int i = 0; i < n; i++) pool.push_back((Real *)grids[i]);
+            int bi, bj;
+            int rc = search_pair(pool, bi, bj);
+            if (rc) return rc;
+            u0 = pool[bi]; u1 = pool[bj];
+            idx[0] = bi; idx[1] = bj;
+         }
+         return PF_OK;
+      }
       std::vector<Real *> pool;
       for (int i = 0; i < n; i++) pool.push_back((Real *)grids[i]);
       int w[4] = {0, 1, 2, 3};

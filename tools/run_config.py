@@ -76,7 +76,7 @@ if a.energy:
                gvox_per_s=round(sd.Npts * sd.Nt / el / 1e9, 3))
 else:
     K, W = min(a.steps, sd.Nt - a.warmup), a.warmup
-    # state grids owned here and pre-filled with seeded noise of the magnitude of a running simulation: every cell is live
+    # state grids (the engine's own: it also places them) pre-filled with seeded noise of the magnitude of a running simulation: every cell is live
     # from step 0 (receivers included -- the source's own wave needs thousands of steps to reach them at this resolution),
     # and the clocks see the data activity of a real run (all-zero fields clock higher)
     import torch
@@ -84,10 +84,13 @@ else:
     P = engine.grid_pitch(sd.Nz, rb)
     gen = torch.Generator(device="cuda")
     gen.manual_seed(7)
-    grids = [((torch.rand((sd.Nx, sd.Ny * P), generator=gen, device="cuda", dtype=torch.float32 if rb == 4 else torch.float64) * 2 - 1) * 1e-3)
-             for _ in range(2)]
+    from pffdtd_amd.dist import _DevMem
+    eng = engine.HipEngine(sd, timing=True, debug=a.debug, air_variant=a.variant)
+    for p in eng.state_grids():
+        g = torch.as_tensor(_DevMem(p, (sd.Nx, sd.Ny * P), "<f4" if rb == 4 else "<f8"), device="cuda")
+        assert g.data_ptr() == p
+        g.copy_((torch.rand(g.shape, generator=gen, device="cuda", dtype=g.dtype) * 2 - 1) * 1e-3)
     torch.cuda.synchronize()
-    eng = engine.HipEngine(sd, timing=True, debug=a.debug, air_variant=a.variant, ext_u0=grids[0].data_ptr(), ext_u1=grids[1].data_ptr())
     eng.run(0, W)
     eng.sync()
     eng.timing(reset=True)
