@@ -585,7 +585,7 @@ template <typename Real> struct Engine : EngineBase {
          }
          if (best < 0) return PF_OK; // no room for a single row segment
       }
-      szl = tbz0; szr = tbz1; // (widened to whole 128-byte lines, the overlap computed twice: slower, 2.32 -> 2.34-2.53 ms/step)
+      szl = tbz0; szr = tbz1; // (widened to whole 128-byte lines or 32-byte sectors, the overlap with the box computed twice: 0-2 % slower, re-measured with the grids placed)
       if (vbase == 41) tbx1 = tbx0; // driver test: everything goes through the out-of-place single-step path
       tb_xr.clear();
       // rows of a workgroup: 4 waves x R = 3 (7-point); 13-point: 6 inner waves x R = 2 with 64-lane segments (k_tb2_fcc_x), else 4 x 2
