@@ -129,6 +129,41 @@ def test_virtual_slabs_with_blocked_pairs_fp64():
     _run_blocked_pairs(2, 15, [49, 30, 150], "double")
 
 
+def test_virtual_slabs_stepping_singly_choose_their_two_grids_from_the_pool():
+    """Slabs whose cross-section is too small for blocked pairs (512 x 512 < 600 x 600) but whose grids are large enough to
+    be worth placing (>= 64 MB): pf_engine_place_grids picks the fastest PAIR of the pool; results as the oracle's."""
+    from pffdtd_amd import sim_data, synth
+    n, G = (134, 512, 512), 2
+    sim = synth.shoebox(*n, Nt=8, Nm=2, Mb=[11, 3], src=[66, 250, 255], rcv=[[64, 250, 250], [69, 260, 252], [7, 8, 9], [120, 500, 40]])
+    ref = sim_data.SimData.from_sim(sim, "single")
+    ref.scale_input()
+    oracle.run_sim(ref)
+    sd = sim_data.SimData.from_sim(sim, "single", build_mask=False)
+    sd.scale_input()
+    parts = [slab.split(sd, G, r) for r in range(G)]
+    st = [pdist.HipSlabStepper(loc, info, 0, pairs=True, timing=True) for loc, info in parts]
+    for s in st:
+        assert not s.paired and len(s.grids) == 2 and s.grids[0].data_ptr() != s.grids[1].data_ptr()
+        assert list(s.eng.state_grids()) == [g.data_ptr() for g in s.grids]
+        assert s.eng.timing()["place_candidates"] >= 3
+    for k in range(sd.Nt):
+        for s in st:
+            s.step_begin(k)
+        planes = [s.halo_tensors() for s in st]
+        torch.cuda.synchronize()
+        planes[1][2].copy_(planes[0][1])
+        planes[0][3].copy_(planes[1][0])
+        torch.cuda.synchronize()
+        for s in st:
+            s.step_end(k)
+    for s in st:
+        s.finish()
+    out = slab.merge_outputs(sd, [p[0] for p in parts])
+    for s in st:
+        s.close()
+    assert np.abs(ref.u_out).max() > 0 and np.array_equal(out, ref.u_out)
+
+
 def test_place_grids_argument_errors():
     from pffdtd_amd import engine, sim_data, synth
     sim = synth.shoebox(96, 64, 280, Nt=6, Nm=2, Mb=[11, 3], src=None, rcv=[[50, 30, 140]])
