@@ -294,7 +294,7 @@ def main():
         tfile, pfile = ROOT / "profiles" / "r02_bench_n1_hbm_traffic.json", ROOT / "profiles" / "r02_bench_n1.json"
         if world == 1 and tm.get("tb2_launches", 0) > 0 and tfile.exists():
             inst = (f"pf::k_tb2_fcc<{'float' if real_bytes == 4 else 'double'}, 2, 4, {int(tm['tb2_lw'])}>" if args.fcc else
-                    f"pf::k_tb2_reg<{'float' if real_bytes == 4 else 'double'}, 3, 4, false, {int(tm['tb2_lw'])}>")
+                    f"pf::k_tb2_reg<{'float' if real_bytes == 4 else 'double'}, 3, 4, false, {int(tm['tb2_lw'])}, false>")  # (..., true> = creation-time probes)
             try:
                 ks = json.load(open(tfile))["kernels"]
                 # (pfile absent = the profile collection itself, tools/collect_n1_profile.sh: the passes just taken are of this build)

@@ -31,7 +31,9 @@ struct Tb2Params {
 // u^{n+1} on its R rows + 1 above + 1 below from u^n rows R+4 (halo rows re-read through L1/L2 by the waves above and
 // below).  Per plane and lane: R+4 row loads of u^n, R+2 of u^{n-1}, R stores of u^{n+1}, R of u^{n+2}.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename Real, int R, int WY, bool NTA = true, int LW = 64>
+// PROBE: the same code under another name, for the creation-time measurements (grid placement search, path choice): per-kernel
+// profiler statistics of k_tb2_reg<..., false> then hold the launches of the time loop only.
+template <typename Real, int R, int WY, bool NTA = true, int LW = 64, bool PROBE = false>
 __global__ __launch_bounds__(64 * WY) void k_tb2_reg(Tb2Params tp, Real a1, Real a2) {
    typedef typename VecOf<Real>::type vec;
    // LW lanes span a row segment of LW*V columns whose first and last lane are z halo (their u^{n+1} values feed their
