@@ -306,6 +306,10 @@ def main():
                     res["roofline"]["traffic"] = round(hit[0]["total_bytes"] / 1e9, 3)
                     res["roofline"]["traffic_unit"] = f"GB per launch of {inst} (PMC, profiles/r02_bench_n1_hbm_traffic.json)"
                     res["roofline"]["algorithmic_GB_per_launch"] = round(units * bpv / 1e9, 3)
+                    res["roofline"]["measured_traffic_GBs"] = round(hit[0]["total_bytes"] / 1e9 / (kernel_ms * 1e-3), 1)
+                    res["roofline"]["note"] = ("a launch advances its cells by TWO steps: achieved = 2 x 12.125 B per cell / launch time (SURVEY 8d's per-update "
+                                               "figure x the updates of a launch), which temporal blocking is allowed to beat; measured_traffic_GBs = the "
+                                               "HBM bytes the launch really moves / launch time")
                 else:
                     res["roofline"]["traffic_note"] = "committed profile is of another kernel instantiation / workload: not quoted"
             except (OSError, KeyError, ValueError):
