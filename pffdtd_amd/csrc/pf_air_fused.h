@@ -408,6 +408,8 @@ struct LeanParams {
    const void *u0_src;      // out-of-place step: u^{n-1} is read from here, u^{n+1} written to u0 (null: in place)
    int32_t yt0;             // first y tile of this launch (row-strip launches); nyt counts from there
    int32_t yt_split, yt_hi0; // two row strips in one launch: tiles [yt0, yt0+yt_split) and [yt_hi0, ...) (yt_split < 0: off)
+   int32_t x2_begin, x2_nlo; // k_air_cart_lean, two x slabs in one launch (x2_nlo > 0): chunks [0, x2_nlo) march [x_begin, x_lo_end),
+   int32_t x_lo_end;         //   the others [x2_begin, x_end)
 };
 
 template <typename Real, int R, int WY, bool FMA, bool NT = false, bool RIG = false>
@@ -438,8 +440,9 @@ __global__ __launch_bounds__(64 * WY) void k_air_cart_lean(LeanParams fp, Real a
    const bool active = z0 < P;
    const int zl = active ? z0 : 0;
    const int y0 = 1 + (yt * WY + w) * R;
-   const int xs = fp.x_begin + xc * fp.chunk;
-   const int xe = min(xs + fp.chunk, fp.x_end);
+   const bool lo_slab = fp.x2_nlo > 0 && xc < fp.x2_nlo;   // two x slabs in one launch
+   const int xs = (fp.x2_nlo > 0 && !lo_slab) ? fp.x2_begin + (xc - fp.x2_nlo) * fp.chunk : fp.x_begin + xc * fp.chunk;
+   const int xe = min(xs + fp.chunk, lo_slab ? fp.x_lo_end : fp.x_end);
    const bool top_wave = (w == 0), bot_wave = (w == WY - 1);
 
    auto rowsrc = [&](int y) {

@@ -174,6 +174,7 @@ template <typename Real> struct Engine : EngineBase {
    int sh_nyt = 0, sh_nzt = 0;
    const Real *u0_src = nullptr;                          // out-of-place single-step launches read u^{n-1} here
    int lean_yt0 = 0, lean_nyt = -1;                       // row-strip launches of the lean kernel (-1: all tiles)
+   int lean_x2_begin = 0, lean_x2_end = 0;                // a second x slab for the next lean launch (launch_shell_rest)
    // boundary nodes inside the column strips are updated by k_air_zstrip itself (it streams their lines anyway; in
    // the list kernel the floor / ceiling nodes of a box room cost half of the whole boundary pass)
    uint32_t *zs_map = nullptr;                            // per strip vector: first node number << 4 | node bits (ZStripParams::zvec)
@@ -1214,9 +1215,17 @@ template <typename Real> struct Engine : EngineBase {
    void launch_shell(hipStream_t s, int xlo, int xhi) { // planes [xlo, xhi) (the box lies inside)
       if (fcc) { launch_shell_fcc(s, xlo, xhi, !tb2_slab); return; } // (slab engines flip on the edge stream, after the exchange)
       int xa = xlo;
+      if (tb_xr.size() == 1 && (vbase == 0 || vbase == 40 || vbase == 41) && tb_xr[0].first > xlo && xhi > tb_xr[0].second &&
+          tb_xr[0].first - xlo <= 16 && xhi - tb_xr[0].second <= 16) {
+         // the usual case: two thin x slabs, below and above the box -- one launch instead of two latency-bound ones
+         lean_x2_begin = tb_xr[0].second; lean_x2_end = xhi;
+         launch_air_lean(s, xlo, tb_xr[0].first);
+         lean_x2_begin = lean_x2_end = 0;
+         xa = xhi;
+      }
       for (auto &r : tb_xr) { // x slabs: everything before / between / after the box's plane ranges, full planes
          if (r.first > xa) launch_air_lean(s, xa, r.first);
-         xa = r.second;
+         xa = std::max(xa, r.second);
       }
       if (xhi > xa) launch_air_lean(s, xa, xhi);
       if (tb_xr.empty()) return;
@@ -1487,7 +1496,7 @@ template <typename Real> struct Engine : EngineBase {
    }
 
    template <int R, int WY, bool LDS = false, bool NT = false, bool RIG = false> void launch_lean_cfg(hipStream_t s, int xb, int xe) {
-      pf::LeanParams fp;
+      pf::LeanParams fp{};
       fp.u1 = u1; fp.u0 = u0; fp.mask = RIG ? mask_bn : mask; fp.adj = adj_dense;
       fp.plane = plane;
       fp.Nx = (int)Nx; fp.Ny = (int)Ny; fp.Nz = (int)Nz; fp.P = (int)P;
@@ -1502,9 +1511,15 @@ template <typename Real> struct Engine : EngineBase {
          if (fp.nyt <= 0) return;
       }
       const int nplanes = xe - xb;
-      const int chunk = pick_chunk(nplanes, (int64_t)fp.nzt * fp.nyt, true);
+      int chunk = pick_chunk(nplanes, (int64_t)fp.nzt * fp.nyt, true);
       fp.chunk = chunk;
       fp.nxc = (int)cdiv(nplanes, chunk);
+      if (lean_x2_end > lean_x2_begin && !fcc && !LDS) { // a second x slab [lean_x2_begin, lean_x2_end) in the same launch (both thin: one chunk each)
+         chunk = std::max(nplanes, lean_x2_end - lean_x2_begin);
+         fp.chunk = chunk;
+         fp.x_lo_end = xe; fp.x2_begin = lean_x2_begin; fp.x_end = lean_x2_end;
+         fp.x2_nlo = 1; fp.nxc = 2;
+      }
       fp.swizzle = swizzle_mode((int64_t)fp.nzt * fp.nyt);
       fp.first = op.slab_first; fp.last = op.slab_last;
       fp.do_abc = 1;
