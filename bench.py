@@ -10,11 +10,17 @@ walls 3 cells in, inside wall layer frequency-dependent (Mb=11 branches), outsid
 2 receivers x 8 nodes; state grids pre-filled with seeded U(-1,1)*1e-3 (no all-zero field: see DVFS note in
 DESIGN.md).  One "step" = one whole time step (ghost flips, air stencil, ABC, rigid + FD boundary nodes,
 source/receiver I/O, slab exchange).  The grid is fixed at 1024^3 for every N (strong scaling: BASELINE.json
-names 1024^3 at 1/2/4/8 GPUs); N>1 = Z-slab chain, one rank per GPU, RCCL plane exchange.
+names 1024^3 at 1/2/4/8 GPUs); N>1 = Z-slab chain with a one-plane exchange per step, in one of two arrangements:
+
+  * under torch.distributed.run (WORLD_SIZE == N): one rank per GPU, RCCL p2p through torch.distributed;
+  * plain `python bench.py --gpus N` (no launcher): ONE process drives devices 0..N-1 through the C seam's chain object
+    (pf_multi_create: one host thread per slab, ghost planes by peer copies or native RCCL) -- the reference's own
+    arrangement (gpu_engine.h:680-682).  On a box with fewer than N devices the slabs share devices ("virtual slabs").
 
 Prints ONE JSON line on rank 0: metric Gvoxel-updates/s = Nx*Ny*Nz*K / t / 1e9 (the reference's own formula,
-cpu_engine.h:357 / gpu_engine.h:1253), plus `roofline` (air kernel, HIP-event timed, algorithmic bytes =
-12.125 B/voxel fp32) and `cpu_baseline` (the CPU oracle on this box's host cores, bounded sample).
+cpu_engine.h:357 / gpu_engine.h:1253), plus `roofline` (dominant kernel, HIP-event timed in a region of its own --
+the headline regions run without per-launch events --, algorithmic bytes = 12.125 B/voxel fp32) and `cpu_baseline`
+(the CPU oracle on this box's host cores, bounded sample).
 """
 import argparse
 import json
@@ -29,9 +35,10 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+FAMILY = {0: "lean single steps", 1: "barrier-free single steps", 2: "blocked pairs"}
 
 
-def build_scene(n, steps_total, prec, fcc, lossy, mb, nx=0):
+def build_scene(n, steps_total, prec, fcc, lossy, mb, nx=0, ny=0):
     from pffdtd_amd import sim_data, synth
     if fcc:
         # folded FCC with a stored grid of n x n x n: unfolded Ny = 2(n-1)
@@ -39,7 +46,7 @@ def build_scene(n, steps_total, prec, fcc, lossy, mb, nx=0):
         synth.fold_fcc(sim)
         synth.sort_sim(sim)
     else:
-        sim = synth.shoebox(nx or n, n, n, Nt=steps_total, Nm=1, Mb=mb, lossy=lossy)
+        sim = synth.shoebox(nx or n, ny or n, n, Nt=steps_total, Nm=1, Mb=mb, lossy=lossy)
     sd = sim_data.SimData.from_sim(sim, prec, build_mask=False)
     sd.scale_input()
     return sd
@@ -94,6 +101,183 @@ def cpu_baseline(prec, fcc, mb, lossy, budget_s=12.0):
             "air_fraction": round(t_air / el, 3)}
 
 
+class _DevMem:
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def fill_engine_grids(torch, eng_view, nplanes, plane_elems, real_bytes, device, seed):
+    """Seeded U(-1,1)*1e-3 into both state grids of an engine, written on the device through torch views of its allocations."""
+    ts, dt = ("<f4", torch.float32) if real_bytes == 4 else ("<f8", torch.float64)
+    gen = torch.Generator(device=f"cuda:{device}")
+    gen.manual_seed(seed)
+    with torch.cuda.device(device):
+        for p in eng_view.state_grids():
+            g = torch.as_tensor(_DevMem(p, (nplanes, plane_elems), ts), device=f"cuda:{device}")
+            assert g.data_ptr() == p
+            g.copy_(((torch.rand(g.shape, generator=gen, device=g.device, dtype=torch.float32) * 2.0 - 1.0) * 1e-3).to(dt))
+            del g
+        torch.cuda.synchronize()
+
+
+def roofline_block(args, sd, tm, K, real_bytes, interior_planes):
+    """`roofline` of the bench line from an engine's timing record (collected in a region with per-launch events on)."""
+    bpv = 3 * real_bytes + 0.125  # u1 read, u0 read + write, one mask bit (SURVEY 8d)
+    T = "float" if real_bytes == 4 else "double"
+    upd = interior_planes * (sd.Ny - 2) * (sd.Nz - 2)
+    air_ms_per_step = tm["air_ms_total"] / max(tm["steps"] if tm["steps"] else K, 1)
+    if tm.get("tb2_launches", 0) > 0:
+        # temporal blocking: the dominant kernel advances `tb2_cells` cells by TWO steps per launch; its algorithmic
+        # bytes are therefore 2 x 12.125 B per cell and launch (SURVEY 8d's per-update figure x the updates it performs)
+        lw = int(tm["tb2_lw"])
+        if args.fcc:
+            kernel = "k_tb2_fcc_x" if lw == 64 else "k_tb2_fcc"
+            inst = f"pf::k_tb2_fcc_x<{T}, 2, 8>" if lw == 64 else f"pf::k_tb2_fcc<{T}, 2, 4, {lw}>"
+        else:
+            kernel, inst = "k_tb2_reg", f"pf::k_tb2_reg<{T}, 3, 4, false, {lw}, false>"  # (..., true> = creation-time probes)
+        kernel_ms = tm["tb2_ms_total"] / tm["tb2_launches"]
+        units = 2 * tm["tb2_cells"]
+    else:
+        kernel = "k_air_fcc" if args.fcc else ("k_air_cart" if tm.get("air_path") == 1 else "k_air_cart_lean")
+        inst = f"pf::{kernel}<{T},"
+        kernel_ms, units = air_ms_per_step, upd
+    achieved = units * bpv / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
+    rl = {"bound": "hbm", "kernel": kernel, "kernel_instantiation": inst,
+          "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+          "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
+          "kernel_ms_per_launch": round(kernel_ms, 4), "voxel_updates_per_launch": int(units),
+          "bytes_per_voxel_update": bpv, "air_ms_per_step": round(air_ms_per_step, 4),
+          "interior_voxels_per_step": upd,
+          "timed_how": "HIP events around every launch of the kernel, in a K-step region of its own after the headline regions (which run without per-launch events)",
+          "autotune_ms_per_step": {k: round(v, 4) for k, v in zip(("lean", "barrier_free", "blocked_pair"), tm.get("tune_ms", [0, 0, 0]))},
+          "grid_placement": {"candidates": tm.get("place_candidates", 0),
+                             "kernel_ms_as_allocated_chosen_slowest": [round(v, 4) for v in tm.get("place_ms", [0, 0, 0])]}}
+    return rl, bpv, kernel_ms, units
+
+
+def add_traffic(rl, res, sd, kernel_ms, units, bpv):
+    """HBM bytes per launch of the dominant kernel: from the committed PMC passes of this same command (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 x2 read correction applied; tools/collect_n1_profile.sh) -- counters
+    cannot be read from inside the process.  Only quoted when the committed profile is of the very kernel instantiation this
+    run launched, advancing the same number of voxel updates per launch on the same scene; otherwise null."""
+    for tag in ("r03", "r02"):
+        tfile, pfile = ROOT / "profiles" / f"{tag}_bench_n1_hbm_traffic.json", ROOT / "profiles" / f"{tag}_bench_n1.json"
+        if tfile.exists():
+            break
+    else:
+        return
+    inst = rl["kernel_instantiation"]
+    try:
+        ks = json.load(open(tfile))["kernels"]
+        # (pfile absent = the profile collection itself: the passes just taken are of this build)
+        prof = json.load(open(pfile)) if pfile.exists() else None
+        hit = [v for k, v in ks.items() if inst in k]
+        same = prof is None or (prof["roofline"]["voxel_updates_per_launch"] == int(units) and prof["config"]["grid"] == [sd.Nx, sd.Ny, sd.Nz]
+                                and prof["config"]["Nb"] == sd.Nb and prof["dtype"] == res["dtype"])
+        if hit and same:
+            rl["traffic"] = round(hit[0]["total_bytes"] / 1e9, 3)
+            rl["traffic_unit"] = f"GB per launch of {inst} (PMC, profiles/{tfile.name})"
+            rl["algorithmic_GB_per_launch"] = round(units * bpv / 1e9, 3)
+            rl["measured_traffic_GBs"] = round(hit[0]["total_bytes"] / 1e9 / (kernel_ms * 1e-3), 1)
+            rl["note"] = ("a launch advances its cells by TWO steps: achieved = 2 x 12.125 B per cell / launch time (SURVEY 8d's per-update "
+                          "figure x the updates of a launch), which temporal blocking is allowed to beat; measured_traffic_GBs = the "
+                          "HBM bytes the launch really moves / launch time")
+        else:
+            rl["traffic_note"] = "committed profile is of another kernel instantiation / workload: not quoted"
+    except (OSError, KeyError, ValueError):
+        pass
+
+
+def base_result(args, sd, world, K, W, R, regions, el, real_bytes, lossy, parallelism):
+    gvox = sd.Npts * K / el / 1e9
+    bpv = 3 * real_bytes + 0.125
+    n = args.size
+    return {
+        "metric": "Gvoxel-updates/s", "value": round(gvox, 3), "unit": "Gvoxel-updates/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(el / K * 1e3, 4),
+        "repeats": R, "ms_per_step_min": round(min(regions) / K * 1e3, 4), "ms_per_step_max": round(max(regions) / K * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32" if real_bytes == 4 else "f64", "data": "synthetic",
+        "config": {"workload": f"shoebox {n}^3 {'13-pt folded FCC' if args.fcc else '7-pt Cartesian'} "
+                               f"{'fp32' if real_bytes == 4 else 'fp64'}, "
+                               f"{'Mb=%d freq-dependent walls' % args.mb if lossy else 'rigid walls'} "
+                               "(BASELINE.json configs[3])",
+                   "grid": [sd.Nx, sd.Ny, sd.Nz], "Nb": sd.Nb, "Nbl": sd.Nbl, "Nba": sd.Nba,
+                   "numerics": {0: "cpu-exact", 1: "fma", 2: "safeguarded"}.get(args.numerics, str(args.numerics)),
+                   "parallelism": parallelism, "air_variant": args.variant},
+        "achieved_hbm_GBs_whole_step": round(gvox * bpv, 1),
+        "whole_step_frac_of_hbm_roofline": round(gvox * bpv / HBM_PEAK_GBS, 4),
+    }
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# N > 1 from ONE plain process: the C seam's chain object (pf_multi_*), one host thread per slab
+# ------------------------------------------------------------------------------------------------------------------
+def run_chain(args):
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    from pffdtd_amd import engine
+    ndev = engine.device_count()
+    if not torch.cuda.is_available() or ndev == 0:
+        raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
+    N, K, W, R = args.gpus, args.steps, args.warmup, max(args.repeats, 1)
+    devices = list(range(N)) if ndev >= N else [i % ndev for i in range(N)]
+    lossy = not args.rigid
+    real_bytes = 4 if args.precision == "single" else 8
+    sd = build_scene(args.size, (R + 1) * K + W, args.precision, args.fcc, lossy, args.mb, args.nx, args.ny)
+    transport = {"auto": engine.PF_TRANSPORT_AUTO, "peer": engine.PF_TRANSPORT_PEER, "rccl": engine.PF_TRANSPORT_RCCL}[args.transport]
+    m = engine.HipMulti(sd, devices, numerics=args.numerics, air_variant=args.variant, air_chunk=args.chunk, debug=args.debug,
+                        transport=transport, verify_exchange=min(W, 4))
+    plane_elems = sd.Ny * engine.grid_pitch(sd.Nz, real_bytes)
+    slabs = [m.slab(g) for g in range(N)]
+    for g, sl in enumerate(slabs):
+        nloc = (sl["x1"] - sl["x0"]) + (1 if g > 0 else 0) + (1 if g < N - 1 else 0)
+        fill_engine_grids(torch, sl["engine"], nloc, plane_elems, real_bytes, sl["device"], 1234 + g)
+
+    def sync_all():
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+
+    m.run(0, W)
+
+    def timed_region(n0):
+        sync_all()
+        t0 = time.perf_counter()
+        m.run(n0, K)  # returns when every slab's streams have drained
+        sync_all()
+        return time.perf_counter() - t0
+
+    regions = [timed_region(W + r * K) for r in range(R)]
+    el = sorted(regions)[len(regions) // 2]
+    info = m.info()
+    if not np.isfinite(sd.u_out[:, :W + R * K]).all():
+        raise SystemExit("bench: non-finite receiver samples")
+    # kernel durations: one more region with per-launch events on
+    for sl in slabs:
+        sl["engine"].set_timing(True)
+        sl["engine"].timing(reset=True)
+    m.run(W + R * K, K)
+    tms = [sl["engine"].timing() for sl in slabs]
+    virt = ndev < N
+    parallelism = (f"z-slab x{N}, ONE process, one host thread per slab (pf_multi_create), ghost planes by {info['transport_name']} "
+                   "on the edge stream while the interior planes run"
+                   + (f"; VIRTUAL: the {N} slabs share {ndev} device(s) -- control-flow run, not a scaling figure" if virt else ""))
+    res = base_result(args, sd, N, K, W, R, regions, el, real_bytes, lossy, parallelism)
+    g0 = max(range(N), key=lambda g: slabs[g]["x1"] - slabs[g]["x0"])
+    rl, bpv, kernel_ms, units = roofline_block(args, sd, tms[g0], K, real_bytes, slabs[g0]["x1"] - slabs[g0]["x0"])
+    rl["slab"] = g0
+    res["roofline"] = rl
+    res["exchange_verified"] = info["exchange_verified"]
+    res["exchange"] = {"backend": info["transport_name"], "ranks": N, "checked_steps": info["exchanges_checked"],
+                       "nonzero_planes": info["exchange_nonzero"], "plane_bytes": info["plane_bytes"],
+                       "what": "position-weighted bit-pattern checksums of the received ghost planes == the senders' planes, every slab"}
+    res["slabs"] = [{"device": sl["device"], "planes": [sl["x0"], sl["x1"]], "pairs": sl["paired"],
+                     "air_ms_per_step": round(t["air_ms_total"] / max(t["steps"], 1), 4)} for sl, t in zip(slabs, tms)]
+    res["virtual_slabs"] = virt
+    m.close()
+    print(json.dumps(res), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,8 +285,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--repeats", type=int, default=7, help="the K-step region is timed this many times; value = the MEDIAN region")
     ap.add_argument("--no-rigid-run", action="store_true", help="skip the second, rigid-wall run (SURVEY 8d asks for both)")
+    ap.add_argument("--no-selfcheck", action="store_true", help="skip the family-agreement check of the timed run")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--nx", type=int, default=0, help="override the number of planes along x (experiments only)")
+    ap.add_argument("--ny", type=int, default=0, help="override the number of rows along y (experiments only)")
     ap.add_argument("--precision", default="single", choices=["single", "double"])
     ap.add_argument("--fcc", action="store_true")
     ap.add_argument("--rigid", action="store_true", help="rigid walls only (no FD boundary nodes)")
@@ -112,6 +298,8 @@ def main():
     ap.add_argument("--numerics", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug", type=lambda v: int(v, 0), default=0, help="pf_opts.debug (tuning switches)")
+    ap.add_argument("--transport", default="auto", choices=["auto", "peer", "rccl"],
+                    help="N>1 from one process: how ghost planes travel (pf_opts.transport)")
     ap.add_argument("--split-phase", action="store_true", help="N=1: drive the split-phase step like N>1 does")
     ap.add_argument("--emulate-slab", default="", help="debug: 'r/N' = run only slab r of an N-way split on this GPU, the exchange\n                    replaced by device copies of the same planes (per-rank cost model; physics is wrong)")
     ap.add_argument("--emulate-transport", default="copy", choices=["copy", "rccl"],
@@ -123,7 +311,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+            return run_chain(args)  # no launcher: one process drives every device through the C seam
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
 
     # RCCL's intra-node transport shares device memory between the ranks: this pool's host driver only supports dmabuf
@@ -157,9 +345,10 @@ def main():
     K, W, R = args.steps, args.warmup, max(args.repeats, 1)
     n = args.size
     lossy = not args.rigid
-    sd = build_scene(n, R * K + W, args.precision, args.fcc, lossy, args.mb, args.nx)
+    nt_total = (R + 1) * K + W  # warm-up, R headline regions, one region with per-launch events
+    sd = build_scene(n, nt_total, args.precision, args.fcc, lossy, args.mb, args.nx, args.ny)
     real_bytes = 4 if args.precision == "single" else 8
-    ekw = dict(numerics=args.numerics, air_variant=args.variant, air_chunk=args.chunk, timing=True, debug=args.debug)
+    ekw = dict(numerics=args.numerics, air_variant=args.variant, air_chunk=args.chunk, timing=False, debug=args.debug)
 
     from pffdtd_amd import dist as pdist
     emu = None
@@ -193,19 +382,23 @@ def main():
     else:
         runner, loc, info = pdist.make_hip_runner(sd, rank, world, local_rank, group, **ekw)
     eng = runner.st.eng
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(1234 + rank)
-    for g in runner.st.grids:  # device-side fill of the torch-owned state grids (pad/ghost cells are never read back)
-        g.copy_((torch.rand(g.shape, generator=gen, device=g.device, dtype=torch.float32) * 2.0 - 1.0) * 1e-3)
-    torch.cuda.synchronize()
-    if world == 1 and not args.split_phase and emu is None:
+
+    def fill(st, seed):
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(seed)
+        for g in st.grids:  # device-side fill of the state grids (pad/ghost cells are never read back)
+            g.copy_((torch.rand(g.shape, generator=gen, device=g.device, dtype=torch.float32) * 2.0 - 1.0) * 1e-3)
+        torch.cuda.synchronize()
+
+    fill(runner.st, 1234 + rank)
+    single = world == 1 and not args.split_phase and emu is None
+    if single:
         run = lambda n0, k: eng.run(n0, k)  # noqa: E731  (whole loop inside the C library, one stream)
         parallelism = "1 GPU"
     else:
         run = lambda n0, k: runner.run(n0, k)  # noqa: E731
         parallelism = f"z-slab x{world}, 1 rank/GPU, RCCL p2p plane exchange overlapped with interior planes"
     sync = eng.sync
-    timing = eng.timing
     interior_planes = loc.Nx - 2
 
     def barrier():
@@ -216,7 +409,6 @@ def main():
     runner.verify_steps = min(W, 4) if world > 1 else 0  # N>1: checksum the first exchanges against the senders' planes
     run(0, W)
     sync()
-    timing(reset=True)
 
     def timed_region(n0):
         """K steps bracketed by barrier + synchronize on both sides; max over ranks"""
@@ -237,97 +429,66 @@ def main():
 
     regions = [timed_region(W + r * K) for r in range(R)]
     el = sorted(regions)[len(regions) // 2]  # the median region is the one reported
-    tm = timing()
+    # kernel durations: one more K-step region with HIP events around every launch (not part of `value`)
+    eng.set_timing(True)
+    eng.timing(reset=True)
+    run(W + R * K, K)
+    sync()
+    tm = eng.timing()
 
     # sanity: the field must still be finite
     if not bool(torch.isfinite(runner.st.grids[0][loc.Nx // 2]).all()):
         raise SystemExit("bench: non-finite field")
 
     if rank == 0:
-        gvox = sd.Npts * K / el / 1e9
         if emu is not None:
             print(f"[emulated slab {emu[0]}/{emu[1]}: {loc.Nx} planes, exchange = {args.emulate_transport}] "
                   f"{el / K * 1e3:.4f} ms/step -> {emu[1]} such ranks would give "
                   f"{sd.Npts * K / el / 1e9:.1f} Gvox/s if the exchange hides completely", file=sys.stderr)
-        bpv = 3 * real_bytes + 0.125  # u1 read, u0 read + write, one mask bit
-        # interior update of one step on this rank: the voxels it updates, and the time of all its interior launches
-        upd = interior_planes * (sd.Ny - 2) * (sd.Nz - 2)
-        air_ms_per_step = tm["air_ms_total"] / max(tm["steps"] if tm["steps"] else K, 1)
-        if tm.get("tb2_launches", 0) > 0:
-            # temporal blocking: the dominant kernel advances `tb2_cells` cells by TWO steps per launch; its algorithmic
-            # bytes are therefore 2 x 12.125 B per cell and launch (SURVEY 8d's per-update figure x the updates it performs)
-            kernel, kernel_ms = ("k_tb2_fcc" if args.fcc else "k_tb2_reg"), tm["tb2_ms_total"] / tm["tb2_launches"]
-            units = 2 * tm["tb2_cells"]
-        else:
-            kernel = "k_air_fcc" if args.fcc else ("k_air_cart" if tm.get("air_path") == 1 else "k_air_cart_lean")
-            kernel_ms, units = air_ms_per_step, upd
-        achieved = units * bpv / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
-        res = {
-            "metric": "Gvoxel-updates/s", "value": round(gvox, 3), "unit": "Gvoxel-updates/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(el / K * 1e3, 4),
-            "repeats": R, "ms_per_step_min": round(min(regions) / K * 1e3, 4), "ms_per_step_max": round(max(regions) / K * 1e3, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32" if real_bytes == 4 else "f64", "data": "synthetic",
-            "config": {"workload": f"shoebox {n}^3 {'13-pt folded FCC' if args.fcc else '7-pt Cartesian'} "
-                                   f"{'fp32' if real_bytes == 4 else 'fp64'}, "
-                                   f"{'Mb=%d freq-dependent walls' % args.mb if lossy else 'rigid walls'} "
-                                   "(BASELINE.json configs[3])",
-                       "grid": [sd.Nx, sd.Ny, sd.Nz], "Nb": sd.Nb, "Nbl": sd.Nbl, "Nba": sd.Nba,
-                       "numerics": "cpu-exact" if args.numerics == 0 else "fma",
-                       "parallelism": parallelism, "air_variant": args.variant},
-            "achieved_hbm_GBs_whole_step": round(gvox * bpv, 1),
-            "whole_step_frac_of_hbm_roofline": round(gvox * bpv / HBM_PEAK_GBS, 4),
-            "roofline": {"bound": "hbm", "kernel": kernel,
-                         "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
-                         "kernel_ms_per_launch": round(kernel_ms, 4), "voxel_updates_per_launch": int(units),
-                         "bytes_per_voxel_update": bpv, "air_ms_per_step": round(air_ms_per_step, 4),
-                         "interior_voxels_per_step": upd,
-                         "autotune_ms_per_step": {k: round(v, 4) for k, v in zip(("lean", "barrier_free", "blocked_pair"), tm.get("tune_ms", [0, 0, 0]))},
-                         "grid_placement": {"candidates": tm.get("place_candidates", 0),
-                                            "kernel_ms_as_allocated_chosen_slowest": [round(v, 4) for v in tm.get("place_ms", [0, 0, 0])]}},
-        }
-        # HBM bytes per launch of the dominant kernel: from the committed PMC passes of this same command (rocprofv3 --pmc
-        # FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 x2 read correction applied; tools/collect_n1_profile.sh).  Only
-        # quoted when the committed profile is of the very kernel instantiation this run used, advancing the same number of
-        # voxel updates per launch -- otherwise null.
-        tfile, pfile = ROOT / "profiles" / "r02_bench_n1_hbm_traffic.json", ROOT / "profiles" / "r02_bench_n1.json"
-        if world == 1 and tm.get("tb2_launches", 0) > 0 and tfile.exists():
-            inst = (f"pf::k_tb2_fcc<{'float' if real_bytes == 4 else 'double'}, 2, 4, {int(tm['tb2_lw'])}>" if args.fcc else
-                    f"pf::k_tb2_reg<{'float' if real_bytes == 4 else 'double'}, 3, 4, false, {int(tm['tb2_lw'])}, false>")  # (..., true> = creation-time probes)
-            try:
-                ks = json.load(open(tfile))["kernels"]
-                # (pfile absent = the profile collection itself, tools/collect_n1_profile.sh: the passes just taken are of this build)
-                prof = json.load(open(pfile)) if pfile.exists() else None
-                hit = [v for k, v in ks.items() if inst in k]
-                same = prof is None or (prof["roofline"]["voxel_updates_per_launch"] == int(units) and prof["config"]["grid"] == [sd.Nx, sd.Ny, sd.Nz]
-                        and prof["config"]["Nb"] == sd.Nb and prof["dtype"] == res["dtype"])
-                if hit and same:
-                    res["roofline"]["traffic"] = round(hit[0]["total_bytes"] / 1e9, 3)
-                    res["roofline"]["traffic_unit"] = f"GB per launch of {inst} (PMC, profiles/r02_bench_n1_hbm_traffic.json)"
-                    res["roofline"]["algorithmic_GB_per_launch"] = round(units * bpv / 1e9, 3)
-                    res["roofline"]["measured_traffic_GBs"] = round(hit[0]["total_bytes"] / 1e9 / (kernel_ms * 1e-3), 1)
-                    res["roofline"]["note"] = ("a launch advances its cells by TWO steps: achieved = 2 x 12.125 B per cell / launch time (SURVEY 8d's per-update "
-                                               "figure x the updates of a launch), which temporal blocking is allowed to beat; measured_traffic_GBs = the "
-                                               "HBM bytes the launch really moves / launch time")
-                else:
-                    res["roofline"]["traffic_note"] = "committed profile is of another kernel instantiation / workload: not quoted"
-            except (OSError, KeyError, ValueError):
-                pass
+        res = base_result(args, sd, world, K, W, R, regions, el, real_bytes, lossy, parallelism)
+        rl, bpv, kernel_ms, units = roofline_block(args, sd, tm, K, real_bytes, interior_planes)
+        res["roofline"] = rl
+        if world == 1:
+            add_traffic(rl, res, sd, kernel_ms, units, bpv)
         if world > 1:
             res["exchange_verified"] = runner.exchange_verified
             res["exchange"] = {"backend": backend, "ranks": world, "checked_steps": min(W, 4),
                                "what": "bit-pattern checksums of the received ghost planes == the senders' planes, all ranks"}
+        if single and not args.no_selfcheck:
+            # Did the timed run compute the right thing?  The same steps from the same seeded field through ANOTHER kernel
+            # family (single steps instead of whatever the engine chose -- blocked pairs at this size): every receiver sample
+            # of every step must agree bit for bit (the families share no interior kernel; each is pinned to the CPU oracle
+            # at small sizes by tests/).
+            u_first = loc.u_out.copy()  # (the runner's engine writes its slab's receiver rows: for one slab, all of them)
+            runner.st.close()
+            torch.cuda.empty_cache()
+            # 0x4000: single steps only; 0x8000: no creation-time measurement (static rules pick the single-step kernel)
+            ekw2 = dict(ekw, debug=args.debug | 0x4000 | 0x8000)
+            t0 = time.perf_counter()
+            r2, loc2, _ = pdist.make_hip_runner(sd, 0, 1, local_rank, None, **ekw2)
+            fill(r2.st, 1234 + rank)
+            r2.st.eng.run(0, nt_total)
+            r2.st.eng.sync()
+            tm2 = r2.st.eng.timing()
+            same = bool(np.array_equal(loc2.u_out, u_first))
+            res["selfcheck"] = {"family_agreement": same, "steps": int(nt_total), "receiver_samples": int(u_first.size),
+                                "max_abs_sample": float(np.abs(u_first).max()),
+                                "timed_family": FAMILY.get(tm.get("air_path"), "other"),
+                                "check_family": FAMILY.get(tm2.get("air_path"), "other"),
+                                "seconds": round(time.perf_counter() - t0, 2)}
+            r2.st.close()
+            torch.cuda.empty_cache()
+            if not same or not np.abs(u_first).max() > 0:
+                print(json.dumps(res), flush=True)
+                raise SystemExit("bench: the timed run's receivers differ from the check family's (or are all zero)")
+        elif world == 1:
+            runner.st.close()
+            torch.cuda.empty_cache()
         if world == 1 and lossy and not args.no_rigid_run and emu is None:
             # a rigid-wall run next to the frequency-dependent one (same grid, no branch ODEs)
-            runner.st.close()
-            runner.st.grids.clear()
-            torch.cuda.empty_cache()
-            sd_r = build_scene(n, 3 * K + W, args.precision, args.fcc, False, args.mb, args.nx)
+            sd_r = build_scene(n, 3 * K + W, args.precision, args.fcc, False, args.mb, args.nx, args.ny)
             rr, loc_r, _ = pdist.make_hip_runner(sd_r, 0, 1, local_rank, None, **ekw)
-            for g in rr.st.grids:
-                g.copy_((torch.rand(g.shape, generator=gen, device=g.device, dtype=torch.float32) * 2.0 - 1.0) * 1e-3)
-            torch.cuda.synchronize()
+            fill(rr.st, 99)
             rr.st.eng.run(0, W)
             rr.st.eng.sync()
             ts = []
@@ -343,7 +504,7 @@ def main():
             res["rigid_walls"] = {"value": round(sd_r.Npts * K / t_r / 1e9, 3), "unit": "Gvoxel-updates/s",
                                   "ms_per_step": round(t_r / K * 1e3, 4), "repeats": 3, "Nb": sd_r.Nb,
                                   "whole_step_frac_of_hbm_roofline": round(sd_r.Npts * K / t_r / 1e9 * bpv / HBM_PEAK_GBS, 4),
-                                  "blocked_pairs": tm_r.get("tb2_launches", 0) > 0,
+                                  "blocked_pairs": tm_r.get("air_path") == 2,
                                   "autotune_ms_per_step": {k: round(v, 4) for k, v in zip(("lean", "barrier_free", "blocked_pair"), tm_r.get("tune_ms", [0, 0, 0]))}}
             rr.st.close()
         if not args.no_cpu_baseline and world == 1:

@@ -102,9 +102,18 @@ typedef struct pf_opts {
                              0x10000000 keep a sliver z tile in the blocked kernel */
    int32_t energy;        /* 1 = keep what the energy diagnostic needs (explicit Laplacian grid, unfused kernel
                              sequence); then use pf_engine_energy_cfg + pf_engine_run_energy */
-   int32_t multi_flags;   /* pf_run_sim_devices only: PF_MULTI_* */
-   int32_t reserved[4];
+   int32_t multi_flags;   /* pf_run_sim_devices / pf_multi_create only: PF_MULTI_* */
+   int32_t transport;     /* pf_run_sim_devices / pf_multi_create only: PF_TRANSPORT_* (how ghost planes travel between devices) */
+   int32_t verify_exchange; /* same: the first n exchanges are checksummed on both sides (pf_multi_info.exchange_verified) */
+   int32_t reserved[2];
 } pf_opts;
+
+#define PF_TRANSPORT_AUTO 0 /* peer copies where hipDeviceCanAccessPeer says yes for every neighbouring pair, else RCCL */
+#define PF_TRANSPORT_PEER 1 /* each slab pulls its ghost planes with hipMemcpyPeerAsync on its edge stream (gpu_engine.h:1086-1126
+                               uses cudaMemcpyPeerAsync after a full sync); an error, not a host-staged copy, without peer access */
+#define PF_TRANSPORT_RCCL 2 /* ncclSend / ncclRecv of both planes, grouped per slab on its edge stream, one single-process
+                               communicator clique over the chain (librccl is loaded at run time); environment PFFDTD_TRANSPORT=
+                               peer|rccl|auto overrides pf_opts.transport */
 
 #define PF_MULTI_EVEN_SPLIT  1 /* the reference's Nx/G planes per slab (gpu_engine.h:532-550) instead of the cost-balanced cut */
 #define PF_MULTI_ONE_THREAD  2 /* one host thread drives every slab (the reference's arrangement) instead of one thread per slab */
@@ -152,6 +161,32 @@ double      pf_run_sim_devices(pf_simdata *sd, int32_t nslabs, const int32_t *de
 /* The owned plane ranges such a run uses: cuts[0..nslabs], slab g owns global planes [cuts[g], cuts[g+1]). */
 int         pf_slab_partition(const pf_simdata *sd, int32_t nslabs, int32_t even_split, int64_t *cuts);
 
+/* ---- the same chain as an object (what pf_run_sim_devices does inside): lets a host warm up, time and inspect a
+ * multi-device run -- bench.py --gpus N drives this from one plain process, as the reference drives all its GPUs from one
+ * (gpu_engine.h:680-682, 993-1145).  One persistent host thread per slab.  sd must outlive the object; receivers land in
+ * sd->u_out after every pf_multi_run. */
+typedef struct pf_multi pf_multi;
+typedef struct pf_multi_info {
+   int32_t nslabs;
+   int32_t transport;          /* PF_TRANSPORT_PEER | PF_TRANSPORT_RCCL (0: a single slab, nothing travels) */
+   int32_t rccl_self;          /* 1: RCCL with one 1-rank communicator per slab (all slabs on one device: tests) */
+   int32_t exchange_verified;  /* 1: every checked exchange delivered the senders' planes bit for bit; 0: one did not; -1: none checked */
+   int64_t exchanges_checked;  /* exchanges (steps) checksummed so far */
+   int32_t exchange_nonzero;   /* 1: at least one checked ghost plane was not all zeros (the check was not vacuous) */
+   int32_t pad_;
+   int64_t plane_bytes;        /* bytes of one exchanged plane */
+   double  last_run_seconds;   /* wall time of the last pf_multi_run */
+   char    transport_name[64];
+} pf_multi_info;
+int  pf_multi_create(pf_simdata *sd, int32_t nslabs, const int32_t *devices, const pf_opts *base, pf_multi **out);
+/* steps n0 .. n0+nsteps-1 on every slab; returns when all streams have drained and the receiver rows are in sd->u_out */
+int  pf_multi_run(pf_multi *m, int64_t n0, int64_t nsteps);
+int  pf_multi_get_info(pf_multi *m, pf_multi_info *info);
+/* slab g: owned global planes [x0, x1), device, whether it steps in temporally blocked pairs, and its engine (for
+ * pf_engine_state_grids / pf_engine_timing between runs; do not step it directly) */
+int  pf_multi_get_slab(pf_multi *m, int32_t g, int64_t *x0, int64_t *x1, int32_t *device, int32_t *paired, pf_engine **engine);
+void pf_multi_destroy(pf_multi *m);
+
 /* ---- engine object (what run_sim does inside, exposed for the Python host, slabs and tests) ---- */
 int  pf_engine_create(const pf_simdata *sd, const pf_opts *opts, pf_engine **out);
 void pf_engine_destroy(pf_engine *e);
@@ -177,8 +212,10 @@ int  pf_engine_set_spares(pf_engine *e, void *grid2, void *grid3);
  * where its four grids lie relative to each other in physical memory ("grid placement"), so the engine times
  * assignments of pool members to its four roles and adopts the fastest: idx[0], idx[1] = the state grids from now on,
  * idx[2], idx[3] = the spares; the caller may free the others.  An engine that keeps stepping singly (cf.
- * pf_engine_set_spares) picks the pair of the pool its single step is fastest on and says idx = i, j, -1, -1.  Returns a pf_status.  No counterpart in
- * the reference. */
+ * pf_engine_set_spares) picks the pair of the pool its single step is fastest on and says idx = i, j, -1, -1.  Returns a pf_status.
+ * THE OFFERED GRIDS MUST BE ALL ZEROS AND ARE ZEROED AGAIN: the search runs real step kernels on them.  Initialise the field
+ * (pf_engine_set_grid, device writes) only afterwards; after pf_engine_set_grid the call is refused with PF_ERR_STATE.
+ * No counterpart in the reference. */
 int  pf_engine_place_grids(pf_engine *e, void *const *pool, int32_t n, int32_t idx[4]);
 /* Device pointers of the two state grids as they stand between runs (u_prev = u^{n-1}, overwritten by the next step;
  * u_cur = u^n), each pf_grid_bytes() long: the engine's own allocations unless pf_opts.ext_u0 / ext_u1 were given.
@@ -192,6 +229,9 @@ int  pf_engine_flush_outputs(pf_engine *e);          /* ring -> sd->u_out */
 int  pf_engine_get_grid(pf_engine *e, int32_t which, void *host);
 int  pf_engine_set_grid(pf_engine *e, int32_t which, const void *host);
 int  pf_engine_timing(pf_engine *e, pf_timing *t, int32_t reset);
+/* switch the per-launch HIP events of pf_opts.timing on / off between runs (a host times its headline region without them
+ * and collects kernel durations in a region of its own) */
+int  pf_engine_set_timing(pf_engine *e, int32_t on);
 
 /* ---- energy-conservation diagnostic of the reference Python engine (python/fdtd/sim_fdtd.py:587-620,671-678) ----
  * Needs pf_opts.energy=1 at creation.  DEF = the materials' (D,E,F) triplets, double[Nm*PF_MMB*3] (zero padded),

@@ -37,12 +37,13 @@ FILE_FLAGS = {"pf_tb2_fcc.hip": ["-fno-slp-vectorize"]}  # see the note at the t
 
 
 def _deps(src):
-    """Headers a translation unit depends on (read from its #include "..." lines, one level of nesting is enough here)."""
+    """Headers a translation unit depends on (its #include "..." lines, followed transitively)."""
     seen, todo = set(), [src]
     while todo:
         f = todo.pop()
         for line in f.read_text().splitlines():
-            if line.startswith('#include "'):
+            line = line.strip()
+            if line.startswith("#") and line[1:].lstrip().startswith('include "'):
                 name = line.split('"')[1]
                 for d in (CSRC, ROOT / "include"):
                     if (d / name).exists() and (d / name) not in seen:
@@ -58,11 +59,19 @@ def build_hip(force=False, verbose=False):
     objdir.mkdir(exist_ok=True)
     objs, relink = [], force or not out.exists()
     procs = []
+    import hashlib
     for src in sorted(CSRC.glob("*.hip")):
-        obj = objdir / (src.stem + ".o")
+        flags = [*HIP_FLAGS, *FILE_FLAGS.get(src.name, [])]
+        # the flags are part of the object's name: a changed flag set (e.g. the -fno-slp-vectorize pf_tb2_fcc.hip needs for
+        # bit-exactness) can never link a stale object
+        tag = hashlib.sha1(" ".join(flags).encode()).hexdigest()[:8]
+        obj = objdir / f"{src.stem}.{tag}.o"
         objs.append(obj)
         if force or _newer(obj, _deps(src)):
-            cmd = [hipcc(), *HIP_FLAGS, *FILE_FLAGS.get(src.name, []), "-c", "-I", str(ROOT / "include"), "-I", str(CSRC), str(src), "-o", str(obj)]
+            for old in objdir.glob(src.stem + ".*o"):
+                if old != obj:
+                    old.unlink()
+            cmd = [hipcc(), *flags, "-c", "-I", str(ROOT / "include"), "-I", str(CSRC), str(src), "-o", str(obj)]
             procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
             relink = True
     for cmd, p in procs:  # the translation units compile side by side

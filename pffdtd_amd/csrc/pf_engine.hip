@@ -85,6 +85,7 @@ struct EngineBase {
    virtual int get_grid(int which, void *host) = 0;
    virtual int set_grid(int which, const void *host) = 0;
    virtual int timing(pf_timing *t, int reset) = 0;
+   virtual int set_timing(int on) = 0;
    virtual void *stream(int which) = 0;
    virtual int energy_cfg(double h, double c, double Ts, const double *DEF) = 0;
    virtual int run_energy(int64_t n0, int64_t nsteps, double *H, double *El, double *Ei) = 0;
@@ -140,6 +141,7 @@ template <typename Real> struct Engine : EngineBase {
    hipStream_t s_main = nullptr, s_edge = nullptr;
    hipEvent_t ev_pre = nullptr, ev_edge = nullptr, ev_main = nullptr;
    bool in_step = false;
+   bool state_touched = false; // a caller wrote the field (pf_engine_set_grid): the placement search, which steps and then zeroes the offered grids, is refused
    int64_t steps_done = 0;
    // launch-bound grids: six steps (the period of the u0/u1 swap and the three-deep u0b ring) captured once in a hipGraph
    // and replayed; the step index and the ring column are read from device counters
@@ -1029,6 +1031,7 @@ template <typename Real> struct Engine : EngineBase {
    // idx[2], idx[3]: the spares of pf_engine_set_spares, or idx = 0, 1, -1, -1 when this engine steps singly.
    int place_grids(void *const *grids, int n, int32_t *idx) override {
       if (in_step || pair_phase || steps_done > 0) return set_err(PF_ERR_STATE, "pf_engine_place_grids after the first step");
+      if (state_touched) return set_err(PF_ERR_STATE, "pf_engine_place_grids after pf_engine_set_grid: the placement search runs step kernels on the offered grids and zeroes them");
       if (own_grids) return set_err(PF_ERR_STATE, "pf_engine_place_grids: this engine allocated its own grids");
       if (!grids || !idx || n < 2) return set_err(PF_ERR_ARG, "pf_engine_place_grids: need a pool of at least two grids");
       for (int i = 0; i < n; i++) {
@@ -1990,6 +1993,13 @@ template <typename Real> struct Engine : EngineBase {
       return PF_OK;
    }
 
+   int set_timing(int on) override {
+      if (in_step) return set_err(PF_ERR_STATE, "pf_engine_set_timing inside a step");
+      int rc = harvest();
+      if (rc) return rc;
+      op.timing = on ? 1 : 0;
+      return PF_OK;
+   }
    int get_grid(int which, void *host) override {
       HIPCHK(hipSetDevice(op.device));
       int rc = sync();
@@ -2007,6 +2017,7 @@ template <typename Real> struct Engine : EngineBase {
       int rc = sync();
       if (rc) return rc;
       Real *dst = which == 0 ? u0 : u1;
+      state_touched = true;
       HIPCHK(hipMemcpy2D(dst, P * sizeof(Real), host, Nz * sizeof(Real), Nz * sizeof(Real), Nx * Ny, hipMemcpyHostToDevice));
       return PF_OK;
    }
@@ -2093,6 +2104,7 @@ int pf_engine_flush_outputs(pf_engine *e) { PF_NEED(e); return e->impl->flush();
 int pf_engine_get_grid(pf_engine *e, int32_t which, void *host) { PF_NEED(e); return e->impl->get_grid(which, host); }
 int pf_engine_set_grid(pf_engine *e, int32_t which, const void *host) { PF_NEED(e); return e->impl->set_grid(which, host); }
 int pf_engine_timing(pf_engine *e, pf_timing *t, int32_t reset) { PF_NEED(e); return e->impl->timing(t, reset); }
+int pf_engine_set_timing(pf_engine *e, int32_t on) { PF_NEED(e); return e->impl->set_timing(on); }
 int pf_engine_energy_cfg(pf_engine *e, double h, double c, double Ts, const double *DEF) { PF_NEED(e); if (!DEF) return set_err(PF_ERR_ARG, "null DEF"); return e->impl->energy_cfg(h, c, Ts, DEF); }
 int pf_engine_run_energy(pf_engine *e, int64_t n0, int64_t nsteps, double *H_tot, double *E_lost, double *E_in) {
    PF_NEED(e);

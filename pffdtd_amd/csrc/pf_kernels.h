@@ -632,7 +632,7 @@ static __global__ void k_rigid(const Real *__restrict__ u1, Real *__restrict__ u
 }
 
 // ---- frequency-dependent (lossy) boundary nodes, cpu_engine.h:290-301 + 363-405 (gpu_engine.h:368-432) ------
-// gather + ODE update + scatter in one pass; branch states are SoA [m*Nbl + nb] so that lanes coalesce.
+// gather + ODE update + scatter in one pass; branch states in 64-node blocks (st_idx below) so that lanes coalesce.
 template <typename Real> struct MatQuadT { Real b, bd, bDh, bFh; };
 
 // Branch state (vh1, gh1) layout: blocks of 64 nodes, [node / 64][branch m][node % 64].  A wave of 64 consecutive lossy
@@ -693,7 +693,7 @@ __device__ __forceinline__ Real fd_node_update(Real p, int32_t li, Real *__restr
 }
 
 // ---- frequency-dependent (lossy) boundary nodes as a separate pass, cpu_engine.h:290-301 + 363-405 (gpu_engine.h:368-432):
-// gather + ODE update + scatter; branch states are SoA [m*Nbl + nb] so that lanes coalesce.
+// gather + ODE update + scatter; branch states in 64-node blocks [node / 64][branch][node % 64] (st_idx).
 template <typename Real>
 static __global__ void k_fd_boundary(Real *__restrict__ u0, const int64_t *__restrict__ idx, Real *__restrict__ u0b,
                               const Real *__restrict__ u2b, const Real *__restrict__ ssaf,

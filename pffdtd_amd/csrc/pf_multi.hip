@@ -14,16 +14,28 @@
 //     range here and each engine sorts its own.
 //   * the cut is cost-balanced by default (a wall plane of frequency-dependent nodes costs ~24 interior planes),
 //     PF_MULTI_EVEN_SPLIT gives the reference's Nx/G rule (gpu_engine.h:532-550).
+//   * two transports for the ghost planes (pf_opts.transport / PFFDTD_TRANSPORT): peer copies PULLED by the receiving slab
+//     (hipMemcpyPeerAsync over xGMI; needs hipDeviceCanAccessPeer), or RCCL -- ncclSend / ncclRecv of both planes grouped
+//     per slab on its edge stream over one single-process communicator clique (ncclCommInitAll); librccl is loaded at run
+//     time, only when that transport is asked for.  The first exchanges of a run are CHECKED: every slab checksums (bit
+//     patterns) the planes it sent and received and compares them with its neighbours' (pf_multi_info.exchange_verified).
 // A device id may appear several times in the list ("virtual slabs"): the same code path then runs on one GPU, which is
 // how the exchange logic is tested bit for bit on a 1-GPU box (tests/test_hip_multi.py).
+//
+// The chain is an object (pf_multi_create / _run / _destroy) with one persistent host thread per slab, so that a host can
+// warm up, time and inspect it (bench.py --gpus N without a process launcher); pf_run_sim_devices is create + run + destroy.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h> // types and prototypes only: the library is dlopen()ed (struct Rccl)
+#include <dlfcn.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -156,6 +168,51 @@ int cut_slab(const pf_simdata *sd, const std::vector<int64_t> &cuts, int g, int 
    return PF_OK;
 }
 
+// ---- RCCL, loaded on demand (ncclSend / ncclRecv over xGMI as the second transport; gpu_engine.h:1086-1126 is the
+// reference's peer-copy counterpart).  The library is looked up (1) among what the process already has (a Python host that
+// imported torch carries torch's own librccl), (2) next to the HIP runtime in use, (3) on the loader's path.
+struct Rccl {
+   void *h = nullptr;
+   decltype(&ncclCommInitAll) CommInitAll = nullptr;
+   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+   decltype(&ncclGroupStart) GroupStart = nullptr;
+   decltype(&ncclGroupEnd) GroupEnd = nullptr;
+   decltype(&ncclSend) Send = nullptr;
+   decltype(&ncclRecv) Recv = nullptr;
+   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+   decltype(&ncclGetVersion) GetVersion = nullptr;
+   std::string where;
+   bool load(std::string &err) {
+      if (h) return true;
+      std::vector<std::string> cand;
+      if (const char *ev = getenv("PFFDTD_RCCL_LIB")) cand.push_back(ev);
+      Dl_info di{};
+      if (dladdr((void *)&hipGetDeviceCount, &di) && di.dli_fname) {
+         std::string dir = di.dli_fname;
+         const size_t k = dir.rfind('/');
+         if (k != std::string::npos) { dir.resize(k); cand.push_back(dir + "/librccl.so.1"); cand.push_back(dir + "/librccl.so"); }
+      }
+      cand.push_back("librccl.so.1");
+      cand.push_back("librccl.so");
+      void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+      if (lib) where = "librccl.so.1 (already loaded)";
+      for (size_t i = 0; i < cand.size() && !lib; i++) {
+         lib = dlopen(cand[i].c_str(), RTLD_NOW | RTLD_LOCAL);
+         if (lib) where = cand[i];
+      }
+      if (!lib) { err = std::string("librccl not found (") + (dlerror() ? dlerror() : "dlopen failed") + "); PFFDTD_RCCL_LIB names it explicitly"; return false; }
+#define PF_SYM(field, name) field = (decltype(field))dlsym(lib, name); if (!field) { err = std::string("librccl: symbol ") + name + " missing"; dlclose(lib); return false; }
+      PF_SYM(CommInitAll, "ncclCommInitAll") PF_SYM(CommDestroy, "ncclCommDestroy") PF_SYM(GroupStart, "ncclGroupStart")
+      PF_SYM(GroupEnd, "ncclGroupEnd") PF_SYM(Send, "ncclSend") PF_SYM(Recv, "ncclRecv")
+      PF_SYM(GetErrorString, "ncclGetErrorString") PF_SYM(GetVersion, "ncclGetVersion")
+#undef PF_SYM
+      h = lib;
+      return true;
+   }
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+
 // sense-reversing spin barrier (a step takes 0.3-3 ms; the threads meet within microseconds).  The last thread to arrive
 // samples the error flag and publishes it with the release, so that all threads take the same decision to stop.
 struct SpinBarrier {
@@ -178,9 +235,12 @@ struct SpinBarrier {
    }
 };
 
+enum { TR_PEER = PF_TRANSPORT_PEER, TR_RCCL = PF_TRANSPORT_RCCL };
+
 struct Shared {
    int G = 1;
    std::vector<Slab> slabs;
+   std::vector<int64_t> cuts;
    std::vector<int> dev;
    std::vector<pf_engine *> eng;
    std::vector<hipStream_t> edge;
@@ -196,6 +256,19 @@ struct Shared {
    pf_opts base{};
    int64_t Nt = 0;
    double t_loop = 0;
+   // transport
+   int transport = TR_PEER;
+   bool rccl_self = false;                                       // every slab on one device: one 1-rank communicator per slab,
+                                                                 // planes sent to itself (the RCCL code path on a 1-GPU box)
+   std::vector<ncclComm_t> comm;                                 // [g]
+   std::vector<int> rank;                                        // [g] peer rank of slab g in the clique
+   // exchange self-check: the first `verify_n` exchanges after creation
+   int64_t verify_n = 0;
+   std::vector<int64_t> steps_done;                              // [g]
+   std::vector<uint64_t> sums;                                   // [g*4 + {send_lo, send_hi, recv_lo, recv_hi}]
+   std::vector<std::vector<uint8_t>> hbuf;                       // [g] host staging for the checksums
+   std::atomic<int> verify_bad{0}, verify_nonzero{0};
+   std::atomic<int64_t> verify_checked{0};
    void set_error(int rc, const char *what) {
       int expect = 0;
       if (err.compare_exchange_strong(expect, rc ? rc : PF_ERR_HIP)) {
@@ -221,10 +294,25 @@ struct Shared {
       int _rc = (expr);                                                                                   \
       if (_rc != PF_OK) { S.set_error(_rc, pf_last_error()); return; }                                    \
    } while (0)
+#define NCHK(g, expr)                                                                                     \
+   do {                                                                                                   \
+      ncclResult_t _r = (expr);                                                                           \
+      if (_r != ncclSuccess) {                                                                            \
+         char _b[512];                                                                                    \
+         snprintf(_b, sizeof _b, "slab %d: RCCL error at %s:%d: %s", g, __FILE__, __LINE__, g_rccl.GetErrorString(_r)); \
+         S.set_error(PF_ERR_HIP, _b);                                                                     \
+         return;                                                                                          \
+      }                                                                                                   \
+   } while (0)
+
+// Slabs that share a physical device create their engines one after the other: the creation-time measurements of one
+// must not run beside another's, and an engine's optional allocations must not starve a neighbour's mandatory ones.
+std::mutex g_dev_mu[64];
 
 void create_slab(Shared &S, int g) {
    const Slab &sl = S.slabs[g];
    const int d = S.dev[g];
+   std::lock_guard<std::mutex> dev_lock(g_dev_mu[d & 63]);
    MCHK(g, hipSetDevice(d));
    pf_opts o = S.base;
    o.device = d;
@@ -245,10 +333,18 @@ void create_slab(Shared &S, int g) {
    o.ext_u0 = S.grids[0][g]; o.ext_u1 = S.grids[1][g];
    ECHK(g, pf_engine_create(&sl.sd, &o, &S.eng[g]));
    if (want_pairs) {
-      // a pool of up to eight grids: the engine keeps the four its pair kernel is fastest on (grid placement)
+      // a pool of up to eight grids: the engine keeps the four its pair kernel is fastest on (grid placement).
+      // The pool is bounded by what the device has free, less a reserve (two grids or 1/16 of the device, whichever is
+      // larger) for the neighbours' engines: slabs that share a device are created one at a time (g_dev_mu) and the
+      // rejected candidates are freed before the next one starts.
       std::vector<void *> pool = {S.grids[0][g], S.grids[1][g]};
       int extra = 6;
       if (const char *ev = getenv("PFFDTD_PLACE_EXTRA")) extra = std::min(std::max(atoi(ev), 0), 12) + 2;
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+         const size_t reserve = std::max(2 * gb, total_b / 16);
+         extra = (int)std::min<size_t>((size_t)extra, free_b > reserve ? (free_b - reserve) / gb : 0);
+      }
       for (int k = 0; k < extra; k++) {
          void *p = nullptr;
          if (hipMalloc(&p, gb) != hipSuccess) { (void)hipGetLastError(); break; } // what fits
@@ -267,18 +363,84 @@ void create_slab(Shared &S, int g) {
    }
    S.edge[g] = (hipStream_t)pf_engine_stream(S.eng[g], 1);
    for (int k = 0; k < 2; k++) MCHK(g, hipEventCreateWithFlags(&S.ev[k][g], hipEventDisableTiming));
-   // neighbours' memory: direct peer access where the devices differ (the copies work without it, staged)
-   for (int nb : {g - 1, g + 1})
-      if (nb >= 0 && nb < S.G && S.dev[nb] != d) {
-         int can = 0;
-         if (hipDeviceCanAccessPeer(&can, d, S.dev[nb]) == hipSuccess && can) {
+   // neighbours' memory: direct peer access (checked in choose_transport) for the pulled copies
+   if (S.transport == TR_PEER)
+      for (int nb : {g - 1, g + 1})
+         if (nb >= 0 && nb < S.G && S.dev[nb] != d) {
             const hipError_t e = hipDeviceEnablePeerAccess(S.dev[nb], 0);
-            if (e != hipSuccess) (void)hipGetLastError(); // already enabled (virtual slabs, repeated runs): fine
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+               char b[256];
+               snprintf(b, sizeof b, "slab %d: hipDeviceEnablePeerAccess(%d) from device %d failed: %s", g, S.dev[nb], d, hipGetErrorString(e));
+               S.set_error(PF_ERR_HIP, b);
+               return;
+            }
+            (void)hipGetLastError();
          }
-      }
+   if (S.verify_n > 0) S.hbuf[g].resize(4 * S.plane_bytes);
 }
 
-// ---- the three phases of one step of slab g ----
+// Which transport carries the ghost planes?  requested: PF_TRANSPORT_AUTO / _PEER / _RCCL (pf_opts.transport), overridden by
+// PFFDTD_TRANSPORT=peer|rccl.  AUTO = peer copies when every neighbouring pair of devices can access each other's memory
+// (hipDeviceCanAccessPeer), else RCCL.  Peer copies without peer access would silently stage through host memory: refused.
+int choose_transport(Shared &S, int requested) {
+   if (const char *ev = getenv("PFFDTD_TRANSPORT")) {
+      if (!strcmp(ev, "peer")) requested = PF_TRANSPORT_PEER;
+      else if (!strcmp(ev, "rccl")) requested = PF_TRANSPORT_RCCL;
+      else if (!strcmp(ev, "auto") || !*ev) requested = PF_TRANSPORT_AUTO;
+      else return fail("PFFDTD_TRANSPORT must be peer, rccl or auto (got '%s')", ev);
+   }
+   if (requested != PF_TRANSPORT_AUTO && requested != PF_TRANSPORT_PEER && requested != PF_TRANSPORT_RCCL)
+      return fail("pf_opts.transport must be PF_TRANSPORT_AUTO, _PEER or _RCCL");
+   bool all_same = true, all_distinct = true, peer_ok = true;
+   int bad_a = -1, bad_b = -1;
+   for (int g = 0; g < S.G; g++) {
+      for (int k = 0; k < g; k++) if (S.dev[k] == S.dev[g]) all_distinct = false;
+      if (S.dev[g] != S.dev[0]) all_same = false;
+      if (g + 1 < S.G && S.dev[g] != S.dev[g + 1]) {
+         int ab = 0, ba = 0;
+         if (hipDeviceCanAccessPeer(&ab, S.dev[g], S.dev[g + 1]) != hipSuccess) ab = 0;
+         if (hipDeviceCanAccessPeer(&ba, S.dev[g + 1], S.dev[g]) != hipSuccess) ba = 0;
+         (void)hipGetLastError();
+         if (!(ab && ba) && peer_ok) { peer_ok = false; bad_a = S.dev[g]; bad_b = S.dev[g + 1]; }
+      }
+   }
+   if (requested == PF_TRANSPORT_PEER && !peer_ok) {
+      char b[256];
+      snprintf(b, sizeof b, "devices %d and %d cannot access each other's memory (hipDeviceCanAccessPeer): the peer-copy transport "
+                            "would stage through the host; use the RCCL transport (pf_opts.transport / PFFDTD_TRANSPORT=rccl)", bad_a, bad_b);
+      pf__set_error(b);
+      return PF_ERR_ARG;
+   }
+   S.transport = (requested == PF_TRANSPORT_RCCL || (requested == PF_TRANSPORT_AUTO && !peer_ok)) ? TR_RCCL : TR_PEER;
+   if (S.transport != TR_RCCL) return PF_OK;
+   if (!(all_distinct || all_same))
+      return fail("the RCCL transport needs every slab on its own device (or all slabs on ONE device: self-communicators, tests)");
+   std::lock_guard<std::mutex> lk(g_rccl_mu);
+   std::string err;
+   if (!g_rccl.load(err)) { pf__set_error(err.c_str()); return PF_ERR_ARG; }
+   S.comm.assign(S.G, nullptr);
+   S.rank.assign(S.G, 0);
+   S.rccl_self = all_same && S.G > 1;
+   ncclResult_t r = ncclSuccess;
+   if (S.rccl_self) {
+      // virtual slabs: slab g's communicator has ONE rank (the device); its exchange sends the neighbour's plane -- same
+      // device, directly addressable -- to itself.  Group semantics, stream ordering and error paths as on a real chain.
+      for (int g = 0; g < S.G && r == ncclSuccess; g++) { const int d = S.dev[g]; r = g_rccl.CommInitAll(&S.comm[g], 1, &d); }
+   } else {
+      for (int g = 0; g < S.G; g++) S.rank[g] = g;
+      r = g_rccl.CommInitAll(S.comm.data(), S.G, S.dev.data()); // one clique over the chain's devices, rank g = slab g
+   }
+   if (r != ncclSuccess) {
+      char b[384];
+      snprintf(b, sizeof b, "ncclCommInitAll over %d device(s) failed: %s", S.rccl_self ? 1 : S.G, g_rccl.GetErrorString(r));
+      pf__set_error(b);
+      for (auto &c : S.comm) if (c) { g_rccl.CommDestroy(c); c = nullptr; }
+      return PF_ERR_HIP;
+   }
+   return PF_OK;
+}
+
+// ---- the phases of one step of slab g ----
 // A: enqueue the split-phase step, publish the planes to exchange and the event "my edge planes of step n are computed"
 void phase_begin(Shared &S, int g, int64_t n) {
    if (S.err.load()) return;
@@ -288,8 +450,8 @@ void phase_begin(Shared &S, int g, int64_t n) {
    if (rc != PF_OK) S.set_error(rc, pf_last_error());
    else if (hipEventRecord(S.ev[k][g], S.edge[g]) != hipSuccess) S.set_error(PF_ERR_HIP, "hipEventRecord failed");
 }
-// B (after every slab has done A): pull the neighbours' freshly computed edge planes into my ghost planes, on MY edge
-// stream: ordered after my own edge kernels of this step (which were the last readers of the grid those ghost planes
+// B, peer copies (after every slab has done A): pull the neighbours' freshly computed edge planes into my ghost planes, on MY
+// edge stream: ordered after my own edge kernels of this step (which were the last readers of the grid those ghost planes
 // belong to) and after the neighbour's edge event; the interior keeps running on the main stream meanwhile
 void phase_pull(Shared &S, int g, int64_t n) {
    const int k = (int)(n & 1), d = S.dev[g];
@@ -299,13 +461,69 @@ void phase_pull(Shared &S, int g, int64_t n) {
                                             : hipMemcpyPeerAsync(dst, d, src, S.dev[nb], S.plane_bytes, S.edge[g]);
       if (e != hipSuccess) S.set_error(PF_ERR_HIP, hipGetErrorString(e));
    };
+   static const int64_t drop = getenv("PFFDTD_TEST_DROP_EXCHANGE") ? atoll(getenv("PFFDTD_TEST_DROP_EXCHANGE")) : -1; // test hook: slab 1 misses the planes of that step, the self-check must notice
+   if (drop >= 0 && g == 1 && n == drop) return;
    if (g > 0) pull(g - 1, S.recv_lo[k][g], S.send_hi[k][g - 1]);         // left neighbour's last owned plane -> my plane 0
    if (g < S.G - 1) pull(g + 1, S.recv_hi[k][g], S.send_lo[k][g + 1]);   // right neighbour's first owned plane -> my last plane
+}
+// B, RCCL: slab g SENDS its two edge planes and RECEIVES its two ghost planes, all four operations in one group on its edge
+// stream (ordered after its edge kernels: the sources are complete, and the last readers of the ghost planes are done).
+// grouped: the caller has opened an ncclGroupStart that spans several slabs (one-thread mode: one host thread must not block
+// in the group end of one slab before the matching operations of its neighbour are issued).
+void phase_rccl(Shared &S, int g, int64_t n, bool grouped) {
+   const int k = (int)(n & 1);
+   const size_t nb = S.plane_bytes;
+   if (S.rccl_self) {
+      // 1-rank communicator: the neighbour's plane goes through RCCL to myself (after the neighbour's edge event)
+      for (int q : {g - 1, g + 1})
+         if (q >= 0 && q < S.G && hipStreamWaitEvent(S.edge[g], S.ev[k][q], 0) != hipSuccess) { S.set_error(PF_ERR_HIP, "hipStreamWaitEvent failed"); return; }
+      if (!grouped) NCHK(g, g_rccl.GroupStart());
+      if (g > 0) { NCHK(g, g_rccl.Send(S.send_hi[k][g - 1], nb, ncclInt8, 0, S.comm[g], S.edge[g])); NCHK(g, g_rccl.Recv(S.recv_lo[k][g], nb, ncclInt8, 0, S.comm[g], S.edge[g])); }
+      if (g < S.G - 1) { NCHK(g, g_rccl.Send(S.send_lo[k][g + 1], nb, ncclInt8, 0, S.comm[g], S.edge[g])); NCHK(g, g_rccl.Recv(S.recv_hi[k][g], nb, ncclInt8, 0, S.comm[g], S.edge[g])); }
+      if (!grouped) NCHK(g, g_rccl.GroupEnd());
+      return;
+   }
+   if (!grouped) NCHK(g, g_rccl.GroupStart());
+   if (g > 0) {
+      NCHK(g, g_rccl.Send(S.send_lo[k][g], nb, ncclInt8, S.rank[g - 1], S.comm[g], S.edge[g]));
+      NCHK(g, g_rccl.Recv(S.recv_lo[k][g], nb, ncclInt8, S.rank[g - 1], S.comm[g], S.edge[g]));
+   }
+   if (g < S.G - 1) {
+      NCHK(g, g_rccl.Send(S.send_hi[k][g], nb, ncclInt8, S.rank[g + 1], S.comm[g], S.edge[g]));
+      NCHK(g, g_rccl.Recv(S.recv_hi[k][g], nb, ncclInt8, S.rank[g + 1], S.comm[g], S.edge[g]));
+   }
+   if (!grouped) NCHK(g, g_rccl.GroupEnd());
+}
+// B': exchange self-check, part 1: bit-pattern checksums of the two planes I sent and the two I received (after the edge
+// stream has drained: the exchange of this step is complete on my side)
+void phase_checksum(Shared &S, int g, int64_t n) {
+   const int k = (int)(n & 1);
+   MCHK(g, hipSetDevice(S.dev[g]));
+   uint8_t *hb = S.hbuf[g].data();
+   const void *src[4] = {S.send_lo[k][g], S.send_hi[k][g], S.recv_lo[k][g], S.recv_hi[k][g]};
+   for (int i = 0; i < 4; i++) MCHK(g, hipMemcpyAsync(hb + (size_t)i * S.plane_bytes, src[i], S.plane_bytes, hipMemcpyDeviceToHost, S.edge[g]));
+   MCHK(g, hipStreamSynchronize(S.edge[g]));
+   for (int i = 0; i < 4; i++) {
+      const uint32_t *w = (const uint32_t *)(hb + (size_t)i * S.plane_bytes);
+      uint64_t sum = 0;
+      for (size_t j = 0; j < S.plane_bytes / 4; j++) sum += (uint64_t)w[j] * (uint64_t)(1 + (j & 1023)); // position-weighted: a shifted plane does not pass
+      S.sums[(size_t)g * 4 + i] = sum;
+   }
+}
+// part 2 (after a barrier): what arrived in my ghost planes must be what my neighbours sent
+void phase_compare(Shared &S, int g) {
+   bool ok = true, nz = false;
+   if (g > 0) { ok &= S.sums[(size_t)g * 4 + 2] == S.sums[(size_t)(g - 1) * 4 + 1]; nz |= S.sums[(size_t)g * 4 + 2] != 0; }
+   if (g < S.G - 1) { ok &= S.sums[(size_t)g * 4 + 3] == S.sums[(size_t)(g + 1) * 4 + 0]; nz |= S.sums[(size_t)g * 4 + 3] != 0; }
+   if (!ok) S.verify_bad.store(1);
+   if (nz) S.verify_nonzero.store(1);
+   if (g == 0) S.verify_checked.fetch_add(1);
 }
 // C: join the two streams, rotate the state
 void phase_end(Shared &S, int g, int64_t n) {
    const int rc = pf_engine_step_end(S.eng[g], n);
    if (rc != PF_OK) S.set_error(rc, pf_last_error());
+   S.steps_done[g]++;
 }
 
 void finish_slab(Shared &S, int g) {
@@ -321,27 +539,99 @@ void finish_slab(Shared &S, int g) {
 void destroy_slab(Shared &S, int g) {
    hipSetDevice(S.dev[g]);
    if (S.eng[g]) { pf_engine_sync(S.eng[g]); pf_engine_destroy(S.eng[g]); S.eng[g] = nullptr; }
-   for (int k = 0; k < 2; k++) if (S.ev[k][g]) hipEventDestroy(S.ev[k][g]);
-   for (int k = 0; k < 4; k++) if (S.grids[k][g]) hipFree(S.grids[k][g]);
+   for (int k = 0; k < 2; k++) if (S.ev[k][g]) { hipEventDestroy(S.ev[k][g]); S.ev[k][g] = nullptr; }
+   for (int k = 0; k < 4; k++) if (S.grids[k][g]) { hipFree(S.grids[k][g]); S.grids[k][g] = nullptr; }
 }
 
-void worker(Shared &S, int g) {
-   int local = 0;
-   create_slab(S, g);
-   bool stop = S.bar.wait(local, S.err); // all engines exist, or everybody leaves
-   std::chrono::steady_clock::time_point t0;
-   if (g == 0) t0 = std::chrono::steady_clock::now();
-   for (int64_t n = 0; n < S.Nt && !stop; n++) {
+// steps [n0, n0+ns) of slab g (its own host thread); returns when its streams have drained and its receivers are flushed
+void run_slab(Shared &S, int g, int &local, int64_t n0, int64_t ns) {
+   bool stop = S.err.load() != 0;
+   for (int64_t n = n0; n < n0 + ns && !stop; n++) {
       hipSetDevice(S.dev[g]);
+      const bool verify = S.steps_done[g] < S.verify_n; // the same decision in every thread: all slabs have done the same steps
       phase_begin(S, g, n);
       stop = S.bar.wait(local, S.err); // every slab's edge event of step n is recorded, its plane pointers published
       if (stop) break;
-      phase_pull(S, g, n);
+      if (S.transport == TR_RCCL) phase_rccl(S, g, n, false); else phase_pull(S, g, n);
+      if (verify) {
+         if (!S.err.load()) phase_checksum(S, g, n);
+         stop = S.bar.wait(local, S.err);
+         if (stop) break;
+         phase_compare(S, g);
+      }
       phase_end(S, g, n);
    }
    finish_slab(S, g);
-   S.bar.wait(local, S.err);
-   if (g == 0) S.t_loop = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+} // namespace
+
+// the chain as an object: one persistent host thread per slab, commands posted by the caller's thread
+struct pf_multi {
+   Shared S;
+   pf_simdata *sd = nullptr;
+   std::vector<std::thread> th;
+   std::mutex mu;
+   std::condition_variable cv_cmd, cv_done;
+   int64_t cmd_seq = 0, cmd_n0 = 0, cmd_ns = 0;
+   int cmd_kind = 0;                 // 1 run, 2 quit
+   int done = 0;
+   bool created = false;
+   double last_seconds = 0;
+   bool one_thread = false;
+};
+
+namespace {
+
+void worker(pf_multi *m, int g) {
+   Shared &S = m->S;
+   int local = 0;
+   create_slab(S, g);
+   S.bar.wait(local, S.err); // all engines exist (or an error is up)
+   { std::lock_guard<std::mutex> lk(m->mu); m->done++; }
+   m->cv_done.notify_all();
+   int64_t seen = 0;
+   for (;;) {
+      int kind;
+      int64_t n0, ns;
+      {
+         std::unique_lock<std::mutex> lk(m->mu);
+         m->cv_cmd.wait(lk, [&] { return m->cmd_seq != seen; });
+         seen = m->cmd_seq; kind = m->cmd_kind; n0 = m->cmd_n0; ns = m->cmd_ns;
+      }
+      if (kind == 2) break;
+      run_slab(S, g, local, n0, ns);
+      S.bar.wait(local, S.err);
+      { std::lock_guard<std::mutex> lk(m->mu); m->done++; }
+      m->cv_done.notify_all();
+   }
+}
+
+void post(pf_multi *m, int kind, int64_t n0, int64_t ns) {
+   {
+      std::lock_guard<std::mutex> lk(m->mu);
+      m->cmd_kind = kind; m->cmd_n0 = n0; m->cmd_ns = ns; m->done = 0; m->cmd_seq++;
+   }
+   m->cv_cmd.notify_all();
+}
+void wait_done(pf_multi *m) {
+   std::unique_lock<std::mutex> lk(m->mu);
+   m->cv_done.wait(lk, [&] { return m->done == m->S.G; });
+}
+
+void scatter_outputs(pf_multi *m) { // receivers: every slab filled its own rows (gpu_engine.h:1066-1075)
+   Shared &S = m->S;
+   pf_simdata *sd = m->sd;
+   if (!sd->u_out) return;
+   for (int g = 0; g < S.G; g++) {
+      const Slab &sl = S.slabs[g];
+      for (size_t r = 0; r < sl.out_rows.size(); r++)
+         memcpy(sd->u_out + sl.out_rows[r] * sd->Nt, sl.u_out.data() + r * (size_t)sd->Nt, sizeof(double) * (size_t)sd->Nt);
+   }
+}
+
+const char *transport_name(const Shared &S) {
+   return S.G == 1 ? "none (one slab)" : (S.transport == TR_RCCL ? (S.rccl_self ? "rccl (self-communicators, one device)" : "rccl") : "peer copies");
 }
 
 } // namespace
@@ -357,81 +647,165 @@ int pf_slab_partition(const pf_simdata *sd, int32_t nslabs, int32_t even_split, 
    return PF_OK;
 }
 
-// run_sim on a chain of slabs, slab g on device devices[g] (ids may repeat).  base: engine options common to all slabs
-// (numerics, air_variant, readout_chunk, debug, multi_flags); NULL = defaults.
-double pf_run_sim_devices(pf_simdata *sd, int32_t nslabs, const int32_t *devices, const pf_opts *base) {
-   if (!sd || nslabs < 1 || !devices) { fail("pf_run_sim_devices: bad argument"); return -1.0; }
+int pf_multi_create(pf_simdata *sd, int32_t nslabs, const int32_t *devices, const pf_opts *base, pf_multi **out) {
+   if (!sd || nslabs < 1 || !devices || !out) return fail("pf_multi_create: bad argument");
+   *out = nullptr;
    int ndev = 0;
-   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { pf__set_error("no HIP device visible"); return -1.0; }
+   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { pf__set_error("no HIP device visible"); return PF_ERR_NODEV; }
    for (int g = 0; g < nslabs; g++)
-      if (devices[g] < 0 || devices[g] >= ndev) { fail("pf_run_sim_devices: device id out of range"); return -1.0; }
-   Shared S;
+      if (devices[g] < 0 || devices[g] >= ndev) return fail("pf_multi_create: device id out of range");
+   pf_multi *m = new pf_multi();
+   Shared &S = m->S;
+   m->sd = sd;
    if (base) S.base = *base; else pf_opts_default(&S.base);
-   if (nslabs == 1) { // plain single-domain engine
-      pf_opts o = S.base;
-      o.device = devices[0]; o.slab_first = o.slab_last = 1;
-      pf_engine *e = nullptr;
-      if (pf_engine_create(sd, &o, &e) != PF_OK) return -1.0;
-      auto t0 = std::chrono::steady_clock::now();
-      int rc = pf_engine_run(e, 0, sd->Nt);
-      if (rc == PF_OK) rc = pf_engine_sync(e);
-      const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      std::string keep = pf_last_error();
-      pf_engine_destroy(e);
-      if (rc != PF_OK) { pf__set_error(keep.c_str()); return -1.0; }
-      return el;
-   }
    const int G = nslabs;
-   std::vector<int64_t> cuts;
-   if (partition(sd, G, (S.base.multi_flags & PF_MULTI_EVEN_SPLIT) != 0, cuts)) return -1.0;
    S.G = G; S.Nt = sd->Nt;
-   S.slabs.resize(G);
-   for (int g = 0; g < G; g++)
-      if (cut_slab(sd, cuts, g, G, S.slabs[g])) return -1.0;
    S.dev.assign(devices, devices + G);
    S.eng.assign(G, nullptr);
    S.edge.assign(G, nullptr);
    S.paired.assign(G, 0);
+   S.steps_done.assign(G, 0);
    for (int k = 0; k < 2; k++) {
       S.ev[k].assign(G, nullptr);
       S.send_lo[k].assign(G, nullptr); S.send_hi[k].assign(G, nullptr);
       S.recv_lo[k].assign(G, nullptr); S.recv_hi[k].assign(G, nullptr);
    }
    for (int k = 0; k < 4; k++) S.grids[k].assign(G, nullptr);
-   S.plane_bytes = (size_t)(sd->Ny * pf_grid_pitch(sd->Nz, sd->real_bytes)) * (size_t)sd->real_bytes;
+   if (G == 1) { // plain single-domain engine
+      pf_opts o = S.base;
+      o.device = devices[0]; o.slab_first = o.slab_last = 1;
+      S.cuts = {0, sd->Nx};
+      const int rc = pf_engine_create(sd, &o, &S.eng[0]);
+      if (rc != PF_OK) { delete m; return rc; }
+      m->created = true;
+      *out = m;
+      return PF_OK;
+   }
+   int rc = partition(sd, G, (S.base.multi_flags & PF_MULTI_EVEN_SPLIT) != 0, S.cuts);
+   S.slabs.resize(G);
+   for (int g = 0; g < G && rc == PF_OK; g++) rc = cut_slab(sd, S.cuts, g, G, S.slabs[g]);
+   S.plane_bytes = pf_grid_bytes(1, sd->Ny, sd->Nz, sd->real_bytes);
+   S.verify_n = S.base.verify_exchange > 0 ? S.base.verify_exchange : 0;
+   if (const char *ev = getenv("PFFDTD_VERIFY_EXCHANGE")) S.verify_n = std::max(atoi(ev), 0);
+   S.sums.assign((size_t)G * 4, 0);
+   S.hbuf.resize(G);
+   if (rc == PF_OK) rc = choose_transport(S, S.base.transport);
+   if (rc != PF_OK) { delete m; return rc; }
    S.bar.n = G;
-   if (S.base.multi_flags & PF_MULTI_ONE_THREAD) {
+   m->one_thread = (S.base.multi_flags & PF_MULTI_ONE_THREAD) != 0;
+   if (m->one_thread) {
       // the reference's arrangement (one host thread drives every GPU, gpu_engine.h:993-1145): kept for debugging
       for (int g = 0; g < G && !S.err.load(); g++) create_slab(S, g);
-      auto t0 = std::chrono::steady_clock::now();
-      for (int64_t n = 0; n < S.Nt && !S.err.load(); n++) {
-         for (int g = 0; g < G; g++) phase_begin(S, g, n);
-         for (int g = 0; g < G && !S.err.load(); g++) { hipSetDevice(S.dev[g]); phase_pull(S, g, n); }
-         for (int g = 0; g < G && !S.err.load(); g++) phase_end(S, g, n);
-      }
-      for (int g = 0; g < G; g++) finish_slab(S, g);
-      S.t_loop = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
    } else {
-      std::vector<std::thread> th;
-      for (int g = 1; g < G; g++) th.emplace_back(worker, std::ref(S), g);
-      worker(S, 0);
-      for (auto &t : th) t.join();
+      for (int g = 0; g < G; g++) m->th.emplace_back(worker, m, g);
+      wait_done(m);
    }
-   // receivers: every slab filled its own rows (gpu_engine.h:1066-1075)
-   if (!S.err.load() && sd->u_out)
-      for (int g = 0; g < G; g++) {
-         const Slab &sl = S.slabs[g];
-         for (size_t r = 0; r < sl.out_rows.size(); r++)
-            memcpy(sd->u_out + sl.out_rows[r] * sd->Nt, sl.u_out.data() + r * (size_t)sd->Nt, sizeof(double) * (size_t)sd->Nt);
-      }
-   for (int g = 0; g < G; g++) destroy_slab(S, g);
-   if (S.err.load()) { pf__set_error(S.err_msg.c_str()); return -1.0; }
+   m->created = true;
+   if (S.err.load()) { const std::string keep = S.err_msg; const int code = S.err.load(); pf_multi_destroy(m); pf__set_error(keep.c_str()); return code; }
    if (getenv("PFFDTD_VERBOSE")) {
-      fprintf(stderr, "pffdtd_hip: %d slabs:", G);
-      for (int g = 0; g < G; g++) fprintf(stderr, " [dev %d: planes %ld-%ld%s]", S.dev[g], (long)cuts[g], (long)cuts[g + 1] - 1, S.paired[g] ? ", pairs" : "");
+      fprintf(stderr, "pffdtd_hip: %d slabs, ghost planes by %s%s%s:", G, transport_name(S), S.transport == TR_RCCL ? ", " : "", S.transport == TR_RCCL ? g_rccl.where.c_str() : "");
+      for (int g = 0; g < G; g++) fprintf(stderr, " [dev %d: planes %ld-%ld%s]", S.dev[g], (long)S.cuts[g], (long)S.cuts[g + 1] - 1, S.paired[g] ? ", pairs" : "");
       fprintf(stderr, "\n");
    }
-   return S.t_loop;
+   *out = m;
+   return PF_OK;
+}
+
+int pf_multi_run(pf_multi *m, int64_t n0, int64_t nsteps) {
+   if (!m) return fail("pf_multi_run: null object");
+   Shared &S = m->S;
+   if (n0 < 0 || nsteps < 0 || n0 + nsteps > m->sd->Nt) return fail("pf_multi_run: steps outside [0, Nt)");
+   const auto t0 = std::chrono::steady_clock::now();
+   if (S.G == 1) {
+      int rc = pf_engine_run(S.eng[0], n0, nsteps);
+      if (rc == PF_OK) rc = pf_engine_sync(S.eng[0]);
+      m->last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      return rc;
+   }
+   if (S.err.load()) { pf__set_error(S.err_msg.c_str()); return S.err.load(); }
+   if (m->one_thread) {
+      const int G = S.G;
+      for (int64_t n = n0; n < n0 + nsteps && !S.err.load(); n++) {
+         const bool verify = S.steps_done[0] < S.verify_n;
+         for (int g = 0; g < G; g++) { hipSetDevice(S.dev[g]); phase_begin(S, g, n); }
+         if (S.err.load()) break;
+         if (S.transport == TR_RCCL) {
+            bool open = g_rccl.GroupStart() == ncclSuccess;
+            for (int g = 0; g < G && !S.err.load(); g++) { hipSetDevice(S.dev[g]); phase_rccl(S, g, n, true); }
+            if (!open || g_rccl.GroupEnd() != ncclSuccess) S.set_error(PF_ERR_HIP, "RCCL group call failed");
+         } else {
+            for (int g = 0; g < G && !S.err.load(); g++) { hipSetDevice(S.dev[g]); phase_pull(S, g, n); }
+         }
+         if (verify) {
+            for (int g = 0; g < G && !S.err.load(); g++) phase_checksum(S, g, n);
+            for (int g = 0; g < G && !S.err.load(); g++) phase_compare(S, g);
+         }
+         for (int g = 0; g < G && !S.err.load(); g++) { hipSetDevice(S.dev[g]); phase_end(S, g, n); }
+      }
+      for (int g = 0; g < G; g++) finish_slab(S, g);
+   } else {
+      post(m, 1, n0, nsteps);
+      wait_done(m);
+   }
+   m->last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+   if (S.err.load()) { pf__set_error(S.err_msg.c_str()); return S.err.load(); }
+   scatter_outputs(m);
+   return PF_OK;
+}
+
+int pf_multi_get_info(pf_multi *m, pf_multi_info *info) {
+   if (!m || !info) return fail("pf_multi_get_info: null argument");
+   const Shared &S = m->S;
+   memset(info, 0, sizeof *info);
+   info->nslabs = S.G;
+   info->transport = S.G == 1 ? 0 : S.transport;
+   info->rccl_self = S.rccl_self ? 1 : 0;
+   info->exchanges_checked = S.verify_checked.load();
+   info->exchange_verified = S.verify_checked.load() > 0 ? (S.verify_bad.load() ? 0 : 1) : -1;
+   info->exchange_nonzero = S.verify_nonzero.load();
+   info->last_run_seconds = m->last_seconds;
+   info->plane_bytes = (int64_t)S.plane_bytes;
+   snprintf(info->transport_name, sizeof info->transport_name, "%s", transport_name(S));
+   return PF_OK;
+}
+
+int pf_multi_get_slab(pf_multi *m, int32_t g, int64_t *x0, int64_t *x1, int32_t *device, int32_t *paired, pf_engine **engine) {
+   if (!m || g < 0 || g >= m->S.G) return fail("pf_multi_get_slab: slab index out of range");
+   const Shared &S = m->S;
+   if (x0) *x0 = S.cuts[g];
+   if (x1) *x1 = S.cuts[g + 1];
+   if (device) *device = S.dev[g];
+   if (paired) *paired = S.paired[g];
+   if (engine) *engine = S.eng[g];
+   return PF_OK;
+}
+
+void pf_multi_destroy(pf_multi *m) {
+   if (!m) return;
+   Shared &S = m->S;
+   if (!m->th.empty()) {
+      post(m, 2, 0, 0);
+      for (auto &t : m->th) t.join();
+   }
+   if (S.G == 1) { if (S.eng[0]) { pf_engine_destroy(S.eng[0]); S.eng[0] = nullptr; } }
+   else for (int g = 0; g < S.G; g++) destroy_slab(S, g);
+   for (auto &c : S.comm) if (c) { g_rccl.CommDestroy(c); c = nullptr; }
+   delete m;
+}
+
+// run_sim on a chain of slabs, slab g on device devices[g] (ids may repeat).  base: engine options common to all slabs
+// (numerics, air_variant, readout_chunk, debug, multi_flags, transport, verify_exchange); NULL = defaults.
+double pf_run_sim_devices(pf_simdata *sd, int32_t nslabs, const int32_t *devices, const pf_opts *base) {
+   pf_multi *m = nullptr;
+   if (pf_multi_create(sd, nslabs, devices, base, &m) != PF_OK) return -1.0;
+   const int rc = pf_multi_run(m, 0, sd->Nt);
+   const double el = m->last_seconds;
+   std::string keep = pf_last_error();
+   const bool bad = m->S.verify_bad.load() != 0;
+   pf_multi_destroy(m);
+   if (rc != PF_OK) { pf__set_error(keep.c_str()); return -1.0; }
+   if (bad) { pf__set_error("slab exchange self-check failed: a ghost plane does not hold what the neighbour sent"); return -1.0; }
+   return el;
 }
 
 // double run_sim(struct SimData *sd): cpu_engine.h:52 / gpu_engine.h:665.  Like the reference's GPU engine it uses every
@@ -454,11 +828,15 @@ double pf_run_sim(pf_simdata *sd) {
    if (devs.empty()) {
       int n = ndev;
       if (const char *ev = getenv("PFFDTD_NGPUS")) n = std::max(1, std::min(atoi(ev), ndev));
-      // every slab should keep a few planes of its own (the reference only asks for ngpus < Nx, gpu_engine.h:682)
-      n = (int)std::max<int64_t>(1, std::min<int64_t>(n, (sd->Nx - 2) / 4));
+      // every slab should be worth a device: at least 16 planes and ~17 M cells of its own (the reference only asks for
+      // ngpus < Nx, gpu_engine.h:682; a 3e6-cell grid cut eight ways is slower than on one GPU)
+      n = (int)std::max<int64_t>(1, std::min<int64_t>(n, std::min<int64_t>((sd->Nx - 2) / 16, sd->Npts >> 24)));
       for (int i = 0; i < n; i++) devs.push_back(i);
    }
-   return pf_run_sim_devices(sd, (int32_t)devs.size(), devs.data(), nullptr);
+   pf_opts o;
+   pf_opts_default(&o);
+   o.verify_exchange = devs.size() > 1 ? 2 : 0; // first contact: the first two exchanges are checksummed
+   return pf_run_sim_devices(sd, (int32_t)devs.size(), devs.data(), &o);
 }
 
 } // extern "C"

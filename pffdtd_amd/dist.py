@@ -100,6 +100,11 @@ class HipSlabStepper:
         self.eng.sync()
 
     def close(self):
+        # a single domain's `grids` are views of the ENGINE's allocations: drop them before the engine frees the memory
+        if self.grids and self.grids[0].is_cuda:
+            torch.cuda.synchronize(self.device)
+        self.grids = []
+        self._by_ptr = {}
         self.eng.close()
 
 

@@ -24,7 +24,8 @@ class PfOpts(ctypes.Structure):
                 ("slab_last", ctypes.c_int32), ("readout_chunk", ctypes.c_int32), ("air_variant", ctypes.c_int32),
                 ("air_chunk", ctypes.c_int32), ("timing", ctypes.c_int32), ("ext_u0", ctypes.c_void_p),
                 ("ext_u1", ctypes.c_void_p), ("x_global0", ctypes.c_int32), ("debug", ctypes.c_int32),
-                ("energy", ctypes.c_int32), ("multi_flags", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4)]
+                ("energy", ctypes.c_int32), ("multi_flags", ctypes.c_int32), ("transport", ctypes.c_int32),
+                ("verify_exchange", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2)]
 
 
 class PfTiming(ctypes.Structure):
@@ -35,6 +36,13 @@ class PfTiming(ctypes.Structure):
                 ("tb2_dirty_tiles", ctypes.c_int64), ("place_candidates", ctypes.c_int64), ("place_ms", ctypes.c_double * 3)]
 
 
+class PfMultiInfo(ctypes.Structure):
+    _fields_ = [("nslabs", ctypes.c_int32), ("transport", ctypes.c_int32), ("rccl_self", ctypes.c_int32),
+                ("exchange_verified", ctypes.c_int32), ("exchanges_checked", ctypes.c_int64),
+                ("exchange_nonzero", ctypes.c_int32), ("pad_", ctypes.c_int32), ("plane_bytes", ctypes.c_int64),
+                ("last_run_seconds", ctypes.c_double), ("transport_name", ctypes.c_char * 64)]
+
+
 class PfError(RuntimeError):
     pass
 
@@ -42,11 +50,13 @@ class PfError(RuntimeError):
 EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_grid_bytes", "pf_grid_pitch", "pf_opts_default",
            "pf_run_sim", "pf_engine_create", "pf_engine_destroy", "pf_engine_run", "pf_engine_step_begin",
            "pf_engine_halo_ptrs", "pf_engine_step_end", "pf_engine_state_grids", "pf_engine_place_grids", "pf_engine_set_spares", "pf_engine_stream", "pf_engine_sync",
-           "pf_engine_flush_outputs", "pf_engine_get_grid", "pf_engine_set_grid", "pf_engine_timing",
-           "pf_engine_energy_cfg", "pf_engine_run_energy", "pf_run_sim_devices", "pf_slab_partition"]
+           "pf_engine_flush_outputs", "pf_engine_get_grid", "pf_engine_set_grid", "pf_engine_timing", "pf_engine_set_timing",
+           "pf_engine_energy_cfg", "pf_engine_run_energy", "pf_run_sim_devices", "pf_slab_partition",
+           "pf_multi_create", "pf_multi_run", "pf_multi_get_info", "pf_multi_get_slab", "pf_multi_destroy"]
 
 
 PF_MULTI_EVEN_SPLIT, PF_MULTI_ONE_THREAD, PF_MULTI_NO_PAIRS, PF_MULTI_FORCE_PAIRS = 1, 2, 4, 8
+PF_TRANSPORT_AUTO, PF_TRANSPORT_PEER, PF_TRANSPORT_RCCL = 0, 1, 2
 
 
 def _preload_torch_hip():
@@ -111,6 +121,7 @@ def lib():
         L.pf_engine_get_grid.argtypes = [vp, i32, vp]
         L.pf_engine_set_grid.argtypes = [vp, i32, vp]
         L.pf_engine_timing.argtypes = [vp, ctypes.POINTER(PfTiming), i32]
+        L.pf_engine_set_timing.argtypes = [vp, i32]
         dp = ctypes.POINTER(ctypes.c_double)
         L.pf_engine_energy_cfg.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, dp]
         L.pf_engine_run_energy.argtypes = [vp, i64, i64, dp, dp, dp]
@@ -118,6 +129,12 @@ def lib():
         L.pf_run_sim_devices.argtypes = [ctypes.POINTER(PfSimData), i32, ctypes.POINTER(i32), ctypes.POINTER(PfOpts)]
         L.pf_slab_partition.argtypes = [ctypes.POINTER(PfSimData), i32, i32, ctypes.POINTER(i64)]
         L.pf_engine_set_spares.argtypes = [vp, vp, vp]
+        L.pf_multi_create.argtypes = [ctypes.POINTER(PfSimData), i32, ctypes.POINTER(i32), ctypes.POINTER(PfOpts), ctypes.POINTER(vp)]
+        L.pf_multi_run.argtypes = [vp, i64, i64]
+        L.pf_multi_get_info.argtypes = [vp, ctypes.POINTER(PfMultiInfo)]
+        L.pf_multi_get_slab.argtypes = [vp, i32, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(vp)]
+        L.pf_multi_destroy.argtypes = [vp]
+        L.pf_multi_destroy.restype = None
         _LIB = L
     return _LIB
 
@@ -149,16 +166,80 @@ def run_sim_devices(sd, devices, multi_flags=0, **opts):
     slabs on one GPU).  opts: numerics, air_variant, readout_chunk, debug.  Fills sd.u_out, returns seconds."""
     L = lib()
     s = sd.as_struct()
-    o = PfOpts()
-    L.pf_opts_default(ctypes.byref(o))
-    for k, v in opts.items():
-        setattr(o, k, int(v))
-    o.multi_flags = int(multi_flags)
+    o = _multi_opts(multi_flags, opts)
     devs = (ctypes.c_int32 * len(devices))(*[int(d) for d in devices])
     el = L.pf_run_sim_devices(ctypes.byref(s), len(devices), devs, ctypes.byref(o))
     if el < 0:
         raise PfError(f"pf_run_sim_devices failed: {L.pf_last_error().decode()}")
     return el
+
+
+def _multi_opts(multi_flags, opts):
+    o = PfOpts()
+    lib().pf_opts_default(ctypes.byref(o))
+    for k, v in opts.items():
+        setattr(o, k, int(v))
+    o.multi_flags = int(multi_flags)
+    return o
+
+
+class HipMulti:
+    """A chain of Z-slabs on several devices behind ONE C object (pf_multi_create): one persistent host thread per slab,
+    ghost planes by peer copies or RCCL.  devices[g] = HIP device of slab g (ids may repeat: virtual slabs on one GPU).
+    opts: pf_opts fields common to all slabs (numerics, air_variant, readout_chunk, debug, timing, transport,
+    verify_exchange)."""
+
+    def __init__(self, sd, devices, multi_flags=0, **opts):
+        L = lib()
+        self.sd = sd
+        self._s = sd.as_struct()
+        o = _multi_opts(multi_flags, opts)
+        devs = (ctypes.c_int32 * len(devices))(*[int(d) for d in devices])
+        self._h = ctypes.c_void_p()
+        _check(L.pf_multi_create(ctypes.byref(self._s), len(devices), devs, ctypes.byref(o), ctypes.byref(self._h)))
+        self.nslabs = len(devices)
+
+    def run(self, n0, nsteps):
+        _check(lib().pf_multi_run(self._h, int(n0), int(nsteps)))
+
+    def info(self):
+        i = PfMultiInfo()
+        _check(lib().pf_multi_get_info(self._h, ctypes.byref(i)))
+        return {"nslabs": i.nslabs, "transport": i.transport, "transport_name": i.transport_name.decode(),
+                "rccl_self": bool(i.rccl_self), "exchanges_checked": i.exchanges_checked,
+                "exchange_verified": None if i.exchange_verified < 0 else bool(i.exchange_verified),
+                "exchange_nonzero": bool(i.exchange_nonzero), "plane_bytes": i.plane_bytes,
+                "last_run_seconds": i.last_run_seconds}
+
+    def slab(self, g):
+        """-> dict(x0, x1, device, paired, engine): engine = a non-owning HipEngine view of slab g's engine (state_grids, timing)"""
+        x0, x1, dev, pr, eh = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_void_p()
+        _check(lib().pf_multi_get_slab(self._h, int(g), ctypes.byref(x0), ctypes.byref(x1), ctypes.byref(dev), ctypes.byref(pr), ctypes.byref(eh)))
+        return {"x0": x0.value, "x1": x1.value, "device": dev.value, "paired": bool(pr.value), "engine": _EngineView(eh, self.sd.real_bytes)}
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().pf_multi_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _EngineView:
+    """Borrowed handle of an engine owned by a HipMulti: inspection calls only."""
+
+    def __init__(self, handle, real_bytes):
+        self._h = handle
+        self.dtype = np.float32 if real_bytes == 4 else np.float64
+
+    state_grids = lambda self: HipEngine.state_grids(self)  # noqa: E731
+    timing = lambda self, reset=False: HipEngine.timing(self, reset)  # noqa: E731
+    sync = lambda self: HipEngine.sync(self)  # noqa: E731
+    set_timing = lambda self, on: HipEngine.set_timing(self, on)  # noqa: E731
 
 
 def slab_partition(sd, nslabs, even=False):
@@ -272,6 +353,9 @@ class HipEngine:
                 "steps": t.steps, "tb2_ms_total": t.tb2_ms_total, "tb2_launches": t.tb2_launches, "tb2_cells": t.tb2_cells,
                 "tune_ms": list(t.tune_ms), "air_path": t.air_path, "tb2_lw": t.tb2_lw, "tb2_dirty_tiles": t.tb2_dirty_tiles,
                 "place_candidates": t.place_candidates, "place_ms": list(t.place_ms)}
+
+    def set_timing(self, on):
+        _check(lib().pf_engine_set_timing(self._h, int(bool(on))))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -126,3 +126,60 @@ def test_fcc_slabs_in_temporally_blocked_pairs(prec):
         sd = make()
         engine.run_sim_devices(sd, devs, multi_flags=engine.PF_MULTI_FORCE_PAIRS, air_variant=40)
         assert np.array_equal(sd.u_out, ref.u_out), devs
+
+
+# ---- the chain as an object (pf_multi_*): transports, exchange self-check --------------------------------------------
+@pytest.mark.parametrize("transport,flags", [(engine.PF_TRANSPORT_PEER, 0), (engine.PF_TRANSPORT_RCCL, 0),
+                                             (engine.PF_TRANSPORT_RCCL, engine.PF_MULTI_ONE_THREAD)])
+@pytest.mark.parametrize("name,prec", [("cart_outside", "single"), ("fcc2_mb11", "double")])
+def test_chain_object_both_transports_checked_exchanges(transport, flags, name, prec):
+    """pf_multi_create / _run in pieces / _destroy on three virtual slabs: ghost planes by device copies and by RCCL
+    (ncclSend / ncclRecv on the edge stream; on one device every slab owns a 1-rank communicator and sends the neighbour's
+    plane to itself), every exchange checksummed on both sides, receivers = the single-domain oracle's bit for bit"""
+    want = _ref(name, prec)
+    sd = cases.make_sd(name, prec)
+    m = engine.HipMulti(sd, [0, 0, 0], multi_flags=flags, transport=transport, verify_exchange=int(sd.Nt))
+    m.run(0, 7)
+    m.run(7, int(sd.Nt) - 7)
+    info = m.info()
+    sl = [m.slab(g) for g in range(3)]
+    m.close()
+    assert info["nslabs"] == 3 and info["transport"] == transport
+    assert ("rccl" in info["transport_name"]) == (transport == engine.PF_TRANSPORT_RCCL)
+    assert info["exchange_verified"] is True and info["exchanges_checked"] == sd.Nt and info["exchange_nonzero"]
+    assert sl[0]["x0"] == 0 and sl[2]["x1"] == sd.Nx and sl[0]["x1"] == sl[1]["x0"]
+    assert np.array_equal(sd.u_out, want)
+
+
+@pytest.mark.parametrize("transport", [engine.PF_TRANSPORT_PEER, engine.PF_TRANSPORT_RCCL])
+def test_chain_object_pairs_through_both_transports(transport):
+    kw = dict(Nx=100, Ny=70, Nz=276, Nt=45, wall=3, Nm=1, Mb=3, src=[47, 30, 100], rcv=[[30, 25, 96], [66, 36, 110], [48, 35, 104], [47, 4, 101]])
+    sd = sim_data.SimData.from_sim(synth.shoebox(**kw), "single")
+    sd.scale_input()
+    oracle.run_sim(sd)
+    want = sd.u_out.copy()
+    sd2 = sim_data.SimData.from_sim(synth.shoebox(**kw), "single")
+    sd2.scale_input()
+    m = engine.HipMulti(sd2, [0, 0], multi_flags=engine.PF_MULTI_FORCE_PAIRS, air_variant=40, transport=transport, verify_exchange=45)
+    m.run(0, 45)
+    info, paired = m.info(), [m.slab(g)["paired"] for g in range(2)]
+    m.close()
+    assert all(paired) and info["exchange_verified"] is True
+    assert np.array_equal(sd2.u_out, want)
+
+
+def test_exchange_self_check_notices_a_missing_plane(tmp_path):
+    """PFFDTD_TEST_DROP_EXCHANGE=n makes slab 1 skip the pull of its ghost planes in step n: the run must fail, naming the check"""
+    code = ("import sys; sys.path[:0] = [%r, %r]; import cases; from pffdtd_amd import engine; "
+            "sd = cases.make_sd('cart_outside', 'single'); "
+            "engine.run_sim_devices(sd, [0, 0, 0], verify_exchange=int(sd.Nt))" % (str(ROOT), str(ROOT / "tests")))
+    r = subprocess.run([os.sys.executable, "-c", code], env={**os.environ, "PFFDTD_TEST_DROP_EXCHANGE": "40"}, capture_output=True, text=True)
+    assert r.returncode != 0 and "self-check failed" in r.stderr, r.stderr[-1500:]
+    r = subprocess.run([os.sys.executable, "-c", code], env=os.environ, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+
+
+def test_transport_requests_are_validated():
+    sd = cases.make_sd("cart_rigid", "single")
+    with pytest.raises(engine.PfError, match="transport"):
+        engine.HipMulti(sd, [0, 0], transport=7)
