@@ -76,9 +76,11 @@ typedef enum pf_status {
 } pf_status;
 
 /* numerics modes */
-#define PF_NUM_CPU_EXACT 0 /* operation order and rounding of cpu_engine.h:174-301,363-405; no FMA contraction:
-                              results are bit-identical to the reference C CPU engine */
-#define PF_NUM_FMA       1 /* same association, FMA contraction allowed (faster VALU, not bit-identical) */
+#define PF_NUM_CPU_EXACT       0 /* operation order and rounding of the reference C CPU engine (cpu_engine.h:174-301,363-405), no
+                                    contraction: results are bit-identical to it (the parity target) */
+#define PF_NUM_GPU_SAFEGUARDED 2 /* the reference GPU engine's arithmetic for the air and rigid-node updates (fdtd_common.h:44-71,
+                                    gpu_engine.h:220-274,288-348): pairwise neighbour sums -- in fp32 rounded TOWARDS ZERO, its
+                                    long-run stability safeguard -- then two round-to-nearest FMAs; single-step kernels only */
 
 typedef struct pf_opts {
    int32_t device;        /* HIP device ordinal */
@@ -86,20 +88,18 @@ typedef struct pf_opts {
    int32_t slab_first;    /* 1 if this grid holds the global ix=0 ghost plane (gpu_engine.h:1030-1032) */
    int32_t slab_last;     /* 1 if this grid holds the global ix=Nx-1 ghost plane (gpu_engine.h:1033-1035) */
    int32_t readout_chunk; /* receiver ring depth in steps before a D2H flush (0 = default) */
-   int32_t air_variant;   /* 0 = automatic; 1-9 unfused marching kernels, 10-14 generic fused, 20-28 lean fused 7-point
-                             (25 = the single-step default), 40/41 temporal blocking forced / driver only; see DESIGN.md 4 */
+   int32_t air_variant;   /* 0 = automatic (measured at creation); 3 = the reference's kernel sequence (flips, air, ABC lists); 4 / 7 =
+                             barrier-free marching kernel with virtual ghosts / in-kernel ABC; 25 = lean fused kernel (7-point); 40 =
+                             temporally blocked pairs forced (41: their driver only); | 256 = separate rigid / branch-ODE kernels */
    int32_t air_chunk;     /* planes marched per workgroup (0 = auto, <0 = that many equal chunks) */
    int32_t timing;        /* 1 = bracket the air kernel with HIP events every step (pf_engine_timing) */
    void   *ext_u0;        /* optional caller-owned DEVICE buffers for the two state grids, each of */
    void   *ext_u1;        /*   pf_grid_bytes() bytes, zero-filled by the caller; NULL = engine allocates */
    int32_t x_global0;     /* global ix of this grid's plane 0 (slabs): only its parity matters, for the FCC
                              checkerboard form (fcc_flag 1) whose existing nodes have even ix+iy+iz */
-   int32_t debug;         /* tuning switches, 0 in production: 0x100 / 0x200 force 32- / 16-lane row segments in the
-                             barrier-free kernels, 0x400 forces 64; 0x800 in-kernel rigid update from a cell-byte grid;
-                             0x2000 column-strip kernel does rigid update AND branch ODEs of the boundary nodes inside its strips (default: rigid only, ODEs in a dense pass), 0x20000000: neither (list kernel visits every node); 0x4000 single
-                             steps only (no temporally blocked pairs); 0x8000 no creation-time measurement (static
-                             rules pick the interior kernel); bits 16-23 x chunk of the column-strip kernel;
-                             0x10000000 keep a sliver z tile in the blocked kernel */
+   int32_t debug;         /* test switches, 0 in production: 0x100 / 0x200 / 0x400 force 32- / 16- / 64-lane row segments; 0x4000 single
+                             steps only (no blocked pairs); 0x8000 no creation-time measurement (static rules choose the kernel);
+                             0x20000000 the boundary-list kernel visits every node (none left to the column-strip kernel) */
    int32_t energy;        /* 1 = keep what the energy diagnostic needs (explicit Laplacian grid, unfused kernel
                              sequence); then use pf_engine_energy_cfg + pf_engine_run_energy */
    int32_t multi_flags;   /* pf_run_sim_devices / pf_multi_create only: PF_MULTI_* */

@@ -23,6 +23,10 @@ def lib():
             getattr(L, "oracle_run_sim" + sfx).restype = ctypes.c_double
             getattr(L, "oracle_run_sim" + sfx).argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                                                            ctypes.POINTER(ctypes.c_double)]
+            getattr(L, "oracle_run_sim_num" + sfx).restype = ctypes.c_double
+            getattr(L, "oracle_run_sim_num" + sfx).argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
+                                                               ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+            getattr(L, "orc_set_numerics" + sfx).argtypes = [ctypes.c_void_p, ctypes.c_int]
             getattr(L, "orc_create" + sfx).restype = ctypes.c_void_p
             getattr(L, "orc_create" + sfx).argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
             getattr(L, "orc_step" + sfx).argtypes = [ctypes.c_void_p, ctypes.c_int64]
@@ -55,14 +59,15 @@ def _sfx(sd):
     return "_f32" if sd.real_bytes == 4 else "_f64"
 
 
-def run_sim(sd, threads=None):
-    """oracle analogue of run_sim(struct SimData*): fills sd.u_out, returns (elapsed, t_air, t_bn)."""
+def run_sim(sd, threads=None, safeguarded=False):
+    """oracle analogue of run_sim(struct SimData*): fills sd.u_out, returns (elapsed, t_air, t_bn).
+    safeguarded=True: the arithmetic of the reference's CUDA engine instead of its C CPU engine's (parity unpinned)."""
     L = lib()
     if threads:
         L.oracle_set_threads(int(threads))
     s = sd.as_struct()
     ta, tb = ctypes.c_double(), ctypes.c_double()
-    el = getattr(L, "oracle_run_sim" + _sfx(sd))(ctypes.byref(s), ctypes.byref(ta), ctypes.byref(tb))
+    el = getattr(L, "oracle_run_sim_num" + _sfx(sd))(ctypes.byref(s), ctypes.byref(ta), ctypes.byref(tb), int(bool(safeguarded)))
     if el < 0:
         raise RuntimeError("oracle_run_sim failed")
     return el, ta.value, tb.value
@@ -71,7 +76,7 @@ def run_sim(sd, threads=None):
 class Engine:
     """Step-wise oracle engine (used by the slab tests as the per-slab stepper and for grid comparisons)."""
 
-    def __init__(self, sd, slab_first=True, slab_last=True):
+    def __init__(self, sd, slab_first=True, slab_last=True, safeguarded=False):
         self.L = lib()
         self.sd = sd
         self.sfx = _sfx(sd)
@@ -79,6 +84,8 @@ class Engine:
         self.h = getattr(self.L, "orc_create" + self.sfx)(ctypes.byref(self._s), int(slab_first), int(slab_last))
         if not self.h:
             raise RuntimeError("orc_create failed")
+        if safeguarded:
+            getattr(self.L, "orc_set_numerics" + self.sfx)(self.h, 1)
 
     def step(self, n):
         getattr(self.L, "orc_step" + self.sfx)(self.h, int(n))

@@ -8,12 +8,17 @@
  * where they lie under /root/reference) and against the golden vectors under tests/golden/ that
  * were captured from those binaries.
  *
+ * A second mode (orc_set_numerics / oracle_run_sim_num with safeguarded = 1) restates the arithmetic of the reference's CUDA
+ * engine (c_cuda/gpu_engine.h:220-274,288-365); that mode is PARITY-UNPINNED (no nvcc here), see pf_oracle_impl.inc.
+ *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  * Build: see oracle/Makefile (-O3 -fopenmp -ffp-contract=off, baseline x86-64 like the reference Makefile).
  */
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fenv.h>
+#include <math.h>
 #include <omp.h>
 #include "pffdtd_hip.h"
 

@@ -106,21 +106,16 @@ template <typename Real> struct Engine : EngineBase {
    std::vector<float> place_ms;                           // sample_placement: ms per launch of every candidate
    bool tb2_probe = false;                                // launch_tb2 under its creation-time name (k_tb2_reg<..., PROBE>)
    std::vector<Real *> own_list;
-   uint8_t *mask = nullptr;      // skip-mask of the unfused kernels (boundary nodes + ghost z + pad + parity)
-   uint8_t *mask_bn = nullptr;   // boundary nodes only (fused kernel)
-   int32_t *segstart = nullptr;  // first boundary node of every (row, z segment) (fused rigid update)
-   uint8_t *adj_dense = nullptr; // lean kernel with in-kernel rigid update: adjacency byte per padded cell
-   bool lean_rigid = false;
+   uint8_t *mask = nullptr;      // skip-mask (boundary nodes + ghost z + pad + parity)
    Real *v1_dst = nullptr;       // autotune: destination of the barrier-free 7-point kernel (null = in place)
    int lw_force = 0;             // autotune: lanes per row segment of the barrier-free kernels (0 = pick_lw's rule)
    float tune_ms[3] = {0, 0, 0}; // measured at creation: lean / barrier-free / blocked pair (per step), ms
-   bool v1_rigb = false;         // barrier-free 7-point kernel with the rigid update in-kernel from a cell-byte grid
-   uint8_t *cellb = nullptr;     // that grid: 0 air, 0x40 skip, 0x80|adjacency at boundary nodes
-   bool fused = false, fused_rigid = false, lean = false, need_fold_row = false;
-   bool vg = false;          // unfused marching kernels with virtual ghost shell + in-kernel ABC (variants 4-6)
-   bool abck = false;        // unfused marching kernels with memory flips but the ABC loss in-kernel (variants 7, 8)
-   int vbase = 0;            // air_variant without its flag bits (64: no XCD swizzle, 128: old fused kernel without rigid fusion)
-   int fused_nzt = 0;
+   bool lean = false, need_fold_row = false; // lean: the fused 7-point kernel of pf_air_fused.h (air_variant 25)
+   bool vg = false;          // barrier-free marching kernel with virtual ghost shell + in-kernel ABC (air_variant 4)
+   bool abck = false;        // barrier-free marching kernel with memory flips but the ABC loss in-kernel (air_variant 7)
+   int vbase = 0;            // air_variant without its flag bit (256: separate rigid / branch-ODE kernels)
+   bool sg = false;          // PF_NUM_GPU_SAFEGUARDED
+   int lean_nzt = 0;
    int64_t *d_bn = nullptr, *d_bnl = nullptr, *d_bna = nullptr, *d_in = nullptr, *d_out = nullptr;
    uint16_t *d_adj = nullptr;
    int32_t *d_lossy = nullptr;   // per boundary node: index into the lossy-node arrays or -1 (fused boundary pass)
@@ -171,7 +166,7 @@ template <typename Real> struct Engine : EngineBase {
    // 13-point pairs (folded FCC): whatever of the box is not a clean tile's core is stepped by k_air_fcc over its own tiles
    // (256 columns x 16 rows x the same x chunks), listed here
    int32_t *sh_tiles = nullptr;
-   int fcc_wt = 8; // waves per workgroup of k_tb2_fcc_x (two of them halo providers); 0: the register-only k_tb2_fcc
+   static constexpr int fcc_wt = 8; // waves per workgroup of k_tb2_fcc_x (two of them halo providers)
    int64_t sh_ntiles = 0;
    int sh_nyt = 0, sh_nzt = 0;
    const Real *u0_src = nullptr;                          // out-of-place single-step launches read u^{n-1} here
@@ -184,7 +179,7 @@ template <typename Real> struct Engine : EngineBase {
    int32_t *zs_li = nullptr;
    int32_t *zs_rest = nullptr;                            // the other boundary nodes (positions in the boundary list)
    int64_t zs_nrest = 0;
-   int zs_mode = 0;                                       // 0: list kernel does them; 1: strip kernel, rigid + FD inline (debug 0x2000);
+   int zs_mode = 0;                                       // 0: the list kernel does them (debug 0x20000000, and the fallback);
                                                           // 2: strip kernel does the rigid update, k_fd_sel the branch ODEs (default)
    int32_t *zs_fd = nullptr;                              // mode 2: the lossy nodes (indices into the lossy arrays) inside the strips
    int64_t zs_nfd = 0;
@@ -206,7 +201,7 @@ template <typename Real> struct Engine : EngineBase {
       auto F = [](void *p) { if (p) hipFree(p); };
       for (Real *g : own_list) F(g); // state grids this engine allocated (u0/u1 unless external, the temporal-blocking spares)
       own_list.clear();
-      F(d_lossy); F(mask); F(mask_bn); F(cellb); F(zs_map); F(zs_adj); F(zs_li); F(zs_rest); F(zs_fd); F(tb_clean); F(tb_dirty); F(sh_tiles); F(segstart); F(adj_dense); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
+      F(d_lossy); F(mask); F(zs_map); F(zs_adj); F(zs_li); F(zs_rest); F(zs_fd); F(tb_clean); F(tb_dirty); F(sh_tiles); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
       F(d_beta); F(d_insig); F(d_mq); F(ub[0]); F(ub[1]); F(ub[2]); F(u2ba); F(vh1); F(gh1); F(ring);
       if (h_ring) hipHostFree(h_ring);
       for (auto &p : air_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -328,6 +323,7 @@ template <typename Real> struct Engine : EngineBase {
       HIPCHK(hipEventCreateWithFlags(&ev_edge, hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
       use_dpp = check_dpp(s_main) == 1;
+      if (!use_dpp) return set_err(PF_ERR_HIP, "DPP wave-shift self-test failed on device %d: this library is built for gfx950 (wave64, row_shr / row_shl with bank masks)", op.device);
 
       // ---- state grids ----
       if (op.ext_u0 && op.ext_u1) {
@@ -377,73 +373,49 @@ template <typename Real> struct Engine : EngineBase {
          if ((rc = upload(&d_adj, adj.data(), Nb))) return rc;
          plane_ranges(idx, bn_lo, bn_mid, bn_hi);
          plane_ranges(idx, bn_lo2, bn_mid2, bn_hi2, 2);
-         // which interior path? 0 = auto; 1-3 unfused marching kernels; 9 naive; 10-14 generic fused kernel
-         // (virtual ghosts + ABC + rigid in-kernel); 20-24 lean fused 7-point kernel (virtual ghosts + ABC)
-         vbase = op.air_variant & 63;
+         // which interior path?  0 = automatic; 3 = the reference's kernel sequence (memory flips, marching kernel, ABC list
+         // kernels); 4 = barrier-free marching kernel with virtual ghost shell + in-kernel ABC; 7 = the same with the flips in
+         // memory (the 13-point default); 25 = lean fused kernel (7-point); 40 / 41 = temporally blocked pairs forced / driver only
+         vbase = op.air_variant & 255;
+         if (op.air_variant & ~(255 | 256)) return set_err(PF_ERR_ARG, "air_variant %d: unknown flag bits", op.air_variant);
+         if (vbase != 0 && vbase != 3 && vbase != 4 && vbase != 7 && vbase != 25 && vbase != 40 && vbase != 41)
+            return set_err(PF_ERR_ARG, "air_variant %d: choose 0 (auto), 3 (unfused reference sequence), 4 / 7 (barrier-free kernel: virtual ghosts / "
+                                       "in-kernel ABC), 25 (lean fused kernel, 7-point), 40 / 41 (blocked pairs); the other variants were retired", op.air_variant);
+         if (op.numerics != PF_NUM_CPU_EXACT && op.numerics != PF_NUM_GPU_SAFEGUARDED)
+            return set_err(PF_ERR_ARG, "numerics must be PF_NUM_CPU_EXACT (0) or PF_NUM_GPU_SAFEGUARDED (2)");
+         sg = op.numerics == PF_NUM_GPU_SAFEGUARDED;
+         if (sg && !use_dpp) return set_err(PF_ERR_ARG, "the safeguarded numerics run on the DPP builds of the kernels only");
          const bool ok = fused_ok();
-         if (op.energy) { if (vbase >= 10 || (vbase >= 4 && vbase <= 8)) return set_err(PF_ERR_ARG, "the energy diagnostic runs the unfused kernels (air_variant 0-9)"); lean = fused = false; }
-         else if (vbase == 0) {
-            // 13-point: the unfused marching kernel is faster; narrow rows (most of the last 256-column segment idle):
-            // the barrier-free unfused kernel loses less to the idle lanes (measured)
-            const int64_t Wseg = 64 * pf::VecOf<Real>::V;
-            const double lane_util = (double)P / (double)(cdiv(P, Wseg) * Wseg);
-            lean = ok && !fcc && lane_util >= 0.8;
-            fused = false;
+         // narrow rows (most of the last 256-column segment idle): the barrier-free kernel loses less to the idle lanes
+         const int64_t Wseg = 64 * pf::VecOf<Real>::V;
+         const bool wide = (double)P / (double)(cdiv(P, Wseg) * Wseg) >= 0.8;
+         if (op.energy) { if (vbase != 0 && vbase != 3) return set_err(PF_ERR_ARG, "the energy diagnostic runs the unfused kernel sequence (air_variant 0 or 3)"); }
+         else if (vbase == 0 || vbase == 40 || vbase == 41) {
+            if ((vbase == 40 || vbase == 41) && !ok) return set_err(PF_ERR_ARG, "air_variant %d (blocked pairs) requested but the fused-path preconditions do not hold", op.air_variant);
+            lean = ok && !fcc && (wide || vbase != 0);
             abck = ok && fcc;          // 13-point: flips stay in memory, the ABC loss moves into the interior kernel
-            vg = ok && !lean && !fcc; // narrow 7-point rows: barrier-free marching kernel, still without flip / ABC launches
-                                      // (13-point: the ghost patches on 3x(R+2) rows cost more than the flip kernels they replace)
+            vg = ok && !lean && !fcc; // (13-point: the ghost patches on 3x(R+2) rows cost more than the flip kernels they replace)
          }
-         else if (vbase == 7 || vbase == 8) { abck = true; if (!ok) return set_err(PF_ERR_ARG, "air_variant %d (in-kernel ABC) requested but its preconditions do not hold", op.air_variant); }
-         else if (vbase >= 4 && vbase <= 6) { vg = true; if (!ok) return set_err(PF_ERR_ARG, "air_variant %d (virtual ghost shell) requested but its preconditions do not hold", op.air_variant); }
-         else if (fcc && (vbase == 40 || vbase == 41)) { abck = true; if (!ok) return set_err(PF_ERR_ARG, "air_variant %d (blocked pairs) requested but the fused-path preconditions do not hold", op.air_variant); }
-         else if (vbase >= 20) { lean = true; fused = false; }
-         else if (vbase >= 10) { fused = true; lean = false; }
-         if ((lean || fused) && !ok)
-            return set_err(PF_ERR_ARG, "air_variant %d (fused kernel) requested but its preconditions do not hold", op.air_variant);
-         if (lean && fcc && (vbase >= 30)) return set_err(PF_ERR_ARG, "the LDS-DMA kernel is 7-point Cartesian only");
-         fused_rigid = fused && !(op.air_variant & 128);
+         else if (vbase == 7) { abck = true; if (!ok) return set_err(PF_ERR_ARG, "air_variant 7 (in-kernel ABC) requested but its preconditions do not hold"); }
+         else if (vbase == 4) { vg = true; if (!ok) return set_err(PF_ERR_ARG, "air_variant 4 (virtual ghost shell) requested but its preconditions do not hold"); }
+         else if (vbase == 25) {
+            lean = true;
+            if (fcc) return set_err(PF_ERR_ARG, "air_variant 25 (lean fused kernel) is 7-point Cartesian only");
+            if (!ok) return set_err(PF_ERR_ARG, "air_variant 25 (lean fused kernel) requested but its preconditions do not hold");
+         }
          need_fold_row = fold && !rigid_separable();
-         // 7-point lean kernel with the rigid boundary update fused in (variants 0/auto, 27, 28)
-         lean_rigid = lean && !fcc && Nb > 0 && (vbase == 27 || vbase == 28); // correct but slower than the list kernel
-         v1_rigb = vg && !fcc && Nb > 0 && use_dpp && (vbase == 0 || vbase == 4) && want_rigb();
          HIPCHK(hipDeviceSynchronize()); // memsets above ran on the null stream; our streams are non-blocking
-         if (fused) {
-            if ((rc = dzalloc(&mask_bn, npad / 8))) return rc;
-            HIPCHK(hipDeviceSynchronize());
-            if (Nb) hipLaunchKernelGGL(pf::k_mask_set, dim3((unsigned)cdiv(Nb, 256)), dim3(256), 0, s_main, mask_bn, d_bn, Nb);
-            constexpr int V = pf::VecOf<Real>::V;
-            fused_nzt = (int)cdiv(P, 64 * V);
-            const int64_t nseg = Nx * Ny * fused_nzt;
-            if (Nb >= (int64_t)1 << 31) return set_err(PF_ERR_ARG, "too many boundary nodes for 32-bit ranks");
-            if ((rc = dzalloc(&segstart, nseg))) return rc;
-            HIPCHK(hipDeviceSynchronize());
-            hipLaunchKernelGGL(pf::k_segstart, dim3((unsigned)cdiv(nseg, 256)), dim3(256), 0, s_main, d_bn, Nb, segstart, Nx * Ny, fused_nzt, P, 64 * V);
-         } else if (lean_rigid) {
-            fused_nzt = (int)cdiv(P, 64 * pf::VecOf<Real>::V);
-            if ((rc = dzalloc(&mask_bn, npad / 8))) return rc;
-            if ((rc = dzalloc(&adj_dense, npad + 64))) return rc;
-            HIPCHK(hipDeviceSynchronize());
-            hipLaunchKernelGGL(pf::k_mask_set, dim3((unsigned)cdiv(Nb, 256)), dim3(256), 0, s_main, mask_bn, d_bn, Nb);
-            hipLaunchKernelGGL(pf::k_adj_dense_set, dim3((unsigned)cdiv(Nb, 256)), dim3(256), 0, s_main, adj_dense, d_bn, d_adj, Nb);
-         } else {
-            fused_nzt = (int)cdiv(P, 64 * pf::VecOf<Real>::V);
-            // skip-mask: ghost z / pad / parity, then the boundary nodes
-            if ((rc = dzalloc(&mask, npad / 8))) return rc;
-            HIPCHK(hipDeviceSynchronize());
-            {
-               const int64_t nrows = Nx * Ny;
-               dim3 gm((unsigned)cdiv(P / 8, 64), (unsigned)std::min<int64_t>(nrows, 65535), (unsigned)cdiv(nrows, 65535));
-               hipLaunchKernelGGL(pf::k_mask_init, gm, dim3(64), 0, s_main, mask, Nx, Ny, P, Nz,
-                               sd.fcc_flag == 1 ? 1 + (op.x_global0 & 1) : 0);
-            }
-            if (Nb) hipLaunchKernelGGL(pf::k_mask_set, dim3((unsigned)cdiv(Nb, 256)), dim3(256), 0, s_main, mask, d_bn, Nb);
-            if (v1_rigb) {
-               if ((rc = dzalloc(&cellb, npad + 64))) return rc;
-               HIPCHK(hipDeviceSynchronize());
-               hipLaunchKernelGGL(pf::k_cellbytes_init, dim3((unsigned)cdiv(npad, 256)), dim3(256), 0, s_main, cellb, Nx * Ny, P, Nz);
-               hipLaunchKernelGGL(pf::k_adj_dense_set, dim3((unsigned)cdiv(Nb, 256)), dim3(256), 0, s_main, cellb, d_bn, d_adj, Nb);
-            }
+         lean_nzt = (int)cdiv(P, 64 * pf::VecOf<Real>::V);
+         // skip-mask: ghost z / pad / parity, then the boundary nodes
+         if ((rc = dzalloc(&mask, npad / 8))) return rc;
+         HIPCHK(hipDeviceSynchronize());
+         {
+            const int64_t nrows = Nx * Ny;
+            dim3 gm((unsigned)cdiv(P / 8, 64), (unsigned)std::min<int64_t>(nrows, 65535), (unsigned)cdiv(nrows, 65535));
+            hipLaunchKernelGGL(pf::k_mask_init, gm, dim3(64), 0, s_main, mask, Nx, Ny, P, Nz,
+                            sd.fcc_flag == 1 ? 1 + (op.x_global0 & 1) : 0);
          }
+         if (Nb) hipLaunchKernelGGL(pf::k_mask_set, dim3((unsigned)cdiv(Nb, 256)), dim3(256), 0, s_main, mask, d_bn, Nb);
          HIPCHK(hipGetLastError());
       }
       { // lossy nodes
@@ -527,6 +499,11 @@ template <typename Real> struct Engine : EngineBase {
       graph_ok = false;
       if (const char *ev = getenv("PFFDTD_GRAPH"))
          graph_ok = ev[0] == '1' && op.slab_first && op.slab_last && !tb2 && !op.timing && !op.energy;
+      if (getenv("PFFDTD_VERBOSE") && atoi(getenv("PFFDTD_VERBOSE")) > 0)
+         fprintf(stderr, "pffdtd_hip: engine on device %d, %ldx%ldx%ld %s %s, interior path: %s%s, numerics: %s\n", op.device, (long)Nx, (long)Ny, (long)Nz,
+                 fcc ? "13-point" : "7-point", sizeof(Real) == 4 ? "fp32" : "fp64",
+                 tb2 ? "temporally blocked pairs" : (lean ? "lean fused kernel" : (vg ? "barrier-free kernel, virtual ghosts" : (abck ? "barrier-free kernel, in-kernel ABC" : "unfused reference sequence"))),
+                 tb2_geom && !tb2 ? " (pairs when the caller hands over four grids)" : "", sg ? "GPU-safeguarded" : "CPU-exact");
       HIPCHK(hipDeviceSynchronize());
       return PF_OK;
    }
@@ -540,13 +517,12 @@ template <typename Real> struct Engine : EngineBase {
    // off and nothing changes.  air_variant 0 (auto) and 40 enable it, 41 = same driver with the box disabled (tests).
    int init_tb2() {
       tb2 = tb2_geom = tb2_slab = false;
-      if (const char *ev = getenv("PFFDTD_TB2_CHUNK")) tb2_chunk = std::min(std::max(atoi(ev), 4), 256);
       const bool single = op.slab_first && op.slab_last;
-      if (lean_rigid || v1_rigb || op.energy || (op.debug & 0x4000)) return PF_OK; // 0x4000: single steps only
+      if (op.energy || (op.debug & 0x4000)) return PF_OK; // 0x4000: single steps only
       // 7-point: the fused single-step kernels carry the shell; 13-point: folded grids with the flips in memory and the ABC
       // loss in the interior kernel (the automatic 13-point arrangement)
       if (fcc ? !(fold && abck) : !(lean || vg)) return PF_OK;
-      if (!(vbase == 0 || vbase == 40 || vbase == 41) || op.numerics != PF_NUM_CPU_EXACT || !use_dpp) return PF_OK;
+      if (!(vbase == 0 || vbase == 40 || vbase == 41) || sg || !use_dpp) return PF_OK; // (the blocked kernels exist in the CPU-exact arithmetic only)
       if (Nb > 0 && !boundary_fused()) return PF_OK;
       // Margins of the box: three cells off every grid face (the ABC cells sit at index 1 and the box must stay two cells
       // away from anything that is not a plain air update), deeper where a wall layer hugs the face -- a face whose plane at
@@ -583,7 +559,7 @@ template <typename Real> struct Engine : EngineBase {
             const int TC = (lw - 2) * V;
             int z1 = (int)((Nz - mz1) / 4 * 4);
             const int nz = z1 - tbz0, rem = nz % TC;
-            if (!(op.debug & 0x10000000) && nz > TC && rem > 0 && rem * (int)sizeof(Real) <= 256) z1 -= rem;
+            if (nz > TC && rem > 0 && rem * (int)sizeof(Real) <= 256) z1 -= rem;
             if (z1 - tbz0 < TC / 2) continue;
             const int64_t lanes = cdiv(z1 - tbz0, TC) * lw;
             if (best < 0 || lanes < best) { best = lanes; tb_lw = lw; tbz1 = z1; }
@@ -594,14 +570,13 @@ template <typename Real> struct Engine : EngineBase {
       if (vbase == 41) tbx1 = tbx0; // driver test: everything goes through the out-of-place single-step path
       tb_xr.clear();
       // rows of a workgroup: 4 waves x R = 3 (7-point); 13-point: 6 inner waves x R = 2 with 64-lane segments (k_tb2_fcc_x), else 4 x 2
-      if (const char *ev = getenv("PFFDTD_FCC_WT")) { const int v = atoi(ev); if (v == 6 || v == 8 || v == 0) fcc_wt = v; }
       const int TC = (tb_lw - 2) * V, TR = fcc ? ((tb_lw == 64 && fcc_wt) ? 2 * (fcc_wt - 2) : 8 * (64 / tb_lw)) : 12 * (64 / tb_lw);
       int64_t vol = 0;
       if (tbx1 - tbx0 >= 16 && tby1 - tby0 >= 24 && tbz1 - tbz0 >= TC / 2) {
          tb_xr.push_back({tbx0, tbx1});
          const int np = tbx1 - tbx0;
          // ~16-plane chunks, even split (tools/tb2_probe.py); 13-point: ~24 (3.93 vs 4.07 ms per launch at 1024^3, 32-48 the same)
-         const int want_chunk = (fcc && !getenv("PFFDTD_TB2_CHUNK")) ? 24 : tb2_chunk;
+         const int want_chunk = fcc ? 24 : tb2_chunk;
          tb_chunk = (int)cdiv(np, std::max<int64_t>(cdiv(np, want_chunk), 1));
          tb_nxc = (int)cdiv(np, tb_chunk); tb_nyt = (int)cdiv(tby1 - tby0, TR); tb_nzt = (int)cdiv(tbz1 - tbz0, TC);
          const int64_t ntile = (int64_t)tb_nxc * tb_nyt * tb_nzt;
@@ -632,7 +607,6 @@ template <typename Real> struct Engine : EngineBase {
                    (std::min(tby0 + (yt + 1) * TR, tby1) - (tby0 + yt * TR)) * (std::min(tbz0 + (zt + 1) * TC, tbz1) - (tbz0 + zt * TC));
          }
          tb_order_band = true;
-         if (const char *ev = getenv("PFFDTD_TB2_ORDER")) tb_order_band = ev[0] != 'd'; // "dense": plain tile order
          if (tb_order_band && !cl.empty()) {
             // XCD-banded order: hardware places block b on XCD b % 8; each XCD gets a contiguous band of the clean tiles of
             // every x chunk (tiles that share halo rows then share an L2), blocks b .. b+7 walking the 8 bands in step.
@@ -712,11 +686,11 @@ template <typename Real> struct Engine : EngineBase {
       // their six neighbours in registers (in k_boundary the floor / ceiling nodes of a box room -- stride-P neighbours,
       // one 128-byte line of u1 and of u0 per two nodes -- cost half of the pass: 0.30 of 0.63 ms at 1024^3).  The strip
       // kernel does the RIGID update only and leaves the result in u0b[li]; the branch ODEs of the lossy ones follow in
-      // k_fd_sel, dense over the compact arrays (mode 2).  Doing the ODEs inside the strip kernel as well (mode 1, debug
-      // 0x2000) is bit-identical but slower: they run on the few lanes per wave that hold a node (2.92 vs 2.59 ms per step).
-      // debug 0x20000000: mode 0, the list kernel visits every boundary node (the round-1 arrangement).
-      zs_mode = fcc ? 0 : ((op.debug & 0x2000) ? 1 : ((op.debug & 0x20000000) ? 0 : 2));
-      if (Nb > 0 && !tb_xr.empty() && zs_mode > 0 && Nbl < ((int64_t)1 << 31)) {
+      // k_fd_sel, dense over the compact arrays (mode 2).  (Doing the ODEs inside the strip kernel as well was bit-identical
+      // but slower -- they ran on the few lanes per wave that hold a node, 2.92 vs 2.59 ms per step -- and was retired.)
+      // debug 0x20000000: mode 0, the list kernel visits every boundary node (the round-1 arrangement; also the fallback).
+      zs_mode = fcc ? 0 : ((op.debug & 0x20000000) ? 0 : 2);
+      if (Nb > 0 && !tb_xr.empty() && zs_mode == 2 && Nbl < ((int64_t)1 << 31)) {
          const int xb = tb_xr.front().first, xe = tb_xr.back().second;
          constexpr int V = pf::VecOf<Real>::V;
          const int nl = szl / V, nv = nl + (int)(P - szr) / V;
@@ -753,10 +727,8 @@ template <typename Real> struct Engine : EngineBase {
             if ((rc = upload(&zs_adj, sadj.data(), (int64_t)sadj.size()))) return rc;
             if ((rc = upload(&zs_li, sli.data(), (int64_t)sli.size()))) return rc;
             if ((rc = upload(&zs_rest, rest.data(), zs_nrest))) return rc;
-            if (zs_mode == 2) {
-               zs_nfd = (int64_t)fd.size();
-               if ((rc = upload(&zs_fd, fd.data(), zs_nfd))) return rc;
-            }
+            zs_nfd = (int64_t)fd.size();
+            if ((rc = upload(&zs_fd, fd.data(), zs_nfd))) return rc;
          }
       } else zs_mode = 0;
       return PF_OK;
@@ -1072,7 +1044,7 @@ template <typename Real> struct Engine : EngineBase {
    }
    int autotune() {
       if (fcc) return autotune_fcc();
-      if (vbase != 0 || fcc || op.energy || (op.debug & 0x8000) || !use_dpp || !(lean || vg) || v1_rigb || lean_rigid) return PF_OK;
+      if (vbase != 0 || fcc || op.energy || (op.debug & 0x8000) || !use_dpp || !(lean || vg)) return PF_OK;
       if (Nx * Ny * Nz < ((int64_t)1 << 22)) return PF_OK; // tiny grids: launch-bound either way
       Real *scr = bufC;
       bool own = false;
@@ -1164,9 +1136,8 @@ template <typename Real> struct Engine : EngineBase {
       tp.tiles = (tb_ndirty > 0 || tb_order_band) ? tb_clean : nullptr; // all clean: the dense order (identical to the list's)
       const dim3 g((uint32_t)tb_nclean), b(256);
       if (fcc) {
-         if (tb_lw == 64 && fcc_wt == 8) hipLaunchKernelGGL((pf::k_tb2_fcc_x<Real, 2, 8>), g, dim3(512), 0, s, tp, a1, a2);      // 12-row tiles
-         else if (tb_lw == 64 && fcc_wt == 6) hipLaunchKernelGGL((pf::k_tb2_fcc_x<Real, 2, 6>), g, dim3(384), 0, s, tp, a1, a2); // 8-row tiles
-         else pf::launch_tb2_fcc<Real>(s, tp, a1, a2, tb_lw, (uint32_t)tb_nclean, fcc_wt);
+         if (tb_lw == 64) hipLaunchKernelGGL((pf::k_tb2_fcc_x<Real, 2, 8>), g, dim3(512), 0, s, tp, a1, a2); // 12-row tiles
+         else pf::launch_tb2_fcc<Real>(s, tp, a1, a2, tb_lw, (uint32_t)tb_nclean);
          return;
       }
       if (tb_lw == 32) hipLaunchKernelGGL((pf::k_tb2_reg<Real, 3, 4, false, 32>), g, b, 0, s, tp, a1, a2);
@@ -1236,7 +1207,7 @@ template <typename Real> struct Engine : EngineBase {
       // beside the box: the two row strips in one lean launch (tile height of the default configuration: 16 rows) ...
       const int th = 8; // lean<2,4>: 8-row tiles (the strips are 5-7 rows thick in a box-shaped room)
       lean_nyt = (int)cdiv(tby0 - 1, th); lean_yt0 = (tby1 - 1) / th;
-      launch_lean_cfg<2, 4, false, true>(s, xb, xe);
+      launch_lean_cfg<2, 4>(s, xb, xe);
       lean_nyt = -1; lean_yt0 = 0;
       // ... and the two column strips
       {
@@ -1246,13 +1217,10 @@ template <typename Real> struct Engine : EngineBase {
          zp.plane = plane; zp.Nx = (int)Nx; zp.Ny = (int)Ny; zp.Nz = (int)Nz; zp.P = (int)P;
          zp.x_begin = xb; zp.x_end = xe; zp.zl = szl; zp.zr = szr; zp.first = op.slab_first; zp.last = op.slab_last;
          if (zs_map && bnd_sel) { // (inside step_pair) the strips' boundary nodes are updated right here
-            zp.zvec = zs_map; zp.adjv = zs_adj; zp.lossy = zs_li; zp.u0b = ub[0]; zp.u2b = ub[2];
-            zp.ssaf = d_ssaf; zp.beta = d_beta; zp.mat = d_mat; zp.Mb = d_Mb;
-            zp.mq = d_mq; zp.vh1 = vh1; zp.gh1 = gh1;
-            zp.lo2 = lo2; zp.sl2 = sl2; zp.mmax = mb_max; zp.fd_split = zs_mode == 2 ? 1 : 0;
+            zp.zvec = zs_map; zp.adjv = zs_adj; zp.lossy = zs_li; zp.u0b = ub[0]; zp.sl2 = sl2;
          }
          const int64_t nthreads = (int64_t)(zp.zl / V + (P - zp.zr) / V) * (Ny - 2);
-         const int xchunk = (op.debug >> 16) & 0xff ? (op.debug >> 16) & 0xff : 16;
+         const int xchunk = 16;
          hipLaunchKernelGGL(pf::k_air_zstrip<Real>, dim3((unsigned)cdiv(nthreads, 256), (unsigned)cdiv(xe - xb, xchunk)), dim3(256), 0, s, zp,
                             a1, a2, l, xchunk);
       }
@@ -1309,22 +1277,8 @@ template <typename Real> struct Engine : EngineBase {
          else { hipEventCreate(&ev.first); hipEventCreate(&ev.second); }
          hipEventRecord(ev.first, s);
       }
-      if (vbase == 9) {
-         dim3 g((unsigned)cdiv(Nz, 256), (unsigned)(Ny - 2), (unsigned)(xe - xb));
-         if (fcc) {
-            if (op.numerics == PF_NUM_FMA) hipLaunchKernelGGL((pf::k_air_naive<Real, true, true>), g, dim3(256), 0, s, u1, u0, mask, a1, a2, Ny, Nz, P, plane, xb, xe);
-            else hipLaunchKernelGGL((pf::k_air_naive<Real, true, false>), g, dim3(256), 0, s, u1, u0, mask, a1, a2, Ny, Nz, P, plane, xb, xe);
-         } else {
-            if (op.numerics == PF_NUM_FMA) hipLaunchKernelGGL((pf::k_air_naive<Real, false, true>), g, dim3(256), 0, s, u1, u0, mask, a1, a2, Ny, Nz, P, plane, xb, xe);
-            else hipLaunchKernelGGL((pf::k_air_naive<Real, false, false>), g, dim3(256), 0, s, u1, u0, mask, a1, a2, Ny, Nz, P, plane, xb, xe);
-         }
-      } else if (lean) {
-         launch_air_lean(s, xb, xe);
-      } else if (fused) {
-         launch_air_fused(s, xb, xe);
-      } else {
-         launch_air_march(s, xb, xe);
-      }
+      if (lean) launch_air_lean(s, xb, xe);
+      else launch_air_march(s, xb, xe);
       if (op.timing) { hipEventRecord(ev.second, s); air_ev.push_back(ev); }
    }
 
@@ -1358,11 +1312,6 @@ template <typename Real> struct Engine : EngineBase {
    // Lanes per row segment of the barrier-free kernels: 64 lanes x 16 B = 1 KiB of z per wave row wastes lanes on narrow
    // grids (Nz=309 -> pitch 320: two 256-column segments, 62 % used).  With 32 or 16 lanes per segment a wave stacks 2 or
    // 4 segments in y instead; pick the width with the least padding (ties: the widest).
-   // in-kernel rigid update for the barrier-free 7-point kernel (meant for rooms with scattered boundary nodes, where the
-   // list kernel's neighbour gathers fetch a 128-byte line per 4 useful bytes).  Measured on the CTK church at
-   // 894x579x309: the interior kernel +73 us (one more byte per cell, the rigid arithmetic), the boundary pass -78 us:
-   // +0.8 % overall -- kept as a tested option (debug 0x800), off by default.
-   bool want_rigb() const { return (op.debug & 0x800) != 0; }
    int pick_lw() const {
       constexpr int V = pf::VecOf<Real>::V;
       if (op.debug & 0x300) return (op.debug & 0x100) ? 32 : 16; // tuning override
@@ -1385,26 +1334,19 @@ template <typename Real> struct Engine : EngineBase {
    // Banded wins on large planes (1024^2: k_air_fcc 2.46 -> 2.32 ms, barrier-free 7-point 2.45 -> 2.29, lean 2.33 -> 2.28;
    // Musikverein 552 x 850: 3.60 -> 3.44), the per-XCD run on small ones, where a whole chunk of planes fits one L2 and a band
    // is a handful of tiles (CTK church 579 x 309, 50 tiles per chunk: 0.392 vs 0.425 ms): banded from 96 tiles per chunk.
-   int swizzle_mode(int64_t tiles_per_chunk) const {
-      static const int env = [] { const char *e = getenv("PFFDTD_SWIZZLE"); return e ? atoi(e) : -1; }();
-      if (op.air_variant & 64) return 0;
-      return env >= 0 ? env : (tiles_per_chunk >= 96 ? 2 : 1);
-   }
+   int swizzle_mode(int64_t tiles_per_chunk) const { return tiles_per_chunk >= 96 ? 2 : 1; }
    static uint32_t grid_blocks(int swz, int nzt, int nyt, int nxc) {
       return swz == 2 ? pf::xcd_band_blocks((uint32_t)nzt * nyt, (uint32_t)nxc) : (uint32_t)nzt * nyt * nxc;
    }
-   template <int R, int WY, int WZ> void launch_air_cfg(hipStream_t s, int xb, int xe) {
-      if constexpr (R == 4 && WY == 4 && WZ == 1) {
-         if (use_dpp && !(op.debug & 0x400)) {
-            const int lw = pick_lw();
-            if (lw == 32) return launch_air_cfg_lw<R, WY, WZ, 32>(s, xb, xe);
-            if (lw == 16) return launch_air_cfg_lw<R, WY, WZ, 16>(s, xb, xe);
-         }
-      }
-      launch_air_cfg_lw<R, WY, WZ, 64>(s, xb, xe);
+   // the barrier-free marching kernels (pf_kernels.h): R = 4 rows per lane, 4 waves stacked in y
+   void launch_air_march(hipStream_t s, int xb, int xe) {
+      const int lw = (op.debug & 0x400) ? 64 : pick_lw();
+      if (lw == 32) launch_march_lw<32>(s, xb, xe);
+      else if (lw == 16) launch_march_lw<16>(s, xb, xe);
+      else launch_march_lw<64>(s, xb, xe);
    }
-   template <int R, int WY, int WZ, int LW> void launch_air_cfg_lw(hipStream_t s, int xb, int xe) {
-      constexpr int V = pf::VecOf<Real>::V;
+   template <int LW> void launch_march_lw(hipStream_t s, int xb, int xe) {
+      constexpr int V = pf::VecOf<Real>::V, R = 4, WY = 4, WZ = 1;
       pf::AirParams ap;
       ap.Ny = Ny; ap.P = P; ap.plane = plane;
       ap.x_begin = xb; ap.x_end = xe;
@@ -1418,93 +1360,30 @@ template <typename Real> struct Engine : EngineBase {
       ap.Nx = (int)Nx; ap.Nz = (int)Nz; ap.first = op.slab_first; ap.last = op.slab_last; ap.fold = fold ? 1 : 0;
       const uint32_t total = grid_blocks(ap.swizzle, ap.nzt, ap.nyt, ap.nxc);
       dim3 g(total), b(64 * WY * WZ);
-      const bool fma = op.numerics == PF_NUM_FMA;
-      if constexpr (R == 4 && WY == 4 && WZ == 1) {
-         if (v1_dst && vg && !fcc) { // autotune: the same kernel writing to a scratch grid
-            hipLaunchKernelGGL((pf::k_air_cart<Real, R, WY, WZ, false, true, true, false, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l, sl2, v1_dst);
-            return;
-         }
-         if (v1_rigb && vg && !fcc) { // 7-point, virtual ghosts, rigid update in-kernel from the cell-byte grid
-            if (fma) hipLaunchKernelGGL((pf::k_air_cart<Real, R, WY, WZ, true, true, true, false, LW, true>), g, b, 0, s, u1, u0, cellb, a1, a2, ap, l, sl2);
-            else hipLaunchKernelGGL((pf::k_air_cart<Real, R, WY, WZ, false, true, true, false, LW, true>), g, b, 0, s, u1, u0, cellb, a1, a2, ap, l, sl2);
-            return;
-         }
+      if (v1_dst && vg && !fcc) { // autotune: the 7-point kernel writing to a scratch grid
+         hipLaunchKernelGGL((pf::k_air_cart<Real, R, WY, WZ, false, true, true, false, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l, v1_dst);
+         return;
       }
-#define PF_LAUNCH(K, FMA, DPP) do { if (vg) hipLaunchKernelGGL((K<Real, R, WY, WZ, FMA, DPP, true, false, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l); \
-                                    else if (abck) hipLaunchKernelGGL((K<Real, R, WY, WZ, FMA, DPP, false, true, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l); \
-                                    else hipLaunchKernelGGL((K<Real, R, WY, WZ, FMA, DPP, false, false, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l); } while (0)
-      if constexpr (R == 4 && WY == 4 && WZ == 1) {
-         if (fcc && abck && use_dpp && !fma && u0_src) { // out of place (shell of a temporally blocked pair, creation-time measurement)
-            hipLaunchKernelGGL((pf::k_air_fcc<Real, R, WY, WZ, false, true, false, true, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l, u0_src, (const int32_t *)nullptr);
-            return;
-         }
+      if (fcc && abck && !sg && u0_src) { // out of place (shell of a temporally blocked pair, creation-time measurement)
+         hipLaunchKernelGGL((pf::k_air_fcc<Real, R, WY, WZ, false, true, false, true, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l, u0_src, (const int32_t *)nullptr);
+         return;
       }
-      if constexpr (LW == 64) {
-         if (fcc) {
-            if (fma) { if (use_dpp) PF_LAUNCH(pf::k_air_fcc, true, true); else PF_LAUNCH(pf::k_air_fcc, true, false); }
-            else { if (use_dpp) PF_LAUNCH(pf::k_air_fcc, false, true); else PF_LAUNCH(pf::k_air_fcc, false, false); }
-         } else {
-            if (fma) { if (use_dpp) PF_LAUNCH(pf::k_air_cart, true, true); else PF_LAUNCH(pf::k_air_cart, true, false); }
-            else { if (use_dpp) PF_LAUNCH(pf::k_air_cart, false, true); else PF_LAUNCH(pf::k_air_cart, false, false); }
-         }
-      } else { // narrow row segments: DPP builds only
-         if (fcc) { if (fma) PF_LAUNCH(pf::k_air_fcc, true, true); else PF_LAUNCH(pf::k_air_fcc, false, true); }
-         else { if (fma) PF_LAUNCH(pf::k_air_cart, true, true); else PF_LAUNCH(pf::k_air_cart, false, true); }
-      }
+#define PF_LAUNCH(K, SG) do { if (vg) hipLaunchKernelGGL((K<Real, R, WY, WZ, SG, true, true, false, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l); \
+                              else if (abck) hipLaunchKernelGGL((K<Real, R, WY, WZ, SG, true, false, true, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l); \
+                              else hipLaunchKernelGGL((K<Real, R, WY, WZ, SG, true, false, false, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l); } while (0)
+      if (fcc) { if (sg) PF_LAUNCH(pf::k_air_fcc, true); else PF_LAUNCH(pf::k_air_fcc, false); }
+      else { if (sg) PF_LAUNCH(pf::k_air_cart, true); else PF_LAUNCH(pf::k_air_cart, false); }
 #undef PF_LAUNCH
    }
 
-   void launch_air_march(hipStream_t s, int xb, int xe) {
-      switch (vbase) {
-         case 1: case 5: case 8: launch_air_cfg<2, 4, 1>(s, xb, xe); break;
-         case 2: case 6: launch_air_cfg<4, 1, 4>(s, xb, xe); break;
-         default: launch_air_cfg<4, 4, 1>(s, xb, xe); break;
-      }
-   }
-
-   template <int R, int WY> void launch_fused_cfg(hipStream_t s, int xb, int xe) {
-      pf::FusedParams fp;
-      fp.u1 = u1; fp.u0 = u0; fp.mask = mask_bn; fp.adj = d_adj; fp.segstart = segstart;
-      fp.plane = plane;
-      fp.Nx = (int)Nx; fp.Ny = (int)Ny; fp.Nz = (int)Nz; fp.P = (int)P;
-      fp.x_begin = xb; fp.x_end = xe;
-      fp.nzt = fused_nzt;
-      fp.nyt = (int)cdiv(Ny - 2, (int64_t)WY * R);
-      const int nplanes = xe - xb;
-      const int chunk = pick_chunk(nplanes, (int64_t)fp.nzt * fp.nyt, true);
-      fp.chunk = chunk;
-      fp.nxc = (int)cdiv(nplanes, chunk);
-      fp.swizzle = swizzle_mode((int64_t)fp.nzt * fp.nyt);
-      fp.first = op.slab_first; fp.last = op.slab_last;
-      fp.fold = fold ? 1 : 0; fp.parity = sd.fcc_flag == 1 ? 1 + (op.x_global0 & 1) : 0;
-      fp.do_abc = 1; fp.do_rigid = (fused_rigid && Nb > 0) ? 1 : 0;
-      dim3 g(grid_blocks(fp.swizzle, fp.nzt, fp.nyt, fp.nxc)), b(64 * WY);
-      const bool fma = op.numerics == PF_NUM_FMA;
-      if (fcc) {
-         if (fma) hipLaunchKernelGGL((pf::k_air_fused<Real, true, R, WY, true>), g, b, 0, s, fp, a1, a2, sl2, l);
-         else hipLaunchKernelGGL((pf::k_air_fused<Real, true, R, WY, false>), g, b, 0, s, fp, a1, a2, sl2, l);
-      } else {
-         if (fma) hipLaunchKernelGGL((pf::k_air_fused<Real, false, R, WY, true>), g, b, 0, s, fp, a1, a2, sl2, l);
-         else hipLaunchKernelGGL((pf::k_air_fused<Real, false, R, WY, false>), g, b, 0, s, fp, a1, a2, sl2, l);
-      }
-   }
-   void launch_air_fused(hipStream_t s, int xb, int xe) {
-      switch (vbase) {
-         case 11: launch_fused_cfg<4, 4>(s, xb, xe); break;
-         case 12: launch_fused_cfg<2, 4>(s, xb, xe); break;
-         case 13: launch_fused_cfg<1, 8>(s, xb, xe); break;
-         case 14: launch_fused_cfg<4, 8>(s, xb, xe); break;
-         default: launch_fused_cfg<2, 8>(s, xb, xe); break; // 0 (auto) and 10
-      }
-   }
-
-   template <int R, int WY, bool LDS = false, bool NT = false, bool RIG = false> void launch_lean_cfg(hipStream_t s, int xb, int xe) {
+   // the lean fused 7-point kernel (pf_air_fused.h).  R x WY = rows per lane x waves per workgroup; NT = nontemporal u0 traffic
+   template <int R, int WY, bool NT = true> void launch_lean_cfg(hipStream_t s, int xb, int xe) {
       pf::LeanParams fp{};
-      fp.u1 = u1; fp.u0 = u0; fp.mask = RIG ? mask_bn : mask; fp.adj = adj_dense;
+      fp.u1 = u1; fp.u0 = u0; fp.mask = mask;
       fp.plane = plane;
       fp.Nx = (int)Nx; fp.Ny = (int)Ny; fp.Nz = (int)Nz; fp.P = (int)P;
       fp.x_begin = xb; fp.x_end = xe;
-      fp.nzt = fused_nzt;
+      fp.nzt = lean_nzt;
       fp.nyt = (int)cdiv(Ny - 2, (int64_t)WY * R);
       fp.u0_src = u0_src; fp.yt0 = 0; fp.yt_split = -1; fp.yt_hi0 = 0;
       if (lean_nyt >= 0) { // row strips: tiles [0, lean_nyt) and [lean_yt0, all) in units of this configuration's tile height
@@ -1517,7 +1396,7 @@ template <typename Real> struct Engine : EngineBase {
       int chunk = pick_chunk(nplanes, (int64_t)fp.nzt * fp.nyt, true);
       fp.chunk = chunk;
       fp.nxc = (int)cdiv(nplanes, chunk);
-      if (lean_x2_end > lean_x2_begin && !fcc && !LDS) { // a second x slab [lean_x2_begin, lean_x2_end) in the same launch (both thin: one chunk each)
+      if (lean_x2_end > lean_x2_begin) { // a second x slab [lean_x2_begin, lean_x2_end) in the same launch (both thin: one chunk each)
          chunk = std::max(nplanes, lean_x2_end - lean_x2_begin);
          fp.chunk = chunk;
          fp.x_lo_end = xe; fp.x2_begin = lean_x2_begin; fp.x_end = lean_x2_end;
@@ -1526,52 +1405,18 @@ template <typename Real> struct Engine : EngineBase {
       fp.swizzle = swizzle_mode((int64_t)fp.nzt * fp.nyt);
       fp.first = op.slab_first; fp.last = op.slab_last;
       fp.do_abc = 1;
-      fp.debug = op.debug;
       dim3 g(grid_blocks(fp.swizzle, fp.nzt, fp.nyt, fp.nxc)), b(64 * WY);
-      if (fcc) {
-         if constexpr (!LDS && R <= 2) {
-            if (op.numerics == PF_NUM_FMA) hipLaunchKernelGGL((pf::k_air_fcc_lean<Real, R, WY, true>), g, b, 0, s, fp, a1, a2, l, fold ? 1 : 0);
-            else hipLaunchKernelGGL((pf::k_air_fcc_lean<Real, R, WY, false>), g, b, 0, s, fp, a1, a2, l, fold ? 1 : 0);
-         }
-      } else if constexpr (LDS) {
-         if (op.numerics == PF_NUM_FMA) hipLaunchKernelGGL((pf::k_air_cart_lds<Real, R, WY, true>), g, b, 0, s, fp, a1, a2, l);
-         else hipLaunchKernelGGL((pf::k_air_cart_lds<Real, R, WY, false>), g, b, 0, s, fp, a1, a2, l);
-      } else {
-         if (op.numerics == PF_NUM_FMA) hipLaunchKernelGGL((pf::k_air_cart_lean<Real, R, WY, true, NT, RIG>), g, b, 0, s, fp, a1, a2, l, sl2);
-         else hipLaunchKernelGGL((pf::k_air_cart_lean<Real, R, WY, false, NT, RIG>), g, b, 0, s, fp, a1, a2, l, sl2);
-      }
+      if (sg) hipLaunchKernelGGL((pf::k_air_cart_lean<Real, R, WY, true, NT>), g, b, 0, s, fp, a1, a2, l);
+      else hipLaunchKernelGGL((pf::k_air_cart_lean<Real, R, WY, false, NT>), g, b, 0, s, fp, a1, a2, l);
    }
    void launch_air_lean(hipStream_t s, int xb, int xe) {
-      if (fcc) { // 13-point: R <= 2 only (register budget)
-         switch (vbase) {
-            case 23: launch_lean_cfg<2, 4>(s, xb, xe); break;
-            case 24: launch_lean_cfg<1, 8>(s, xb, xe); break;
-            default: launch_lean_cfg<2, 8>(s, xb, xe); break;
-         }
-         return;
-      }
-      switch (vbase) {
-         case 21: launch_lean_cfg<4, 8>(s, xb, xe); break;
-         case 23: launch_lean_cfg<2, 4>(s, xb, xe); break;
-         case 24: launch_lean_cfg<1, 8>(s, xb, xe); break;
-         case 20: launch_lean_cfg<2, 8>(s, xb, xe); break;
-         case 26: launch_lean_cfg<2, 8, false, true>(s, xb, xe); break;
-         case 33: launch_lean_cfg<1, 8, true>(s, xb, xe); break;
-         case 35: launch_lean_cfg<1, 4, true>(s, xb, xe); break;
-         case 22: launch_lean_cfg<4, 4>(s, xb, xe); break;
-         case 25: launch_lean_cfg<4, 4, false, true>(s, xb, xe); break;
-         case 28: if (lean_rigid) launch_lean_cfg<2, 8, false, true, true>(s, xb, xe); else launch_lean_cfg<2, 8, false, true>(s, xb, xe); break;
-         default: // 0 (auto) and 25: fastest measured on MI355X (fp32: R=4,WY=4; fp64: R=2,WY=8 -- register budget);
-                  // 27 = same with the rigid update fused in
-            if (vbase == 0 && sizeof(Real) == 8) { launch_lean_cfg<2, 8, false, true>(s, xb, xe); break; }
-            if (lean_rigid) launch_lean_cfg<4, 4, false, true, true>(s, xb, xe);
-            else launch_lean_cfg<4, 4, false, true>(s, xb, xe);
-            break;
-      }
+      // fastest measured on MI355X: fp32 R = 4 x 4 waves, fp64 R = 2 x 8 waves (register budget)
+      if (sizeof(Real) == 8) launch_lean_cfg<2, 8>(s, xb, xe);
+      else launch_lean_cfg<4, 4>(s, xb, xe);
    }
 
    void launch_pre(hipStream_t s) {
-      if (fused || lean || vg) return; // ghost shell is virtual, u2ba is the old u0 in registers
+      if (lean || vg) return; // ghost shell is virtual, u2ba is the old u0 in registers
       launch_flips(s);
       if (Nba && !abck) hipLaunchKernelGGL(pf::k_abc_save<Real>, dim3((unsigned)cdiv(Nba, 256)), dim3(256), 0, s, u0, d_bna, u2ba, Nba);
    }
@@ -1584,14 +1429,16 @@ template <typename Real> struct Engine : EngineBase {
          hipLaunchKernelGGL(pf::k_flip_x<Real>, dim3((unsigned)cdiv(plane, 256)), dim3(256), 0, s, u1, Nx, plane, op.slab_first, op.slab_last);
    }
    void launch_abc(hipStream_t s, Range r) {
-      if (!fused && !lean && !vg && !abck && r.e > r.b) hipLaunchKernelGGL(pf::k_abc_loss<Real>, dim3((unsigned)cdiv(r.e - r.b, 256)), dim3(256), 0, s, u0, d_bna, d_Q, u2ba, l, r.b, r.e);
+      if (lean || vg || abck || r.e <= r.b) return;
+      if (sg) hipLaunchKernelGGL((pf::k_abc_loss<Real, true>), dim3((unsigned)cdiv(r.e - r.b, 256)), dim3(256), 0, s, u0, d_bna, d_Q, u2ba, l, r.b, r.e);
+      else hipLaunchKernelGGL((pf::k_abc_loss<Real, false>), dim3((unsigned)cdiv(r.e - r.b, 256)), dim3(256), 0, s, u0, d_bna, d_Q, u2ba, l, r.b, r.e);
    }
    // Virtual-ghost modes: boundary nodes next to the folded ghost row read it from MEMORY, so that one row is kept
    // materialised.  In a split-phase step the main stream only touches planes [1, Nx-1): the slab's ghost planes may
    // be receiving the neighbours' data at that moment (the edge stream, ordered after the exchange, does those).
    int fold_x0 = 0, fold_x1 = 0; // plane range of the next launch_fold_row (set by the step drivers)
    void launch_fold_row(hipStream_t s) {
-      if (!((lean || fused || vg) && fold && need_fold_row) || fold_x1 <= fold_x0) return;
+      if (!((lean || vg) && fold && need_fold_row) || fold_x1 <= fold_x0) return;
       dim3 gy((unsigned)cdiv(Nz, 256), (unsigned)(fold_x1 - fold_x0));
       hipLaunchKernelGGL(pf::k_flip_y<Real>, gy, dim3(256), 0, s, u1 + (int64_t)fold_x0 * plane, (int64_t)(fold_x1 - fold_x0), Ny, P, Nz, 4);
    }
@@ -1600,24 +1447,22 @@ template <typename Real> struct Engine : EngineBase {
       if (r.e <= r.b) return;
       launch_fold_row(s);
       dim3 g((unsigned)cdiv(r.e - r.b, 128)), b(128);
-      const bool fma = op.numerics == PF_NUM_FMA;
 #define PF_BND(F, M) hipLaunchKernelGGL((pf::k_boundary<Real, F, M>), g, b, 0, s, u1, u0, d_bn, d_adj, d_lossy, a2, sl2, P, plane, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq, d_beta, vh1, gh1, lo2, (int64_t)mb_max, r.b, r.e, u0_src ? u0_src : (const Real *)u0, bnd_sel)
-      if (fcc) { if (fma) PF_BND(true, true); else PF_BND(true, false); }
-      else { if (fma) PF_BND(false, true); else PF_BND(false, false); }
+      if (fcc) { if (sg) PF_BND(true, true); else PF_BND(true, false); }
+      else { if (sg) PF_BND(false, true); else PF_BND(false, false); }
 #undef PF_BND
    }
-   bool boundary_fused() const { return fuse_boundary && !(fused && fused_rigid) && !lean_rigid && !v1_rigb; }
+   bool boundary_fused() const { return fuse_boundary; }
    void launch_rigid(hipStream_t s, Range r) {
       if (boundary_fused()) { launch_boundary(s, r); return; }
-      if (r.e <= r.b || (fused && fused_rigid) || lean_rigid || v1_rigb) return;
+      if (r.e <= r.b) return;
       launch_fold_row(s);
       dim3 g((unsigned)cdiv(r.e - r.b, 256)), b(256);
-      const bool fma = op.numerics == PF_NUM_FMA;
       if (fcc) {
-         if (fma) hipLaunchKernelGGL((pf::k_rigid<Real, true, true>), g, b, 0, s, u1, u0, d_bn, d_adj, a2, sl2, P, plane, r.b, r.e);
+         if (sg) hipLaunchKernelGGL((pf::k_rigid<Real, true, true>), g, b, 0, s, u1, u0, d_bn, d_adj, a2, sl2, P, plane, r.b, r.e);
          else hipLaunchKernelGGL((pf::k_rigid<Real, true, false>), g, b, 0, s, u1, u0, d_bn, d_adj, a2, sl2, P, plane, r.b, r.e);
       } else {
-         if (fma) hipLaunchKernelGGL((pf::k_rigid<Real, false, true>), g, b, 0, s, u1, u0, d_bn, d_adj, a2, sl2, P, plane, r.b, r.e);
+         if (sg) hipLaunchKernelGGL((pf::k_rigid<Real, false, true>), g, b, 0, s, u1, u0, d_bn, d_adj, a2, sl2, P, plane, r.b, r.e);
          else hipLaunchKernelGGL((pf::k_rigid<Real, false, false>), g, b, 0, s, u1, u0, d_bn, d_adj, a2, sl2, P, plane, r.b, r.e);
       }
    }
@@ -1853,7 +1698,7 @@ template <typename Real> struct Engine : EngineBase {
          pair_now = true;
          return PF_OK;
       }
-      if (!(fused || lean || vg)) { // ghost flips / ABC save touch the whole grid: the interior must see them
+      if (!(lean || vg)) { // ghost flips / ABC save touch the whole grid: the interior must see them
          launch_pre(s_edge);
          HIPCHK(hipEventRecord(ev_pre, s_edge));
          HIPCHK(hipStreamWaitEvent(s_main, ev_pre, 0));
@@ -2005,7 +1850,7 @@ template <typename Real> struct Engine : EngineBase {
       int rc = sync();
       if (rc) return rc;
       const Real *src = which == 0 ? (pair_phase == 1 ? pB : u0) : u1; // mid-pair u0 already names the grid being written
-      if ((fused || lean || vg) && which == 1) { // write the virtual ghost shell out, exactly as the reference's flips would have
+      if ((lean || vg) && which == 1) { // write the virtual ghost shell out, exactly as the reference's flips would have
          launch_flips(s_main);
          HIPCHK(hipStreamSynchronize(s_main));
       }

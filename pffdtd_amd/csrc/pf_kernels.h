@@ -8,8 +8,8 @@
 // odd-parity cells that do not exist on the subgrid (cpu_engine.h:200,219).
 //
 // Numerics: every kernel follows the operation order of the reference C CPU engine (file:line cited at each
-// kernel); with FMA=false nothing is contracted (the TU is built with -ffp-contract=off), so results are
-// bit-identical to cpu_engine.h.  FMA=true fuses each `p += a2*x` into one fma.
+// kernel); with SG=false nothing is contracted (the TU is built with -ffp-contract=off), so results are
+// bit-identical to cpu_engine.h.  SG=true is the reference GPU engine's "safeguarded" arithmetic (see upd7 below).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -67,9 +67,118 @@ static __global__ void k_dpp_selftest(int *out) {
    if (lane == 0) out[0] = (all == ~0ull) ? 1 : 0;
 }
 
-template <bool FMA, typename Real> __device__ __forceinline__ Real acc(Real p, Real a2, Real x) {
-   if (FMA) return __builtin_fma(a2, x, p);
-   return p + a2 * x;
+// =============================================================================================================
+// Numerics of the air and rigid-node updates (pf_opts.numerics), template flag SG:
+//   SG = false, PF_NUM_CPU_EXACT: the reference C CPU engine's expression, accumulated left to right with separate
+//     multiplies and adds (cpu_engine.h:175-223,234-287) -- bit-identical to it.
+//   SG = true, PF_NUM_GPU_SAFEGUARDED: the reference GPU engine's arithmetic (fdtd_common.h:44-71, gpu_engine.h:220-274,
+//     288-348): the neighbours are summed pairwise ("divide-conquer add"), in fp32 with every add rounded TOWARDS ZERO
+//     (ADD_O = __fadd_rz: a sum that never rounds away from zero cannot pump energy into the scheme -- the reference's
+//     long-run fp32 stability measure), then two round-to-nearest FMAs  c1*u1 + (c2*sum - u0).  In fp64 the same tree and
+//     FMAs with round-to-nearest throughout (ADD_O = __dadd_rn).
+// The fp32 tree runs inside ONE asm statement bracketed by two s_setreg writes of MODE.FP_ROUND[1:0] (3 = towards zero for
+// single precision, 0 = nearest even): nothing else can be scheduled into the window, and the mode is back to the default
+// before any other instruction issues.
+// =============================================================================================================
+__device__ __forceinline__ float fma_rn(float a, float b, float c) { return __builtin_fmaf(a, b, c); }   // FMA_D = __fmaf_rn
+__device__ __forceinline__ double fma_rn(double a, double b, double c) { return __builtin_fma(a, b, c); } // FMA_D = __fma_rn
+__device__ __forceinline__ float sg_sum6(float a0, float a1, float a2, float a3, float a4, float a5) {
+   float t1, t2; // ((a0 + a1) + (a2 + a3)) + (a4 + a5), gpu_engine.h:230-234
+   asm("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+       "v_add_f32 %0, %2, %3\n\t"
+       "v_add_f32 %1, %4, %5\n\t"
+       "v_add_f32 %0, %0, %1\n\t"
+       "v_add_f32 %1, %6, %7\n\t"
+       "v_add_f32 %0, %0, %1\n\t"
+       "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+       : "=&v"(t1), "=&v"(t2)
+       : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5));
+   return t1;
+}
+__device__ __forceinline__ double sg_sum6(double a0, double a1, double a2, double a3, double a4, double a5) {
+   double t1 = a0 + a1, t2 = a2 + a3;
+   t1 = t1 + t2;
+   t2 = a4 + a5;
+   return t1 + t2;
+}
+// 13-point: n[0..11] in the adjacency-bit order (+x+y)(-x-y)(+y+z)(-y-z)(+x+z)(-x-z)(+x-y)(-x+y)(+y-z)(-y+z)(+x-z)(-x+z);
+// tree of gpu_engine.h:257-267
+__device__ __forceinline__ float sg_sum12(const float (&n)[12]) {
+   float t1, t2, t3, t4;
+   asm("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+       "v_add_f32 %0, %4, %5\n\t"    // t1 = n0 + n1
+       "v_add_f32 %1, %6, %7\n\t"    // t2 = n2 + n3
+       "v_add_f32 %0, %0, %1\n\t"    // t1 += t2
+       "v_add_f32 %2, %8, %9\n\t"    // t3 = n4 + n5
+       "v_add_f32 %3, %10, %11\n\t"  // t4 = n6 + n7
+       "v_add_f32 %2, %2, %3\n\t"    // t3 += t4
+       "v_add_f32 %1, %12, %13\n\t"  // t2 = n8 + n9
+       "v_add_f32 %0, %0, %1\n\t"    // t1 += t2
+       "v_add_f32 %3, %14, %15\n\t"  // t4 = n10 + n11
+       "v_add_f32 %2, %2, %3\n\t"    // t3 += t4
+       "v_add_f32 %0, %0, %2\n\t"    // t1 += t3
+       "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+       : "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4)
+       : "v"(n[0]), "v"(n[1]), "v"(n[2]), "v"(n[3]), "v"(n[4]), "v"(n[5]), "v"(n[6]), "v"(n[7]), "v"(n[8]), "v"(n[9]),
+         "v"(n[10]), "v"(n[11]));
+   return t1;
+}
+__device__ __forceinline__ double sg_sum12(const double (&n)[12]) {
+   double t1 = n[0] + n[1], t2 = n[2] + n[3];
+   t1 = t1 + t2;
+   double t3 = n[4] + n[5], t4 = n[6] + n[7];
+   t3 = t3 + t4;
+   t2 = n[8] + n[9];
+   t1 = t1 + t2;
+   t4 = n[10] + n[11];
+   t3 = t3 + t4;
+   return t1 + t3;
+}
+// one 7-point air update; neighbours in the order +x, -x, +y, -y, +z, -z (file axes: x = slowest, z = unit stride)
+template <bool SG, typename Real>
+__device__ __forceinline__ Real upd7(Real a1, Real a2, Real c, Real old, Real xp, Real xm, Real yp, Real ym, Real zp, Real zm) {
+   if (SG) return fma_rn(a1, c, fma_rn(a2, sg_sum6(xp, xm, yp, ym, zp, zm), -old)); // gpu_engine.h:235
+   Real p = a1 * c - old; // cpu_engine.h:181-191
+   p = p + a2 * xp; p = p + a2 * xm; p = p + a2 * yp; p = p + a2 * ym; p = p + a2 * zp; p = p + a2 * zm;
+   return p;
+}
+// one 13-point air update, n[] in the adjacency-bit order
+template <bool SG, typename Real> __device__ __forceinline__ Real upd13(Real a1, Real a2, Real c, Real old, const Real (&n)[12]) {
+   if (SG) return fma_rn(a1, c, fma_rn(a2, sg_sum12(n), -old)); // gpu_engine.h:268
+   Real p = a1 * c - old; // cpu_engine.h:200-218
+#pragma unroll
+   for (int k = 0; k < 12; k++) p = p + a2 * n[k];
+   return p;
+}
+// rigid boundary node: centre coefficient 2 - sl2*K, neighbour k present when adjacency bit k is set
+// (cpu_engine.h:234-287; gpu_engine.h:288-348: products bit*u1 exact, tree of towards-zero adds, two FMAs)
+template <bool SG, int NN, typename Real>
+__device__ __forceinline__ Real upd_rigid(Real a2, Real sl2, uint32_t adj, Real c, Real old, const Real (&nb)[NN]) {
+   const Real two = 2.0, K = (Real)__popc(adj);
+   if (SG) {
+      Real w[NN];
+#pragma unroll
+      for (int k = 0; k < NN; k++) w[k] = (Real)((adj >> k) & 1u) * nb[k];
+      const Real b1 = two - sl2 * K; // (gpu_engine.h:300: `_2 - csl2*K`)
+      Real sum;
+      if constexpr (NN == 6) sum = sg_sum6(w[0], w[1], w[2], w[3], w[4], w[5]); else sum = sg_sum12(w);
+      return fma_rn(b1, c, fma_rn(a2, sum, -old));
+   }
+   const Real b1 = two - sl2 * K;
+   Real p = b1 * c - old;
+#pragma unroll
+   for (int k = 0; k < NN; k++) {
+      const Real wk = a2 * (Real)((adj >> k) & 1u);
+      p = p + wk * nb[k];
+   }
+   return p;
+}
+// ABC loss u0 = (u0 + lQ*u2) / (1 + lQ).  CPU engine: the literal 1.0 makes denominator and division double even in the
+// float build (cpu_engine.h:228) -- reproduced; GPU engine: all in Real (gpu_engine.h:351-365, `Real _1`)
+template <bool SG, typename Real> __device__ __forceinline__ Real abc_loss(Real u, Real u2, Real lQ) {
+   if (SG) { const Real one = 1.0; return (u + lQ * u2) / (one + lQ); }
+   const Real num = u + lQ * u2;
+   return (Real)((double)num / (1.0 + (double)lQ));
 }
 
 // ---- XCD-aware workgroup order (guide T1): hardware places block b on XCD b%8; give each XCD one contiguous
@@ -121,14 +230,10 @@ struct AirParams {
 // cells, cf. pf_air_fused.h) and the ABC loss is applied in-kernel, so no flip / ABC kernels run around it.
 // ABCK = true (without VG): only the ABC loss moves in-kernel; the ghost shell is still maintained in memory by the
 // flip kernels (cheaper than VG's per-row patches for the 13-point kernel).
-// RIGB = true (with VG): `mask` is not the 1-bit skip-mask but one byte per padded cell -- 0 air, 0x40 skip (ghost column /
-// pad), 0x80|adjacency bits at a boundary node -- and the rigid boundary update (cpu_engine.h:234-257) is done here, from
-// the neighbour values the stencil already holds, instead of by gathers in the boundary-list kernel: in rooms with
-// scattered geometry those gathers fetch a 128-byte line per neighbour for 4 useful bytes.
-template <typename Real, int R, int WY, int WZ, bool FMA, bool DPP, bool VG = false, bool ABCK = false, int LW = 64, bool RIGB = false>
+template <typename Real, int R, int WY, int WZ, bool SG, bool DPP, bool VG = false, bool ABCK = false, int LW = 64>
 __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restrict__ u1, Real *__restrict__ u0,
                                                           const uint8_t *__restrict__ mask, Real a1, Real a2,
-                                                          AirParams ap, Real labc, Real sl2 = Real(0),
+                                                          AirParams ap, Real labc,
                                                           Real *u0_dst = nullptr) { // u0_dst: write there instead of in place
    typedef typename VecOf<Real>::type vec;
    constexpr int V = VecOf<Real>::V;
@@ -224,12 +329,7 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
 #pragma unroll
       for (int r = 0; r < R; r++) {
          old[r] = __builtin_nontemporal_load((const vec *)(po + soff[r]));
-         if (RIGB) {
-            const uint8_t *pb = mask + (int64_t)x * plane + soff[r];
-            mb[r] = (V == 4) ? *(const uint32_t *)pb : (uint32_t) * (const uint16_t *)pb;
-         } else {
-            mb[r] = pmk[soff[r] >> 3];
-         }
+         mb[r] = pmk[soff[r] >> 3];
          nxtL[r] = need_l ? pn[roff[r + 1] - 1] : Real(0);
          nxtR[r] = need_r ? pn[roff[r + 1] + V] : Real(0);
          patch(nxt[r + 1], nxtL[r]);
@@ -243,20 +343,14 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
          if (lane == 0) zm = curL[r];
          if (lane == LW - 1) zp = curR[r];
          if (fixR) zp = c[V - 2]; // my right neighbour is the ghost column
-         const uint32_t bits = RIGB ? 0u : mb[r] >> (uint32_t)(soff[r] & 7);
+         const uint32_t bits = mb[r] >> (uint32_t)(soff[r] & 7);
          vec o;
 #pragma unroll
          for (int i = 0; i < V; i++) {
             const Real left = (i == 0) ? zm : c[i > 0 ? i - 1 : 0];
             const Real right = (i == V - 1) ? zp : c[i < V - 1 ? i + 1 : V - 1];
-            Real p = a1 * c[i] - old[r][i];
-            p = acc<FMA>(p, a2, nxt[r + 1][i]);  // +NzNy
-            p = acc<FMA>(p, a2, prev[r][i]);     // -NzNy
-            p = acc<FMA>(p, a2, cur[r + 2][i]);  // +Nz
-            p = acc<FMA>(p, a2, cur[r][i]);      // -Nz
-            p = acc<FMA>(p, a2, right);          // +1
-            p = acc<FMA>(p, a2, left);           // -1
-            o[i] = p;
+            // +NzNy, -NzNy, +Nz, -Nz, +1, -1
+            o[i] = upd7<SG>(a1, a2, c[i], old[r][i], nxt[r + 1][i], prev[r][i], cur[r + 2][i], cur[r][i], right, left);
          }
          if (VG || ABCK) { // ABC loss (cpu_engine.h:225-229); u2ba is the old value of the cell
             const int64_t y = y0 + r;
@@ -268,44 +362,15 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
                   if (qxy > 0 || __ballot(zq) != 0ull) {
                      const int Q = qxy + (zq ? 1 : 0);
                      if (Q > 0) {
-                        const Real lQ = labc * (Real)Q;
-                        const Real num = o[i] + lQ * old[r][i];
-                        o[i] = (Real)((double)num / (1.0 + (double)lQ));
+                        o[i] = abc_loss<SG>(o[i], old[r][i], labc * (Real)Q);
                      }
                   }
                }
             }
          }
-         if (RIGB) {
-            const uint32_t cb = mb[r];
-            if (__ballot((cb & 0x80808080u) != 0u) != 0ull) { // some lane of the wave holds a boundary node in this row
 #pragma unroll
-               for (int i = 0; i < V; i++) {
-                  const uint32_t a = (cb >> (8 * i)) & 0xffu;
-                  if (a & 0x80u) {
-                     const Real left = (i == 0) ? zm : c[i > 0 ? i - 1 : 0];
-                     const Real right = (i == V - 1) ? zp : c[i < V - 1 ? i + 1 : V - 1];
-                     const Real nbk[6] = {nxt[r + 1][i], prev[r][i], cur[r + 2][i], cur[r][i], right, left};
-                     const Real two = 2.0;
-                     const Real b1 = two - sl2 * (Real)__popc(a & 0x3fu);
-                     Real p = b1 * c[i] - old[r][i];
-#pragma unroll
-                     for (int k = 0; k < 6; k++) {
-                        const Real wk = a2 * (Real)((a >> k) & 1u);
-                        p = FMA ? __builtin_fma(wk, nbk[k], p) : p + wk * nbk[k];
-                     }
-                     o[i] = p;
-                  }
-               }
-            }
-#pragma unroll
-            for (int i = 0; i < V; i++)
-               if ((cb >> (8 * i)) & 0x40u) o[i] = old[r][i];
-         } else {
-#pragma unroll
-            for (int i = 0; i < V; i++)
-               if ((bits >> i) & 1u) o[i] = old[r][i];
-         }
+         for (int i = 0; i < V; i++)
+            if ((bits >> i) & 1u) o[i] = old[r][i];
          if (active && (y0 + r <= Ny - 2))
             __builtin_nontemporal_store(o, (vec *)((u0_dst ? u0_dst + (int64_t)x * plane : po) + soff[r]));
       }
@@ -327,7 +392,7 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
 // Same marching scheme; all three planes keep R+2 rows, and every row used with a z offset gets its wave-edge
 // columns from the edge lanes.
 // =============================================================================================================
-template <typename Real, int R, int WY, int WZ, bool FMA, bool DPP, bool VG = false, bool ABCK = false, int LW = 64>
+template <typename Real, int R, int WY, int WZ, bool SG, bool DPP, bool VG = false, bool ABCK = false, int LW = 64>
 __global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict__ u1, Real *u0,
                                                          const uint8_t *__restrict__ mask, Real a1, Real a2,
                                                          AirParams ap, Real labc, const Real *u0_src = nullptr,
@@ -468,20 +533,10 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict
          vec o;
 #pragma unroll
          for (int i = 0; i < V; i++) {
-            Real p = a1 * c[i] - old[r][i];
-            p = acc<FMA>(p, a2, nxt[j + 1][i]);  // +NzNy+Nz
-            p = acc<FMA>(p, a2, prev[j - 1][i]); // -NzNy-Nz
-            p = acc<FMA>(p, a2, cu_hi[i]);       // +Nz+1
-            p = acc<FMA>(p, a2, cd_lo[i]);       // -Nz-1
-            p = acc<FMA>(p, a2, n_hi[i]);        // +NzNy+1
-            p = acc<FMA>(p, a2, p_lo[i]);        // -NzNy-1
-            p = acc<FMA>(p, a2, nxt[j - 1][i]);  // +NzNy-Nz
-            p = acc<FMA>(p, a2, prev[j + 1][i]); // -NzNy+Nz
-            p = acc<FMA>(p, a2, cu_lo[i]);       // +Nz-1
-            p = acc<FMA>(p, a2, cd_hi[i]);       // -Nz+1
-            p = acc<FMA>(p, a2, n_lo[i]);        // +NzNy-1
-            p = acc<FMA>(p, a2, p_hi[i]);        // -NzNy+1
-            o[i] = p;
+            // +NzNy+Nz, -NzNy-Nz, +Nz+1, -Nz-1, +NzNy+1, -NzNy-1, +NzNy-Nz, -NzNy+Nz, +Nz-1, -Nz+1, +NzNy-1, -NzNy+1
+            const Real nb[12] = {nxt[j + 1][i], prev[j - 1][i], cu_hi[i], cd_lo[i], n_hi[i], p_lo[i],
+                                 nxt[j - 1][i], prev[j + 1][i], cu_lo[i], cd_hi[i], n_lo[i], p_hi[i]};
+            o[i] = upd13<SG>(a1, a2, c[i], old[r][i], nb);
          }
          if (VG || ABCK) { // ABC loss (cpu_engine.h:225-229)
             const int64_t y = y0 + r;
@@ -493,9 +548,7 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict
                   if (qxy > 0 || __ballot(zq) != 0ull) {
                      const int Q = qxy + (zq ? 1 : 0);
                      if (Q > 0) {
-                        const Real lQ = labc * (Real)Q;
-                        const Real num = o[i] + lQ * old[r][i];
-                        o[i] = (Real)((double)num / (1.0 + (double)lQ));
+                        o[i] = abc_loss<SG>(o[i], old[r][i], labc * (Real)Q);
                      }
                   }
                }
@@ -512,42 +565,6 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict
          cur[j] = nxt[j];  curL[j] = nxtL[j];  curR[j] = nxtR[j];
       }
    }
-}
-
-// Naive one-thread-per-cell air kernels: debugging reference variant (air_variant 9), same arithmetic.
-template <typename Real, bool FCC, bool FMA>
-static __global__ void k_air_naive(const Real *__restrict__ u1, Real *__restrict__ u0, const uint8_t *__restrict__ mask,
-                            Real a1, Real a2, int64_t Ny, int64_t Nz, int64_t P, int64_t plane, int32_t x_begin,
-                            int32_t x_end) {
-   const int64_t iz = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-   const int64_t iy = 1 + blockIdx.y;
-   const int64_t ix = x_begin + blockIdx.z;
-   if (iz < 1 || iz > Nz - 2 || iy > Ny - 2 || ix >= x_end) return;
-   const int64_t jj = ix * plane + iy * P + iz;
-   if ((mask[jj >> 3] >> (jj & 7)) & 1) return;
-   Real p = a1 * u1[jj] - u0[jj];
-   if (!FCC) {
-      p = acc<FMA>(p, a2, u1[jj + plane]);
-      p = acc<FMA>(p, a2, u1[jj - plane]);
-      p = acc<FMA>(p, a2, u1[jj + P]);
-      p = acc<FMA>(p, a2, u1[jj - P]);
-      p = acc<FMA>(p, a2, u1[jj + 1]);
-      p = acc<FMA>(p, a2, u1[jj - 1]);
-   } else {
-      p = acc<FMA>(p, a2, u1[jj + plane + P]);
-      p = acc<FMA>(p, a2, u1[jj - plane - P]);
-      p = acc<FMA>(p, a2, u1[jj + P + 1]);
-      p = acc<FMA>(p, a2, u1[jj - P - 1]);
-      p = acc<FMA>(p, a2, u1[jj + plane + 1]);
-      p = acc<FMA>(p, a2, u1[jj - plane - 1]);
-      p = acc<FMA>(p, a2, u1[jj + plane - P]);
-      p = acc<FMA>(p, a2, u1[jj - plane + P]);
-      p = acc<FMA>(p, a2, u1[jj + P - 1]);
-      p = acc<FMA>(p, a2, u1[jj - P + 1]);
-      p = acc<FMA>(p, a2, u1[jj + plane - 1]);
-      p = acc<FMA>(p, a2, u1[jj - plane + 1]);
-   }
-   u0[jj] = p;
 }
 
 // ---- ghost-shell maintenance (cpu_engine.h:135-172; gpu_engine.h:277-285,435-494) ---------------------------
@@ -588,21 +605,31 @@ static __global__ void k_abc_save(const Real *__restrict__ u0, const int64_t *__
    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (i < n) u2ba[i] = u0[idx[i]];
 }
-template <typename Real>
+template <typename Real, bool SG>
 static __global__ void k_abc_loss(Real *__restrict__ u0, const int64_t *__restrict__ idx, const int8_t *__restrict__ Q,
                            const Real *__restrict__ u2ba, Real l, int64_t begin, int64_t end) {
    const int64_t i = begin + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (i >= end) return;
-   const Real lQ = l * (Real)Q[i];
    const int64_t ib = idx[i];
-   const Real num = u0[ib] + lQ * u2ba[i];
-   // the reference divides by (1.0 + lQ) with a double literal: denominator and division are double even in
-   // the float build (cpu_engine.h:228) -- reproduced
-   u0[ib] = (Real)((double)num / (1.0 + (double)lQ));
+   u0[ib] = abc_loss<SG>(u0[ib], u2ba[i], l * (Real)Q[i]); // (cpu_engine.h:225-229 incl. the double division of :228)
 }
 
 // ---- rigid boundary nodes, cpu_engine.h:234-287 (gpu_engine.h:288-348) --------------------------------------
-template <typename Real, bool FCC, bool FMA>
+// gather the NN neighbours of a boundary node in the adjacency-bit order (cpu_engine.h:241-246 / 262-273)
+template <typename Real, bool FCC>
+__device__ __forceinline__ void gather_nb(const Real *__restrict__ u1, int64_t ii, int64_t P, int64_t plane, Real (&nb)[FCC ? 12 : 6]) {
+   if (!FCC) {
+      const int64_t off[6] = {plane, -plane, P, -P, 1, -1};
+#pragma unroll
+      for (int j = 0; j < 6; j++) nb[j] = u1[ii + off[j]];
+   } else {
+      const int64_t off[12] = {plane + P, -plane - P, P + 1, -P - 1, plane + 1, -plane - 1,
+                               plane - P, -plane + P, P - 1, -P + 1, plane - 1, -plane + 1};
+#pragma unroll
+      for (int j = 0; j < 12; j++) nb[j] = u1[ii + off[j]];
+   }
+}
+template <typename Real, bool FCC, bool SG>
 static __global__ void k_rigid(const Real *__restrict__ u1, Real *__restrict__ u0, const int64_t *__restrict__ idx,
                         const uint16_t *__restrict__ adjv, Real a2, Real sl2, int64_t P, int64_t plane,
                         int64_t begin, int64_t end) {
@@ -610,25 +637,9 @@ static __global__ void k_rigid(const Real *__restrict__ u1, Real *__restrict__ u
    if (nb >= end) return;
    const int64_t ii = idx[nb];
    const uint32_t adj = adjv[nb];
-   const Real two = 2.0, K = (Real)__popc(adj), b2 = a2, b1 = (two - sl2 * K);
-   Real p = b1 * u1[ii] - u0[ii];
-   if (!FCC) {
-      const int64_t off[6] = {plane, -plane, P, -P, 1, -1};
-#pragma unroll
-      for (int j = 0; j < 6; j++) {
-         const Real w = b2 * (Real)((adj >> j) & 1u);
-         p = FMA ? __builtin_fma(w, u1[ii + off[j]], p) : p + w * u1[ii + off[j]];
-      }
-   } else {
-      const int64_t off[12] = {plane + P, -plane - P, P + 1, -P - 1, plane + 1, -plane - 1,
-                               plane - P, -plane + P, P - 1, -P + 1, plane - 1, -plane + 1};
-#pragma unroll
-      for (int j = 0; j < 12; j++) {
-         const Real w = b2 * (Real)((adj >> j) & 1u);
-         p = FMA ? __builtin_fma(w, u1[ii + off[j]], p) : p + w * u1[ii + off[j]];
-      }
-   }
-   u0[ii] = p;
+   Real v[FCC ? 12 : 6];
+   gather_nb<Real, FCC>(u1, ii, P, plane, v);
+   u0[ii] = upd_rigid<SG, FCC ? 12 : 6>(a2, sl2, adj, u1[ii], u0[ii], v);
 }
 
 // ---- frequency-dependent (lossy) boundary nodes, cpu_engine.h:290-301 + 363-405 (gpu_engine.h:368-432) ------
@@ -728,7 +739,7 @@ static __global__ void k_fd_sel(Real *u0, const int64_t *__restrict__ idx_l, con
 // indices increase along the (sorted) boundary list, so the branch-state accesses stay coalesced.
 // sel != null: visit the nodes sel[begin..end) instead of begin..end (temporal blocking leaves the column-strip nodes
 // to k_air_zstrip).
-template <typename Real, bool FCC, bool FMA>
+template <typename Real, bool FCC, bool SG>
 static __global__ void k_boundary(const Real *__restrict__ u1, Real *u0, const int64_t *__restrict__ idx,
                            const uint16_t *__restrict__ adjv, const int32_t *__restrict__ lossy, Real a2, Real sl2,
                            int64_t P, int64_t plane, Real *__restrict__ u0b, const Real *__restrict__ u2b,
@@ -741,24 +752,9 @@ static __global__ void k_boundary(const Real *__restrict__ u1, Real *u0, const i
    const int64_t nb = sel ? (int64_t)sel[t] : t;
    const int64_t ii = idx[nb];
    const uint32_t adj = adjv[nb];
-   const Real two = 2.0, K = (Real)__popc(adj), b2 = a2, b1 = (two - sl2 * K);
-   Real p = b1 * u1[ii] - u0_old[ii];
-   if (!FCC) {
-      const int64_t off[6] = {plane, -plane, P, -P, 1, -1};
-#pragma unroll
-      for (int j = 0; j < 6; j++) {
-         const Real w = b2 * (Real)((adj >> j) & 1u);
-         p = FMA ? __builtin_fma(w, u1[ii + off[j]], p) : p + w * u1[ii + off[j]];
-      }
-   } else {
-      const int64_t off[12] = {plane + P, -plane - P, P + 1, -P - 1, plane + 1, -plane - 1,
-                               plane - P, -plane + P, P - 1, -P + 1, plane - 1, -plane + 1};
-#pragma unroll
-      for (int j = 0; j < 12; j++) {
-         const Real w = b2 * (Real)((adj >> j) & 1u);
-         p = FMA ? __builtin_fma(w, u1[ii + off[j]], p) : p + w * u1[ii + off[j]];
-      }
-   }
+   Real v[FCC ? 12 : 6];
+   gather_nb<Real, FCC>(u1, ii, P, plane, v);
+   Real p = upd_rigid<SG, FCC ? 12 : 6>(a2, sl2, adj, u1[ii], u0_old[ii], v);
    const int32_t li = lossy[nb];
    if (li >= 0) p = fd_node_update<Real>(p, li, u0b, u2b, ssaf, mat, Mb, mq, beta, vh1, gh1, lo2, mmax);
    u0[ii] = p;
@@ -767,15 +763,6 @@ static __global__ void k_boundary(const Real *__restrict__ u1, Real *u0, const i
 // device-side step counters of the graph-replayed loop: ctr[0] = step index, ctr[1] = receiver ring column
 static __global__ void k_ctr_set(int64_t *ctr, int64_t n, int64_t col) { ctr[0] = n; ctr[1] = col; }
 static __global__ void k_ctr_tick(int64_t *ctr) { ctr[0]++; ctr[1]++; }
-
-// one byte per padded cell for the RIGB kernels: 0x40 at ghost z columns and pad columns (never updated), 0 elsewhere;
-// boundary nodes are then stamped with 0x80 | adjacency bits (k_adj_dense_set)
-static __global__ void k_cellbytes_init(uint8_t *__restrict__ cb, int64_t nrows, int64_t P, int64_t Nz) {
-   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-   if (i >= nrows * P) return;
-   const int64_t z = i % P;
-   cb[i] = (z == 0 || z >= Nz - 1) ? 0x40 : 0x00;
-}
 
 // ---- receivers (read time n from u1) and sources (add to time n+1 in u0), cpu_engine.h:304-313 --------------
 // one launch: threads [0,Nr) gather into the ring column, thread Nr (alone) applies all sources in list order

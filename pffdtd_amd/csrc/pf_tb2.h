@@ -403,7 +403,7 @@ __global__ __launch_bounds__(64 * WT) void k_tb2_fcc_x(Tb2Params tp, Real a1, Re
 }
 
 // host-side launcher, defined (and the kernel instantiated) in pf_tb2_fcc.hip, which is built with its own flags
-template <typename Real> void launch_tb2_fcc(hipStream_t s, const Tb2Params &tp, Real a1, Real a2, int lw, uint32_t nblocks, int wt);
+template <typename Real> void launch_tb2_fcc(hipStream_t s, const Tb2Params &tp, Real a1, Real a2, int lw, uint32_t nblocks);
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_tb1_tile -- ONE 7-point air update of the tiles k_tb2_reg must leave alone (a boundary node, a source or the ABC
@@ -512,15 +512,9 @@ template <typename Real> struct ZStripParams {
    const uint32_t *zvec;
    const uint16_t *adjv;     // [strip node]
    const int32_t *lossy;     // [strip node] position in the lossy arrays or -1
-   Real *u0b;
-   const Real *u2b, *ssaf, *beta;
-   const int8_t *mat, *Mb;
-   const MatQuadT<Real> *mq;
-   Real *vh1, *gh1;
-   Real lo2, sl2;
-   int64_t mmax;             // largest branch count of the scene's materials (fd_node_update)
-   int32_t fd_split;         // 1: lossy nodes get their RIGID update here (value left in u0b[li] and in the grid); the
-                             // branch ODEs follow in k_fd_sel, dense over the compact lossy arrays
+   Real *u0b;                // lossy nodes: the RIGID result is left here (and in the grid); the branch ODEs follow in k_fd_sel,
+                             // dense over the compact lossy arrays
+   Real sl2;
 };
 
 template <typename Real>
@@ -601,10 +595,7 @@ __global__ __launch_bounds__(256) void k_air_zstrip(ZStripParams<Real> zp, Real 
                   p = p + w * nbk[k];
                }
                const int32_t li = zp.lossy[nb];
-               if (li >= 0) {
-                  if (zp.fd_split) zp.u0b[li] = p;
-                  else p = fd_node_update<Real>(p, li, zp.u0b, zp.u2b, zp.ssaf, zp.mat, zp.Mb, zp.mq, zp.beta, zp.vh1, zp.gh1, zp.lo2, zp.mmax);
-               }
+               if (li >= 0) zp.u0b[li] = p;
             }
          }
          o[i] = p;

@@ -8,15 +8,14 @@
 
 namespace pf {
 
-template <typename Real> void launch_tb2_fcc(hipStream_t s, const Tb2Params &tp, Real a1, Real a2, int lw, uint32_t nblocks, int wt) {
+// (32- and 16-lane row segments only; the 64-lane LDS-exchange variant k_tb2_fcc_x is launched from pf_engine.hip: it has
+// registers to spare and gains 16 % from the packed fp32 operations this translation unit switches off)
+template <typename Real> void launch_tb2_fcc(hipStream_t s, const Tb2Params &tp, Real a1, Real a2, int lw, uint32_t nblocks) {
    const dim3 g(nblocks), b(256);
-   (void)wt; // (the LDS-exchange variant k_tb2_fcc_x is launched from pf_engine.hip: it has registers to spare and gains
-             // 16 % from the packed fp32 operations this translation unit switches off)
    if (lw == 32) hipLaunchKernelGGL((k_tb2_fcc<Real, 2, 4, 32>), g, b, 0, s, tp, a1, a2);
-   else if (lw == 16) hipLaunchKernelGGL((k_tb2_fcc<Real, 2, 4, 16>), g, b, 0, s, tp, a1, a2);
-   else hipLaunchKernelGGL((k_tb2_fcc<Real, 2, 4, 64>), g, b, 0, s, tp, a1, a2);
+   else hipLaunchKernelGGL((k_tb2_fcc<Real, 2, 4, 16>), g, b, 0, s, tp, a1, a2);
 }
-template void launch_tb2_fcc<float>(hipStream_t, const Tb2Params &, float, float, int, uint32_t, int);
-template void launch_tb2_fcc<double>(hipStream_t, const Tb2Params &, double, double, int, uint32_t, int);
+template void launch_tb2_fcc<float>(hipStream_t, const Tb2Params &, float, float, int, uint32_t);
+template void launch_tb2_fcc<double>(hipStream_t, const Tb2Params &, double, double, int, uint32_t);
 
 } // namespace pf

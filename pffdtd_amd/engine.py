@@ -16,7 +16,7 @@ _HERE = Path(__file__).resolve().parent
 _LIB = None
 
 PF_NUM_CPU_EXACT = 0
-PF_NUM_FMA = 1
+PF_NUM_GPU_SAFEGUARDED = 2
 
 
 class PfOpts(ctypes.Structure):

@@ -94,7 +94,7 @@ def test_random_field_one_step_all_paths_agree():
         e.step(n)
     ref = e.grid(1)[1:-1, 1:-1, 1:-1].copy()
     e.close()
-    for v in (0, 3, 10, 9):
+    for v in (0, 3, 4, 25):
         eng = engine.HipEngine(sd, air_variant=v)
         eng.set_grid(0, u0)
         eng.set_grid(1, u1)

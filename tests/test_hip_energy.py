@@ -49,3 +49,26 @@ def test_energy_requires_flag():
     with pytest.raises(engine.PfError):
         eng.energy_cfg(sd.h, sd.c, sd.Ts, sd.DEF)
     eng.close()
+
+
+def test_baseline_config0_ctk_cart_viz_energy_balance(tmp_path):
+    """BASELINE.json configs[0] itself: the CTK church of test_script_CTK_cart_viz.py (fmax 500 Hz, PPW 7.5, 0.1 s: grid
+    234 x 154 x 85, fp64, dhann30 input, not differentiated), built from the scene export by sim_setup (device voxelizer),
+    all 651 steps with the energy diagnostic on: the normalised balance H_tot + E_lost - E_in must stay at round-off
+    (the reference prints the same quantity, sim_fdtd.py:671-678, at ~1e-15 with its summation order)."""
+    from pffdtd_amd import scenes
+    from pffdtd_amd.sim_setup import sim_setup
+    mats = scenes.write_materials(tmp_path / "materials")
+    folder = tmp_path / "cfg0"
+    sim_setup(**scenes.setup_kwargs("ctk_cart_viz", folder, mats, save_folder_gpu=folder, compress=0))
+    sd = sim_data.SimData.from_folder(folder, "double", build_mask=False)
+    assert (sd.Nx, sd.Ny, sd.Nz) == (234, 154, 85) and sd.Nt == 651 and sd.fcc_flag == 0
+    eng = engine.HipEngine(sd, energy=True)
+    eng.energy_cfg(sd.h, sd.c, sd.Ts, sd.DEF)
+    H, El, Ei = np.zeros(sd.Nt), np.zeros(sd.Nt + 1), np.zeros(sd.Nt + 1)
+    eng.run_energy(0, sd.Nt, H, El, Ei)
+    eng.close()
+    bal = rel_diff(H + El[:-1], Ei[:-1])
+    assert np.isfinite(sd.u_out).all() and np.abs(sd.u_out).max() > 0
+    assert Ei[-1] > 0 and El[-1] > 0 and H.max() > 0          # energy went in, some was absorbed by the walls
+    assert np.abs(bal).max() <= 1e-12, f"energy balance {np.abs(bal).max():.3e}"

@@ -31,9 +31,9 @@ def _run(sd, **kw):
 
 
 def test_kernel_families_agree_bitwise_at_512(scene):
-    ref_out, ref_plane = _run(scene, air_variant=9)
+    ref_out, ref_plane = _run(scene, air_variant=3)  # the reference's kernel sequence: memory flips, marching kernel, ABC lists
     assert np.abs(ref_out).max() > 0
-    for v in (0, 3, 4, 20, 10, 40):  # 40: temporally blocked pairs (auto keeps them for >= 600-cell cross-sections)
+    for v in (0, 4, 25, 40, 3 + 256):  # 40: temporally blocked pairs (auto keeps them for >= 600-cell cross-sections)
         out, plane = _run(scene, air_variant=v)
         assert np.array_equal(out, ref_out), f"variant {v}"
         assert np.array_equal(plane[1:-1, 1:-1], ref_plane[1:-1, 1:-1]), f"variant {v}"

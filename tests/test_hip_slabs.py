@@ -24,10 +24,10 @@ def _reference(name, prec):
 @pytest.mark.parametrize("G", [2, 3])
 @pytest.mark.parametrize("name,prec,variant", [("cart_outside", "single", 0), ("cart_outside", "double", 0),
                                                ("fcc2_outside", "single", 0), ("cart_lossy", "single", 3),
-                                               ("fcc1_outside", "double", 10), ("fcc1_outside", "single", 3),
-                                               ("fcc2_outside", "double", 10), ("cart_outside", "single", 20),
-                                               ("cart_outside_oddz", "double", 22), ("fcc2_outside", "single", 4),
-                                               ("fcc1_outside", "double", 5), ("cart_outside", "double", 6), ("fcc2_outside", "double", 7)])
+                                               ("fcc1_outside", "double", 7), ("fcc1_outside", "single", 3),
+                                               ("fcc2_outside", "double", 3 + 256), ("cart_outside", "single", 25),
+                                               ("cart_outside_oddz", "double", 25), ("fcc2_outside", "single", 4),
+                                               ("fcc1_outside", "double", 4), ("cart_outside", "double", 4), ("fcc2_outside", "double", 7)])
 def test_virtual_slabs_equal_single_domain(name, prec, variant, G):
     ref = _reference(name, prec)
     sd = cases.make_sd(name, prec)
@@ -93,7 +93,7 @@ def test_single_domain_stepper_grids_are_the_engines(torch_grids, monkeypatch):
     for g in init:  # interior cells only (ghost shell and pad columns stay zero, as after any step)
         g[0], g[-1], g[:, 0], g[:, -1], g[:, :, 0], g[:, :, sd.Nz - 1:] = 0, 0, 0, 0, 0, 0
     outs = []
-    for variant in (20, 40):
+    for variant in (25, 40):
         sd = make_sd()
         runner, loc, info = pdist.make_hip_runner(sd, 0, 1, 0, air_variant=variant, timing=True)
         st = runner.st

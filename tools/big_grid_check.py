@@ -41,7 +41,9 @@ gen.manual_seed(11)
 init = [((torch.rand(shape, generator=gen, device="cuda", dtype=tdt) * 2 - 1) * 1e-3) for _ in range(2)]
 g = [torch.empty(shape, dtype=tdt, device="cuda") for _ in range(2)]
 ref_out, ref_g = None, None
-for v in ((0, 2, 5, 9) if fcc else (40, 0, 25, 4, 2)):  # 40 = blocked pairs forced, 0 = what the engine picks, 9 = naive
+# 40 = blocked pairs forced, 0 = what the engine picks, 4 = barrier-free kernel with virtual ghosts, 25 = lean fused kernel
+# (7-point), 3 = the reference's kernel sequence (memory flips, marching kernel, ABC list kernels)
+for v in ((40, 0, 4, 3) if fcc else (40, 0, 25, 4, 3)):
     for a, b in zip(g, init):
         a.copy_(b)
     sd.u_out[:] = 0
@@ -53,6 +55,8 @@ for v in ((0, 2, 5, 9) if fcc else (40, 0, 25, 4, 2)):  # 40 = blocked pairs for
     eng.close()
     out = sd.u_out.copy()
     print(f"variant {v}: {time.time()-t0:.1f}s, blocked launches {tm['tb2_launches']}, peak |out| {np.abs(out).max():.3e}", flush=True)
+    if v == 40:
+        assert tm["tb2_launches"] > 0, "pairs were forced but the two-steps-per-pass kernel never ran"
     view = [t.view(n[0], n[1], P)[1:-1, 1:-1, 1:n[2] - 1] for t in g]
     if ref_out is None:
         ref_out, ref_g = out, [t.clone() for t in g]

@@ -36,9 +36,9 @@ gen.manual_seed(23)
 init = [(torch.rand(shape, generator=gen, device="cuda") * 2 - 1) * 1e-3 for _ in range(2)]
 g = [torch.empty(shape, dtype=torch.float32, device="cuda") for _ in range(2)]
 ref_out, ref_g = None, None
-# 13-point: 0 = what the engine picks (barrier-free, ABC in-kernel), 2 = unfused other tiling, 5 = virtual ghosts, 9 = naive
-# 7-point: 0 = what the engine picks, 25 = lean fused, 4 = barrier-free + virtual ghosts, 2 = unfused, 9 = naive
-for v in ((0, 2, 5, 9) if fcc else (0, 25, 4, 2, 9)):
+# 13-point: 0 = what the engine picks (barrier-free, ABC in-kernel), 4 = virtual ghosts, 3 = the reference's kernel sequence
+# 7-point: 0 = what the engine picks, 25 = lean fused, 4 = barrier-free + virtual ghosts, 3 = the reference's kernel sequence
+for v in ((0, 4, 3, 3 + 256) if fcc else (0, 25, 4, 3)):
     for a, b in zip(g, init):
         a.copy_(b)
     sd.u_out[:] = 0

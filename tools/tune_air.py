@@ -20,7 +20,7 @@ ap.add_argument("--nz", type=int, default=0)
 ap.add_argument("--precision", default="single")
 ap.add_argument("--fcc", action="store_true")
 ap.add_argument("--rigid", action="store_true")
-ap.add_argument("--variants", default="0,1,2,3,4,5,6,9")
+ap.add_argument("--variants", default="0,3,4,7,25,40")
 ap.add_argument("--chunks", default="0")
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--numerics", type=int, default=0)
