@@ -161,6 +161,9 @@ template <typename Real> struct Engine : EngineBase {
    // node or a source within one cell of their core ("dirty") take single steps (k_tb1_tile), the others pairs
    int tb_lw = 64, tb_chunk = 16, tb_nxc = 0, tb_nyt = 0, tb_nzt = 0;
    int32_t *tb_clean = nullptr, *tb_dirty = nullptr;      // tile ids (xc*nyt + yt)*nzt + zt
+   int32_t *tb_sample = nullptr;                          // placement search: the clean tiles of every k-th x chunk (same order)
+   int64_t tb_nsample = 0;
+   double tb_sample_frac = 1.0;                           // their share of the clean cells
    int64_t tb_nclean = 0, tb_ndirty = 0, tb_clean_cells = 0;
    bool tb_order_band = false;
    // 13-point pairs (folded FCC): whatever of the box is not a clean tile's core is stepped by k_air_fcc over its own tiles
@@ -201,7 +204,7 @@ template <typename Real> struct Engine : EngineBase {
       auto F = [](void *p) { if (p) hipFree(p); };
       for (Real *g : own_list) F(g); // state grids this engine allocated (u0/u1 unless external, the temporal-blocking spares)
       own_list.clear();
-      F(d_lossy); F(mask); F(zs_map); F(zs_adj); F(zs_li); F(zs_rest); F(zs_fd); F(tb_clean); F(tb_dirty); F(sh_tiles); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
+      F(d_lossy); F(mask); F(zs_map); F(zs_adj); F(zs_li); F(zs_rest); F(zs_fd); F(tb_clean); F(tb_dirty); F(tb_sample); F(sh_tiles); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
       F(d_beta); F(d_insig); F(d_mq); F(ub[0]); F(ub[1]); F(ub[2]); F(u2ba); F(vh1); F(gh1); F(ring);
       if (h_ring) hipHostFree(h_ring);
       for (auto &p : air_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -637,6 +640,30 @@ template <typename Real> struct Engine : EngineBase {
          if (tb_dirty) { hipFree(tb_dirty); tb_dirty = nullptr; }
          if ((rc = upload(&tb_clean, cl.data(), tb_nclean))) return rc;
          if ((rc = upload(&tb_dirty, di.data(), tb_ndirty))) return rc;
+         { // The placement search times the pair kernel on a SAMPLE of the clean tiles: every k-th x chunk, whole chunks in the
+           // launch's own order (the effect it looks for is a property of how the four grids' pages lie relative to each
+           // other, the same all along x), so a candidate costs 1/k of a launch.  PFFDTD_PLACE_SAMPLE=k (default 4, 1 = all).
+            int k = 4;
+            if (const char *ev = getenv("PFFDTD_PLACE_SAMPLE")) k = std::min(std::max(atoi(ev), 1), 16);
+            if (tb_nxc < 8 * k) k = std::max(tb_nxc / 8, 1);
+            std::vector<int32_t> sm;
+            int64_t svol = 0;
+            const int64_t per_chunk = (int64_t)tb_nyt * tb_nzt;
+            for (int32_t t : cl) {
+               const int xc = (int)(t / per_chunk);
+               if (xc % k != k / 2) continue;
+               sm.push_back(t);
+               const int zt = (int)(t % tb_nzt), yt = (int)((t / tb_nzt) % tb_nyt);
+               svol += (int64_t)(std::min(tbx0 + (xc + 1) * tb_chunk, tbx1) - (tbx0 + xc * tb_chunk)) *
+                       (std::min(tby0 + (yt + 1) * TR, tby1) - (tby0 + yt * TR)) * (std::min(tbz0 + (zt + 1) * TC, tbz1) - (tbz0 + zt * TC));
+            }
+            if (tb_sample) { hipFree(tb_sample); tb_sample = nullptr; }
+            tb_nsample = 0; tb_sample_frac = 1.0;
+            if (k > 1 && !sm.empty() && vol > 0) {
+               tb_nsample = (int64_t)sm.size(); tb_sample_frac = (double)svol / (double)vol;
+               if ((rc = upload(&tb_sample, sm.data(), tb_nsample))) return rc;
+            }
+         }
          if (tb_nclean == 0) tb_xr.clear();
          if (fcc && !tb_xr.empty()) {
             // the single-step kernel's own tiling of the box's planes: 256 (fp64: 128) columns x 16 rows x the same x
@@ -802,15 +829,17 @@ template <typename Real> struct Engine : EngineBase {
       const bool verbose = getenv("PFFDTD_VERBOSE") && atoi(getenv("PFFDTD_VERBOSE")) > 0;
       hipEvent_t e0, e1;
       HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+      const bool sampled = tb_sample && tb_nsample > 0;
+      const float scale = sampled ? (float)(1.0 / tb_sample_frac) : 1.f; // sampled times are reported as whole-launch equivalents
       auto time_fwd = [&](Real *A, Real *B, Real *C, Real *D) -> float {
          hipEventRecord(e0, s_main);
-         launch_tb2(s_main, A, B, C, D);
-         launch_tb2(s_main, A, B, C, D);
+         launch_tb2(s_main, A, B, C, D, true);
+         launch_tb2(s_main, A, B, C, D, true);
          hipEventRecord(e1, s_main);
          hipEventSynchronize(e1);
          float ms = 0;
          hipEventElapsedTime(&ms, e0, e1);
-         return ms / 2;
+         return ms / 2 * scale;
       };
       auto grid = [&](int i, Real *fallback) { return i >= 0 ? pool[i] : fallback; };
       for (int i = 0; i < 4; i++) launch_tb2(s_main, grid(first[0], u0), grid(first[1], u1), pool[first[2]], pool[first[3]]); // clocks up
@@ -862,9 +891,20 @@ template <typename Real> struct Engine : EngineBase {
       place_ms.clear();
       for (auto &c : cands) place_ms.push_back(c.ms);
       if (verbose) {
-         fprintf(stderr, "pffdtd_hip: grid placement, %d candidates of a pool of %d:", (int)cands.size(), n);
+         fprintf(stderr, "pffdtd_hip: grid placement, %d candidates of a pool of %d%s:", (int)cands.size(), n, sampled ? " (timed on a sample of the tiles, scaled to a whole launch)" : "");
          for (size_t i = 0; i < cands.size(); i++) fprintf(stderr, " %.3f%s", cands[i].ms, i == best ? "*" : "");
          fprintf(stderr, " ms per launch\n");
+         if (sampled) { // how good is the sample?  the chosen and the first candidate once more on ALL tiles
+            for (size_t i : {best, (size_t)0}) {
+               const Cand &c = cands[i];
+               Real *A = grid(c.r[0], u0), *B = grid(c.r[1], u1), *C = pool[c.r[2]], *D = pool[c.r[3]];
+               hipEventRecord(e0, s_main);
+               launch_tb2(s_main, A, B, C, D); launch_tb2(s_main, A, B, C, D);
+               hipEventRecord(e1, s_main); hipEventSynchronize(e1);
+               float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+               fprintf(stderr, "pffdtd_hip:   candidate %zu on all tiles: %.3f ms per launch (sample said %.3f)\n", i, ms / 2, c.ms);
+            }
+         }
       }
       for (int i = 0; i < 4; i++) chosen[i] = cands[best].r[i];
       hipEventDestroy(e0); hipEventDestroy(e1);
@@ -1129,12 +1169,14 @@ template <typename Real> struct Engine : EngineBase {
       return tp;
    }
    // two steps of the clean tiles
-   void launch_tb2(hipStream_t s, const Real *A, const Real *B, Real *C, Real *D) {
+   void launch_tb2(hipStream_t s, const Real *A, const Real *B, Real *C, Real *D, bool sample = false) {
       if (tb_xr.empty() || tb_nclean <= 0) return;
       pf::Tb2Params tp = tile_params();
       tp.A = A; tp.B = B; tp.C = C; tp.D = D;
       tp.tiles = (tb_ndirty > 0 || tb_order_band) ? tb_clean : nullptr; // all clean: the dense order (identical to the list's)
-      const dim3 g((uint32_t)tb_nclean), b(256);
+      sample = sample && tb_sample && tb_nsample > 0;
+      if (sample) tp.tiles = tb_sample;
+      const dim3 g((uint32_t)(sample ? tb_nsample : tb_nclean)), b(256);
       if (fcc) {
          if (tb_lw == 64) hipLaunchKernelGGL((pf::k_tb2_fcc_x<Real, 2, 8>), g, dim3(512), 0, s, tp, a1, a2); // 12-row tiles
          else pf::launch_tb2_fcc<Real>(s, tp, a1, a2, tb_lw, (uint32_t)tb_nclean);
