@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h> // types and prototypes only: the library is dlopen()ed (struct Rccl)
 #include <dlfcn.h>
+#include <unistd.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -422,6 +423,11 @@ int choose_transport(Shared &S, int requested) {
    S.rank.assign(S.G, 0);
    S.rccl_self = all_same && S.G > 1;
    ncclResult_t r = ncclSuccess;
+   // RCCL greets with a version banner on STDOUT when NCCL_DEBUG asks for one; a host that prints machine-readable results
+   // there (bench.py: one JSON line) must not find it in between: stdout points at stderr while the communicators are made
+   fflush(stdout);
+   const int saved_out = dup(1);
+   if (saved_out >= 0) dup2(2, 1);
    if (S.rccl_self) {
       // virtual slabs: slab g's communicator has ONE rank (the device); its exchange sends the neighbour's plane -- same
       // device, directly addressable -- to itself.  Group semantics, stream ordering and error paths as on a real chain.
@@ -430,6 +436,7 @@ int choose_transport(Shared &S, int requested) {
       for (int g = 0; g < S.G; g++) S.rank[g] = g;
       r = g_rccl.CommInitAll(S.comm.data(), S.G, S.dev.data()); // one clique over the chain's devices, rank g = slab g
    }
+   if (saved_out >= 0) { fflush(stdout); dup2(saved_out, 1); close(saved_out); }
    if (r != ncclSuccess) {
       char b[384];
       snprintf(b, sizeof b, "ncclCommInitAll over %d device(s) failed: %s", S.rccl_self ? 1 : S.G, g_rccl.GetErrorString(r));

@@ -29,7 +29,7 @@ def test_struct_layout_matches_header():
     """ctypes mirror of pf_simdata: same size as the C struct (checked through a tiny compiled probe)."""
     import subprocess
     import tempfile
-    src = '#include <stdio.h>\n#include "pffdtd_hip.h"\nint main(){printf("%zu %zu %zu", sizeof(pf_simdata), sizeof(pf_opts), sizeof(pf_timing));}'
+    src = '#include <stdio.h>\n#include "pffdtd_hip.h"\nint main(){printf("%zu %zu %zu %zu", sizeof(pf_simdata), sizeof(pf_opts), sizeof(pf_timing), sizeof(pf_multi_info));}'
     with tempfile.TemporaryDirectory() as d:
         c = Path(d) / "p.c"
         c.write_text(src)
@@ -38,6 +38,7 @@ def test_struct_layout_matches_header():
     assert int(out[0]) == ctypes.sizeof(sim_data.PfSimData)
     assert int(out[1]) == ctypes.sizeof(engine.PfOpts)
     assert int(out[2]) == ctypes.sizeof(engine.PfTiming)
+    assert int(out[3]) == ctypes.sizeof(engine.PfMultiInfo)
 
 
 def test_no_device_is_an_error_not_a_fallback():
