@@ -111,6 +111,7 @@ template <typename Real> struct Engine : EngineBase {
    Real *v1_dst = nullptr;       // autotune: destination of the barrier-free 7-point kernel (null = in place)
    int lw_force = 0;             // autotune: lanes per row segment of the barrier-free kernels (0 = pick_lw's rule)
    float tune_ms[3] = {0, 0, 0}; // measured at creation: lean / barrier-free / blocked pair (per step), ms
+   float pair_margin = 0.99f;    // the pair path stays when it takes less than this fraction of the best single step
    bool lean = false, need_fold_row = false; // lean: the fused 7-point kernel of pf_air_fused.h (air_variant 25)
    bool vg = false;          // barrier-free marching kernel with virtual ghost shell + in-kernel ABC (air_variant 4)
    bool abck = false;        // barrier-free marching kernel with memory flips but the ABC loss in-kernel (air_variant 7)
@@ -413,12 +414,8 @@ template <typename Real> struct Engine : EngineBase {
          // skip-mask: ghost z / pad / parity, then the boundary nodes
          if ((rc = dzalloc(&mask, npad / 8))) return rc;
          HIPCHK(hipDeviceSynchronize());
-         {
-            const int64_t nrows = Nx * Ny;
-            dim3 gm((unsigned)cdiv(P / 8, 64), (unsigned)std::min<int64_t>(nrows, 65535), (unsigned)cdiv(nrows, 65535));
-            hipLaunchKernelGGL(pf::k_mask_init, gm, dim3(64), 0, s_main, mask, Nx, Ny, P, Nz,
+         hipLaunchKernelGGL(pf::k_mask_init, dim3((unsigned)cdiv(Nx * Ny * (P / 16), 256)), dim3(256), 0, s_main, mask, Nx, Ny, P, Nz,
                             sd.fcc_flag == 1 ? 1 + (op.x_global0 & 1) : 0);
-         }
          if (Nb) hipLaunchKernelGGL(pf::k_mask_set, dim3((unsigned)cdiv(Nb, 256)), dim3(256), 0, s_main, mask, d_bn, Nb);
          HIPCHK(hipGetLastError());
       }
@@ -493,8 +490,15 @@ template <typename Real> struct Engine : EngineBase {
       }
       { int rc = init_tb2(); if (rc) return rc; }
       tb2_probe = true;
+      // pairs or single steps?  A first measurement on the grids as allocated drops pairs that are hopeless (rooms whose clean
+      // tiles are few: CTK, Musikverein) before any placement search is spent on them -- placement is worth up to ~10 %, so a
+      // pair path more than 12 % behind the single steps cannot win; the survivors get their grids placed and are measured again
+      pair_margin = 1.12f;
+      { int rc = autotune(); if (rc) { tb2_probe = false; return rc; } }
       { int rc = sample_placement(); if (rc) { tb2_probe = false; return rc; } }
-      { int rc = autotune(); tb2_probe = false; if (rc) return rc; }
+      pair_margin = 0.99f;
+      if (tb2) { int rc = autotune(); if (rc) { tb2_probe = false; return rc; } }
+      tb2_probe = false;
       if (!tb2 && op.slab_first && op.slab_last) { int rc = sample_placement_single(); if (rc) return rc; }
       // hipGraph replay of the step loop (six steps per graph): measured on MI355X / ROCm 7.2 it does not beat plain
       // launches even on launch-bound grids (234x154x85: 0.0503 vs 0.0473 ms/step, 256^3: 0.0951 vs 0.0921) -- the gaps
@@ -801,7 +805,7 @@ template <typename Real> struct Engine : EngineBase {
          u0_src = U1; u1 = bufC; u0 = bufD; launch_shell(s_main);
       });
       u0_src = nullptr; u0 = U0; u1 = U1;
-      if (!(tune_ms[2] < 0.99f * tune_ms[1])) { // not worth it: drop the pair path and its two grids
+      if (!(tune_ms[2] < pair_margin * tune_ms[1])) { // not worth it: drop the pair path and its two grids
          tb2 = false;
          for (Real *g : {bufC, bufD}) { own_list.erase(std::remove(own_list.begin(), own_list.end(), g), own_list.end()); hipFree(g); }
          bufC = bufD = nullptr;
@@ -1169,7 +1173,7 @@ template <typename Real> struct Engine : EngineBase {
             u0_src = U1; u1 = bufC; u0 = bufD; launch_shell(s_main);
             u0_src = nullptr; u0 = U0; u1 = U1;
          });
-         if (!(tune_ms[2] < 0.99f * std::min(tune_ms[0], tune_ms[1]))) { // not worth it: drop the pair path and its two grids
+         if (!(tune_ms[2] < pair_margin * std::min(tune_ms[0], tune_ms[1]))) { // not worth it: drop the pair path and its two grids
             tb2 = false;
             for (Real *g : {bufC, bufD}) { own_list.erase(std::remove(own_list.begin(), own_list.end(), g), own_list.end()); hipFree(g); }
             if (scr == bufC) scr = nullptr;

@@ -784,20 +784,21 @@ static __global__ void k_io(const Real *__restrict__ u1, Real *__restrict__ u0, 
 // build the engine's skip-mask rows for ghost z columns / pad / odd parity (boundary-node bits are OR-ed in
 // afterwards by k_mask_set)
 static __global__ void k_mask_init(uint8_t *__restrict__ mask, int64_t Nx, int64_t Ny, int64_t P, int64_t Nz, int parity) {
-   // one thread per mask byte of a row; blockIdx.y = row (ix*Ny + iy): no 64-bit divisions per bit
-   const int64_t bcol = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; // byte within the row
-   const int64_t row = blockIdx.y + (int64_t)blockIdx.z * 65535;
-   if (bcol >= P / 8 || row >= Nx * Ny) return;
+   // one thread per 32 cells (one mask word) of a row: P is a multiple of 32 for fp32 and of 16 for fp64 (two bytes then)
+   const int64_t wpr = P / 16;                           // 16-bit pieces per row
+   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (t >= Nx * Ny * wpr) return;
+   const int64_t row = t / wpr, piece = t % wpr;
    const int64_t iy = row % Ny, ix = row / Ny;
-   const int64_t iz0 = bcol * 8;
+   const int64_t iz0 = piece * 16;
    uint32_t m = 0;
-   for (int i = 0; i < 8; i++) {
+   for (int i = 0; i < 16; i++) {
       const int64_t iz = iz0 + i;
       bool skip = (iz == 0) || (iz >= Nz - 1);
       if (parity && (((ix + iy + iz + (parity - 1)) & 1) != 0)) skip = true; // parity-1 = parity of the global ix of plane 0
       if (skip) m |= 1u << i;
    }
-   mask[row * (P / 8) + bcol] = (uint8_t)m;
+   ((uint16_t *)mask)[row * wpr + piece] = (uint16_t)m;
 }
 static __global__ void k_mask_set(uint8_t *__restrict__ mask, const int64_t *__restrict__ idx, int64_t n) {
    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
