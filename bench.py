@@ -228,11 +228,10 @@ def run_chain(args):
     transport = {"auto": engine.PF_TRANSPORT_AUTO, "peer": engine.PF_TRANSPORT_PEER, "rccl": engine.PF_TRANSPORT_RCCL}[args.transport]
     m = engine.HipMulti(sd, devices, numerics=args.numerics, air_variant=args.variant, air_chunk=args.chunk, debug=args.debug,
                         transport=transport, verify_exchange=min(W, 4))
-    plane_elems = sd.Ny * engine.grid_pitch(sd.Nz, real_bytes)
     slabs = [m.slab(g) for g in range(N)]
     for g, sl in enumerate(slabs):
-        nloc = (sl["x1"] - sl["x0"]) + (1 if g > 0 else 0) + (1 if g < N - 1 else 0)
-        fill_engine_grids(torch, sl["engine"], nloc, plane_elems, real_bytes, sl["device"], 1234 + g)
+        (nloc, ny, _), pitch, _ = sl["engine"].layout()
+        fill_engine_grids(torch, sl["engine"], nloc, ny * pitch, real_bytes, sl["device"], 1234 + g)
 
     def sync_all():
         for d in sorted(set(devices)):
@@ -437,7 +436,7 @@ def main():
     tm = eng.timing()
 
     # sanity: the field must still be finite
-    if not bool(torch.isfinite(runner.st.grids[0][loc.Nx // 2]).all()):
+    if not bool(torch.isfinite(runner.st.grids[0][len(runner.st.grids[0]) // 2]).all()):
         raise SystemExit("bench: non-finite field")
 
     if rank == 0:

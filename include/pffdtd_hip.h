@@ -99,7 +99,8 @@ typedef struct pf_opts {
                              checkerboard form (fcc_flag 1) whose existing nodes have even ix+iy+iz */
    int32_t debug;         /* test switches, 0 in production: 0x100 / 0x200 / 0x400 force 32- / 16- / 64-lane row segments; 0x4000 single
                              steps only (no blocked pairs); 0x8000 no creation-time measurement (static rules choose the kernel);
-                             0x20000000 the boundary-list kernel visits every node (none left to the column-strip kernel) */
+                             0x20000000 the boundary-list kernel visits every node (none left to the column-strip kernel); 0x1000 /
+                             0x2000 store the grid with the file's x and z axes exchanged / never (default: decided per scene) */
    int32_t energy;        /* 1 = keep what the energy diagnostic needs (explicit Laplacian grid, unfused kernel
                              sequence); then use pf_engine_energy_cfg + pf_engine_run_energy */
    int32_t multi_flags;   /* pf_run_sim_devices / pf_multi_create only: PF_MULTI_* */
@@ -222,6 +223,11 @@ int  pf_engine_place_grids(pf_engine *e, void *const *pool, int32_t n, int32_t i
  * Lets a host that left the allocation to the engine (which then also chooses WHERE the grids live, see DESIGN.md
  * "placement") initialise or inspect the field on the device.  No counterpart in the reference. */
 int  pf_engine_state_grids(pf_engine *e, void **u_prev, void **u_cur);
+/* How those grids are laid out: dims[0..2] = planes, rows, columns as STORED, pitch = elements per row (a grid holds
+ * dims[0] * dims[1] * pitch elements), exchanged = 1 when the engine stores the file's x and z axes exchanged (unit stride along
+ * file x; only engines that own their grids may choose to, see DESIGN.md 5: rooms whose large surfaces are normal to file z).
+ * pf_engine_get_grid / _set_grid and every index in pf_simdata stay in file order whatever the storage. */
+int  pf_engine_layout(pf_engine *e, int64_t *dims, int64_t *pitch, int32_t *exchanged);
 void *pf_engine_stream(pf_engine *e, int32_t which); /* 0 main, 1 edge: hipStream_t */
 int  pf_engine_sync(pf_engine *e);
 int  pf_engine_flush_outputs(pf_engine *e);          /* ring -> sd->u_out */

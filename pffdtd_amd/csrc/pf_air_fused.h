@@ -47,6 +47,7 @@ struct LeanParams {
    int32_t nzt, nyt, nxc, swizzle;
    int32_t first, last;
    int32_t do_abc;
+   int32_t swz;             // storage has the file's x and z axes exchanged (AirParams::swz)
    const void *u0_src;      // out-of-place step: u^{n-1} is read from here, u^{n+1} written to u0 (null: in place)
    int32_t yt0;             // first y tile of this launch (row-strip launches); nyt counts from there
    int32_t yt_split, yt_hi0; // two row strips in one launch: tiles [yt0, yt0+yt_split) and [yt_hi0, ...) (yt_split < 0: off)
@@ -198,12 +199,19 @@ __global__ __launch_bounds__(64 * WY) void k_air_cart_lean(LeanParams fp, Real a
          const vec ym = (r == 0) ? above : cur[r > 0 ? r - 1 : 0];
          const vec yp = (r == R - 1) ? below : cur[r < R - 1 ? r + 1 : R - 1];
          const uint32_t bits = (mb[r] >> (so[r] & 7u)) & ((1u << V) - 1u);
-         vec o;
+         vec o, zpv, zmv;
 #pragma unroll
          for (int i = 0; i < V; i++) {
-            const Real zp = (i == V - 1) ? curR[r] : c[i < V - 1 ? i + 1 : V - 1];
-            const Real zm = (i == 0) ? curL[r] : c[i > 0 ? i - 1 : 0];
-            o[i] = upd7<SG>(a1, a2, c[i], old[r][i], nxt[r][i], prev[r][i], yp[i], ym[i], zp, zm); // +NzNy, -NzNy, +Nz, -Nz, +1, -1
+            zpv[i] = (i == V - 1) ? curR[r] : c[i < V - 1 ? i + 1 : V - 1];
+            zmv[i] = (i == 0) ? curL[r] : c[i > 0 ? i - 1 : 0];
+         }
+         // file order +x, -x, +y, -y, +z, -z = storage +NzNy, -NzNy, +Nz, -Nz, +1, -1 (axes exchanged: +1, -1, +Nz, -Nz, +NzNy, -NzNy)
+         if (fp.swz) {
+#pragma unroll
+            for (int i = 0; i < V; i++) o[i] = upd7<SG>(a1, a2, c[i], old[r][i], zpv[i], zmv[i], yp[i], ym[i], nxt[r][i], prev[r][i]);
+         } else {
+#pragma unroll
+            for (int i = 0; i < V; i++) o[i] = upd7<SG>(a1, a2, c[i], old[r][i], nxt[r][i], prev[r][i], yp[i], ym[i], zpv[i], zmv[i]);
          }
          if (fp.do_abc) {
             // ABC loss (cpu_engine.h:225-229): u2ba is the old value of the cell, Q from the coordinates

@@ -79,6 +79,7 @@ struct EngineBase {
    virtual int step_end(int64_t n) = 0;
    virtual int halo_ptrs(void **slo, void **shi, void **rlo, void **rhi, size_t *bytes) = 0;
    virtual int state_grids(void **up, void **uc) = 0;
+   virtual int layout(int64_t *dims, int64_t *pitch, int32_t *exchanged) = 0;
    virtual int sync() = 0;
    virtual int flush() = 0;
    virtual int set_spares(void *g2, void *g3) = 0;
@@ -95,7 +96,16 @@ struct EngineBase {
 template <typename Real> struct Engine : EngineBase {
    pf_simdata sd{};
    pf_opts op{};
-   int64_t Nx = 0, Ny = 0, Nz = 0, P = 0, plane = 0, npad = 0;
+   int64_t Nx = 0, Ny = 0, Nz = 0, P = 0, plane = 0, npad = 0; // STORAGE dimensions (= the file's unless swz)
+   // Axis exchange: the reference's GPU preparation sorts the axes by size (rotate_sim_data.py:30-130), which makes the SMALLEST
+   // dimension the unit-stride one -- and the room's largest surfaces (floor, ceiling: normal to it) the ones whose nodes lie a
+   // whole row apart, a 128-byte line of u^n, u^{n-1} and u^{n+1} per node in the boundary pass.  With swz the engine STORES
+   // the grid with the file's x and z axes exchanged (unit stride along file x, the longest axis): the strided surfaces are
+   // then the smallest ones.  Kernels work in storage coordinates; the order in which neighbours enter the sums, the adjacency
+   // bits and every index the caller sees stay in file terms, so the bits do not change.  Single-domain engines with their
+   // own grids only (a slab's ghost planes must be contiguous; caller-owned grids have the documented layout).
+   bool swz = false;
+   int64_t fNx = 0, fNy = 0, fNz = 0;                          // the file's dimensions
    int64_t Nb = 0, Nbl = 0, Nba = 0, Ns = 0, Nr = 0, Nt = 0;
    int mb_max = 0; // largest branch count of the materials
    bool fcc = false, fold = false;
@@ -224,7 +234,16 @@ template <typename Real> struct Engine : EngineBase {
    }
 
    // file-layout linear index -> padded index
-   inline int64_t pad_idx(int64_t ii) const { return (ii / Nz) * P + (ii % Nz); }
+   // file-layout linear index -> storage coordinates
+   inline void decode(int64_t ii, int64_t &ix, int64_t &iy, int64_t &iz) const {
+      const int64_t fz = ii % fNz, fy = (ii / fNz) % fNy, fx = ii / (fNz * fNy);
+      ix = swz ? fz : fx; iy = fy; iz = swz ? fx : fz;
+   }
+   inline int64_t pad_idx(int64_t ii) const {
+      int64_t ix, iy, iz;
+      decode(ii, ix, iy, iz);
+      return (ix * Ny + iy) * P + iz;
+   }
 
    template <typename T> int upload(T **dst, const T *src, int64_t n) {
       *dst = nullptr;
@@ -269,15 +288,15 @@ template <typename Real> struct Engine : EngineBase {
       if (plane >= ((int64_t)1 << 31)) return false;   // 32-bit in-plane offsets
       // boundary nodes must not sit in the ABC shell (the reference applies ABC before the rigid update there)
       for (int64_t i = 0; i < Nb; i++) {
-         const int64_t ii = sd.bn_ixyz[i];
-         const int64_t iz = ii % Nz, iy = (ii / Nz) % Ny, ix = ii / (Nz * Ny);
+         int64_t ix, iy, iz;
+         decode(sd.bn_ixyz[i], ix, iy, iz);
          if ((op.slab_first && ix == 1) || (op.slab_last && ix == Nx - 2) || iy == 1 || iz == 1 || iz == Nz - 2) return false;
          if (!fold && iy == Ny - 2) return false;
       }
       // receivers must not read ghost cells (their memory copy is not maintained)
       for (int64_t i = 0; i < Nr; i++) {
-         const int64_t ii = sd.out_ixyz[i];
-         const int64_t iz = ii % Nz, iy = (ii / Nz) % Ny, ix = ii / (Nz * Ny);
+         int64_t ix, iy, iz;
+         decode(sd.out_ixyz[i], ix, iy, iz);
          if (ix < 1 || iy < 1 || iz < 1 || ix > Nx - 2 || iy > Ny - 2 || iz > Nz - 2) return false;
       }
       // the ABC list must be the canonical shell (it is generated by the loader; a caller could pass anything)
@@ -291,13 +310,58 @@ template <typename Real> struct Engine : EngineBase {
    bool rigid_separable() const {
       if (!fold) return true;
       for (int64_t i = 0; i < Nb; i++)
-         if ((sd.bn_ixyz[i] / Nz) % Ny == Ny - 2) return false;
+         if ((sd.bn_ixyz[i] / fNz) % fNy == fNy - 2) return false;
       return true;
+   }
+
+   // Store the grid with the file's x and z axes exchanged?  debug 0x1000 forces it (tests), 0x2000 forbids it.  Automatic:
+   // rooms only (a box-shaped room -- most boundary nodes within a few cells of a grid face -- steps in blocked pairs, which
+   // exist for the file's axis order only), when clearly more boundary nodes have their successor ALONG FILE X in the list
+   // than along file z: those runs become unit-stride runs, the others a row apart.
+   int decide_swap() {
+      swz = false;
+      const bool single = op.slab_first && op.slab_last, ext = op.ext_u0 && op.ext_u1;
+      const int vb = op.air_variant & 255;
+      if (op.debug & 0x1000) {
+         if (!single || ext || op.energy || vb == 40 || vb == 41)
+            return set_err(PF_ERR_ARG, "debug 0x1000 (axes exchanged in storage): single-domain engines with their own grids, single steps, no energy diagnostic");
+         swz = true;
+         return PF_OK;
+      }
+      if ((op.debug & 0x2000) || !single || ext || op.energy || vb == 40 || vb == 41) return PF_OK;
+      if (sd.Nb < 100000 || sd.Npts > ((int64_t)1 << 33) || fNx <= fNz) return PF_OK; // (small scenes: nothing to gain; the bitmap below is Npts / 8 bytes)
+      const int64_t NzNy = fNz * fNy;
+      std::vector<uint64_t> bits((size_t)(sd.Npts >> 6) + 1, 0);
+      int64_t near_face = 0;
+      for (int64_t i = 0; i < sd.Nb; i++) {
+         const int64_t ii = sd.bn_ixyz[i];
+         if (ii < 0 || ii >= sd.Npts) return PF_OK; // (reported by the checks that follow)
+         bits[(size_t)(ii >> 6)] |= (uint64_t)1 << (ii & 63);
+         const int64_t fz = ii % fNz, fy = (ii / fNz) % fNy, fx = ii / NzNy;
+         const int64_t d = std::min(std::min(std::min(fx, fNx - 1 - fx), std::min(fy, fNy - 1 - fy)), std::min(fz, fNz - 1 - fz));
+         near_face += d < 16;
+      }
+      if (near_face * 10 >= sd.Nb * 8) return PF_OK; // a box-shaped room
+      auto has = [&](int64_t ii) { return ii < sd.Npts && ((bits[(size_t)(ii >> 6)] >> (ii & 63)) & 1u) != 0; };
+      int64_t run_z = 0, run_x = 0;
+      for (int64_t i = 0; i < sd.Nb; i++) {
+         const int64_t ii = sd.bn_ixyz[i];
+         run_z += has(ii + 1);
+         run_x += has(ii + NzNy);
+      }
+      // measured (profiles/r03_reference_configs.jsonl): CTK church 3.46 M / 2.75 M (x / z successors) +12-15 % exchanged, Musikverein
+      // 17.2 M / 14.4 M +11 %
+      swz = (double)run_x > 1.1 * (double)run_z && run_x - run_z > sd.Nb / 20;
+      if (getenv("PFFDTD_VERBOSE") && atoi(getenv("PFFDTD_VERBOSE")) > 0)
+         fprintf(stderr, "pffdtd_hip: %ld of %ld boundary nodes have their successor along file x, %ld along file z: storage %s\n", (long)run_x,
+                 (long)sd.Nb, (long)run_z, swz ? "with the x and z axes exchanged (unit stride along file x)" : "in file order");
+      return PF_OK;
    }
 
    int init(const pf_simdata *s, const pf_opts *o) {
       sd = *s;
       op = *o;
+      fNx = sd.Nx; fNy = sd.Ny; fNz = sd.Nz;
       Nx = sd.Nx; Ny = sd.Ny; Nz = sd.Nz;
       Nb = sd.Nb; Nbl = sd.Nbl; Nba = sd.Nba; Ns = sd.Ns; Nr = sd.Nr; Nt = sd.Nt;
       if (Nx < 3 || Ny < 3 || Nz < 3) return set_err(PF_ERR_ARG, "grid must be at least 3x3x3 (got %ld %ld %ld)", (long)Nx, (long)Ny, (long)Nz);
@@ -312,6 +376,8 @@ template <typename Real> struct Engine : EngineBase {
       fcc = sd.fcc_flag > 0;
       fold = sd.fcc_flag == 2;
       a1 = (Real)sd.a1; a2 = (Real)sd.a2; sl2 = (Real)sd.sl2; lo2 = (Real)sd.lo2; l = (Real)sd.l;
+      { int rc = decide_swap(); if (rc) return rc; }
+      if (swz) std::swap(Nx, Nz);
       P = grid_pitch(Nz, sizeof(Real));
       plane = Ny * P;
       npad = Nx * plane;
@@ -341,21 +407,23 @@ template <typename Real> struct Engine : EngineBase {
       }
 
       // ---- sorted, re-based node lists ----
-      auto sorted_perm = [&](const int64_t *src, int64_t n, std::vector<int64_t> &idx) {
-         std::vector<int64_t> perm(n);
+      auto sorted_perm = [&](const int64_t *src, int64_t n, std::vector<int64_t> &idx) { // by STORAGE index (= file order unless swz)
+         std::vector<int64_t> perm(n), key(n);
          std::iota(perm.begin(), perm.end(), 0);
+         for (int64_t i = 0; i < n; i++) key[i] = pad_idx(src[i]);
          bool is_sorted = true;
-         for (int64_t i = 1; i < n && is_sorted; i++) is_sorted = src[i - 1] <= src[i];
-         if (!is_sorted) std::stable_sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) { return src[a] < src[b]; });
+         for (int64_t i = 1; i < n && is_sorted; i++) is_sorted = key[i - 1] <= key[i];
+         if (!is_sorted) std::stable_sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) { return key[a] < key[b]; });
          idx.resize(n);
-         for (int64_t i = 0; i < n; i++) idx[i] = pad_idx(src[perm[i]]);
+         for (int64_t i = 0; i < n; i++) idx[i] = key[perm[i]];
          return perm;
       };
       auto in_interior = [&](const int64_t *src, int64_t n, const char *what) -> int {
          for (int64_t i = 0; i < n; i++) {
             const int64_t ii = src[i];
             if (ii < 0 || ii >= sd.Npts) return set_err(PF_ERR_ARG, "%s[%ld]=%ld outside the grid", what, (long)i, (long)ii);
-            const int64_t iz = ii % Nz, iy = (ii / Nz) % Ny, ix = ii / (Nz * Ny);
+            int64_t ix, iy, iz;
+            decode(ii, ix, iy, iz);
             if (ix < 1 || iy < 1 || iz < 1 || ix > Nx - 2 || iy > Ny - 2 || iz > Nz - 2)
                return set_err(PF_ERR_ARG, "%s[%ld]=%ld is not an interior node", what, (long)i, (long)ii); // fdtd_common.h:83-101
          }
@@ -511,7 +579,7 @@ template <typename Real> struct Engine : EngineBase {
          fprintf(stderr, "pffdtd_hip: engine on device %d, %ldx%ldx%ld %s %s, interior path: %s%s, numerics: %s\n", op.device, (long)Nx, (long)Ny, (long)Nz,
                  fcc ? "13-point" : "7-point", sizeof(Real) == 4 ? "fp32" : "fp64",
                  tb2 ? "temporally blocked pairs" : (lean ? "lean fused kernel" : (vg ? "barrier-free kernel, virtual ghosts" : (abck ? "barrier-free kernel, in-kernel ABC" : "unfused reference sequence"))),
-                 tb2_geom && !tb2 ? " (pairs when the caller hands over four grids)" : "", sg ? "GPU-safeguarded" : "CPU-exact");
+                 tb2_geom && !tb2 ? " (pairs when the caller hands over four grids)" : (swz ? " (stored with the file's x and z axes exchanged)" : ""), sg ? "GPU-safeguarded" : "CPU-exact");
       HIPCHK(hipDeviceSynchronize());
       return PF_OK;
    }
@@ -526,7 +594,7 @@ template <typename Real> struct Engine : EngineBase {
    int init_tb2() {
       tb2 = tb2_geom = tb2_slab = false;
       const bool single = op.slab_first && op.slab_last;
-      if (op.energy || (op.debug & 0x4000)) return PF_OK; // 0x4000: single steps only
+      if (op.energy || (op.debug & 0x4000) || swz) return PF_OK; // 0x4000: single steps only; exchanged axes: single-step kernels only
       // 7-point: the fused single-step kernels carry the shell; 13-point: folded grids with the flips in memory and the ABC
       // loss in the interior kernel (the automatic 13-point arrangement)
       if (fcc ? !(fold && abck) : !(lean || vg)) return PF_OK;
@@ -1255,7 +1323,7 @@ template <typename Real> struct Engine : EngineBase {
          pf::AirParams ap;
          ap.Ny = Ny; ap.P = P; ap.plane = plane;
          ap.x_begin = tbx0; ap.x_end = tbx1; ap.chunk = tb_chunk; ap.nxc = tb_nxc; ap.nzt = sh_nzt; ap.nyt = sh_nyt;
-         ap.swizzle = 0;
+         ap.swizzle = 0; ap.swz = 0;
          ap.Nx = (int)Nx; ap.Nz = (int)Nz; ap.first = op.slab_first; ap.last = op.slab_last; ap.fold = fold ? 1 : 0;
          hipLaunchKernelGGL((pf::k_air_fcc<Real, 4, 4, 1, false, true, false, true, 64>), dim3((uint32_t)sh_ntiles), dim3(256), 0, s, u1, u0, mask, a1, a2,
                             ap, l, u0_src, sh_tiles);
@@ -1433,6 +1501,7 @@ template <typename Real> struct Engine : EngineBase {
       ap.nxc = (int)cdiv(nplanes, chunk);
       ap.swizzle = swizzle_mode((int64_t)ap.nzt * ap.nyt);
       ap.Nx = (int)Nx; ap.Nz = (int)Nz; ap.first = op.slab_first; ap.last = op.slab_last; ap.fold = fold ? 1 : 0;
+      ap.swz = swz ? 1 : 0;
       const uint32_t total = grid_blocks(ap.swizzle, ap.nzt, ap.nyt, ap.nxc);
       dim3 g(total), b(64 * WY * WZ);
       if (v1_dst && vg && !fcc) { // autotune: the 7-point kernel writing to a scratch grid
@@ -1480,6 +1549,7 @@ template <typename Real> struct Engine : EngineBase {
       fp.swizzle = swizzle_mode((int64_t)fp.nzt * fp.nyt);
       fp.first = op.slab_first; fp.last = op.slab_last;
       fp.do_abc = 1;
+      fp.swz = swz ? 1 : 0;
       dim3 g(grid_blocks(fp.swizzle, fp.nzt, fp.nyt, fp.nxc)), b(64 * WY);
       if (sg) hipLaunchKernelGGL((pf::k_air_cart_lean<Real, R, WY, true, NT>), g, b, 0, s, fp, a1, a2, l);
       else hipLaunchKernelGGL((pf::k_air_cart_lean<Real, R, WY, false, NT>), g, b, 0, s, fp, a1, a2, l);
@@ -1522,7 +1592,7 @@ template <typename Real> struct Engine : EngineBase {
       if (r.e <= r.b) return;
       launch_fold_row(s);
       dim3 g((unsigned)cdiv(r.e - r.b, 128)), b(128);
-#define PF_BND(F, M) hipLaunchKernelGGL((pf::k_boundary<Real, F, M>), g, b, 0, s, u1, u0, d_bn, d_adj, d_lossy, a2, sl2, P, plane, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq, d_beta, vh1, gh1, lo2, (int64_t)mb_max, r.b, r.e, u0_src ? u0_src : (const Real *)u0, bnd_sel)
+#define PF_BND(F, M) hipLaunchKernelGGL((pf::k_boundary<Real, F, M>), g, b, 0, s, u1, u0, d_bn, d_adj, d_lossy, a2, sl2, P, plane, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq, d_beta, vh1, gh1, lo2, (int64_t)mb_max, r.b, r.e, u0_src ? u0_src : (const Real *)u0, bnd_sel, swz ? 1 : 0)
       if (fcc) { if (sg) PF_BND(true, true); else PF_BND(true, false); }
       else { if (sg) PF_BND(false, true); else PF_BND(false, false); }
 #undef PF_BND
@@ -1534,11 +1604,11 @@ template <typename Real> struct Engine : EngineBase {
       launch_fold_row(s);
       dim3 g((unsigned)cdiv(r.e - r.b, 256)), b(256);
       if (fcc) {
-         if (sg) hipLaunchKernelGGL((pf::k_rigid<Real, true, true>), g, b, 0, s, u1, u0, d_bn, d_adj, a2, sl2, P, plane, r.b, r.e);
-         else hipLaunchKernelGGL((pf::k_rigid<Real, true, false>), g, b, 0, s, u1, u0, d_bn, d_adj, a2, sl2, P, plane, r.b, r.e);
+         if (sg) hipLaunchKernelGGL((pf::k_rigid<Real, true, true>), g, b, 0, s, u1, u0, d_bn, d_adj, a2, sl2, P, plane, r.b, r.e, swz ? 1 : 0);
+         else hipLaunchKernelGGL((pf::k_rigid<Real, true, false>), g, b, 0, s, u1, u0, d_bn, d_adj, a2, sl2, P, plane, r.b, r.e, swz ? 1 : 0);
       } else {
-         if (sg) hipLaunchKernelGGL((pf::k_rigid<Real, false, true>), g, b, 0, s, u1, u0, d_bn, d_adj, a2, sl2, P, plane, r.b, r.e);
-         else hipLaunchKernelGGL((pf::k_rigid<Real, false, false>), g, b, 0, s, u1, u0, d_bn, d_adj, a2, sl2, P, plane, r.b, r.e);
+         if (sg) hipLaunchKernelGGL((pf::k_rigid<Real, false, true>), g, b, 0, s, u1, u0, d_bn, d_adj, a2, sl2, P, plane, r.b, r.e, swz ? 1 : 0);
+         else hipLaunchKernelGGL((pf::k_rigid<Real, false, false>), g, b, 0, s, u1, u0, d_bn, d_adj, a2, sl2, P, plane, r.b, r.e, swz ? 1 : 0);
       }
    }
    void launch_fd(hipStream_t s, Range r) {
@@ -1804,6 +1874,12 @@ template <typename Real> struct Engine : EngineBase {
       if (uc) *uc = u1;
       return PF_OK;
    }
+   int layout(int64_t *dims, int64_t *pitch, int32_t *exchanged) override {
+      if (dims) { dims[0] = Nx; dims[1] = Ny; dims[2] = Nz; }
+      if (pitch) *pitch = P;
+      if (exchanged) *exchanged = swz ? 1 : 0;
+      return PF_OK;
+   }
    int halo_ptrs(void **slo, void **shi, void **rlo, void **rhi, size_t *bytes) override {
       // new state is u0 until step_end rotates (gpu_engine.h:1086-1126 sends the same planes)
       if (slo) *slo = u0 + plane;
@@ -1929,6 +2005,16 @@ template <typename Real> struct Engine : EngineBase {
          launch_flips(s_main);
          HIPCHK(hipStreamSynchronize(s_main));
       }
+      if (swz) { // storage -> file order through a device-side transposition
+         Real *tmp = nullptr;
+         HIPCHK(hipMalloc((void **)&tmp, (size_t)sd.Npts * sizeof(Real)));
+         hipLaunchKernelGGL((pf::k_storage_to_file<Real>), dim3((unsigned)cdiv(sd.Npts, 256)), dim3(256), 0, s_main, src, tmp, fNx, fNy, fNz, Ny, P);
+         const hipError_t e = hipMemcpyAsync(host, tmp, (size_t)sd.Npts * sizeof(Real), hipMemcpyDeviceToHost, s_main);
+         hipStreamSynchronize(s_main);
+         hipFree(tmp);
+         HIPCHK(e);
+         return PF_OK;
+      }
       HIPCHK(hipMemcpy2D(host, Nz * sizeof(Real), src, P * sizeof(Real), Nz * sizeof(Real), Nx * Ny, hipMemcpyDeviceToHost));
       return PF_OK;
    }
@@ -1938,6 +2024,16 @@ template <typename Real> struct Engine : EngineBase {
       if (rc) return rc;
       Real *dst = which == 0 ? u0 : u1;
       state_touched = true;
+      if (swz) {
+         Real *tmp = nullptr;
+         HIPCHK(hipMalloc((void **)&tmp, (size_t)sd.Npts * sizeof(Real)));
+         hipError_t e = hipMemcpyAsync(tmp, host, (size_t)sd.Npts * sizeof(Real), hipMemcpyHostToDevice, s_main);
+         hipLaunchKernelGGL((pf::k_file_to_storage<Real>), dim3((unsigned)cdiv(sd.Npts, 256)), dim3(256), 0, s_main, tmp, dst, fNx, fNy, fNz, Ny, P);
+         hipStreamSynchronize(s_main);
+         hipFree(tmp);
+         HIPCHK(e);
+         return PF_OK;
+      }
       HIPCHK(hipMemcpy2D(dst, P * sizeof(Real), host, Nz * sizeof(Real), Nz * sizeof(Real), Nx * Ny, hipMemcpyHostToDevice));
       return PF_OK;
    }
@@ -2016,6 +2112,7 @@ int pf_engine_halo_ptrs(pf_engine *e, void **send_lo, void **send_hi, void **rec
 }
 int pf_engine_step_end(pf_engine *e, int64_t n) { PF_NEED(e); return e->impl->step_end(n); }
 int pf_engine_state_grids(pf_engine *e, void **u_prev, void **u_cur) { PF_NEED(e); return e->impl->state_grids(u_prev, u_cur); }
+int pf_engine_layout(pf_engine *e, int64_t *dims, int64_t *pitch, int32_t *exchanged) { PF_NEED(e); return e->impl->layout(dims, pitch, exchanged); }
 int pf_engine_set_spares(pf_engine *e, void *g2, void *g3) { PF_NEED(e); return e->impl->set_spares(g2, g3); }
 int pf_engine_place_grids(pf_engine *e, void *const *grids, int32_t n, int32_t *idx) { PF_NEED(e); return e->impl->place_grids(grids, n, idx); }
 void *pf_engine_stream(pf_engine *e, int32_t which) { return (e && e->impl) ? e->impl->stream(which) : nullptr; }

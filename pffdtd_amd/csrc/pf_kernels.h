@@ -213,6 +213,10 @@ struct AirParams {
    int32_t swizzle;
    // VG (virtual ghost shell + in-kernel ABC) only:
    int32_t Nx, Nz, first, last, fold;
+   // 1: the grid is stored with the file's x and z axes exchanged (Engine::swz: unit stride along file x).  The kernels work in
+   // storage coordinates; only the ORDER in which the neighbours enter the sums follows the file's axes, so that the bits are
+   // the reference's whatever the storage order
+   int32_t swz;
 };
 
 // =============================================================================================================
@@ -344,13 +348,20 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_cart(const Real *__restric
          if (lane == LW - 1) zp = curR[r];
          if (fixR) zp = c[V - 2]; // my right neighbour is the ghost column
          const uint32_t bits = mb[r] >> (uint32_t)(soff[r] & 7);
-         vec o;
+         vec o, lft, rgt;
 #pragma unroll
          for (int i = 0; i < V; i++) {
-            const Real left = (i == 0) ? zm : c[i > 0 ? i - 1 : 0];
-            const Real right = (i == V - 1) ? zp : c[i < V - 1 ? i + 1 : V - 1];
-            // +NzNy, -NzNy, +Nz, -Nz, +1, -1
-            o[i] = upd7<SG>(a1, a2, c[i], old[r][i], nxt[r + 1][i], prev[r][i], cur[r + 2][i], cur[r][i], right, left);
+            lft[i] = (i == 0) ? zm : c[i > 0 ? i - 1 : 0];
+            rgt[i] = (i == V - 1) ? zp : c[i < V - 1 ? i + 1 : V - 1];
+         }
+         // file order +x, -x, +y, -y, +z, -z = storage +NzNy, -NzNy, +Nz, -Nz, +1, -1 (axes exchanged: +1, -1, +Nz, -Nz, +NzNy, -NzNy);
+         // one wave-uniform branch around the whole row
+         if (ap.swz) {
+#pragma unroll
+            for (int i = 0; i < V; i++) o[i] = upd7<SG>(a1, a2, c[i], old[r][i], rgt[i], lft[i], cur[r + 2][i], cur[r][i], nxt[r + 1][i], prev[r][i]);
+         } else {
+#pragma unroll
+            for (int i = 0; i < V; i++) o[i] = upd7<SG>(a1, a2, c[i], old[r][i], nxt[r + 1][i], prev[r][i], cur[r + 2][i], cur[r][i], rgt[i], lft[i]);
          }
          if (VG || ABCK) { // ABC loss (cpu_engine.h:225-229); u2ba is the old value of the cell
             const int64_t y = y0 + r;
@@ -531,12 +542,23 @@ __global__ __launch_bounds__(64 * WY * WZ) void k_air_fcc(const Real *__restrict
          const vec p_lo = shift_lo(prev[j], prevL[j]), p_hi = shift_hi(prev[j], prevR[j]);
          const uint32_t bits = mb[r] >> (uint32_t)(soff[r] & 7);
          vec o;
+         // file order of the twelve neighbours = storage +NzNy+Nz, -NzNy-Nz, +Nz+1, -Nz-1, +NzNy+1, -NzNy-1, +NzNy-Nz, -NzNy+Nz, +Nz-1,
+         // -Nz+1, +NzNy-1, -NzNy+1; with the axes exchanged file (dx, dy, dz) = storage (dz, dy, dx): entries 0<->2, 1<->3, 6<->9,
+         // 7<->8, 10<->11 change places.  One wave-uniform branch around the whole row.
+         if (ap.swz) {
 #pragma unroll
-         for (int i = 0; i < V; i++) {
-            // +NzNy+Nz, -NzNy-Nz, +Nz+1, -Nz-1, +NzNy+1, -NzNy-1, +NzNy-Nz, -NzNy+Nz, +Nz-1, -Nz+1, +NzNy-1, -NzNy+1
-            const Real nb[12] = {nxt[j + 1][i], prev[j - 1][i], cu_hi[i], cd_lo[i], n_hi[i], p_lo[i],
-                                 nxt[j - 1][i], prev[j + 1][i], cu_lo[i], cd_hi[i], n_lo[i], p_hi[i]};
-            o[i] = upd13<SG>(a1, a2, c[i], old[r][i], nb);
+            for (int i = 0; i < V; i++) {
+               const Real nbs[12] = {cu_hi[i], cd_lo[i], nxt[j + 1][i], prev[j - 1][i], n_hi[i], p_lo[i],
+                                     cd_hi[i], cu_lo[i], prev[j + 1][i], nxt[j - 1][i], p_hi[i], n_lo[i]};
+               o[i] = upd13<SG>(a1, a2, c[i], old[r][i], nbs);
+            }
+         } else {
+#pragma unroll
+            for (int i = 0; i < V; i++) {
+               const Real nb[12] = {nxt[j + 1][i], prev[j - 1][i], cu_hi[i], cd_lo[i], n_hi[i], p_lo[i],
+                                    nxt[j - 1][i], prev[j + 1][i], cu_lo[i], cd_hi[i], n_lo[i], p_hi[i]};
+               o[i] = upd13<SG>(a1, a2, c[i], old[r][i], nb);
+            }
          }
          if (VG || ABCK) { // ABC loss (cpu_engine.h:225-229)
             const int64_t y = y0 + r;
@@ -616,15 +638,17 @@ static __global__ void k_abc_loss(Real *__restrict__ u0, const int64_t *__restri
 
 // ---- rigid boundary nodes, cpu_engine.h:234-287 (gpu_engine.h:288-348) --------------------------------------
 // gather the NN neighbours of a boundary node in the adjacency-bit order (cpu_engine.h:241-246 / 262-273)
+// (axes exchanged in storage: sx = stride of the file's x axis = 1, sz = stride of its z axis = plane)
 template <typename Real, bool FCC>
-__device__ __forceinline__ void gather_nb(const Real *__restrict__ u1, int64_t ii, int64_t P, int64_t plane, Real (&nb)[FCC ? 12 : 6]) {
+__device__ __forceinline__ void gather_nb(const Real *__restrict__ u1, int64_t ii, int64_t P, int64_t plane_, Real (&nb)[FCC ? 12 : 6], bool swz = false) {
+   const int64_t plane = swz ? 1 : plane_, one = swz ? plane_ : 1;
    if (!FCC) {
-      const int64_t off[6] = {plane, -plane, P, -P, 1, -1};
+      const int64_t off[6] = {plane, -plane, P, -P, one, -one};
 #pragma unroll
       for (int j = 0; j < 6; j++) nb[j] = u1[ii + off[j]];
    } else {
-      const int64_t off[12] = {plane + P, -plane - P, P + 1, -P - 1, plane + 1, -plane - 1,
-                               plane - P, -plane + P, P - 1, -P + 1, plane - 1, -plane + 1};
+      const int64_t off[12] = {plane + P, -plane - P, P + one, -P - one, plane + one, -plane - one,
+                               plane - P, -plane + P, P - one, -P + one, plane - one, -plane + one};
 #pragma unroll
       for (int j = 0; j < 12; j++) nb[j] = u1[ii + off[j]];
    }
@@ -632,13 +656,13 @@ __device__ __forceinline__ void gather_nb(const Real *__restrict__ u1, int64_t i
 template <typename Real, bool FCC, bool SG>
 static __global__ void k_rigid(const Real *__restrict__ u1, Real *__restrict__ u0, const int64_t *__restrict__ idx,
                         const uint16_t *__restrict__ adjv, Real a2, Real sl2, int64_t P, int64_t plane,
-                        int64_t begin, int64_t end) {
+                        int64_t begin, int64_t end, int swz) {
    const int64_t nb = begin + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (nb >= end) return;
    const int64_t ii = idx[nb];
    const uint32_t adj = adjv[nb];
    Real v[FCC ? 12 : 6];
-   gather_nb<Real, FCC>(u1, ii, P, plane, v);
+   gather_nb<Real, FCC>(u1, ii, P, plane, v, swz != 0);
    u0[ii] = upd_rigid<SG, FCC ? 12 : 6>(a2, sl2, adj, u1[ii], u0[ii], v);
 }
 
@@ -746,14 +770,14 @@ static __global__ void k_boundary(const Real *__restrict__ u1, Real *u0, const i
                            const Real *__restrict__ ssaf, const int8_t *__restrict__ mat, const int8_t *__restrict__ Mb,
                            const MatQuadT<Real> *__restrict__ mq, const Real *__restrict__ beta, Real *__restrict__ vh1,
                            Real *__restrict__ gh1, Real lo2, int64_t mmax, int64_t begin, int64_t end,
-                           const Real *u0_old, const int32_t *__restrict__ sel) { // u0_old: where u^{n-1} lives (== u0 in place)
+                           const Real *u0_old, const int32_t *__restrict__ sel, int swz) { // u0_old: where u^{n-1} lives (== u0 in place)
    const int64_t t = begin + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (t >= end) return;
    const int64_t nb = sel ? (int64_t)sel[t] : t;
    const int64_t ii = idx[nb];
    const uint32_t adj = adjv[nb];
    Real v[FCC ? 12 : 6];
-   gather_nb<Real, FCC>(u1, ii, P, plane, v);
+   gather_nb<Real, FCC>(u1, ii, P, plane, v, swz != 0);
    Real p = upd_rigid<SG, FCC ? 12 : 6>(a2, sl2, adj, u1[ii], u0_old[ii], v);
    const int32_t li = lossy[nb];
    if (li >= 0) p = fd_node_update<Real>(p, li, u0b, u2b, ssaf, mat, Mb, mq, beta, vh1, gh1, lo2, mmax);
@@ -799,6 +823,21 @@ static __global__ void k_mask_init(uint8_t *__restrict__ mask, int64_t Nx, int64
       if (skip) m |= 1u << i;
    }
    ((uint16_t *)mask)[row * wpr + piece] = (uint16_t)m;
+}
+// exchanged-axes storage (Engine::swz) <-> file order: file cell (fx, fy, fz) lives at storage ((fz*Ny + fy)*P + fx)
+template <typename Real>
+static __global__ void k_storage_to_file(const Real *__restrict__ st, Real *__restrict__ file, int64_t fNx, int64_t fNy, int64_t fNz, int64_t Ny, int64_t P) {
+   const int64_t ii = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (ii >= fNx * fNy * fNz) return;
+   const int64_t fz = ii % fNz, fy = (ii / fNz) % fNy, fx = ii / (fNz * fNy);
+   file[ii] = st[(fz * Ny + fy) * P + fx];
+}
+template <typename Real>
+static __global__ void k_file_to_storage(const Real *__restrict__ file, Real *__restrict__ st, int64_t fNx, int64_t fNy, int64_t fNz, int64_t Ny, int64_t P) {
+   const int64_t ii = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   if (ii >= fNx * fNy * fNz) return;
+   const int64_t fz = ii % fNz, fy = (ii / fNz) % fNy, fx = ii / (fNz * fNy);
+   st[(fz * Ny + fy) * P + fx] = file[ii];
 }
 static __global__ void k_mask_set(uint8_t *__restrict__ mask, const int64_t *__restrict__ idx, int64_t n) {
    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;

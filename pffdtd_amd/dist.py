@@ -41,8 +41,9 @@ class HipSlabStepper:
             self.eng = engine.HipEngine(loc, device=device, slab_first=info.first, slab_last=info.last, x_global0=info.xlo,
                                         **engine_kw)
             ts = "<f4" if loc.real_bytes == 4 else "<f8"
+            (nx, ny, _), pitch, _ = self.eng.layout()  # as STORED: the engine may keep the file's x and z axes exchanged
             with torch.cuda.device(self.device):
-                self.grids = [torch.as_tensor(_DevMem(p, (loc.Nx, self.plane), ts), device=self.device)
+                self.grids = [torch.as_tensor(_DevMem(p, (nx, ny * pitch), ts), device=self.device)
                               for p in self.eng.state_grids()]
             if [g.data_ptr() for g in self.grids] != list(self.eng.state_grids()):
                 raise RuntimeError("torch copied the engine's state grids instead of wrapping them")

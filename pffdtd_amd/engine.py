@@ -49,7 +49,7 @@ class PfError(RuntimeError):
 
 EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_grid_bytes", "pf_grid_pitch", "pf_opts_default",
            "pf_run_sim", "pf_engine_create", "pf_engine_destroy", "pf_engine_run", "pf_engine_step_begin",
-           "pf_engine_halo_ptrs", "pf_engine_step_end", "pf_engine_state_grids", "pf_engine_place_grids", "pf_engine_set_spares", "pf_engine_stream", "pf_engine_sync",
+           "pf_engine_halo_ptrs", "pf_engine_step_end", "pf_engine_state_grids", "pf_engine_layout", "pf_engine_place_grids", "pf_engine_set_spares", "pf_engine_stream", "pf_engine_sync",
            "pf_engine_flush_outputs", "pf_engine_get_grid", "pf_engine_set_grid", "pf_engine_timing", "pf_engine_set_timing",
            "pf_engine_energy_cfg", "pf_engine_run_energy", "pf_run_sim_devices", "pf_slab_partition",
            "pf_multi_create", "pf_multi_run", "pf_multi_get_info", "pf_multi_get_slab", "pf_multi_destroy"]
@@ -113,6 +113,7 @@ def lib():
         L.pf_engine_halo_ptrs.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
                                           ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
         L.pf_engine_state_grids.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
+        L.pf_engine_layout.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i32)]
         L.pf_engine_place_grids.argtypes = [vp, ctypes.POINTER(vp), i32, ctypes.POINTER(i32)]
         L.pf_engine_stream.restype = vp
         L.pf_engine_stream.argtypes = [vp, i32]
@@ -237,6 +238,7 @@ class _EngineView:
         self.dtype = np.float32 if real_bytes == 4 else np.float64
 
     state_grids = lambda self: HipEngine.state_grids(self)  # noqa: E731
+    layout = lambda self: HipEngine.layout(self)  # noqa: E731
     timing = lambda self, reset=False: HipEngine.timing(self, reset)  # noqa: E731
     sync = lambda self: HipEngine.sync(self)  # noqa: E731
     set_timing = lambda self, on: HipEngine.set_timing(self, on)  # noqa: E731
@@ -295,6 +297,13 @@ class HipEngine:
         up, uc = vp(), vp()
         _check(lib().pf_engine_state_grids(self._h, ctypes.byref(up), ctypes.byref(uc)))
         return up.value, uc.value
+
+    def layout(self):
+        """-> ((planes, rows, columns) as stored, pitch in elements, exchanged): exchanged = the engine stores the file's x and z
+        axes exchanged; a state grid holds planes * rows * pitch elements (pf_engine_layout)."""
+        dims, pitch, ex = (ctypes.c_int64 * 3)(), ctypes.c_int64(), ctypes.c_int32()
+        _check(lib().pf_engine_layout(self._h, dims, ctypes.byref(pitch), ctypes.byref(ex)))
+        return (int(dims[0]), int(dims[1]), int(dims[2])), int(pitch.value), bool(ex.value)
 
     def place_grids(self, ptrs):
         """Offer a pool of >= 4 zero-filled caller-owned grids to a slab engine (pf_engine_place_grids).  -> (paired, idx):

@@ -86,8 +86,10 @@ else:
     gen.manual_seed(7)
     from pffdtd_amd.dist import _DevMem
     eng = engine.HipEngine(sd, timing=True, debug=a.debug, air_variant=a.variant)
+    (snx, sny, _), spitch, exchanged = eng.layout()  # as stored (rooms: the engine may keep the file's x and z axes exchanged)
+    res["axes_exchanged"] = exchanged
     for p in eng.state_grids():
-        g = torch.as_tensor(_DevMem(p, (sd.Nx, sd.Ny * P), "<f4" if rb == 4 else "<f8"), device="cuda")
+        g = torch.as_tensor(_DevMem(p, (snx, sny * spitch), "<f4" if rb == 4 else "<f8"), device="cuda")
         assert g.data_ptr() == p
         g.copy_((torch.rand(g.shape, generator=gen, device="cuda", dtype=g.dtype) * 2 - 1) * 1e-3)
     torch.cuda.synchronize()
