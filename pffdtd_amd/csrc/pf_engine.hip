@@ -329,7 +329,7 @@ template <typename Real> struct Engine : EngineBase {
          return PF_OK;
       }
       if ((op.debug & 0x2000) || !single || ext || op.energy || vb == 40 || vb == 41) return PF_OK;
-      if (sd.Nb < 100000 || sd.Npts > ((int64_t)1 << 33) || fNx <= fNz) return PF_OK; // (small scenes: nothing to gain; the bitmap below is Npts / 8 bytes)
+      if (sd.Nb < 100000 || sd.Npts > ((int64_t)1 << 34) || fNx <= fNz) return PF_OK; // (small scenes: nothing to gain; the bitmap below is Npts / 8 bytes)
       const int64_t NzNy = fNz * fNy;
       std::vector<uint64_t> bits((size_t)(sd.Npts >> 6) + 1, 0);
       int64_t near_face = 0;
