@@ -195,7 +195,7 @@ template <typename Real> struct Engine : EngineBase {
    int32_t *zs_rest = nullptr;                            // the other boundary nodes (positions in the boundary list)
    int64_t zs_nrest = 0;
    int zs_mode = 0;                                       // 0: the list kernel does them (debug 0x20000000, and the fallback);
-                                                          // 2: strip kernel does the rigid update, k_fd_sel the branch ODEs (default)
+                                                          // 2: strip kernel does the rigid update, extra threads of the k_boundary launch the branch ODEs (default)
    int32_t *zs_fd = nullptr;                              // mode 2: the lossy nodes (indices into the lossy arrays) inside the strips
    int64_t zs_nfd = 0;
    const int32_t *bnd_sel = nullptr;                      // launch_boundary visits bnd_sel[range] when set
@@ -566,6 +566,7 @@ template <typename Real> struct Engine : EngineBase {
       { int rc = sample_placement(); if (rc) { tb2_probe = false; return rc; } }
       pair_margin = 0.99f;
       if (tb2) { int rc = autotune(); if (rc) { tb2_probe = false; return rc; } }
+      else if (fcc) { int rc = autotune_fcc_lw(); if (rc) { tb2_probe = false; return rc; } } // (pairs dropped or never offered)
       tb2_probe = false;
       if (!tb2 && op.slab_first && op.slab_last) { int rc = sample_placement_single(); if (rc) return rc; }
       // hipGraph replay of the step loop (six steps per graph): measured on MI355X / ROCm 7.2 it does not beat plain
@@ -576,10 +577,10 @@ template <typename Real> struct Engine : EngineBase {
       if (const char *ev = getenv("PFFDTD_GRAPH"))
          graph_ok = ev[0] == '1' && op.slab_first && op.slab_last && !tb2 && !op.timing && !op.energy;
       if (getenv("PFFDTD_VERBOSE") && atoi(getenv("PFFDTD_VERBOSE")) > 0)
-         fprintf(stderr, "pffdtd_hip: engine on device %d, %ldx%ldx%ld %s %s, interior path: %s%s, numerics: %s\n", op.device, (long)Nx, (long)Ny, (long)Nz,
+         fprintf(stderr, "pffdtd_hip: engine on device %d, %ldx%ldx%ld %s %s, interior path: %s%s, numerics: %s, %d-lane row segments\n", op.device, (long)Nx, (long)Ny, (long)Nz,
                  fcc ? "13-point" : "7-point", sizeof(Real) == 4 ? "fp32" : "fp64",
                  tb2 ? "temporally blocked pairs" : (lean ? "lean fused kernel" : (vg ? "barrier-free kernel, virtual ghosts" : (abck ? "barrier-free kernel, in-kernel ABC" : "unfused reference sequence"))),
-                 tb2_geom && !tb2 ? " (pairs when the caller hands over four grids)" : (swz ? " (stored with the file's x and z axes exchanged)" : ""), sg ? "GPU-safeguarded" : "CPU-exact");
+                 tb2_geom && !tb2 ? " (pairs when the caller hands over four grids)" : (swz ? " (stored with the file's x and z axes exchanged)" : ""), sg ? "GPU-safeguarded" : "CPU-exact", tb2 ? tb_lw : (lean ? 64 : pick_lw()));
       HIPCHK(hipDeviceSynchronize());
       return PF_OK;
    }
@@ -786,7 +787,7 @@ template <typename Real> struct Engine : EngineBase {
       // their six neighbours in registers (in k_boundary the floor / ceiling nodes of a box room -- stride-P neighbours,
       // one 128-byte line of u1 and of u0 per two nodes -- cost half of the pass: 0.30 of 0.63 ms at 1024^3).  The strip
       // kernel does the RIGID update only and leaves the result in u0b[li]; the branch ODEs of the lossy ones follow in
-      // k_fd_sel, dense over the compact arrays (mode 2).  (Doing the ODEs inside the strip kernel as well was bit-identical
+      // extra threads of the k_boundary launch, dense over the compact arrays (mode 2).  (Doing the ODEs inside the strip kernel as well was bit-identical
       // but slower -- they ran on the few lanes per wave that hold a node, 2.92 vs 2.59 ms per step -- and was retired.)
       // debug 0x20000000: mode 0, the list kernel visits every boundary node (the round-1 arrangement; also the fallback).
       zs_mode = fcc ? 0 : ((op.debug & 0x20000000) ? 0 : 2);
@@ -847,8 +848,48 @@ template <typename Real> struct Engine : EngineBase {
    // (7-point only; explicit air_variant requests and debug 0x8000 skip it.)  Sizes decide in ways no static rule
    // caught: 1024^3 fp32 pair 411 > lean 377 > barrier-free 364 Gvox/s, 896^3 barrier-free 362 > pair 335 > lean 303.
    // 13-point: one in-place-equivalent single step (written to scratch) against half a blocked pair with its shell
+   // 13-point single steps: lanes per row segment of k_air_fcc (64 / 32 / 16) measured where they pad the rows differently --
+   // the static rule asks for a 25 % narrower padded row before it leaves 64 lanes, which rooms stored along their longest axis
+   // (2852 columns = 11.1 segments of 256) never offer, although the half-empty last segment costs them 7 % of the lanes
+   int autotune_fcc_lw() {
+      if (!fcc || !abck || sg || vbase != 0 || (op.debug & 0x8300) || lw_force || !(op.slab_first && op.slab_last)) return PF_OK;
+      if (Nx * Ny * Nz < ((int64_t)1 << 22)) return PF_OK;
+      constexpr int V = pf::VecOf<Real>::V;
+      if (cdiv(P, (int64_t)64 * V) * 64 == cdiv(P, (int64_t)32 * V) * 32 && cdiv(P, (int64_t)64 * V) * 64 == cdiv(P, (int64_t)16 * V) * 16) return PF_OK;
+      Real *scr = try_dzalloc<Real>(npad);
+      if (!scr) return PF_OK;
+      hipEvent_t e0, e1;
+      HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+      Real *U0 = u0;
+      u0_src = U0; u0 = scr; // (out of place: the state is not touched)
+      int best_lw = 0;
+      float best = 0;
+      int64_t seen = -1;
+      for (int lw : {64, 32, 16}) {
+         const int64_t w = cdiv(P, (int64_t)lw * V) * lw * V;
+         if (w == seen) continue; // same padded width as the wider segment: the wider one wins anyway
+         seen = w;
+         lw_force = lw;
+         launch_air_march(s_main, 1, (int)Nx - 1);
+         hipEventRecord(e0, s_main);
+         for (int i = 0; i < 3; i++) launch_air_march(s_main, 1, (int)Nx - 1);
+         hipEventRecord(e1, s_main);
+         hipEventSynchronize(e1);
+         float ms = 0;
+         hipEventElapsedTime(&ms, e0, e1);
+         if (best_lw == 0 || ms < 0.98f * best) { best = ms; best_lw = lw; }
+      }
+      lw_force = best_lw;
+      tune_ms[1] = best / 3;
+      u0 = U0; u0_src = nullptr;
+      hipEventDestroy(e0); hipEventDestroy(e1);
+      HIPCHK(hipStreamSynchronize(s_main));
+      hipFree(scr);
+      return hipGetLastError() == hipSuccess ? PF_OK : set_err(PF_ERR_HIP, "13-point segment-width measurement: kernel launch failed");
+   }
    int autotune_fcc() {
-      if (!tb2 || vbase != 0 || (op.debug & 0x8000)) return PF_OK;
+      if (!tb2) return autotune_fcc_lw();
+      if (vbase != 0 || (op.debug & 0x8000)) return PF_OK;
       hipEvent_t e0, e1;
       HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
       HIPCHK(hipDeviceSynchronize());
@@ -1387,7 +1428,6 @@ template <typename Real> struct Engine : EngineBase {
       launch_shell(s);
       if (op.timing) { hipEventRecord(eva.second, s); air_ev.push_back(eva); eva = get_ev(); }
       launch_rigid(s, bnd);
-      launch_fd_sel(s);
       launch_fd(s, {0, Nbl});
       launch_io(s, n, true, {0, Ns});
       { Real *t = ub[2]; ub[2] = ub[1]; ub[1] = ub[0]; ub[0] = t; }
@@ -1398,7 +1438,6 @@ template <typename Real> struct Engine : EngineBase {
       launch_shell(s);
       if (op.timing) { hipEventRecord(eva.second, s); air_ev.push_back(eva); }
       launch_rigid(s, bnd);
-      launch_fd_sel(s);
       bnd_sel = nullptr;
       launch_fd(s, {0, Nbl});
       launch_io(s, n + 1, true, {0, Ns});
@@ -1589,10 +1628,14 @@ template <typename Real> struct Engine : EngineBase {
    }
    // rigid + FD in one pass over the boundary list (plane range given on the boundary list)
    void launch_boundary(hipStream_t s, Range r) {
-      if (r.e <= r.b) return;
+      // (inside step_pair) the branch ODEs of the column strips' lossy nodes ride along in the same launch (k_fd_sel's work)
+      // (a launch of its own, k_fd_sel, until round 3: same time within noise, one kernel fewer)
+      const bool with_fd = zs_mode == 2 && bnd_sel && zs_nfd > 0 && r.b == 0 && r.e == zs_nrest;
+      if (r.e <= r.b && !with_fd) return;
       launch_fold_row(s);
-      dim3 g((unsigned)cdiv(r.e - r.b, 128)), b(128);
-#define PF_BND(F, M) hipLaunchKernelGGL((pf::k_boundary<Real, F, M>), g, b, 0, s, u1, u0, d_bn, d_adj, d_lossy, a2, sl2, P, plane, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq, d_beta, vh1, gh1, lo2, (int64_t)mb_max, r.b, r.e, u0_src ? u0_src : (const Real *)u0, bnd_sel, swz ? 1 : 0)
+      const int64_t nfd = with_fd ? zs_nfd : 0;
+      dim3 g((unsigned)cdiv(r.e - r.b + nfd, 128)), b(128);
+#define PF_BND(F, M) hipLaunchKernelGGL((pf::k_boundary<Real, F, M>), g, b, 0, s, u1, u0, d_bn, d_adj, d_lossy, a2, sl2, P, plane, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq, d_beta, vh1, gh1, lo2, (int64_t)mb_max, r.b, r.e, u0_src ? u0_src : (const Real *)u0, bnd_sel, swz ? 1 : 0, with_fd ? zs_fd : (const int32_t *)nullptr, nfd, d_bnl)
       if (fcc) { if (sg) PF_BND(true, true); else PF_BND(true, false); }
       else { if (sg) PF_BND(false, true); else PF_BND(false, false); }
 #undef PF_BND
@@ -1615,12 +1658,6 @@ template <typename Real> struct Engine : EngineBase {
       if (boundary_fused()) return; // done by launch_boundary
       if (r.e > r.b)
          hipLaunchKernelGGL(pf::k_fd_boundary<Real>, dim3((unsigned)cdiv(r.e - r.b, 128)), dim3(128), 0, s, u0, d_bnl, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq, d_beta, vh1, gh1, lo2, (int64_t)mb_max, r.b, r.e);
-   }
-   // branch ODEs of the lossy nodes whose rigid update the column-strip kernel has just done (zs_mode 2)
-   void launch_fd_sel(hipStream_t s) {
-      if (zs_mode != 2 || !bnd_sel || zs_nfd <= 0) return;
-      hipLaunchKernelGGL(pf::k_fd_sel<Real>, dim3((unsigned)cdiv(zs_nfd, 128)), dim3(128), 0, s, u0, d_bnl, zs_fd, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq,
-                         d_beta, vh1, gh1, lo2, (int64_t)mb_max, zs_nfd);
    }
    // receivers on/off + a range of the (sorted) source list
    void launch_io(hipStream_t s, int64_t n, bool receivers, Range src, const int64_t *ctr = nullptr) {

@@ -677,7 +677,7 @@ template <typename Real> struct MatQuadT { Real b, bd, bDh, bFh; };
 __device__ __host__ __forceinline__ int64_t st_idx(int m, int64_t li) { return (((li >> 6) * 12 + m) << 6) + (li & 63); }
 
 // ---- FD (RLC-branch) update of one lossy node, cpu_engine.h:363-405: p = the node's value after the rigid update ------
-// (shared by k_boundary, k_fd_boundary, k_fd_sel and the column-strip kernel of pf_tb2.h, so that all produce the same bits)
+// (shared by k_boundary and k_fd_boundary, so that all produce the same bits)
 // All branch-state and coefficient loads are issued up front (their addresses do not depend on the arithmetic): with the
 // loads inside the accumulation loop every branch cost a memory round trip and the list kernels ran latency-bound
 // (k_fd_sel 2.6 TB/s); the arithmetic keeps the reference's order.
@@ -742,21 +742,6 @@ static __global__ void k_fd_boundary(Real *__restrict__ u0, const int64_t *__res
    u0[ii] = fd_node_update<Real>(u0[ii], (int32_t)nb, u0b, u2b, ssaf, mat, Mb, mq, beta, vh1, gh1, lo2, mmax);
 }
 
-// ---- FD update of a selection of lossy nodes whose rigid update has been done elsewhere (k_air_zstrip, which holds the
-// six neighbours of its boundary nodes in registers): the rigid result waits in u0b[li]; the final value goes back to
-// u0b[li] and to the grid.  Dense over the compact arrays: no gathers from the grid, one scattered store per node.
-template <typename Real>
-static __global__ void k_fd_sel(Real *u0, const int64_t *__restrict__ idx_l, const int32_t *__restrict__ sel, Real *__restrict__ u0b,
-                         const Real *__restrict__ u2b, const Real *__restrict__ ssaf, const int8_t *__restrict__ mat,
-                         const int8_t *__restrict__ Mb, const MatQuadT<Real> *__restrict__ mq, const Real *__restrict__ beta,
-                         Real *__restrict__ vh1, Real *__restrict__ gh1, Real lo2, int64_t mmax, int64_t n) {
-   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-   if (t >= n) return;
-   const int32_t li = sel[t];
-   const Real p = u0b[li];
-   u0[idx_l[li]] = fd_node_update<Real>(p, li, u0b, u2b, ssaf, mat, Mb, mq, beta, vh1, gh1, lo2, mmax);
-}
-
 // ---- fused boundary pass: rigid update of every boundary node + FD update of the lossy ones in one visit ----------
 // (cpu_engine.h:234-287 then :290-301,363-405 for the same node: identical arithmetic, the gather / scatter of u0
 // between the two is a register).  lossy[nb] = index into the lossy-node arrays, or -1 for a rigid node; lossy
@@ -770,9 +755,19 @@ static __global__ void k_boundary(const Real *__restrict__ u1, Real *u0, const i
                            const Real *__restrict__ ssaf, const int8_t *__restrict__ mat, const int8_t *__restrict__ Mb,
                            const MatQuadT<Real> *__restrict__ mq, const Real *__restrict__ beta, Real *__restrict__ vh1,
                            Real *__restrict__ gh1, Real lo2, int64_t mmax, int64_t begin, int64_t end,
-                           const Real *u0_old, const int32_t *__restrict__ sel, int swz) { // u0_old: where u^{n-1} lives (== u0 in place)
+                           const Real *u0_old, const int32_t *__restrict__ sel, int swz, // u0_old: where u^{n-1} lives (== u0 in place)
+                           const int32_t *__restrict__ fdsel = nullptr, int64_t nfd = 0, const int64_t *__restrict__ idx_l = nullptr) {
+   // fdsel: threads beyond the list do the branch ODEs of nfd lossy nodes whose RIGID update was done elsewhere (the column-strip
+   // kernel left it in u0b[li]): k_fd_sel's work in the same launch -- one kernel, one wait for the index chains, fewer
    const int64_t t = begin + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-   if (t >= end) return;
+   if (t >= end) {
+      const int64_t f = t - end;
+      if (f < nfd) {
+         const int32_t li = fdsel[f];
+         u0[idx_l[li]] = fd_node_update<Real>(u0b[li], li, u0b, u2b, ssaf, mat, Mb, mq, beta, vh1, gh1, lo2, mmax);
+      }
+      return;
+   }
    const int64_t nb = sel ? (int64_t)sel[t] : t;
    const int64_t ii = idx[nb];
    const uint32_t adj = adjv[nb];

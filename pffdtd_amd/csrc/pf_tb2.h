@@ -512,7 +512,7 @@ template <typename Real> struct ZStripParams {
    const uint32_t *zvec;
    const uint16_t *adjv;     // [strip node]
    const int32_t *lossy;     // [strip node] position in the lossy arrays or -1
-   Real *u0b;                // lossy nodes: the RIGID result is left here (and in the grid); the branch ODEs follow in k_fd_sel,
+   Real *u0b;                // lossy nodes: the RIGID result is left here (and in the grid); the branch ODEs follow in extra threads of the k_boundary launch,
                              // dense over the compact lossy arrays
    Real sl2;
 };

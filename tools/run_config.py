@@ -34,6 +34,7 @@ ap.add_argument("--ppw", type=float, default=None, help="override points per wav
 ap.add_argument("--duration", type=float, default=None, help="override the simulated duration (s)")
 ap.add_argument("--debug", type=lambda v: int(v, 0), default=0, help="pf_opts.debug (tuning switches)")
 ap.add_argument("--variant", type=int, default=0, help="pf_opts.air_variant (0 = automatic, 40 = blocked pairs forced)")
+ap.add_argument("--chunk", type=int, default=0, help="pf_opts.air_chunk (planes marched per workgroup; 0 = automatic)")
 ap.add_argument("--energy", action="store_true", help="run all Nt steps with the energy diagnostic (double only)")
 ap.add_argument("--keep", default=None, help="keep the sim folder here instead of a temp dir")
 a = ap.parse_args()
@@ -85,7 +86,7 @@ else:
     gen = torch.Generator(device="cuda")
     gen.manual_seed(7)
     from pffdtd_amd.dist import _DevMem
-    eng = engine.HipEngine(sd, timing=True, debug=a.debug, air_variant=a.variant)
+    eng = engine.HipEngine(sd, timing=True, debug=a.debug, air_variant=a.variant, air_chunk=a.chunk)
     (snx, sny, _), spitch, exchanged = eng.layout()  # as stored (rooms: the engine may keep the file's x and z axes exchanged)
     res["axes_exchanged"] = exchanged
     for p in eng.state_grids():
