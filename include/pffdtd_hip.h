@@ -120,6 +120,10 @@ typedef struct pf_opts {
 #define PF_MULTI_ONE_THREAD  2 /* one host thread drives every slab (the reference's arrangement) instead of one thread per slab */
 #define PF_MULTI_NO_PAIRS    4 /* never step slabs in temporally blocked pairs */
 #define PF_MULTI_FORCE_PAIRS 8 /* ask every slab engine for pairs regardless of its thickness (tests) */
+#define PF_MULTI_CUT_Z      16 /* cut the chain along FILE Z instead of x: the slab engines store the grid with the x and z axes
+                                  exchanged (pf_engine_layout), what rooms whose large surfaces are normal to z gain 11-15 % from;
+                                  chosen automatically for such rooms */
+#define PF_MULTI_CUT_X      32 /* never (the reference's arrangement, gpu_engine.h:516-662) */
 
 typedef struct pf_timing {
    double  air_ms_total;    /* sum of HIP-event durations of the air kernel launches */
@@ -159,7 +163,7 @@ double      pf_run_sim(pf_simdata *sd);
  * peer copies on the edge stream while the interior planes run (replaces gpu_engine.h:516-662,739-823,993-1145).
  * base: options common to all slabs (numerics, air_variant, readout_chunk, debug, multi_flags); NULL = defaults. */
 double      pf_run_sim_devices(pf_simdata *sd, int32_t nslabs, const int32_t *devices, const pf_opts *base);
-/* The owned plane ranges such a run uses: cuts[0..nslabs], slab g owns global planes [cuts[g], cuts[g+1]). */
+/* The owned plane ranges such a run uses when cut along x: cuts[0..nslabs], slab g owns global planes [cuts[g], cuts[g+1]). */
 int         pf_slab_partition(const pf_simdata *sd, int32_t nslabs, int32_t even_split, int64_t *cuts);
 
 /* ---- the same chain as an object (what pf_run_sim_devices does inside): lets a host warm up, time and inspect a
@@ -174,7 +178,7 @@ typedef struct pf_multi_info {
    int32_t exchange_verified;  /* 1: every checked exchange delivered the senders' planes bit for bit; 0: one did not; -1: none checked */
    int64_t exchanges_checked;  /* exchanges (steps) checksummed so far */
    int32_t exchange_nonzero;   /* 1: at least one checked ghost plane was not all zeros (the check was not vacuous) */
-   int32_t pad_;
+   int32_t cut_along_z;        /* 1: the chain is cut along FILE Z (PF_MULTI_CUT_Z or chosen for the scene); pf_multi_get_slab's ranges are then z ranges */
    int64_t plane_bytes;        /* bytes of one exchanged plane */
    double  last_run_seconds;   /* wall time of the last pf_multi_run */
    char    transport_name[64];

@@ -39,6 +39,39 @@ int set_err(int code, const char *fmt, ...) {
 // internal: lets the other translation units of this library (pf_vox.hip) feed pf_last_error()
 extern "C" void pf__set_error(const char *msg) { g_err = msg ? msg : ""; }
 
+// internal (pf_engine.hip, pf_multi.hip): would this scene rather be stored with the file's x and z axes exchanged (Engine::swz)?
+// Rooms only -- a box-shaped room (most boundary nodes within a few cells of a grid face) steps in blocked pairs, which exist
+// for the file's axis order alone --, when clearly more boundary nodes have their successor ALONG FILE X in the list than
+// along file z: those runs become unit-stride runs, the others a row apart.  counts[0..1] = the two run counts.
+extern "C" int pf__axis_exchange_pays(const pf_simdata *sd, int64_t *counts) {
+   if (counts) counts[0] = counts[1] = 0;
+   const int64_t fNx = sd->Nx, fNy = sd->Ny, fNz = sd->Nz;
+   if (sd->Nb < 100000 || sd->Npts > ((int64_t)1 << 34) || fNx <= fNz) return 0; // (small scenes: nothing to gain; the bitmap below is Npts / 8 bytes)
+   const int64_t NzNy = fNz * fNy;
+   std::vector<uint64_t> bits((size_t)(sd->Npts >> 6) + 1, 0);
+   int64_t near_face = 0;
+   for (int64_t i = 0; i < sd->Nb; i++) {
+      const int64_t ii = sd->bn_ixyz[i];
+      if (ii < 0 || ii >= sd->Npts) return 0; // (reported by the engine's own checks)
+      bits[(size_t)(ii >> 6)] |= (uint64_t)1 << (ii & 63);
+      const int64_t fz = ii % fNz, fy = (ii / fNz) % fNy, fx = ii / NzNy;
+      const int64_t d = std::min(std::min(std::min(fx, fNx - 1 - fx), std::min(fy, fNy - 1 - fy)), std::min(fz, fNz - 1 - fz));
+      near_face += d < 16;
+   }
+   if (near_face * 10 >= sd->Nb * 8) return 0; // a box-shaped room
+   auto has = [&](int64_t ii) { return ii < sd->Npts && ((bits[(size_t)(ii >> 6)] >> (ii & 63)) & 1u) != 0; };
+   int64_t run_z = 0, run_x = 0;
+   for (int64_t i = 0; i < sd->Nb; i++) {
+      const int64_t ii = sd->bn_ixyz[i];
+      run_z += has(ii + 1);
+      run_x += has(ii + NzNy);
+   }
+   if (counts) { counts[0] = run_x; counts[1] = run_z; }
+   // measured (profiles/r03_reference_configs.jsonl): CTK church 3.46 M / 2.75 M (x / z successors) +12-15 % exchanged, Musikverein
+   // 17.2 M / 14.4 M +11 %
+   return (double)run_x > 1.1 * (double)run_z && run_x - run_z > sd->Nb / 20;
+}
+
 namespace {
 
 #define HIPCHK(expr)                                                                                          \
@@ -314,47 +347,26 @@ template <typename Real> struct Engine : EngineBase {
       return true;
    }
 
-   // Store the grid with the file's x and z axes exchanged?  debug 0x1000 forces it (tests), 0x2000 forbids it.  Automatic:
-   // rooms only (a box-shaped room -- most boundary nodes within a few cells of a grid face -- steps in blocked pairs, which
-   // exist for the file's axis order only), when clearly more boundary nodes have their successor ALONG FILE X in the list
-   // than along file z: those runs become unit-stride runs, the others a row apart.
+   // Store the grid with the file's x and z axes exchanged?  debug 0x1000 forces it, 0x2000 forbids it; otherwise single-domain
+   // engines that own their grids decide per scene (pf__axis_exchange_pays).  Forced on a slab engine (pf_multi.hip cuts such a
+   // chain along FILE Z, so that the slab axis is the storage's plane axis and ghost planes stay contiguous) its caller-owned
+   // grids must hold pf_grid_bytes(Nz, Ny, Nx): planes of Ny rows of pitch(Nx).
    int decide_swap() {
       swz = false;
       const bool single = op.slab_first && op.slab_last, ext = op.ext_u0 && op.ext_u1;
       const int vb = op.air_variant & 255;
       if (op.debug & 0x1000) {
-         if (!single || ext || op.energy || vb == 40 || vb == 41)
-            return set_err(PF_ERR_ARG, "debug 0x1000 (axes exchanged in storage): single-domain engines with their own grids, single steps, no energy diagnostic");
+         if (op.energy || vb == 40 || vb == 41)
+            return set_err(PF_ERR_ARG, "debug 0x1000 (axes exchanged in storage): single steps only, no energy diagnostic");
          swz = true;
          return PF_OK;
       }
       if ((op.debug & 0x2000) || !single || ext || op.energy || vb == 40 || vb == 41) return PF_OK;
-      if (sd.Nb < 100000 || sd.Npts > ((int64_t)1 << 34) || fNx <= fNz) return PF_OK; // (small scenes: nothing to gain; the bitmap below is Npts / 8 bytes)
-      const int64_t NzNy = fNz * fNy;
-      std::vector<uint64_t> bits((size_t)(sd.Npts >> 6) + 1, 0);
-      int64_t near_face = 0;
-      for (int64_t i = 0; i < sd.Nb; i++) {
-         const int64_t ii = sd.bn_ixyz[i];
-         if (ii < 0 || ii >= sd.Npts) return PF_OK; // (reported by the checks that follow)
-         bits[(size_t)(ii >> 6)] |= (uint64_t)1 << (ii & 63);
-         const int64_t fz = ii % fNz, fy = (ii / fNz) % fNy, fx = ii / NzNy;
-         const int64_t d = std::min(std::min(std::min(fx, fNx - 1 - fx), std::min(fy, fNy - 1 - fy)), std::min(fz, fNz - 1 - fz));
-         near_face += d < 16;
-      }
-      if (near_face * 10 >= sd.Nb * 8) return PF_OK; // a box-shaped room
-      auto has = [&](int64_t ii) { return ii < sd.Npts && ((bits[(size_t)(ii >> 6)] >> (ii & 63)) & 1u) != 0; };
-      int64_t run_z = 0, run_x = 0;
-      for (int64_t i = 0; i < sd.Nb; i++) {
-         const int64_t ii = sd.bn_ixyz[i];
-         run_z += has(ii + 1);
-         run_x += has(ii + NzNy);
-      }
-      // measured (profiles/r03_reference_configs.jsonl): CTK church 3.46 M / 2.75 M (x / z successors) +12-15 % exchanged, Musikverein
-      // 17.2 M / 14.4 M +11 %
-      swz = (double)run_x > 1.1 * (double)run_z && run_x - run_z > sd.Nb / 20;
-      if (getenv("PFFDTD_VERBOSE") && atoi(getenv("PFFDTD_VERBOSE")) > 0)
-         fprintf(stderr, "pffdtd_hip: %ld of %ld boundary nodes have their successor along file x, %ld along file z: storage %s\n", (long)run_x,
-                 (long)sd.Nb, (long)run_z, swz ? "with the x and z axes exchanged (unit stride along file x)" : "in file order");
+      int64_t counts[2];
+      swz = pf__axis_exchange_pays(&sd, counts) != 0;
+      if (counts[0] + counts[1] > 0 && getenv("PFFDTD_VERBOSE") && atoi(getenv("PFFDTD_VERBOSE")) > 0)
+         fprintf(stderr, "pffdtd_hip: %ld of %ld boundary nodes have their successor along file x, %ld along file z: storage %s\n", (long)counts[0],
+                 (long)sd.Nb, (long)counts[1], swz ? "with the x and z axes exchanged (unit stride along file x)" : "in file order");
       return PF_OK;
    }
 

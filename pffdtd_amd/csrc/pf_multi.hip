@@ -44,6 +44,7 @@
 #include "pffdtd_hip.h"
 
 extern "C" void pf__set_error(const char *msg); // pf_engine.hip (feeds pf_last_error)
+extern "C" int pf__axis_exchange_pays(const pf_simdata *sd, int64_t *counts); // pf_engine.hip
 
 namespace {
 
@@ -69,8 +70,9 @@ int fail(const char *fmt, const char *a = "") {
 
 // owned plane ranges.  even: Nx/G planes each, +1 for the first Nx%G (gpu_engine.h:532-550).  balanced: equal estimated
 // cost (interior plane = 1; a full plane of lossy nodes with 11 branches = 24, of rigid nodes = 5: measured on MI355X)
-int partition(const pf_simdata *sd, int G, bool even, std::vector<int64_t> &cuts) {
-   const int64_t Nx = sd->Nx;
+// along_z: the chain is cut along FILE Z instead (slab engines then store the grid with the x and z axes exchanged: Engine::swz)
+int partition(const pf_simdata *sd, int G, bool even, std::vector<int64_t> &cuts, bool along_z = false) {
+   const int64_t Nx = along_z ? sd->Nz : sd->Nx; // planes along the cut axis
    if (G < 1 || G >= Nx) return fail("need 1 <= number of slabs < Nx (gpu_engine.h:682)");
    cuts.assign(G + 1, 0);
    cuts[G] = Nx;
@@ -80,10 +82,11 @@ int partition(const pf_simdata *sd, int G, bool even, std::vector<int64_t> &cuts
       for (int g = 0; g < G; g++) cuts[g + 1] = cuts[g] + base + (g < rem ? 1 : 0);
       return PF_OK;
    }
-   const int64_t NzNy = sd->Ny * sd->Nz;
+   const int64_t NzNy = along_z ? sd->Ny * sd->Nx : sd->Ny * sd->Nz; // cells per plane of the cut axis
    std::vector<double> nb(Nx, 0.0), nl(Nx, 0.0);
-   for (int64_t i = 0; i < sd->Nb; i++) nb[sd->bn_ixyz[i] / NzNy] += 1.0;
-   for (int64_t i = 0; i < sd->Nbl; i++) nl[sd->bnl_ixyz[i] / NzNy] += 1.0;
+   auto plane_of = [&](int64_t ii) { return along_z ? ii % sd->Nz : ii / (sd->Ny * sd->Nz); };
+   for (int64_t i = 0; i < sd->Nb; i++) nb[plane_of(sd->bn_ixyz[i])] += 1.0;
+   for (int64_t i = 0; i < sd->Nbl; i++) nl[plane_of(sd->bnl_ixyz[i])] += 1.0;
    double mb_scale = 1.0;
    if (sd->Nbl > 0) {
       double s = 0;
@@ -106,15 +109,72 @@ int partition(const pf_simdata *sd, int G, bool even, std::vector<int64_t> &cuts
    return PF_OK;
 }
 
+// the same cut along FILE Z: slab g holds the file's columns z in [xlo, xhi) of every row; its local file has Nz = xhi - xlo
+int cut_slab_z(const pf_simdata *sd, int64_t upd0, int64_t upd1, Slab &s) {
+   const int64_t Nz = sd->Nz, Nt = sd->Nt, nzl = s.xhi - s.xlo;
+   const int rb = sd->real_bytes;
+   auto in_upd = [&](int64_t ii) { const int64_t z = ii % Nz; return z >= upd0 && z < upd1; };
+   auto local = [&](int64_t ii) { return (ii / Nz) * nzl + (ii % Nz - s.xlo); };
+   for (int64_t i = 0; i < sd->Nb; i++) {
+      const int64_t ii = sd->bn_ixyz[i];
+      if (!in_upd(ii)) continue;
+      s.bn.push_back(local(ii));
+      s.adj.push_back(sd->adj_bn[i]);
+      if (sd->K_bn) s.K.push_back(sd->K_bn[i]);
+   }
+   for (int64_t i = 0; i < sd->Nbl; i++) {
+      const int64_t ii = sd->bnl_ixyz[i];
+      if (!in_upd(ii)) continue;
+      s.bnl.push_back(local(ii));
+      s.matl.push_back(sd->mat_bnl[i]);
+      const uint8_t *p = (const uint8_t *)sd->ssaf_bnl + (size_t)i * rb;
+      s.ssaf.insert(s.ssaf.end(), p, p + rb);
+   }
+   for (int64_t i = 0; i < sd->Nba; i++) {
+      const int64_t ii = sd->bna_ixyz[i];
+      if (!in_upd(ii)) continue;
+      s.bna.push_back(local(ii));
+      s.Q.push_back(sd->Q_bna[i]);
+   }
+   for (int64_t i = 0; i < sd->Ns; i++) {
+      const int64_t ii = sd->in_ixyz[i];
+      if (!in_upd(ii)) continue;
+      s.in.push_back(local(ii));
+      s.in_sigs.insert(s.in_sigs.end(), sd->in_sigs + i * Nt, sd->in_sigs + (i + 1) * Nt);
+   }
+   for (int64_t i = 0; i < sd->Nr; i++) { // receivers read u1 at any owned column (a global ghost column included)
+      const int64_t ii = sd->out_ixyz[i], z = ii % Nz;
+      if (z < s.x0 || z >= s.x1) continue;
+      s.out.push_back(local(ii));
+      s.out_rows.push_back(i);
+   }
+   s.out_reorder.resize(s.out.size());
+   for (size_t i = 0; i < s.out.size(); i++) s.out_reorder[i] = (int64_t)i;
+   s.u_out.assign(std::max<size_t>(s.out.size() * (size_t)Nt, 1), 0.0);
+   pf_simdata &l = s.sd;
+   l = *sd;
+   l.Nz = nzl;
+   l.Npts = l.Nx * l.Ny * nzl;
+   l.bn_ixyz = s.bn.data(); l.adj_bn = s.adj.data(); l.K_bn = sd->K_bn ? s.K.data() : nullptr; l.Nb = (int64_t)s.bn.size();
+   l.bnl_ixyz = s.bnl.data(); l.mat_bnl = s.matl.data(); l.ssaf_bnl = s.ssaf.data(); l.Nbl = (int64_t)s.bnl.size();
+   l.bna_ixyz = s.bna.data(); l.Q_bna = s.Q.data(); l.Nba = (int64_t)s.bna.size();
+   l.in_ixyz = s.in.data(); l.in_sigs = s.in_sigs.data(); l.Ns = (int64_t)s.in.size();
+   l.out_ixyz = s.out.data(); l.out_reorder = s.out_reorder.data(); l.Nr = (int64_t)s.out.size();
+   l.u_out = s.u_out.data();
+   l.bn_mask = nullptr;
+   return PF_OK;
+}
+
 // local problem of slab g: lists cut to the planes it updates, indices re-based (gpu_engine.h:784-823)
-int cut_slab(const pf_simdata *sd, const std::vector<int64_t> &cuts, int g, int G, Slab &s) {
-   const int64_t Nx = sd->Nx, NzNy = sd->Ny * sd->Nz, Nt = sd->Nt;
+int cut_slab(const pf_simdata *sd, const std::vector<int64_t> &cuts, int g, int G, Slab &s, bool along_z = false) {
+   const int64_t Nx = along_z ? sd->Nz : sd->Nx, NzNy = sd->Ny * sd->Nz, Nt = sd->Nt;
    s.x0 = cuts[g]; s.x1 = cuts[g + 1];
    s.first = g == 0; s.last = g == G - 1;
    s.xlo = s.x0 - (s.first ? 0 : 1);
    s.xhi = s.x1 + (s.last ? 0 : 1);
    const int64_t upd0 = std::max<int64_t>(s.x0, 1), upd1 = std::min<int64_t>(s.x1, Nx - 1);
    if (upd1 - upd0 < 1) return fail("a slab must own at least one interior plane");
+   if (along_z) return cut_slab_z(sd, upd0, upd1, s);
    const int64_t off = s.xlo * NzNy, lo = upd0 * NzNy, hi = upd1 * NzNy;
    const int rb = sd->real_bytes;
    for (int64_t i = 0; i < sd->Nb; i++) {
@@ -258,6 +318,7 @@ struct Shared {
    int64_t Nt = 0;
    double t_loop = 0;
    // transport
+   bool along_z = false;                                         // the chain is cut along file z, its engines store the axes exchanged
    int transport = TR_PEER;
    bool rccl_self = false;                                       // every slab on one device: one 1-rank communicator per slab,
                                                                  // planes sent to itself (the RCCL code path on a 1-GPU box)
@@ -319,11 +380,13 @@ void create_slab(Shared &S, int g) {
    o.device = d;
    o.slab_first = sl.first; o.slab_last = sl.last;
    o.x_global0 = (int32_t)sl.xlo;
-   const size_t gb = pf_grid_bytes(sl.sd.Nx, sl.sd.Ny, sl.sd.Nz, sl.sd.real_bytes);
+   // (cut along file z: the engines store planes of file z, Ny rows of pitch(Nx) each -- debug 0x1000 -- and step singly)
+   const size_t gb = S.along_z ? pf_grid_bytes(sl.sd.Nz, sl.sd.Ny, sl.sd.Nx, sl.sd.real_bytes) : pf_grid_bytes(sl.sd.Nx, sl.sd.Ny, sl.sd.Nz, sl.sd.real_bytes);
+   if (S.along_z) o.debug |= 0x1000;
    // temporally blocked pairs need all four grids in the caller's hands (pf_engine_set_spares); worth it for slabs of
    // >= 96 planes (measured)
    const int flags = S.base.multi_flags;
-   const bool want_pairs = !(flags & PF_MULTI_NO_PAIRS) && ((flags & PF_MULTI_FORCE_PAIRS) || sl.sd.Nx - 2 >= 96);
+   const bool want_pairs = !(flags & PF_MULTI_NO_PAIRS) && ((flags & PF_MULTI_FORCE_PAIRS) || (S.along_z ? sl.sd.Nz : sl.sd.Nx) - 2 >= 96);
    for (int k = 0; k < 2; k++) {
       void *p = nullptr;
       MCHK(g, hipMalloc(&p, gb));
@@ -688,10 +751,22 @@ int pf_multi_create(pf_simdata *sd, int32_t nslabs, const int32_t *devices, cons
       *out = m;
       return PF_OK;
    }
-   int rc = partition(sd, G, (S.base.multi_flags & PF_MULTI_EVEN_SPLIT) != 0, S.cuts);
+   // Which axis?  The reference cuts along x (gpu_engine.h:516-662).  Rooms whose engines would rather store the grid with the
+   // x and z axes exchanged (+11-15 % on the reference's rooms) are cut along FILE Z instead: the slab axis
+   // is then the exchanged storage's plane axis and ghost planes stay contiguous.  PF_MULTI_CUT_Z forces, PF_MULTI_CUT_X forbids.
+   {
+      const int vb = S.base.air_variant & 255;
+      const bool can = !S.base.energy && vb != 40 && vb != 41 && !(S.base.multi_flags & PF_MULTI_FORCE_PAIRS) && G < sd->Nz;
+      if (S.base.multi_flags & PF_MULTI_CUT_Z) {
+         if (!can) { delete m; return fail("PF_MULTI_CUT_Z: single steps only, no energy diagnostic, fewer slabs than Nz"); }
+         S.along_z = true;
+      } else if (!(S.base.multi_flags & PF_MULTI_CUT_X) && !(S.base.debug & 0x2000) && can && (sd->Nz - 2) / G >= 16)
+         S.along_z = pf__axis_exchange_pays(sd, nullptr) != 0;
+   }
+   int rc = partition(sd, G, (S.base.multi_flags & PF_MULTI_EVEN_SPLIT) != 0, S.cuts, S.along_z);
    S.slabs.resize(G);
-   for (int g = 0; g < G && rc == PF_OK; g++) rc = cut_slab(sd, S.cuts, g, G, S.slabs[g]);
-   S.plane_bytes = pf_grid_bytes(1, sd->Ny, sd->Nz, sd->real_bytes);
+   for (int g = 0; g < G && rc == PF_OK; g++) rc = cut_slab(sd, S.cuts, g, G, S.slabs[g], S.along_z);
+   S.plane_bytes = S.along_z ? pf_grid_bytes(1, sd->Ny, sd->Nx, sd->real_bytes) : pf_grid_bytes(1, sd->Ny, sd->Nz, sd->real_bytes);
    S.verify_n = S.base.verify_exchange > 0 ? S.base.verify_exchange : 0;
    if (const char *ev = getenv("PFFDTD_VERIFY_EXCHANGE")) S.verify_n = std::max(atoi(ev), 0);
    S.sums.assign((size_t)G * 4, 0);
@@ -710,7 +785,7 @@ int pf_multi_create(pf_simdata *sd, int32_t nslabs, const int32_t *devices, cons
    m->created = true;
    if (S.err.load()) { const std::string keep = S.err_msg; const int code = S.err.load(); pf_multi_destroy(m); pf__set_error(keep.c_str()); return code; }
    if (getenv("PFFDTD_VERBOSE")) {
-      fprintf(stderr, "pffdtd_hip: %d slabs, ghost planes by %s%s%s:", G, transport_name(S), S.transport == TR_RCCL ? ", " : "", S.transport == TR_RCCL ? g_rccl.where.c_str() : "");
+      fprintf(stderr, "pffdtd_hip: %d slabs%s, ghost planes by %s%s%s:", G, S.along_z ? " cut along file z (engines store the x and z axes exchanged)" : "", transport_name(S), S.transport == TR_RCCL ? ", " : "", S.transport == TR_RCCL ? g_rccl.where.c_str() : "");
       for (int g = 0; g < G; g++) fprintf(stderr, " [dev %d: planes %ld-%ld%s]", S.dev[g], (long)S.cuts[g], (long)S.cuts[g + 1] - 1, S.paired[g] ? ", pairs" : "");
       fprintf(stderr, "\n");
    }
@@ -770,6 +845,7 @@ int pf_multi_get_info(pf_multi *m, pf_multi_info *info) {
    info->exchanges_checked = S.verify_checked.load();
    info->exchange_verified = S.verify_checked.load() > 0 ? (S.verify_bad.load() ? 0 : 1) : -1;
    info->exchange_nonzero = S.verify_nonzero.load();
+   info->cut_along_z = S.along_z ? 1 : 0;
    info->last_run_seconds = m->last_seconds;
    info->plane_bytes = (int64_t)S.plane_bytes;
    snprintf(info->transport_name, sizeof info->transport_name, "%s", transport_name(S));

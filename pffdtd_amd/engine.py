@@ -39,7 +39,7 @@ class PfTiming(ctypes.Structure):
 class PfMultiInfo(ctypes.Structure):
     _fields_ = [("nslabs", ctypes.c_int32), ("transport", ctypes.c_int32), ("rccl_self", ctypes.c_int32),
                 ("exchange_verified", ctypes.c_int32), ("exchanges_checked", ctypes.c_int64),
-                ("exchange_nonzero", ctypes.c_int32), ("pad_", ctypes.c_int32), ("plane_bytes", ctypes.c_int64),
+                ("exchange_nonzero", ctypes.c_int32), ("cut_along_z", ctypes.c_int32), ("plane_bytes", ctypes.c_int64),
                 ("last_run_seconds", ctypes.c_double), ("transport_name", ctypes.c_char * 64)]
 
 
@@ -55,7 +55,7 @@ EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_grid_bytes", "p
            "pf_multi_create", "pf_multi_run", "pf_multi_get_info", "pf_multi_get_slab", "pf_multi_destroy"]
 
 
-PF_MULTI_EVEN_SPLIT, PF_MULTI_ONE_THREAD, PF_MULTI_NO_PAIRS, PF_MULTI_FORCE_PAIRS = 1, 2, 4, 8
+PF_MULTI_EVEN_SPLIT, PF_MULTI_ONE_THREAD, PF_MULTI_NO_PAIRS, PF_MULTI_FORCE_PAIRS, PF_MULTI_CUT_Z, PF_MULTI_CUT_X = 1, 2, 4, 8, 16, 32
 PF_TRANSPORT_AUTO, PF_TRANSPORT_PEER, PF_TRANSPORT_RCCL = 0, 1, 2
 
 
@@ -209,7 +209,7 @@ class HipMulti:
         return {"nslabs": i.nslabs, "transport": i.transport, "transport_name": i.transport_name.decode(),
                 "rccl_self": bool(i.rccl_self), "exchanges_checked": i.exchanges_checked,
                 "exchange_verified": None if i.exchange_verified < 0 else bool(i.exchange_verified),
-                "exchange_nonzero": bool(i.exchange_nonzero), "plane_bytes": i.plane_bytes,
+                "exchange_nonzero": bool(i.exchange_nonzero), "cut_along_z": bool(i.cut_along_z), "plane_bytes": i.plane_bytes,
                 "last_run_seconds": i.last_run_seconds}
 
     def slab(self, g):

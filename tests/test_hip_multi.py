@@ -183,3 +183,45 @@ def test_transport_requests_are_validated():
     sd = cases.make_sd("cart_rigid", "single")
     with pytest.raises(engine.PfError, match="transport"):
         engine.HipMulti(sd, [0, 0], transport=7)
+
+
+# ---- chains cut along FILE Z (slab engines store the x and z axes exchanged) ---------------------------------------------
+@pytest.mark.parametrize("transport", [engine.PF_TRANSPORT_PEER, engine.PF_TRANSPORT_RCCL])
+@pytest.mark.parametrize("name,prec", [("cart_outside", "single"), ("cart_mb11", "double"), ("fcc2_outside", "single"),
+                                       ("fcc1_outside", "double"), ("fcc2_mb11", "double")])
+def test_chain_cut_along_file_z(name, prec, transport):
+    """PF_MULTI_CUT_Z: the slabs own ranges of FILE Z, their engines store planes of file z (unit stride along file x), ghost
+    planes are contiguous storage planes -- same bits as the single-domain oracle, both transports, every exchange checked"""
+    want = _ref(name, prec)
+    for G in (2, 3):
+        sd = cases.make_sd(name, prec)
+        m = engine.HipMulti(sd, [0] * G, multi_flags=engine.PF_MULTI_CUT_Z, transport=transport, verify_exchange=int(sd.Nt))
+        m.run(0, int(sd.Nt))
+        info = m.info()
+        lay = m.slab(0)["engine"].layout()
+        zr = [(m.slab(g)["x0"], m.slab(g)["x1"]) for g in range(G)]
+        m.close()
+        assert info["cut_along_z"] and info["exchange_verified"] is True and info["exchange_nonzero"]
+        assert lay[2] is True and lay[0][2] == sd.Nx and zr[0][0] == 0 and zr[-1][1] == sd.Nz
+        assert np.array_equal(sd.u_out, want), (G, np.abs(sd.u_out - want).max())
+
+
+def test_rooms_are_cut_along_file_z_by_themselves():
+    """the automatic choice of the chain: a hall with six floors is cut along file z (and its engines exchange the axes), a box
+    room along x like the reference's; PF_MULTI_CUT_X keeps the reference's arrangement"""
+    plates = [(8, 190, 8, 90, z, z + 1) for z in (10, 18, 26, 34, 42, 50)]
+    kw = dict(Nx=200, Ny=100, Nz=60, Nt=30, wall=3, Nm=2, Mb=[3, 5], blocks=plates, src=[100, 50, 6], rcv=[[104, 52, 6], [96, 47, 7], [100, 56, 5]])
+    sd = sim_data.SimData.from_sim(synth.shoebox(**kw), "single")
+    sd.scale_input()
+    oracle.run_sim(sd)
+    want = sd.u_out.copy()
+    assert np.abs(want).max() > 0
+    for flags, along_z in ((0, True), (engine.PF_MULTI_CUT_X, False)):
+        sd2 = sim_data.SimData.from_sim(synth.shoebox(**kw), "single")
+        sd2.scale_input()
+        m = engine.HipMulti(sd2, [0, 0], multi_flags=flags, verify_exchange=30)
+        m.run(0, 30)
+        info = m.info()
+        m.close()
+        assert info["cut_along_z"] == along_z and info["exchange_verified"] is True
+        assert np.array_equal(sd2.u_out, want), flags

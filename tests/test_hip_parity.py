@@ -135,8 +135,6 @@ def test_exchanged_axes_set_grid_round_trip_and_refusals():
     eng.close()
     with pytest.raises(engine.PfError, match="0x1000"):
         engine.HipEngine(sd, debug=0x1000, air_variant=40)
-    with pytest.raises(engine.PfError, match="0x1000"):
-        engine.HipEngine(sd, debug=0x1000, slab_last=False)
 
 
 def test_rooms_with_large_surfaces_normal_to_file_z_are_stored_exchanged():
