@@ -914,7 +914,15 @@ double pf_run_sim(pf_simdata *sd) {
       // every slab should be worth a device: at least 16 planes and ~17 M cells of its own (the reference only asks for
       // ngpus < Nx, gpu_engine.h:682; a 3e6-cell grid cut eight ways is slower than on one GPU)
       n = (int)std::max<int64_t>(1, std::min<int64_t>(n, std::min<int64_t>((sd->Nx - 2) / 16, sd->Npts >> 24)));
-      for (int i = 0; i < n; i++) devs.push_back(i);
+      // Rooms (scenes the chain cuts along file z) run as TWO slabs per device when only one device is in use: the halves' kernels
+      // overlap -- one half's boundary pass runs beside the other's interior kernel -- which a single domain's dependent launches
+      // cannot.  Measured on one MI355X, whole step: CTK church 313 against 288 Gvox/s as one domain (3, 4, 6 slabs: 280, 279,
+      // 199), Musikverein 354 against 341-345 (3, 4 slabs: 330, 351).  PFFDTD_SLABS_PER_DEVICE=1 switches it off.
+      int per_dev = 1;
+      if (n == 1 && sd->Nz >= 64 && pf__axis_exchange_pays(sd, nullptr)) per_dev = 2;
+      if (const char *ev = getenv("PFFDTD_SLABS_PER_DEVICE")) per_dev = std::max(1, std::min(atoi(ev), 8));
+      for (int i = 0; i < n; i++)
+         for (int k = 0; k < per_dev; k++) devs.push_back(i);
    }
    pf_opts o;
    pf_opts_default(&o);

@@ -225,3 +225,24 @@ def test_rooms_are_cut_along_file_z_by_themselves():
         m.close()
         assert info["cut_along_z"] == along_z and info["exchange_verified"] is True
         assert np.array_equal(sd2.u_out, want), flags
+
+
+def test_run_sim_runs_a_room_as_two_slabs_on_one_device(tmp_path):
+    """pf_run_sim with ONE device in use: a room (cut along file z) is stepped as two slabs on that device -- their kernels overlap;
+    PFFDTD_SLABS_PER_DEVICE=1 keeps one domain; same bits either way"""
+    plates = [(8, 190, 8, 90, z, z + 1) for z in (10, 18, 26, 34, 42, 50, 58, 66)]
+    kw = dict(Nx=200, Ny=100, Nz=76, Nt=24, wall=3, Nm=2, Mb=[3, 5], blocks=plates, src=[100, 50, 6], rcv=[[104, 52, 6], [96, 47, 7], [100, 56, 5]])
+    sd = sim_data.SimData.from_sim(synth.shoebox(**kw), "single")
+    sd.scale_input()
+    oracle.run_sim(sd)
+    want = sd.u_out.copy()
+    assert np.abs(want).max() > 0
+    code = ("import sys; sys.path[:0] = [%r]; import numpy as np; from pffdtd_amd import engine, sim_data, synth; "
+            "sd = sim_data.SimData.from_sim(synth.shoebox(**%r), 'single'); sd.scale_input(); engine.run_sim(sd); np.save(%r, sd.u_out)"
+            % (str(ROOT), kw, str(tmp_path / "u.npy")))
+    for extra, expect in (({}, "2 slabs cut along file z"), ({"PFFDTD_SLABS_PER_DEVICE": "1"}, None)):
+        r = subprocess.run([os.sys.executable, "-c", code], env={**os.environ, "PFFDTD_NGPUS": "1", "PFFDTD_VERBOSE": "1", **extra},
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert (expect in r.stderr) if expect else ("slabs" not in r.stderr), r.stderr[-1500:]
+        assert np.array_equal(np.load(tmp_path / "u.npy"), want)
