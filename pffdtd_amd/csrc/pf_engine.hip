@@ -86,7 +86,9 @@ inline int64_t round_up(int64_t a, int64_t m) { return (a + m - 1) / m * m; }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // z pitch: rows start on 128-byte lines.  (Measured and dropped: one extra line on pitches that are a multiple of 4 KiB,
-// to spread a column's rows over more memory channels -- every kernel got slower, lean 2.31 -> 2.53 ms, 13-point 2.45 -> 2.58.)
+// to spread a column's rows over more memory channels -- every kernel got slower, lean 2.31 -> 2.53 ms, 13-point 2.45 -> 2.58.
+// Re-measured in round 3 on the pair path at 1024^3, alternating runs: 472-476 Gvox/s without, 455 with one extra line, 435 with
+// two; the pair kernel itself gains 0.5 %, the shell around it loses 6 %: the lean kernel pays a fifth, mostly empty segment.)
 int64_t grid_pitch(int64_t Nz, int32_t real_bytes) { return round_up(Nz, 128 / real_bytes); }
 
 // DPP wave-shift semantics verified once per process on the device
