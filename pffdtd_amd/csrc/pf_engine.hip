@@ -88,7 +88,9 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // z pitch: rows start on 128-byte lines.  (Measured and dropped: one extra line on pitches that are a multiple of 4 KiB,
 // to spread a column's rows over more memory channels -- every kernel got slower, lean 2.31 -> 2.53 ms, 13-point 2.45 -> 2.58.
 // Re-measured in round 3 on the pair path at 1024^3, alternating runs: 472-476 Gvox/s without, 455 with one extra line, 435 with
-// two; the pair kernel itself gains 0.5 %, the shell around it loses 6 %: the lean kernel pays a fifth, mostly empty segment.)
+// two; per kernel (rocprofv3, pad 0 -> 1): pair kernel 3.06 -> 3.03 ms, boundary launch 0.411 -> 0.384 (its scattered stores do
+// spread over more channels), but the column-strip kernel 0.243 -> 0.343 (its right strip then spans the pad columns too) and the
+// lean kernel pays a fifth, mostly empty segment: a net loss unless those two learn about the pad, worth 2 % at best.)
 int64_t grid_pitch(int64_t Nz, int32_t real_bytes) { return round_up(Nz, 128 / real_bytes); }
 
 // DPP wave-shift semantics verified once per process on the device
