@@ -90,7 +90,9 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // Re-measured in round 3 on the pair path at 1024^3, alternating runs: 472-476 Gvox/s without, 455 with one extra line, 435 with
 // two; per kernel (rocprofv3, pad 0 -> 1): pair kernel 3.06 -> 3.03 ms, boundary launch 0.411 -> 0.384 (its scattered stores do
 // spread over more channels), but the column-strip kernel 0.243 -> 0.343 (its right strip then spans the pad columns too) and the
-// lean kernel pays a fifth, mostly empty segment: a net loss unless those two learn about the pad, worth 2 % at best.)
+// lean kernel pays a fifth, mostly empty segment: a net loss unless those two learn about the pad, worth 2 % at best.  Nor does
+// a padded pitch remove the grid-placement lottery: 40 candidates of the search span 2.939 ... 3.42 ms per launch with it
+// (median 3.15) against 2.975 ... 3.65 without (median 3.23).)
 int64_t grid_pitch(int64_t Nz, int32_t real_bytes) { return round_up(Nz, 128 / real_bytes); }
 
 // DPP wave-shift semantics verified once per process on the device
