@@ -60,4 +60,26 @@ for v in ((0, 4, 3, 3 + 256) if fcc else (0, 25, 4, 3)):
         assert np.array_equal(out, ref_out), f"variant {v}: receivers differ, max|d|={np.abs(out-ref_out).max()}"
         for t, r in zip(view, ref_g):
             assert bool(torch.equal(t, r.view(n[0], n[1], P)[1:-1, 1:-1, 1:n[2] - 1])), f"variant {v}: fields differ"
+# ... and the arrangement the engine picks by itself for these rooms: its OWN grids, stored with the file's x and z axes exchanged
+# (pf_engine_layout).  Same initial field (written and read back in FILE order through pf_engine_set_grid / _get_grid), same
+# receivers, same field.
+sd.u_out[:] = 0
+eng = engine.HipEngine(sd, timing=True)
+dims, pitch, exchanged = eng.layout()
+for k in range(2):
+    eng.set_grid(k, init[k].view(n[0], n[1], P)[:, :, :n[2]].contiguous().cpu().numpy())
+t0 = time.time()
+eng.run(0, Nt)
+eng.sync()
+out = sd.u_out[:, :Nt].copy()
+print(f"engine-owned grids: stored {dims} pitch {pitch}, axes exchanged: {exchanged}; {time.time()-t0:.1f}s", flush=True)
+assert np.array_equal(out, ref_out), f"engine-owned grids: receivers differ, max|d|={np.abs(out-ref_out).max()}"
+for k in range(2):
+    got = torch.from_numpy(eng.get_grid(k))[1:-1, 1:-1, 1:-1]
+    want = ref_g[k].view(n[0], n[1], P)[1:-1, 1:-1, 1:n[2] - 1].cpu()
+    assert bool(torch.equal(got, want)), f"engine-owned grids: field {k} differs"
+    del got, want
+eng.close()
+if name in ("ctk_cart_gpu", "mv_fcc_gpu"):
+    assert exchanged, "these rooms are expected to be stored with the axes exchanged"
 print("config family check OK: all kernel families agree bit for bit on every cell")
