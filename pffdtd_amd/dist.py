@@ -48,8 +48,14 @@ class HipSlabStepper:
             if [g.data_ptr() for g in self.grids] != list(self.eng.state_grids()):
                 raise RuntimeError("torch copied the engine's state grids instead of wrapping them")
         else:
+            # a slab of a chain cut along FILE Z: the engine stores planes of file z, Ny rows of pitch(Nx) each (debug 0x1000)
+            zcut = bool(getattr(info, "along_z", False))
+            if zcut:
+                self.plane = loc.Ny * engine.grid_pitch(loc.Nx, loc.real_bytes)
+                engine_kw = dict(engine_kw, debug=int(engine_kw.get("debug", 0)) | 0x1000)
+            self.nplanes = loc.Nz if zcut else loc.Nx
             with torch.cuda.device(self.device):
-                self.grids = [torch.zeros((loc.Nx, self.plane), dtype=self.tdtype, device=self.device) for _ in range(2)]
+                self.grids = [torch.zeros((self.nplanes, self.plane), dtype=self.tdtype, device=self.device) for _ in range(2)]
                 torch.cuda.synchronize()
             self.eng = engine.HipEngine(loc, device=device, slab_first=info.first, slab_last=info.last, x_global0=info.xlo,
                                         ext_u0=self.grids[0].data_ptr(), ext_u1=self.grids[1].data_ptr(), **engine_kw)
@@ -63,7 +69,7 @@ class HipSlabStepper:
             try:
                 with torch.cuda.device(self.device):
                     for _ in range(int(os.environ.get("PFFDTD_PLACE_EXTRA", "4")) + 2):
-                        pool.append(torch.zeros((loc.Nx, self.plane), dtype=self.tdtype, device=self.device))
+                        pool.append(torch.zeros((self.nplanes, self.plane), dtype=self.tdtype, device=self.device))
                     torch.cuda.synchronize()
             except torch.OutOfMemoryError:  # no room for more: what fits
                 torch.cuda.empty_cache()
@@ -82,7 +88,7 @@ class HipSlabStepper:
 
     def halo_tensors(self):
         g = self._by_ptr[self.eng.halo_ptrs()[2]]  # the grid the step in flight writes (its plane 0 = recv_lo)
-        Nx = self.loc.Nx
+        Nx = len(g)                                # storage planes: file x planes, or file z planes of a chain cut along z
         return g[1], g[Nx - 2], g[0], g[Nx - 1]  # send_lo, send_hi, recv_lo, recv_hi
 
     def comm_context(self):
@@ -205,15 +211,31 @@ def gather_outputs(sd, loc, info, group=None):
     return sd.u_out
 
 
-def make_hip_runner(sd, rank, world, device, group=None, balance=True, **engine_kw):
+def scene_prefers_exchanged_axes(sd):
+    """The library's rule (pf_engine.hip: pf__axis_exchange_pays) -- rooms whose boundary nodes run along file x rather than z."""
+    import ctypes
+    from . import engine
+    fn = engine.lib().pf__axis_exchange_pays
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    s = sd.as_struct()
+    return bool(fn(ctypes.byref(s), None))
+
+
+def make_hip_runner(sd, rank, world, device, group=None, balance=True, along_z=None, **engine_kw):
+    """along_z: cut the chain along FILE Z (slab engines store the x and z axes exchanged; what rooms gain 11-15 % from, DESIGN.md
+    5); None = the library's rule for the scene, like the C chain object (csrc/pf_multi.hip)."""
     import os
-    loc, info = slab_mod.split(sd, world, rank, balance=balance)
+    if along_z is None:
+        pairs_forced = engine_kw.get("pairs") or (engine_kw.get("air_variant", 0) & 255) in (40, 41)
+        along_z = (world > 1 and not pairs_forced and not engine_kw.get("energy") and (sd.Nz - 2) // world >= 16
+                   and not (int(engine_kw.get("debug", 0)) & 0x2000) and scene_prefers_exchanged_axes(sd))
+    loc, info = slab_mod.split(sd, world, rank, balance=balance, along_z=bool(along_z) and world > 1)
     # temporally blocked step pairs in slab engines (four state grids per rank): measured on MI355X (1024^3, per-rank cost
     # model with an RCCL self-exchange, old / new on the same box) +3..14 % at 2 ranks, +5..10 % at 4, +7 % on the interior
     # slabs of 8 ranks (136 planes) and +0..2 % on its end slabs.  Default: on for slabs of at least 96 planes;
     # PFFDTD_SLAB_PAIRS=1 / 0 forces it on / off.  (The engine itself declines when the scene has no boundary-free box
     # or the y-z cross-section is small: pf_engine_set_spares returns 1 and it keeps stepping singly.)
     env = os.environ.get("PFFDTD_SLAB_PAIRS", "")
-    engine_kw.setdefault("pairs", env == "1" or (env != "0" and loc.Nx - 2 >= 96))
+    engine_kw.setdefault("pairs", not getattr(info, "along_z", False) and (env == "1" or (env != "0" and loc.Nx - 2 >= 96)))
     st = HipSlabStepper(loc, info, device, **engine_kw)
     return SlabRunner(st, info, group), loc, info

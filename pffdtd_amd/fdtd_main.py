@@ -100,7 +100,9 @@ def run_rank(a, world):
         sd.scale_input()
         runner, loc, info = pdist.make_hip_runner(sd, rank, world, local_rank, None, timing=True)
         if rank == 0:
-            print(f"--{world} GPUs, Z-slabs of {[x1 - x0 for x0, x1 in pdist.slab_mod.partition_weighted(sd, world)]} planes")
+            az = bool(getattr(info, "along_z", False))
+            print(f"--{world} GPUs, slabs of {[x1 - x0 for x0, x1 in pdist.slab_mod.partition_weighted(sd, world, az)]} planes"
+                  + (" cut along file z (engines store the x and z axes exchanged)" if az else " along x"))
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -27,18 +27,19 @@ LOSSY_PLANE_EQ = 24.0
 RIGID_PLANE_EQ = 5.0
 
 
-def partition_weighted(sd, G):
+def partition_weighted(sd, G, along_z=False):
     """Owned plane ranges balanced by estimated cost instead of plane count: the end slabs of a room carry whole
     wall planes of boundary nodes, which the reference's even split (gpu_engine.h:532-550) leaves unbalanced.
-    Deterministic (every rank computes the same cut)."""
-    Nx = sd.Nx
+    Deterministic (every rank computes the same cut).  along_z: ranges of FILE Z instead of x (rooms, see split)."""
+    Nx = sd.Nz if along_z else sd.Nx
     if G < 1 or G >= Nx:
         raise ValueError(f"need 1 <= ngpus < Nx (got {G}, Nx={Nx})")
     if G == 1:
         return [(0, Nx)]
-    NzNy = sd.Ny * sd.Nz
-    nb = np.bincount(sd.bn_ixyz // NzNy, minlength=Nx).astype(np.float64)
-    nl = np.bincount(sd.bnl_ixyz // NzNy, minlength=Nx).astype(np.float64) if sd.Nbl else np.zeros(Nx)
+    NzNy = sd.Ny * (sd.Nx if along_z else sd.Nz)
+    plane_of = (lambda ii: ii % sd.Nz) if along_z else (lambda ii: ii // (sd.Ny * sd.Nz))
+    nb = np.bincount(plane_of(sd.bn_ixyz), minlength=Nx).astype(np.float64)
+    nl = np.bincount(plane_of(sd.bnl_ixyz), minlength=Nx).astype(np.float64) if sd.Nbl else np.zeros(Nx)
     mb_scale = 1.0
     if sd.Nbl:
         mb_scale = float(np.mean(sd.Mb[sd.mat_bnl])) / 11.0
@@ -67,50 +68,80 @@ class SlabInfo:
         # global planes this slab updates: its owned planes minus the global ghost planes 0 / Nx-1
         self.upd0 = max(x0, 1)
         self.upd1 = min(x1, Nx - 1)
+        self.along_z = False                          # (split sets it: the plane numbers above are FILE Z then)
 
 
-def split(sd, G, rank, balance=False):
+def split(sd, G, rank, balance=False, along_z=False):
     """Local SimData of slab `rank` of `G` (a shallow variant of `sd` with re-based lists) and its SlabInfo.
-    balance=False: the reference's even split; True: cost-balanced cut (partition_weighted)."""
-    parts = partition_weighted(sd, G) if balance else partition(sd.Nx, G)
+    balance=False: the reference's even split; True: cost-balanced cut (partition_weighted).
+    along_z: the chain is cut along FILE Z instead of x -- for rooms whose engines store the grid with the x and z axes
+    exchanged (pf_engine_layout; csrc/pf_multi.hip does the same): the slab then holds the file's columns z in [xlo, xhi) of
+    every row, its local file has Nz = xhi - xlo, and `info`'s plane numbers are z."""
+    nplanes = sd.Nz if along_z else sd.Nx
+    parts = partition_weighted(sd, G, along_z) if balance else partition(nplanes, G)
     x0, x1 = parts[rank]
-    info = SlabInfo(rank, G, x0, x1, sd.Nx)
+    info = SlabInfo(rank, G, x0, x1, nplanes)
+    info.along_z = along_z
     if info.upd1 - info.upd0 < 1:
         raise ValueError("a slab must own at least one interior plane")
     NzNy = sd.Ny * sd.Nz
-    off = info.xlo * NzNy                              # local index = global - off (gpu_engine.h:784-823)
-    lo, hi = info.upd0 * NzNy, info.upd1 * NzNy
+    if along_z:
+        nzl = info.Nxh
 
-    def cut(idx):
-        return (idx >= lo) & (idx < hi)
+        def cut(idx):
+            z = idx % sd.Nz
+            return (z >= info.upd0) & (z < info.upd1)
+
+        def local(idx):
+            return (idx // sd.Nz) * nzl + (idx % sd.Nz - info.xlo)
+
+        def owned(idx):
+            z = idx % sd.Nz
+            return (z >= x0) & (z < x1)
+    else:
+        off = info.xlo * NzNy                          # local index = global - off (gpu_engine.h:784-823)
+        lo, hi = info.upd0 * NzNy, info.upd1 * NzNy
+
+        def cut(idx):
+            return (idx >= lo) & (idx < hi)
+
+        def local(idx):
+            return idx - off
+
+        def owned(idx):
+            return (idx >= x0 * NzNy) & (idx < x1 * NzNy)
 
     loc = copy.copy(sd)
     loc._keep = []
-    loc.Nx = info.Nxh
-    loc.Npts = info.Nxh * NzNy
+    if along_z:
+        loc.Nz = info.Nxh
+        loc.Npts = sd.Nx * sd.Ny * info.Nxh
+    else:
+        loc.Nx = info.Nxh
+        loc.Npts = info.Nxh * NzNy
     kb = cut(sd.bn_ixyz)
-    loc.bn_ixyz = np.ascontiguousarray(sd.bn_ixyz[kb] - off)
+    loc.bn_ixyz = np.ascontiguousarray(local(sd.bn_ixyz[kb]))
     loc.adj_bn = np.ascontiguousarray(sd.adj_bn[kb])
     loc.K_bn = np.ascontiguousarray(sd.K_bn[kb])
     loc.Nb = int(kb.sum())
     kl = cut(sd.bnl_ixyz)
-    loc.bnl_ixyz = np.ascontiguousarray(sd.bnl_ixyz[kl] - off)
+    loc.bnl_ixyz = np.ascontiguousarray(local(sd.bnl_ixyz[kl]))
     loc.mat_bnl = np.ascontiguousarray(sd.mat_bnl[kl])
     loc.ssaf_bnl = np.ascontiguousarray(sd.ssaf_bnl[kl])
     if hasattr(sd, "saf_bnl"):
         loc.saf_bnl = sd.saf_bnl[kl]
     loc.Nbl = int(kl.sum())
     ka = cut(sd.bna_ixyz)
-    loc.bna_ixyz = np.ascontiguousarray(sd.bna_ixyz[ka] - off)
+    loc.bna_ixyz = np.ascontiguousarray(local(sd.bna_ixyz[ka]))
     loc.Q_bna = np.ascontiguousarray(sd.Q_bna[ka])
     loc.Nba = int(ka.sum())
     ki = cut(sd.in_ixyz)
-    loc.in_ixyz = np.ascontiguousarray(sd.in_ixyz[ki] - off)
+    loc.in_ixyz = np.ascontiguousarray(local(sd.in_ixyz[ki]))
     loc.in_sigs = np.ascontiguousarray(sd.in_sigs[ki])
     loc.Ns = int(ki.sum())
     # receivers read u1 at any owned plane (incl. a global ghost plane if someone asks for it)
-    ko = (sd.out_ixyz >= x0 * NzNy) & (sd.out_ixyz < x1 * NzNy)
-    loc.out_ixyz = np.ascontiguousarray(sd.out_ixyz[ko] - off)
+    ko = owned(sd.out_ixyz)
+    loc.out_ixyz = np.ascontiguousarray(local(sd.out_ixyz[ko]))
     loc.Nr = int(ko.sum())
     loc.out_rows = np.flatnonzero(ko)                  # rows of the global u_out this slab fills
     loc.out_reorder = np.arange(loc.Nr, dtype=np.int64)

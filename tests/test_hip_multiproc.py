@@ -23,15 +23,17 @@ def _big_sd(prec):
     return sd
 
 
-def _worker(rank, world, port, name, prec, q):
+def _worker(rank, world, port, name, prec, q, along_z=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from pffdtd_amd import dist as pdist
         paired = name == "box_pairs"
         sd = _big_sd(prec) if paired else cases.make_sd(name, prec)
-        runner, loc, info = pdist.make_hip_runner(sd, rank, world, 0, **(dict(air_variant=40, pairs=True) if paired else {}))
-        assert runner.st.paired == paired
+        runner, loc, info = pdist.make_hip_runner(sd, rank, world, 0, along_z=along_z, **(dict(air_variant=40, pairs=True) if paired else {}))
+        assert runner.st.paired == paired and bool(getattr(info, "along_z", False)) == along_z
+        if along_z:
+            assert runner.st.eng.layout()[2] is True and len(runner.st.grids[0]) == loc.Nz
         runner.run(0, sd.Nt)
         runner.finish()
         out = pdist.gather_outputs(sd, loc, info)
@@ -43,16 +45,19 @@ def _worker(rank, world, port, name, prec, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,name,prec", [(2, "cart_outside", "single"), (3, "fcc2_outside", "double"),
-                                             (2, "box_pairs", "single"), (3, "box_pairs", "single")])
-def test_multiprocess_hip_slabs(world, name, prec):
+@pytest.mark.parametrize("world,name,prec,along_z", [(2, "cart_outside", "single", False), (3, "fcc2_outside", "double", False),
+                                                     (2, "box_pairs", "single", False), (3, "box_pairs", "single", False),
+                                                     (2, "cart_outside", "single", True), (3, "fcc2_outside", "double", True),
+                                                     (2, "fcc1_outside", "single", True)])
+def test_multiprocess_hip_slabs(world, name, prec, along_z):
+    """(along_z: the chain cut along FILE Z, every rank's engine storing the x and z axes exchanged -- what rooms get by default)"""
     sd = _big_sd(prec) if name == "box_pairs" else cases.make_sd(name, prec)
     oracle.run_sim(sd)
     ref = sd.u_out.copy()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29700 + (os.getpid() % 200) + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, name, prec, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, prec, q, along_z)) for r in range(world)]
     for p in procs:
         p.start()
     out = q.get(timeout=300)
