@@ -179,9 +179,10 @@ def add_traffic(rl, res, sd, kernel_ms, units, bpv):
             rl["traffic_unit"] = f"GB per launch of {inst} (PMC, profiles/{tfile.name})"
             rl["algorithmic_GB_per_launch"] = round(units * bpv / 1e9, 3)
             rl["measured_traffic_GBs"] = round(hit[0]["total_bytes"] / 1e9 / (kernel_ms * 1e-3), 1)
+            rl["measured_traffic_frac"] = round(rl["measured_traffic_GBs"] / HBM_PEAK_GBS, 4)  # the fraction of a hardware limit
             rl["note"] = ("a launch advances its cells by TWO steps: achieved = 2 x 12.125 B per cell / launch time (SURVEY 8d's per-update "
-                          "figure x the updates of a launch), which temporal blocking is allowed to beat; measured_traffic_GBs = the "
-                          "HBM bytes the launch really moves / launch time")
+                          "figure x the updates of a launch), which temporal blocking is allowed to beat (frac may exceed 1); measured_traffic_GBs = the "
+                          "HBM bytes the launch really moves / launch time, measured_traffic_frac = that over the 8 TB/s peak")
         else:
             rl["traffic_note"] = "committed profile is of another kernel instantiation / workload: not quoted"
     except (OSError, KeyError, ValueError):
