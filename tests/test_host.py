@@ -146,6 +146,29 @@ def test_split_covers_every_list_entry_once(G):
     assert sorted(rows) == list(range(sd.Nr))
 
 
+@pytest.mark.parametrize("G", [2, 3])
+@pytest.mark.parametrize("balance", [False, True])
+def test_split_along_file_z_covers_every_list_entry_once(G, balance):
+    """chains cut along FILE Z (rooms: the slab engines store the x and z axes exchanged): every list entry lands in exactly one
+    slab, interior to it along z, and maps back to its global index"""
+    sd = cases.make_sd("cart_outside", "double")
+    seen = {k: 0 for k in ("Nb", "Nbl", "Nba", "Ns")}
+    rows, back = [], []
+    for r in range(G):
+        loc, info = slab.split(sd, G, r, balance=balance, along_z=True)
+        assert info.along_z and loc.Nx == sd.Nx and loc.Nz == info.Nxh and loc.Npts == loc.Nx * loc.Ny * loc.Nz
+        for k in seen:
+            seen[k] += getattr(loc, k)
+        rows += loc.out_rows.tolist()
+        for arr in (loc.bn_ixyz, loc.bnl_ixyz, loc.bna_ixyz, loc.in_ixyz):
+            iz = arr % loc.Nz
+            assert ((iz >= 1) & (iz <= loc.Nz - 2)).all()  # everything a slab updates is interior to it along z
+        back.append((loc.bn_ixyz // loc.Nz) * sd.Nz + loc.bn_ixyz % loc.Nz + info.xlo)
+    assert seen == {k: getattr(sd, k) for k in seen}
+    assert sorted(rows) == list(range(sd.Nr))
+    assert np.array_equal(np.sort(np.concatenate(back)), np.sort(sd.bn_ixyz))
+
+
 def test_weighted_partition_covers_and_balances():
     sd = cases.make_sd("cart_lossy", "double")
     for G in (2, 3, 5):
