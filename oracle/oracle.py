@@ -27,6 +27,7 @@ def lib():
             getattr(L, "oracle_run_sim_num" + sfx).argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                                                                ctypes.POINTER(ctypes.c_double), ctypes.c_int]
             getattr(L, "orc_set_numerics" + sfx).argtypes = [ctypes.c_void_p, ctypes.c_int]
+            getattr(L, "orc_set_slab_axis" + sfx).argtypes = [ctypes.c_void_p, ctypes.c_int]
             getattr(L, "orc_create" + sfx).restype = ctypes.c_void_p
             getattr(L, "orc_create" + sfx).argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
             getattr(L, "orc_step" + sfx).argtypes = [ctypes.c_void_p, ctypes.c_int64]
@@ -76,7 +77,7 @@ def run_sim(sd, threads=None, safeguarded=False):
 class Engine:
     """Step-wise oracle engine (used by the slab tests as the per-slab stepper and for grid comparisons)."""
 
-    def __init__(self, sd, slab_first=True, slab_last=True, safeguarded=False):
+    def __init__(self, sd, slab_first=True, slab_last=True, safeguarded=False, along_z=False):
         self.L = lib()
         self.sd = sd
         self.sfx = _sfx(sd)
@@ -86,6 +87,8 @@ class Engine:
             raise RuntimeError("orc_create failed")
         if safeguarded:
             getattr(self.L, "orc_set_numerics" + self.sfx)(self.h, 1)
+        if along_z:  # a slab of a chain cut along file z: the flags gate the z flips
+            getattr(self.L, "orc_set_slab_axis" + self.sfx)(self.h, 1)
 
     def step(self, n):
         getattr(self.L, "orc_step" + self.sfx)(self.h, int(n))
