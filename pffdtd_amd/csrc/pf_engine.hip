@@ -159,6 +159,7 @@ template <typename Real> struct Engine : EngineBase {
    uint8_t *mask = nullptr;      // skip-mask (boundary nodes + ghost z + pad + parity)
    Real *v1_dst = nullptr;       // autotune: destination of the barrier-free 7-point kernel (null = in place)
    int lw_force = 0;             // autotune: lanes per row segment of the barrier-free kernels (0 = pick_lw's rule)
+   int order_force = -1;         // autotune: tile order of the marching kernels (-1 = swizzle_mode's rule; 0 plain, 2 XCD-banded)
    float tune_ms[3] = {0, 0, 0}; // measured at creation: lean / barrier-free / blocked pair (per step), ms
    float pair_margin = 0.99f;    // the pair path stays when it takes less than this fraction of the best single step
    bool lean = false, need_fold_row = false; // lean: the fused 7-point kernel of pf_air_fused.h (air_variant 25)
@@ -873,7 +874,6 @@ template <typename Real> struct Engine : EngineBase {
       if (!fcc || !abck || sg || vbase != 0 || (op.debug & 0x8300) || lw_force || !(op.slab_first && op.slab_last)) return PF_OK;
       if (Nx * Ny * Nz < ((int64_t)1 << 22)) return PF_OK;
       constexpr int V = pf::VecOf<Real>::V;
-      if (cdiv(P, (int64_t)64 * V) * 64 == cdiv(P, (int64_t)32 * V) * 32 && cdiv(P, (int64_t)64 * V) * 64 == cdiv(P, (int64_t)16 * V) * 16) return PF_OK;
       Real *scr = try_dzalloc<Real>(npad);
       if (!scr) return PF_OK;
       hipEvent_t e0, e1;
@@ -898,6 +898,20 @@ template <typename Real> struct Engine : EngineBase {
          if (best_lw == 0 || ms < 0.98f * best) { best = ms; best_lw = lw; }
       }
       lw_force = best_lw;
+      // ... and the tile order: XCD-banded (the rule for large planes) against the plain order.  Rooms stored along their longest
+      // axis have long rows (Musikverein: 23 segments of 128 columns) and run 1-3 % faster, and steadier, in the plain order
+      // (345.0-345.3 against 335-342 Gvox/s in alternating runs); cubes keep the banded one (2.32 against 2.46 ms at 1024^3).
+      for (int mode : {0}) {
+         order_force = mode;
+         launch_air_march(s_main, 1, (int)Nx - 1);
+         hipEventRecord(e0, s_main);
+         for (int i = 0; i < 3; i++) launch_air_march(s_main, 1, (int)Nx - 1);
+         hipEventRecord(e1, s_main);
+         hipEventSynchronize(e1);
+         float ms = 0;
+         hipEventElapsedTime(&ms, e0, e1);
+         if (ms < 0.985f * best) best = ms; else order_force = -1;
+      }
       tune_ms[1] = best / 3;
       u0 = U0; u0_src = nullptr;
       hipEventDestroy(e0); hipEventDestroy(e1);
@@ -1534,7 +1548,7 @@ template <typename Real> struct Engine : EngineBase {
    // Banded wins on large planes (1024^2: k_air_fcc 2.46 -> 2.32 ms, barrier-free 7-point 2.45 -> 2.29, lean 2.33 -> 2.28;
    // Musikverein 552 x 850: 3.60 -> 3.44), the per-XCD run on small ones, where a whole chunk of planes fits one L2 and a band
    // is a handful of tiles (CTK church 579 x 309, 50 tiles per chunk: 0.392 vs 0.425 ms): banded from 96 tiles per chunk.
-   int swizzle_mode(int64_t tiles_per_chunk) const { return tiles_per_chunk >= 96 ? 2 : 1; }
+   int swizzle_mode(int64_t tiles_per_chunk) const { return order_force >= 0 ? order_force : (tiles_per_chunk >= 96 ? 2 : 1); }
    static uint32_t grid_blocks(int swz, int nzt, int nyt, int nxc) {
       return swz == 2 ? pf::xcd_band_blocks((uint32_t)nzt * nyt, (uint32_t)nxc) : (uint32_t)nzt * nyt * nxc;
    }
