@@ -206,7 +206,7 @@ template <typename Real> struct Engine : EngineBase {
    int tbx0 = 0, tbx1 = 0, tby0 = 0, tby1 = 0, tbz0 = 0, tbz1 = 0; // box of cells k_tb2_reg produces
    int szl = 0, szr = 0;                                  // 7-point column strips: columns [0, szl) and [szr, P)
    // planes per x chunk of k_tb2_reg: 12-20 are equally fast, 24 is 1 % and 48 is 6 % slower although longer chunks
-   // re-read fewer prologue planes (1024^3, tools/tb2_probe.py); PFFDTD_TB2_CHUNK overrides for such sweeps
+   // re-read fewer prologue planes (1024^3, tools/tb2_probe.py)
    int tb2_chunk = 16;
    std::vector<std::pair<int, int>> tb_xr;                // its x range (empty: no box)
    // the box is cut into tiles (x chunk x rows of one workgroup x core columns of one row segment); tiles with a boundary
