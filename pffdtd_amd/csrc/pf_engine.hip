@@ -19,6 +19,7 @@
 #include "pf_air_fused.h"
 #include "pf_energy.h"
 #include "pf_tb2.h"
+#include "pf_wall.h"
 
 namespace {
 
@@ -239,6 +240,17 @@ template <typename Real> struct Engine : EngineBase {
    int32_t *zs_fd = nullptr;                              // mode 2: the lossy nodes (indices into the lossy arrays) inside the strips
    int64_t zs_nfd = 0;
    const int32_t *bnd_sel = nullptr;                      // launch_boundary visits bnd_sel[range] when set
+   // wall regions (pf_wall.h): the shell of a blocked pair -- wall layers, ABC cells, ghost mirrors -- stepped in pairs too
+   bool wl_on = false;
+   pf::WallRegion wl_sreg[4], wl_vreg[2];                 // regions normal to x / y (lanes along z), normal to z (lanes along y)
+   int wl_nsreg = 0, wl_nvreg = 0, wl_dpv = 0;            // wl_dpv: cells per pencil of the regions normal to z (12 | 20)
+   uint32_t wl_sblocks = 0, wl_vblocks = 0;
+   uint2 *wl_pen = nullptr;                               // per pencil: node mask, first record
+   uint32_t *wl_rec = nullptr;                            // per node of a pencil: adjacency bits | lossy flag | lossy position
+   int32_t *wl_rest = nullptr;                            // boundary nodes no wall region owns (inside the box): the list kernel's
+   int64_t wl_nrest = 0;
+   Real *vh1b = nullptr, *gh1b = nullptr;                 // the other half of the double-buffered branch state
+   Real *bs_vout = nullptr, *bs_gout = nullptr;           // launch_boundary: where the new branch state goes (null: in place)
    // energy diagnostic (pf_energy.h)
    Real *Lu = nullptr, *vh_old = nullptr, *u2in = nullptr;
    double *d_acc = nullptr, *d_DEF = nullptr;
@@ -256,7 +268,7 @@ template <typename Real> struct Engine : EngineBase {
       auto F = [](void *p) { if (p) hipFree(p); };
       for (Real *g : own_list) F(g); // state grids this engine allocated (u0/u1 unless external, the temporal-blocking spares)
       own_list.clear();
-      F(d_lossy); F(mask); F(zs_map); F(zs_adj); F(zs_li); F(zs_rest); F(zs_fd); F(tb_clean); F(tb_dirty); F(tb_sample); F(sh_tiles); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
+      F(wl_pen); F(wl_rec); F(wl_rest); F(vh1b); F(gh1b); F(d_lossy); F(mask); F(zs_map); F(zs_adj); F(zs_li); F(zs_rest); F(zs_fd); F(tb_clean); F(tb_dirty); F(tb_sample); F(sh_tiles); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
       F(d_beta); F(d_insig); F(d_mq); F(ub[0]); F(ub[1]); F(ub[2]); F(u2ba); F(vh1); F(gh1); F(ring);
       if (h_ring) hipHostFree(h_ring);
       for (auto &p : air_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -662,6 +674,20 @@ template <typename Real> struct Engine : EngineBase {
          }
          if (best < 0) return PF_OK; // no room for a single row segment
       }
+      // Wall regions (init_walls): a column strip costs one 128-byte line per row whatever its width, but its pencils live in
+      // registers -- a sliver cut off the box is shared between the two strips instead of all going to the right one.
+      if (!fcc && !sg && single && !(op.debug & 0x10000000)) {
+         const int z1full = (int)((Nz - mz1) / 4 * 4);
+         if (tbz1 < z1full) {
+            const int rem = z1full - tbz1;
+            int best_sh = 0, best_need = 1 << 30;
+            for (int sh = 0; sh <= rem; sh += 4) {
+               const int need = std::max(tbz0 + sh + 2, (int)Nz - ((tbz1 + sh - 2) / 4 * 4));
+               if (need < best_need) { best_need = need; best_sh = sh; }
+            }
+            tbz0 += best_sh; tbz1 += best_sh;
+         }
+      }
       szl = tbz0; szr = tbz1; // (widened to whole 128-byte lines or 32-byte sectors, the overlap with the box computed twice: 0-2 % slower, re-measured with the grids placed)
       if (vbase == 41) tbx1 = tbx0; // driver test: everything goes through the out-of-place single-step path
       tb_xr.clear();
@@ -802,6 +828,8 @@ template <typename Real> struct Engine : EngineBase {
       }
       own_list.push_back(bufC); own_list.push_back(bufD);
       tb2 = true;
+      { int rcw = init_walls(); if (rcw) return rcw; }
+      if (wl_on) { zs_mode = 0; return PF_OK; } // (no single-step shell: nothing for the column-strip kernel to share)
       // Boundary nodes inside the column strips are updated by k_air_zstrip, which streams their lines anyway and holds
       // their six neighbours in registers (in k_boundary the floor / ceiling nodes of a box room -- stride-P neighbours,
       // one 128-byte line of u1 and of u0 per two nodes -- cost half of the pass: 0.30 of 0.63 ms at 1024^3).  The strip
@@ -851,6 +879,227 @@ template <typename Real> struct Engine : EngineBase {
             if ((rc = upload(&zs_fd, fd.data(), zs_nfd))) return rc;
          }
       } else zs_mode = 0;
+      return PF_OK;
+   }
+
+   // ---------------- wall regions: the shell of a blocked pair in pairs (pf_wall.h) ----------------
+   // Six regions around the box: two whole-plane slabs normal to x, two row strips normal to y (the box's planes), two
+   // column strips normal to z (the box's planes and rows) -- every interior cell outside the box belongs to exactly one.
+   // Conditions: 7-point, CPU-exact arithmetic, single domain, margins that fit the pencils (8 cells for the strided ones,
+   // 12 or 20 for the column strips), no source within one cell of the shell (a source is added BETWEEN the two steps,
+   // which a region that keeps u^{n+1} in registers cannot see), fused boundary pass.  Otherwise the single-step shell of
+   // round 2 runs (debug 0x10000000 forces that).
+   // The frequency-dependent nodes are renumbered region by region in the order the lanes visit them (march, lane, pencil
+   // cell), so that a wave's branch-state accesses are contiguous; the nodes inside the box follow in list order.
+   void free_walls() {
+      auto F = [](auto *&p) { if (p) hipFree((void *)p); p = nullptr; };
+      F(wl_pen); F(wl_rec); F(wl_rest); F(vh1b); F(gh1b);
+      wl_on = false; wl_nsreg = wl_nvreg = 0;
+   }
+   int init_walls() {
+      wl_on = false;
+      const bool single = op.slab_first && op.slab_last;
+      if (!tb2 || fcc || sg || !single || tb_xr.empty() || swz || (op.debug & 0x10000000)) return PF_OK;
+      if (Nb > 0 && !fuse_boundary) return PF_OK;
+      if (Nbl >= ((int64_t)1 << 24) || Nb >= ((int64_t)1 << 31)) return PF_OK;
+      constexpr int DPS = 8, V = pf::VecOf<Real>::V;
+      if (tbx0 + 2 > DPS || Nx - tbx1 + 2 > DPS || tby0 + 2 > DPS || Ny - tby1 + 2 > DPS) return PF_OK;
+      if (Nx < 2 * DPS || Ny < 2 * DPS) return PF_OK;
+      int dpv = 0, zb = 0;
+      for (int dp : {12, 20}) {
+         if (dp == 20 && sizeof(Real) != 4) break; // (fp64: 20 doubles per pencil and seven pencils do not fit the registers)
+         const int z = std::min((tbz1 - 2) / 4 * 4, (int)P - dp);
+         if (tbz0 + 2 <= dp && z >= 0 && z + dp >= Nz && tbz1 - z >= 2 && z % V == 0) { dpv = dp; zb = z; break; }
+      }
+      if (!dpv) return PF_OK;
+      for (int64_t i = 0; i < Ns; i++) { // sources stay two cells inside the box
+         int64_t ix, iy, iz;
+         decode(sd.in_ixyz[i], ix, iy, iz);
+         if (ix < tbx0 + 1 || ix > tbx1 - 2 || iy < tby0 + 1 || iy > tby1 - 2 || iz < tbz0 + 1 || iz > tbz1 - 2) return PF_OK;
+      }
+      pf::WallRegion reg[6];
+      int dps[6];
+      auto mk = [&](int i, int mode, int nbase, int kg, int ko0, int ko1, int dp, int l0, int l1, int m0, int m1) {
+         pf::WallRegion &R = reg[i];
+         R = pf::WallRegion{};
+         R.mode = mode; R.nbase = nbase; R.kg = kg; R.ko0 = ko0; R.ko1 = ko1;
+         R.kb0 = std::max(ko0 - 2, 0); R.kb1 = std::min(ko1 + 2, dp);
+         R.l0 = l0; R.l1 = l1; R.m0 = m0; R.m1 = m1;
+         const int len = m1 - m0, nmc = (int)std::max<int64_t>(cdiv(len, 16), 1);
+         R.mchunk = (int)cdiv(len, nmc);
+         R.nlt = (int)cdiv(l1 - l0, pf::WALL_LT);
+         R.nlp = R.nlt * pf::WALL_LT + 4;
+         dps[i] = dp;
+      };
+      mk(0, 0, 0, 0, 1, tbx0, DPS, 1, (int)Nz - 1, 1, (int)Ny - 1);
+      mk(1, 0, (int)Nx - DPS, DPS - 1, tbx1 - ((int)Nx - DPS), DPS - 1, DPS, 1, (int)Nz - 1, 1, (int)Ny - 1);
+      mk(2, 1, 0, 0, 1, tby0, DPS, 1, (int)Nz - 1, tbx0, tbx1);
+      mk(3, 1, (int)Ny - DPS, DPS - 1, tby1 - ((int)Ny - DPS), DPS - 1, DPS, 1, (int)Nz - 1, tbx0, tbx1);
+      mk(4, 2, 0, 0, 1, tbz0, dpv, tby0, tby1, tbx0, tbx1);
+      mk(5, 2, zb, (int)Nz - 1 - zb, tbz1 - zb, (int)Nz - 1 - zb, dpv, tby0, tby1, tbx0, tbx1);
+      int64_t npen = 0;
+      for (int i = 0; i < 6; i++) { reg[i].pen_off = npen; npen += (int64_t)(reg[i].m1 - reg[i].m0 + 2) * reg[i].nlp; }
+      if (npen >= ((int64_t)1 << 31)) return PF_OK;
+      // a node's place in a region's frame
+      auto frame = [&](const pf::WallRegion &R, int64_t ix, int64_t iy, int64_t iz, int &k, int &lc, int &m) {
+         if (R.mode == 0) { k = (int)ix - R.nbase; lc = (int)iz; m = (int)iy; }
+         else if (R.mode == 1) { k = (int)iy - R.nbase; lc = (int)iz; m = (int)ix; }
+         else { k = (int)iz - R.nbase; lc = (int)iy; m = (int)ix; }
+      };
+      std::vector<int64_t> hb(Nb);
+      std::vector<uint16_t> hadj(Nb);
+      std::vector<int32_t> hl(Nb, -1);
+      if (Nb) {
+         HIPCHK(hipMemcpy(hb.data(), d_bn, Nb * sizeof(int64_t), hipMemcpyDeviceToHost));
+         HIPCHK(hipMemcpy(hadj.data(), d_adj, Nb * sizeof(uint16_t), hipMemcpyDeviceToHost));
+         HIPCHK(hipMemcpy(hl.data(), d_lossy, Nb * sizeof(int32_t), hipMemcpyDeviceToHost));
+      }
+      // owners, and the new order of the frequency-dependent nodes
+      std::vector<int8_t> owner(Nb, 6);
+      struct Key { int32_t r, m, lc, k, li; };
+      std::vector<Key> keys;
+      keys.reserve((size_t)Nbl);
+      std::vector<int32_t> rest;
+      for (int64_t nb = 0; nb < Nb; nb++) {
+         const int64_t ix = hb[nb] / plane, rem = hb[nb] % plane, iy = rem / P, iz = rem % P;
+         int r = 6, k = 0, lc = 0, m = 0;
+         for (int i = 0; i < 6; i++) {
+            int kk, ll, mm;
+            frame(reg[i], ix, iy, iz, kk, ll, mm);
+            if (kk >= reg[i].ko0 && kk < reg[i].ko1 && ll >= reg[i].l0 && ll < reg[i].l1 && mm >= reg[i].m0 && mm < reg[i].m1) { r = i; k = kk; lc = ll; m = mm; break; }
+         }
+         owner[nb] = (int8_t)r;
+         if (r == 6) rest.push_back((int32_t)nb);
+         if (hl[nb] >= 0) keys.push_back({r, m, lc, k, hl[nb]});
+      }
+      if ((int64_t)keys.size() != Nbl) return PF_OK; // (a lossy node that is no boundary node: fuse_boundary excludes it)
+      std::stable_sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+         if (a.r != b.r) return a.r < b.r;
+         if (a.r == 6) return a.li < b.li;
+         if (a.m != b.m) return a.m < b.m;
+         if (a.lc != b.lc) return a.lc < b.lc;
+         return a.k < b.k;
+      });
+      std::vector<int32_t> newli((size_t)Nbl);
+      for (int64_t j = 0; j < Nbl; j++) newli[keys[j].li] = (int32_t)j;
+      // pencil tables: node masks, then the records in pencil order (the boundary list is sorted by cell, so a pencil's
+      // nodes arrive in ascending pencil-cell order)
+      std::vector<uint2> pen((size_t)npen, make_uint2(0u, 0u));
+      auto visit = [&](auto &&fn) {
+         for (int64_t nb = 0; nb < Nb; nb++) {
+            const int64_t ix = hb[nb] / plane, rem = hb[nb] % plane, iy = rem / P, iz = rem % P;
+            for (int i = 0; i < 6; i++) {
+               const pf::WallRegion &R = reg[i];
+               int k, lc, m;
+               frame(R, ix, iy, iz, k, lc, m);
+               if (k < std::max(1, R.ko0 - 1) || k > std::min(dps[i] - 2, R.ko1) || lc < R.l0 - 1 || lc > R.l1 || m < R.m0 - 1 || m > R.m1) continue;
+               fn(nb, R.pen_off + (int64_t)(m - (R.m0 - 1)) * R.nlp + (lc - (R.l0 - 2)), k);
+            }
+         }
+      };
+      visit([&](int64_t, int64_t pi, int k) { pen[(size_t)pi].x |= 1u << k; });
+      int64_t nrec = 0;
+      for (int64_t i = 0; i < npen; i++) { pen[(size_t)i].y = (uint32_t)nrec; nrec += __builtin_popcount(pen[(size_t)i].x); }
+      if (nrec >= ((int64_t)1 << 32)) return PF_OK;
+      std::vector<uint32_t> rec((size_t)std::max<int64_t>(nrec, 1), 0u);
+      visit([&](int64_t nb, int64_t pi, int k) {
+         const uint2 e = pen[(size_t)pi];
+         const uint32_t slot = e.y + (uint32_t)__builtin_popcount(e.x & ((1u << k) - 1u));
+         rec[slot] = (uint32_t)(hadj[nb] & 63u) | (hl[nb] >= 0 ? (0x40u | ((uint32_t)newli[hl[nb]] << 8)) : 0u);
+      });
+      int rc;
+      if ((rc = upload(&wl_pen, pen.data(), npen))) return rc;
+      if ((rc = upload(&wl_rec, rec.data(), nrec))) return rc;
+      wl_nrest = (int64_t)rest.size();
+      if ((rc = upload(&wl_rest, rest.data(), wl_nrest))) return rc;
+      // the lossy arrays in the new order (state and node-value arrays are all zeros at creation)
+      if (Nbl) {
+         std::vector<int64_t> bl(Nbl), bl2(Nbl);
+         std::vector<Real> sf(Nbl), sf2(Nbl);
+         std::vector<int8_t> mt(Nbl), mt2(Nbl);
+         HIPCHK(hipMemcpy(bl.data(), d_bnl, Nbl * sizeof(int64_t), hipMemcpyDeviceToHost));
+         HIPCHK(hipMemcpy(sf.data(), d_ssaf, Nbl * sizeof(Real), hipMemcpyDeviceToHost));
+         HIPCHK(hipMemcpy(mt.data(), d_mat, Nbl * sizeof(int8_t), hipMemcpyDeviceToHost));
+         for (int64_t j = 0; j < Nbl; j++) { bl2[newli[j]] = bl[j]; sf2[newli[j]] = sf[j]; mt2[newli[j]] = mt[j]; }
+         HIPCHK(hipMemcpy(d_bnl, bl2.data(), Nbl * sizeof(int64_t), hipMemcpyHostToDevice));
+         HIPCHK(hipMemcpy(d_ssaf, sf2.data(), Nbl * sizeof(Real), hipMemcpyHostToDevice));
+         HIPCHK(hipMemcpy(d_mat, mt2.data(), Nbl * sizeof(int8_t), hipMemcpyHostToDevice));
+         for (int64_t nb = 0; nb < Nb; nb++) if (hl[nb] >= 0) hl[nb] = newli[hl[nb]];
+         HIPCHK(hipMemcpy(d_lossy, hl.data(), Nb * sizeof(int32_t), hipMemcpyHostToDevice));
+      }
+      if ((rc = dzalloc(&vh1b, round_up(Nbl, 64) * PF_MMB))) return rc;
+      if ((rc = dzalloc(&gh1b, round_up(Nbl, 64) * PF_MMB))) return rc;
+      wl_nsreg = 4; wl_nvreg = 2; wl_dpv = dpv;
+      uint32_t b0 = 0;
+      for (int i = 0; i < 4; i++) { reg[i].blk0 = b0; b0 += (uint32_t)reg[i].nlt * (uint32_t)cdiv(reg[i].m1 - reg[i].m0, reg[i].mchunk); wl_sreg[i] = reg[i]; }
+      wl_sblocks = b0;
+      b0 = 0;
+      for (int i = 4; i < 6; i++) { reg[i].blk0 = b0; b0 += (uint32_t)reg[i].nlt * (uint32_t)cdiv(reg[i].m1 - reg[i].m0, reg[i].mchunk); wl_vreg[i - 4] = reg[i]; }
+      wl_vblocks = b0;
+      wl_on = true;
+      if (getenv("PFFDTD_VERBOSE") && atoi(getenv("PFFDTD_VERBOSE")) > 0)
+         fprintf(stderr, "pffdtd_hip: wall regions: box x [%d,%d) y [%d,%d) z [%d,%d), %ld pencils, %ld node records, %ld of %ld boundary nodes left to the list kernel, column pencils of %d cells from column %d\n",
+                 tbx0, tbx1, tby0, tby1, tbz0, tbz1, (long)npen, (long)nrec, (long)wl_nrest, (long)Nb, dpv, zb);
+      return PF_OK;
+   }
+   // both steps of the wall regions: A = u^{n-1}, B = u^n -> C = u^{n+1}, D = u^{n+2}; branch state vh1 / gh1 -> vh1b / gh1b;
+   // node values: P2 = u^{n-1} and P1 = u^n are read, P0 <- u^{n+1}, P1 <- u^{n+2}
+   void launch_walls(hipStream_t s, const Real *A, const Real *B, Real *C, Real *D, Real *P0, Real *P1, const Real *P2) {
+      pf::WallParams<Real> wp{};
+      wp.A = A; wp.B = B; wp.C = C; wp.D = D;
+      wp.plane = plane; wp.Nx = (int)Nx; wp.Ny = (int)Ny; wp.Nz = (int)Nz; wp.P = (int)P; wp.first = op.slab_first; wp.last = op.slab_last;
+      wp.pen = wl_pen; wp.rec = wl_rec;
+      wp.sv_in = vh1; wp.sg_in = gh1; wp.sv_out = vh1b; wp.sg_out = gh1b;
+      wp.x2 = P2; wp.x1 = P1; wp.o1 = P0; wp.o2 = P1;
+      wp.ssaf = d_ssaf; wp.mat = d_mat; wp.Mb = d_Mb; wp.mq = d_mq; wp.beta = d_beta;
+      wp.lo2 = lo2; wp.sl2 = sl2; wp.l = l; wp.mmax = mb_max;
+      if (wl_nsreg > 0 && wl_sblocks > 0) {
+         wp.nreg = wl_nsreg;
+         for (int i = 0; i < wl_nsreg; i++) wp.reg[i] = wl_sreg[i];
+         hipLaunchKernelGGL((pf::k_wall2<Real, 8, false>), dim3(wl_sblocks), dim3(64), 0, s, wp, a1, a2);
+      }
+      if (wl_nvreg > 0 && wl_vblocks > 0) {
+         wp.nreg = wl_nvreg;
+         for (int i = 0; i < wl_nvreg; i++) wp.reg[i] = wl_vreg[i];
+         if (wl_dpv == 12) hipLaunchKernelGGL((pf::k_wall2<Real, 12, true>), dim3(wl_vblocks), dim3(64), 0, s, wp, a1, a2);
+         else if constexpr (sizeof(Real) == 4) hipLaunchKernelGGL((pf::k_wall2<Real, 20, true>), dim3(wl_vblocks), dim3(64), 0, s, wp, a1, a2);
+      }
+   }
+   // steps n and n+1 with the shell in pairs as well.  Order: box (both steps), then the first step of what no wall region
+   // owns -- the box's dirty tiles and the boundary nodes inside it --, source / receivers of step n, the wall regions (both
+   // steps; they read u^{n-1}, u^n and the old branch state only), then the second step of the dirty tiles and their nodes.
+   int step_pair_walls(int64_t n) {
+      hipStream_t s = s_main;
+      Real *A = u0, *B = u1, *C = bufC, *D = bufD;
+      Real *P0 = ub[0], *P1 = ub[1], *P2 = ub[2];
+      auto get_ev = [&]() { std::pair<hipEvent_t, hipEvent_t> e{}; if (!ev_pool.empty()) { e = ev_pool.back(); ev_pool.pop_back(); } else { hipEventCreate(&e.first); hipEventCreate(&e.second); } return e; };
+      std::pair<hipEvent_t, hipEvent_t> ev{}, ev2{}, evt{}, eva{};
+      if (op.timing) { ev = get_ev(); ev2 = get_ev(); evt = get_ev(); eva = get_ev(); hipEventRecord(ev.first, s); hipEventRecord(evt.first, s); }
+      launch_tb2(s, A, B, C, D);
+      if (op.timing) { hipEventRecord(evt.second, s); tb2_ev.push_back(evt); hipEventRecord(eva.first, s); }
+      u0_src = A; u1 = B; u0 = C;
+      launch_dirty_tiles(s);
+      bnd_sel = wl_rest; bs_vout = vh1b; bs_gout = gh1b;
+      launch_rigid(s, {0, wl_nrest});
+      launch_io(s, n, true, {0, Ns});
+      if (ring_fill == 0) ring_n0 = n;
+      ring_fill++; steps_done++;
+      launch_walls(s, A, B, C, D, P0, P1, P2);
+      if (op.timing) { hipEventRecord(eva.second, s); air_ev.push_back(eva); hipEventRecord(ev.second, s); step_ev.push_back(ev); hipEventRecord(ev2.first, s); }
+      std::swap(vh1, vh1b); std::swap(gh1, gh1b); // the state after the pair (the nodes inside the box: after its first step)
+      u0_src = B; u1 = C; u0 = D;
+      launch_dirty_tiles(s);
+      bs_vout = bs_gout = nullptr;
+      ub[0] = P1; ub[2] = P1; // second step of the box's nodes: u2b = u^n of the node, overwritten by its u^{n+2} (where the regions put theirs)
+      launch_rigid(s, {0, wl_nrest});
+      ub[0] = P2; ub[1] = P1; ub[2] = P0;
+      bnd_sel = nullptr;
+      launch_io(s, n + 1, true, {0, Ns});
+      ring_fill++; steps_done++;
+      u0_src = nullptr; u0 = C; u1 = D; bufC = A; bufD = B;
+      if (op.timing) { hipEventRecord(ev2.second, s); step_ev.push_back(ev2); }
+      HIPCHK(hipGetLastError());
+      if (ring_fill == ring_depth) return flush();
       return PF_OK;
    }
    int set_spares(void *g2, void *g3) override {
@@ -1307,15 +1556,34 @@ template <typename Real> struct Engine : EngineBase {
       if (hipGetLastError() != hipSuccess) { lean = lean0; vg = vg0; }
       else if (tune_ms[1] < 0.97f * tune_ms[0]) { lean = false; vg = true; }
       else if (tune_ms[0] < 0.97f * tune_ms[1]) { lean = true; vg = false; }
-      if (tb2) {
+      if (tb2 && wl_on) {
+         // wall regions: the pair then includes the boundary pass, so the single steps get theirs added (fields and branch state
+         // are all zeros at creation and stay so)
+         u0_src = U0; u0 = scr;
+         const float tb = timed([&] { launch_rigid(s_main, {0, Nb}); });
+         u0_src = nullptr; u0 = U0;
+         tune_ms[0] += tb; tune_ms[1] += tb;
+         tune_ms[2] = 0.5f * timed([&] {
+            launch_tb2(s_main, U0, U1, bufC, bufD);
+            bnd_sel = wl_rest;
+            u0_src = U0; u1 = U1; u0 = bufC; launch_dirty_tiles(s_main); launch_rigid(s_main, {0, wl_nrest});
+            launch_walls(s_main, U0, U1, bufC, bufD, ub[0], ub[1], ub[2]);
+            u0_src = U1; u1 = bufC; u0 = bufD; launch_dirty_tiles(s_main); launch_rigid(s_main, {0, wl_nrest});
+            bnd_sel = nullptr;
+            u0_src = nullptr; u0 = U0; u1 = U1;
+         });
+      } else if (tb2) {
          tune_ms[2] = 0.5f * timed([&] {
             launch_tb2(s_main, U0, U1, bufC, bufD);
             u0_src = U0; u1 = U1; u0 = bufC; launch_shell(s_main);
             u0_src = U1; u1 = bufC; u0 = bufD; launch_shell(s_main);
             u0_src = nullptr; u0 = U0; u1 = U1;
          });
+      }
+      if (tb2) {
          if (!(tune_ms[2] < pair_margin * std::min(tune_ms[0], tune_ms[1]))) { // not worth it: drop the pair path and its two grids
             tb2 = false;
+            free_walls();
             for (Real *g : {bufC, bufD}) { own_list.erase(std::remove(own_list.begin(), own_list.end(), g), own_list.end()); hipFree(g); }
             if (scr == bufC) scr = nullptr;
             bufC = bufD = nullptr;
@@ -1445,6 +1713,7 @@ template <typename Real> struct Engine : EngineBase {
    // steps n and n+1 in one go; the state moves from (u0, u1) to (bufC, bufD), which swap roles with them
    int step_pair(int64_t n) {
       if (n < 0 || n + 1 >= Nt) return set_err(PF_ERR_ARG, "step pair %ld outside [0,Nt=%ld)", (long)n, (long)Nt);
+      if (wl_on) return step_pair_walls(n);
       hipStream_t s = s_main;
       Real *A = u0, *B = u1, *C = bufC, *D = bufD;
       std::pair<hipEvent_t, hipEvent_t> ev{}, eva{};
@@ -1667,7 +1936,7 @@ template <typename Real> struct Engine : EngineBase {
       launch_fold_row(s);
       const int64_t nfd = with_fd ? zs_nfd : 0;
       dim3 g((unsigned)cdiv(r.e - r.b + nfd, 128)), b(128);
-#define PF_BND(F, M) hipLaunchKernelGGL((pf::k_boundary<Real, F, M>), g, b, 0, s, u1, u0, d_bn, d_adj, d_lossy, a2, sl2, P, plane, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq, d_beta, vh1, gh1, lo2, (int64_t)mb_max, r.b, r.e, u0_src ? u0_src : (const Real *)u0, bnd_sel, swz ? 1 : 0, with_fd ? zs_fd : (const int32_t *)nullptr, nfd, d_bnl)
+#define PF_BND(F, M) hipLaunchKernelGGL((pf::k_boundary<Real, F, M>), g, b, 0, s, u1, u0, d_bn, d_adj, d_lossy, a2, sl2, P, plane, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq, d_beta, vh1, gh1, bs_vout ? bs_vout : vh1, bs_gout ? bs_gout : gh1, lo2, (int64_t)mb_max, r.b, r.e, u0_src ? u0_src : (const Real *)u0, bnd_sel, swz ? 1 : 0, with_fd ? zs_fd : (const int32_t *)nullptr, nfd, d_bnl)
       if (fcc) { if (sg) PF_BND(true, true); else PF_BND(true, false); }
       else { if (sg) PF_BND(false, true); else PF_BND(false, false); }
 #undef PF_BND

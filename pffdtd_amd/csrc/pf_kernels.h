@@ -681,12 +681,13 @@ __device__ __host__ __forceinline__ int64_t st_idx(int m, int64_t li) { return (
 // All branch-state and coefficient loads are issued up front (their addresses do not depend on the arithmetic): with the
 // loads inside the accumulation loop every branch cost a memory round trip and the list kernels ran latency-bound
 // (k_fd_sel 2.6 TB/s); the arithmetic keeps the reference's order.
+// vin / gin: the branch state before the step, vout / gout: where the state after it goes (the same arrays for the in-place
+// single steps; the other half of a double buffer inside the wall-region pairs, pf_wall.h); wr = false: evaluate only
+// (halo nodes of a wall region: their owner stores).  u2 = the node's value two steps back.
 template <typename Real>
-__device__ __forceinline__ Real fd_node_update(Real p, int32_t li, Real *__restrict__ u0b, const Real *__restrict__ u2b,
-                                               const Real *__restrict__ ssaf, const int8_t *__restrict__ mat,
-                                               const int8_t *__restrict__ Mb, const MatQuadT<Real> *__restrict__ mq,
-                                               const Real *__restrict__ beta, Real *__restrict__ vh1, Real *__restrict__ gh1,
-                                               Real lo2, int64_t mmax) {
+__device__ __forceinline__ Real fd_core(Real p, Real u2, int32_t li, const Real *vin, const Real *gin, Real *vout, Real *gout, bool wr,
+                                        const Real *__restrict__ ssaf, const int8_t *__restrict__ mat, const int8_t *__restrict__ Mb,
+                                        const MatQuadT<Real> *__restrict__ mq, const Real *__restrict__ beta, Real lo2, int64_t mmax) {
    // mmax = the largest branch count of any material of the scene (uniform): the branch-state loads are issued for
    // m < mmax right away, without waiting for the node's own count M = Mb[mat[li]] -- two dependent round trips less per
    // wave (the list kernels are latency-bound: index -> material -> count -> state); states m >= M are loaded and ignored
@@ -695,8 +696,8 @@ __device__ __forceinline__ Real fd_node_update(Real p, int32_t li, Real *__restr
 #pragma unroll
    for (int m = 0; m < 12; m++) {
       if (m < (int)mmax) {
-         v1[m] = vh1[st_idx(m, li)]; // (plain, not nontemporal, loads and stores: measured 12 % faster for k_fd_sel, 5 % for k_boundary)
-         g1[m] = gh1[st_idx(m, li)];
+         v1[m] = vin[st_idx(m, li)]; // (plain, not nontemporal, loads and stores: measured 12 % faster for k_fd_sel, 5 % for k_boundary)
+         g1[m] = gin[st_idx(m, li)];
       }
    }
    const int32_t k = mat[li];
@@ -709,7 +710,6 @@ __device__ __forceinline__ Real fd_node_update(Real p, int32_t li, Real *__restr
    const Real g = lo2 * sf * beta[k];
    const Real fac = two * lo2 * sf / (one + g);
    Real u = p;
-   const Real u2 = u2b[li];
    u = (u + g * u2) / (one + g);
 #pragma unroll
    for (int m = 0; m < 12; m++)
@@ -719,10 +719,21 @@ __device__ __forceinline__ Real fd_node_update(Real p, int32_t li, Real *__restr
    for (int m = 0; m < 12; m++) {
       if (m < M) {
          const Real v0 = q[m].b * du + q[m].bd * v1[m] - two * q[m].bFh * g1[m];
-         gh1[st_idx(m, li)] = g1[m] + (v0 + v1[m]) / two;
-         vh1[st_idx(m, li)] = v0;
+         if (wr) {
+            gout[st_idx(m, li)] = g1[m] + (v0 + v1[m]) / two;
+            vout[st_idx(m, li)] = v0;
+         }
       }
    }
+   return u;
+}
+template <typename Real>
+__device__ __forceinline__ Real fd_node_update(Real p, int32_t li, Real *u0b, const Real *u2b,
+                                               const Real *__restrict__ ssaf, const int8_t *__restrict__ mat,
+                                               const int8_t *__restrict__ Mb, const MatQuadT<Real> *__restrict__ mq,
+                                               const Real *__restrict__ beta, const Real *vh1, const Real *gh1, Real *vh1o, Real *gh1o,
+                                               Real lo2, int64_t mmax) {
+   const Real u = fd_core<Real>(p, u2b[li], li, vh1, gh1, vh1o, gh1o, true, ssaf, mat, Mb, mq, beta, lo2, mmax);
    u0b[li] = u;
    return u;
 }
@@ -734,12 +745,12 @@ static __global__ void k_fd_boundary(Real *__restrict__ u0, const int64_t *__res
                               const Real *__restrict__ u2b, const Real *__restrict__ ssaf,
                               const int8_t *__restrict__ mat, const int8_t *__restrict__ Mb,
                               const MatQuadT<Real> *__restrict__ mq, const Real *__restrict__ beta,
-                              Real *__restrict__ vh1, Real *__restrict__ gh1, Real lo2, int64_t mmax, int64_t begin,
+                              Real *vh1, Real *gh1, Real lo2, int64_t mmax, int64_t begin,
                               int64_t end) {
    const int64_t nb = begin + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (nb >= end) return;
    const int64_t ii = idx[nb];
-   u0[ii] = fd_node_update<Real>(u0[ii], (int32_t)nb, u0b, u2b, ssaf, mat, Mb, mq, beta, vh1, gh1, lo2, mmax);
+   u0[ii] = fd_node_update<Real>(u0[ii], (int32_t)nb, u0b, u2b, ssaf, mat, Mb, mq, beta, vh1, gh1, vh1, gh1, lo2, mmax);
 }
 
 // ---- fused boundary pass: rigid update of every boundary node + FD update of the lossy ones in one visit ----------
@@ -751,10 +762,11 @@ static __global__ void k_fd_boundary(Real *__restrict__ u0, const int64_t *__res
 template <typename Real, bool FCC, bool SG>
 static __global__ void k_boundary(const Real *__restrict__ u1, Real *u0, const int64_t *__restrict__ idx,
                            const uint16_t *__restrict__ adjv, const int32_t *__restrict__ lossy, Real a2, Real sl2,
-                           int64_t P, int64_t plane, Real *__restrict__ u0b, const Real *__restrict__ u2b,
+                           int64_t P, int64_t plane, Real *u0b, const Real *u2b, // (u0b may be u2b: second step of a wall-region pair)
                            const Real *__restrict__ ssaf, const int8_t *__restrict__ mat, const int8_t *__restrict__ Mb,
-                           const MatQuadT<Real> *__restrict__ mq, const Real *__restrict__ beta, Real *__restrict__ vh1,
-                           Real *__restrict__ gh1, Real lo2, int64_t mmax, int64_t begin, int64_t end,
+                           const MatQuadT<Real> *__restrict__ mq, const Real *__restrict__ beta, const Real *vh1,
+                           const Real *gh1, Real *vh1o, Real *gh1o, // branch state before / after (the same arrays: in place)
+                           Real lo2, int64_t mmax, int64_t begin, int64_t end,
                            const Real *u0_old, const int32_t *__restrict__ sel, int swz, // u0_old: where u^{n-1} lives (== u0 in place)
                            const int32_t *__restrict__ fdsel = nullptr, int64_t nfd = 0, const int64_t *__restrict__ idx_l = nullptr) {
    // fdsel: threads beyond the list do the branch ODEs of nfd lossy nodes whose RIGID update was done elsewhere (the column-strip
@@ -764,7 +776,7 @@ static __global__ void k_boundary(const Real *__restrict__ u1, Real *u0, const i
       const int64_t f = t - end;
       if (f < nfd) {
          const int32_t li = fdsel[f];
-         u0[idx_l[li]] = fd_node_update<Real>(u0b[li], li, u0b, u2b, ssaf, mat, Mb, mq, beta, vh1, gh1, lo2, mmax);
+         u0[idx_l[li]] = fd_node_update<Real>(u0b[li], li, u0b, u2b, ssaf, mat, Mb, mq, beta, vh1, gh1, vh1o, gh1o, lo2, mmax);
       }
       return;
    }
@@ -775,7 +787,7 @@ static __global__ void k_boundary(const Real *__restrict__ u1, Real *u0, const i
    gather_nb<Real, FCC>(u1, ii, P, plane, v, swz != 0);
    Real p = upd_rigid<SG, FCC ? 12 : 6>(a2, sl2, adj, u1[ii], u0_old[ii], v);
    const int32_t li = lossy[nb];
-   if (li >= 0) p = fd_node_update<Real>(p, li, u0b, u2b, ssaf, mat, Mb, mq, beta, vh1, gh1, lo2, mmax);
+   if (li >= 0) p = fd_node_update<Real>(p, li, u0b, u2b, ssaf, mat, Mb, mq, beta, vh1, gh1, vh1o, gh1o, lo2, mmax);
    u0[ii] = p;
 }
 

@@ -1,0 +1,280 @@
+// pf_wall.h -- the SHELL of a temporally blocked pair stepped in pairs too (7-point, CPU-exact arithmetic).
+//
+// k_tb2_reg (pf_tb2.h) advances the boundary-free box by two steps per pass; until round 3 everything around it -- the wall
+// layers with their frequency-dependent nodes, the ABC cells, the ghost mirrors -- was stepped twice by single-step kernels:
+// ~12 launches per pair, every branch-ODE state (vh1, gh1: 176 B per node at Mb = 11) read and written once per STEP, the
+// column strips' half-used lines fetched once per step.  k_wall2 does both steps of a wall region in one pass:
+//
+//   * a region = the cells between a grid face and the box ("pencils" of DP cells along the face normal, pencil cell 0 /
+//     DP-1 = the ghost cell), tiled along a "lane" axis (64 lanes, one pencil each, 60 of them owned) and marched along the
+//     third axis in chunks.  Regions normal to x and y have their lanes along z (unit stride: 256-byte runs per pencil cell),
+//     the regions normal to z have their lanes along y and load their pencils as 16-byte vectors (one 128-byte line per row
+//     and side, read once per pair for u^n and u^{n-1}, written once for u^{n+1} and u^{n+2}).
+//   * per march step m: stage 1 = u^{n+1}(m) on the pencil cells 1 .. DP-2 from u^n(m-1 .. m+1) and u^{n-1}(m); stage 2 =
+//     u^{n+2}(m-1) on the OWNED cells from u^{n+1}(m-2 .. m) and u^n(m-1) -- the scheme of k_tb2_reg, but every cell is
+//     generic: air (+ ABC loss by its coordinates), ghost (mirrored in registers: normal axis; by a wave shuffle: lane axis;
+//     by taking the other march plane: march axis), rigid boundary node, frequency-dependent boundary node.  Lane-axis
+//     neighbours come from the DPP wave shifts, so lanes 0 / 63 are halo (stage 1 invalid), lanes 1 / 62 are stage-1-only.
+//   * nodes: per pencil a 32-bit mask of its node cells and the index of their records (adjacency bits, position in the
+//     frequency-dependent arrays).  The wave walks the union of its lanes' masks (box rooms: two turns, one for the rigid
+//     layer, one for the lossy layer, every lane busy), so the branch ODEs run dense.
+//   * everything a region needs beyond its own cells (one cell of halo in every direction, incl. the branch state of the
+//     nodes there) is RECOMPUTED from u^n / u^{n-1}, never read from the grids being written: the regions are independent
+//     of each other, of the box kernel and of the launch order.  For that the branch state is double-buffered (read
+//     sv_in / sg_in, write sv_out / sg_out; the engine swaps after the pair) and the node values of the two steps go to
+//     buffers nobody reads during the pair (o1, o2; x2 = u^{n-1} of the nodes is only read).
+//   * the owner's stage 2 reads the state its own stage 1 stored one march step earlier (same lane, same address: L2).
+//
+// Arithmetic: upd7 / upd_rigid / abc_loss / fd_core of pf_kernels.h, neighbours in FILE order whatever the pencil's
+// orientation -- bit-identical to the single-step kernels and to cpu_engine.h:175-194,225-229,234-257,290-301,363-405.
+#pragma once
+#include <type_traits>
+#include "pf_kernels.h"
+
+namespace pf {
+
+constexpr int WALL_MAXREG = 4;
+constexpr int WALL_LT = 60; // owned lanes per tile (lanes 2 .. 61)
+
+struct WallRegion {
+   int32_t mode;        // pencils along 0: x (lanes z, march y), 1: y (lanes z, march x), 2: z (lanes y, march x; vector loads)
+   int32_t nbase;       // normal coordinate of pencil cell 0
+   int32_t kg;          // pencil index of the ghost cell (mirrors the cell two inside), -1: none
+   int32_t ko0, ko1;    // pencil cells this region owns (writes): [ko0, ko1)
+   int32_t kb0, kb1;    // pencil cells of u^n / u^{n-1} it loads: [kb0, kb1)
+   int32_t l0, l1;      // lane-axis coordinates owned: [l0, l1)
+   int32_t m0, m1;      // march coordinates owned: [m0, m1)
+   int32_t mchunk, nlt; // march steps per block, lane tiles
+   int32_t nlp;         // pencils per march step in the pencil table (nlt * 60 + 4)
+   uint32_t blk0;       // first block of the region in the launch
+   int64_t pen_off;     // the region's pencil table: entry (m - (m0-1)) * nlp + (lc - (l0-2))
+};
+
+template <typename Real> struct WallParams {
+   const Real *A, *B;       // u^{n-1}, u^n
+   Real *C, *D;             // u^{n+1}, u^{n+2}
+   int64_t plane;
+   int32_t Nx, Ny, Nz, P, first, last;
+   int32_t nreg;
+   WallRegion reg[WALL_MAXREG];
+   const uint2 *pen;        // per pencil: .x bit k = pencil cell k is a boundary node, .y = index of its first record
+   const uint32_t *rec;     // per node: adjacency bits (6) | 0x40 frequency-dependent | position in the lossy arrays << 8
+   const Real *sv_in, *sg_in;
+   Real *sv_out, *sg_out;   // branch state vh1 / gh1 before and after the pair (64-node blocks, st_idx)
+   const Real *x2, *x1;     // node values u^{n-1} (step 1) and u^n (step 2): the u2b of cpu_engine.h:290-301
+   Real *o1, *o2;           // node values u^{n+1}, u^{n+2} (o2 may be x1)
+   const Real *ssaf;
+   const int8_t *mat, *Mb;
+   const MatQuadT<Real> *mq;
+   const Real *beta;
+   Real lo2, sl2, l;
+   int32_t mmax;
+};
+
+template <typename Real, int N> __device__ __forceinline__ Real wall_sel(const Real (&a)[N], int k) { // k wave-uniform
+   Real r = a[0];
+#pragma unroll
+   for (int i = 1; i < N; i++) r = (k == i) ? a[i] : r;
+   return r;
+}
+
+template <typename Real, int DP, bool VEC>
+__global__ __launch_bounds__(64) void k_wall2(WallParams<Real> wp, Real a1, Real a2) {
+   typedef typename VecOf<Real>::type vec;
+   constexpr int V = VecOf<Real>::V;
+   static_assert(!VEC || DP % V == 0, "vector pencils hold whole vectors");
+   int r = 0;
+#pragma unroll
+   for (int i = 1; i < WALL_MAXREG; i++)
+      if (i < wp.nreg && blockIdx.x >= wp.reg[i].blk0) r = i;
+   const WallRegion R = wp.reg[r];
+   const uint32_t bl = blockIdx.x - R.blk0;
+   const int j = (int)(bl % (uint32_t)R.nlt), c = (int)(bl / (uint32_t)R.nlt);
+   const int lane = threadIdx.x;
+   const bool mode1 = !VEC && R.mode == 1;
+   const bool mx = VEC || mode1;                                   // the march axis is x
+   const int NL = VEC ? wp.Ny : wp.Nz;                             // extent of the lane axis
+   const int NM = mx ? wp.Nx : wp.Ny;                              // ... of the march axis
+   const int NN = VEC ? wp.Nz : (mode1 ? wp.Ny : wp.Nx);           // ... of the pencil axis
+   const bool mg_lo = mx ? (wp.first != 0) : true, mg_hi = mx ? (wp.last != 0) : true; // ghost planes at the ends of the march axis?
+   const bool ng_lo = (!VEC && !mode1) ? (wp.first != 0) : true, ng_hi = (!VEC && !mode1) ? (wp.last != 0) : true;
+   const int64_t sl = VEC ? (int64_t)wp.P : 1, sm = mx ? wp.plane : (int64_t)wp.P;
+   const int64_t sn = VEC ? 1 : (mode1 ? (int64_t)wp.P : wp.plane);
+   const int lc = R.l0 - 2 + WALL_LT * j + lane;                   // this lane's coordinate on the lane axis
+   int lsrc = min(max(lc, 0), NL - 1);                             // where its u^n comes from: ghost cells mirror
+   if (lsrc == 0) lsrc = 2;
+   else if (lsrc == NL - 1) lsrc = NL - 3;
+   const bool lg_lo = lc == 0, lg_hi = lc == NL - 1;
+   const bool tile_lg = __ballot(lg_lo || lg_hi) != 0ull;
+   const bool own_lane = lane >= 2 && lane <= 61 && lc < R.l1;
+   const bool eval_lane = lane >= 1 && lane <= 62 && lc <= R.l1;   // stage 1 is valid (and needed) here
+   const int ms = R.m0 + c * R.mchunk, me = min(ms + R.mchunk, R.m1);
+   if (ms >= me) return;
+   auto msrc = [&](int m) {
+      m = min(max(m, 0), NM - 1);
+      if (m == 0 && mg_lo) return 2;
+      if (m == NM - 1 && mg_hi) return NM - 3;
+      return m;
+   };
+   const int64_t lbase = (int64_t)lsrc * sl + (int64_t)R.nbase * sn;
+   const int ql = (lc == 1 || lc == NL - 2) ? 1 : 0;
+
+   auto load_pencil = [&](const Real *G, int m, Real(&b)[DP], bool mirror) {
+      const Real *pl = G + (int64_t)msrc(m) * sm + lbase;
+      if constexpr (VEC) {
+#pragma unroll
+         for (int v = 0; v < DP / V; v++) {
+            if ((v + 1) * V > R.kb0 && v * V < R.kb1) {
+               const vec t = *(const vec *)(pl + v * V);
+#pragma unroll
+               for (int i = 0; i < V; i++) b[v * V + i] = t[i];
+            } else {
+#pragma unroll
+               for (int i = 0; i < V; i++) b[v * V + i] = Real(0);
+            }
+         }
+      } else {
+#pragma unroll
+         for (int k = 0; k < DP; k++) b[k] = (k >= R.kb0 && k < R.kb1 && k != R.kg) ? pl[(int64_t)k * sn] : Real(0);
+      }
+      if (mirror) {
+#pragma unroll
+         for (int k = 0; k < DP; k++)
+            if (k == R.kg) b[k] = (k == 0) ? b[2] : b[k >= 2 ? k - 2 : 0];
+      }
+   };
+   auto load_pen = [&](int m) {
+      uint2 p = wp.pen[R.pen_off + (int64_t)(m - (R.m0 - 1)) * R.nlp + (WALL_LT * j + lane)];
+      if (!eval_lane) p.x = 0u;
+      return p;
+   };
+   auto store_pencil = [&](Real *G, int m, const Real(&v)[DP]) {
+      if (!own_lane) return;
+      Real *pl = G + (int64_t)m * sm + (int64_t)lc * sl + (int64_t)R.nbase * sn;
+      if constexpr (VEC) {
+#pragma unroll
+         for (int q = 0; q < DP / V; q++) {
+            if ((q + 1) * V > R.ko0 && q * V < R.ko1) {
+               vec t;
+#pragma unroll
+               for (int i = 0; i < V; i++) t[i] = (R.kg > 0 && q * V + i > R.kg) ? Real(0) : v[q * V + i]; // (pad columns beyond the ghost column)
+               *(vec *)(pl + q * V) = t;
+            }
+         }
+      } else {
+#pragma unroll
+         for (int k = 0; k < DP; k++)
+            if (k >= R.ko0 && k < R.ko1) pl[(int64_t)k * sn] = v[k];
+      }
+   };
+
+   // One update of the pencil cells 1 .. DP-2 at march coordinate m: Out = f(Cur; Prv, Nxt = the march planes before / after;
+   // Old = the value two steps back).  STAGE 1: u^n -> u^{n+1} (halo cells included, their nodes read-only); STAGE 2: owned
+   // cells only.
+   auto update = [&](auto stage, int m, const Real(&Prv)[DP], const Real(&Cur)[DP], const Real(&Nxt)[DP], const Real(&Old)[DP], const uint2 pen,
+                     Real(&Out)[DP], bool own_m) {
+      constexpr int STAGE = decltype(stage)::value;
+      const int qm = mx ? (((wp.first && m == 1) || (wp.last && m == wp.Nx - 2)) ? 1 : 0) : ((m == 1 || m == wp.Ny - 2) ? 1 : 0);
+#pragma unroll
+      for (int k = 1; k < DP - 1; k++) {
+         const Real cc = Cur[k];
+         const Real lm = lane_from_lower<true>(cc), lp = lane_from_upper<true>(cc);
+         const Real np_ = Cur[k + 1], nm = Cur[k - 1], mp = Nxt[k], mm = Prv[k];
+         Real p;
+         if (VEC) p = upd7<false>(a1, a2, cc, Old[k], mp, mm, lp, lm, np_, nm);           // x = march, y = lanes, z = pencil
+         else {                                                                            // z = lanes; x, y = march / pencil
+            const Real xp = mode1 ? mp : np_, xm = mode1 ? mm : nm, yp = mode1 ? np_ : mp, ym = mode1 ? nm : mm;
+            p = upd7<false>(a1, a2, cc, Old[k], xp, xm, yp, ym, lp, lm);
+         }
+         const int nk = R.nbase + k;
+         const int qn = ((ng_lo && nk == 1) || (ng_hi && nk == NN - 2)) ? 1 : 0;
+         const int Q = qn + qm + ql;
+         if (__ballot(Q > 0) != 0ull) {
+            if (Q > 0) p = abc_loss<false>(p, Old[k], wp.l * (Real)Q); // (cpu_engine.h:225-229)
+         }
+         Out[k] = p;
+      }
+      // boundary nodes: the union of the lanes' node masks, one pencil cell per turn
+      uint32_t ub = 0;
+#pragma unroll
+      for (int k = 1; k < DP - 1; k++)
+         if (__ballot((pen.x >> k) & 1u) != 0ull) ub |= 1u << k;
+      while (ub) {
+         const int k = __ffs(ub) - 1;
+         ub &= ub - 1u;
+         const bool has = ((pen.x >> k) & 1u) != 0u;
+         const uint32_t rec = has ? wp.rec[pen.y + __popc(pen.x & ((1u << k) - 1u))] : 0u;
+         const Real cc = wall_sel<Real, DP>(Cur, k), nm = wall_sel<Real, DP>(Cur, k - 1), np_ = wall_sel<Real, DP>(Cur, k + 1);
+         const Real mp = wall_sel<Real, DP>(Nxt, k), mm = wall_sel<Real, DP>(Prv, k), old = wall_sel<Real, DP>(Old, k);
+         const Real lm = lane_from_lower<true>(cc), lp = lane_from_upper<true>(cc);
+         Real nb[6];
+         if (VEC) { nb[0] = mp; nb[1] = mm; nb[2] = lp; nb[3] = lm; nb[4] = np_; nb[5] = nm; }
+         else {
+            nb[0] = mode1 ? mp : np_; nb[1] = mode1 ? mm : nm; nb[2] = mode1 ? np_ : mp; nb[3] = mode1 ? nm : mm; nb[4] = lp; nb[5] = lm;
+         }
+         Real p = upd_rigid<false, 6>(a2, wp.sl2, rec & 63u, cc, old, nb); // (cpu_engine.h:234-257)
+         const bool owner = own_m && own_lane && k >= R.ko0 && k < R.ko1;
+         const bool fd = has && (rec & 64u) != 0u && (STAGE == 1 || owner);
+         if (__ballot(fd) != 0ull) {
+            if (fd) { // (cpu_engine.h:290-301, 363-405)
+               const int32_t li = (int32_t)(rec >> 8);
+               const Real u2 = STAGE == 1 ? wp.x2[li] : wp.x1[li];
+               p = fd_core<Real>(p, u2, li, STAGE == 1 ? wp.sv_in : wp.sv_out, STAGE == 1 ? wp.sg_in : wp.sg_out, wp.sv_out, wp.sg_out, owner, wp.ssaf,
+                                 wp.mat, wp.Mb, wp.mq, wp.beta, wp.lo2, wp.mmax);
+               if (owner) (STAGE == 1 ? wp.o1 : wp.o2)[li] = p;
+            }
+         }
+#pragma unroll
+         for (int i = 1; i < DP - 1; i++) Out[i] = (has && k == i) ? p : Out[i];
+      }
+      // ghost cells of the new field: mirror along the pencil, then along the lanes
+#pragma unroll
+      for (int k = 0; k < DP; k++)
+         if (k == R.kg) Out[k] = (k == 0) ? Out[2] : Out[k >= 2 ? k - 2 : 0];
+      if (STAGE == 1 && tile_lg) {
+#pragma unroll
+         for (int k = 0; k < DP; k++) {
+            const Real t = Out[k];
+            const Real up = __shfl(t, lane + 2, 64), dn = __shfl(t, lane - 2, 64);
+            Out[k] = lg_lo ? up : (lg_hi ? dn : t);
+         }
+      }
+   };
+
+   Real Bm[DP], Bc[DP], Bn[DP], Ac[DP], Vm[DP], Vc[DP], Vn[DP];
+   load_pencil(wp.B, ms - 2, Bm, true);
+   load_pencil(wp.B, ms - 1, Bc, true);
+   load_pencil(wp.B, ms, Bn, true);
+   load_pencil(wp.A, ms - 1, Ac, false);
+#pragma unroll
+   for (int k = 0; k < DP; k++) { Vm[k] = Real(0); Vc[k] = Real(0); Vn[k] = Real(0); }
+   uint2 pen_p = make_uint2(0u, 0u);
+   for (int m = ms - 1; m <= me; m++) {
+      // stage 1: u^{n+1}(m)
+      const uint2 pen_c = load_pen(m);
+      const bool own_m = m >= ms && m < me;
+      update(std::integral_constant<int, 1>(), m, Bm, Bc, Bn, Ac, pen_c, Vn, own_m);
+      if (own_m) store_pencil(wp.C, m, Vn);
+      // stage 2: u^{n+2}(m-1) from u^{n+1}(m-2 .. m); a ghost plane of the march axis is the plane two further in
+      if (m - 1 >= ms) {
+         Real W[DP];
+#pragma unroll
+         for (int k = 0; k < DP; k++) W[k] = Real(0);
+         const bool sub_hi = !mx && m == NM - 1 && mg_hi, sub_lo = !mx && m - 2 == 0 && mg_lo;
+         Real Pv[DP], Nv[DP];
+#pragma unroll
+         for (int k = 0; k < DP; k++) { Pv[k] = sub_lo ? Vn[k] : Vm[k]; Nv[k] = sub_hi ? Vm[k] : Vn[k]; }
+         update(std::integral_constant<int, 2>(), m - 1, Pv, Vc, Nv, Bm, pen_p, W, true);
+         store_pencil(wp.D, m - 1, W);
+      }
+#pragma unroll
+      for (int k = 0; k < DP; k++) { Vm[k] = Vc[k]; Vc[k] = Vn[k]; Bm[k] = Bc[k]; Bc[k] = Bn[k]; }
+      pen_p = pen_c;
+      if (m < me) {
+         load_pencil(wp.B, m + 2, Bn, true);
+         load_pencil(wp.A, m + 1, Ac, false);
+      }
+   }
+}
+
+} // namespace pf
