@@ -71,10 +71,16 @@ template <typename Real> struct WallParams {
    int32_t mmax;
 };
 
+// (each element passes through an empty asm: otherwise the compiler turns the chain of selects over array elements into ONE
+// load with a computed address, which keeps the whole pencil array in scratch memory -- 176 / 576 bytes per lane, 5x slower)
 template <typename Real, int N> __device__ __forceinline__ Real wall_sel(const Real (&a)[N], int k) { // k wave-uniform
    Real r = a[0];
 #pragma unroll
-   for (int i = 1; i < N; i++) r = (k == i) ? a[i] : r;
+   for (int i = 1; i < N; i++) {
+      Real t = a[i];
+      asm("" : "+v"(t));
+      r = (k == i) ? t : r;
+   }
    return r;
 }
 
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(64) void k_wall2(WallParams<Real> wp, Real a1, Real
    const bool eval_lane = lane >= 1 && lane <= 62 && lc <= R.l1;   // stage 1 is valid (and needed) here
    const int ms = R.m0 + c * R.mchunk, me = min(ms + R.mchunk, R.m1);
    if (ms >= me) return;
-   auto msrc = [&](int m) {
+   auto msrc = [&](int m) __attribute__((always_inline)) {
       m = min(max(m, 0), NM - 1);
       if (m == 0 && mg_lo) return 2;
       if (m == NM - 1 && mg_hi) return NM - 3;
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(64) void k_wall2(WallParams<Real> wp, Real a1, Real
    const int64_t lbase = (int64_t)lsrc * sl + (int64_t)R.nbase * sn;
    const int ql = (lc == 1 || lc == NL - 2) ? 1 : 0;
 
-   auto load_pencil = [&](const Real *G, int m, Real(&b)[DP], bool mirror) {
+   auto load_pencil = [&](const Real *G, int m, Real(&b)[DP], bool mirror) __attribute__((always_inline)) {
       const Real *pl = G + (int64_t)msrc(m) * sm + lbase;
       if constexpr (VEC) {
 #pragma unroll
@@ -143,12 +149,12 @@ __global__ __launch_bounds__(64) void k_wall2(WallParams<Real> wp, Real a1, Real
             if (k == R.kg) b[k] = (k == 0) ? b[2] : b[k >= 2 ? k - 2 : 0];
       }
    };
-   auto load_pen = [&](int m) {
+   auto load_pen = [&](int m) __attribute__((always_inline)) {
       uint2 p = wp.pen[R.pen_off + (int64_t)(m - (R.m0 - 1)) * R.nlp + (WALL_LT * j + lane)];
       if (!eval_lane) p.x = 0u;
       return p;
    };
-   auto store_pencil = [&](Real *G, int m, const Real(&v)[DP]) {
+   auto store_pencil = [&](Real *G, int m, const Real(&v)[DP]) __attribute__((always_inline)) {
       if (!own_lane) return;
       Real *pl = G + (int64_t)m * sm + (int64_t)lc * sl + (int64_t)R.nbase * sn;
       if constexpr (VEC) {
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(64) void k_wall2(WallParams<Real> wp, Real a1, Real
    // Old = the value two steps back).  STAGE 1: u^n -> u^{n+1} (halo cells included, their nodes read-only); STAGE 2: owned
    // cells only.
    auto update = [&](auto stage, int m, const Real(&Prv)[DP], const Real(&Cur)[DP], const Real(&Nxt)[DP], const Real(&Old)[DP], const uint2 pen,
-                     Real(&Out)[DP], bool own_m) {
+                     Real(&Out)[DP], bool own_m) __attribute__((always_inline)) {
       constexpr int STAGE = decltype(stage)::value;
       const int qm = mx ? (((wp.first && m == 1) || (wp.last && m == wp.Nx - 2)) ? 1 : 0) : ((m == 1 || m == wp.Ny - 2) ? 1 : 0);
 #pragma unroll
