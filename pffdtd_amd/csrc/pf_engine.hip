@@ -245,7 +245,7 @@ template <typename Real> struct Engine : EngineBase {
    pf::WallRegion wl_sreg[4], wl_vreg[2];                 // regions normal to x / y (lanes along z), normal to z (lanes along y)
    int wl_nsreg = 0, wl_nvreg = 0, wl_dpv = 0;            // wl_dpv: cells per pencil of the regions normal to z (12 | 20)
    uint32_t wl_sblocks = 0, wl_vblocks = 0;
-   uint2 *wl_pen = nullptr;                               // per pencil: node mask, first record
+   uint4 *wl_pen = nullptr;                               // per pencil: node mask, first record, adjacency / flags of the first five nodes (pf_wall.h)
    uint32_t *wl_rec = nullptr;                            // per node of a pencil: adjacency bits | lossy flag | lossy position
    int32_t *wl_rest = nullptr;                            // boundary nodes no wall region owns (inside the box): the list kernel's
    int64_t wl_nrest = 0;
@@ -984,7 +984,7 @@ template <typename Real> struct Engine : EngineBase {
       for (int64_t j = 0; j < Nbl; j++) newli[keys[j].li] = (int32_t)j;
       // pencil tables: node masks, then the records in pencil order (the boundary list is sorted by cell, so a pencil's
       // nodes arrive in ascending pencil-cell order)
-      std::vector<uint2> pen((size_t)npen, make_uint2(0u, 0u));
+      std::vector<uint4> pen((size_t)npen, make_uint4(0u, 0u, 0u, 0u));
       auto visit = [&](auto &&fn) {
          for (int64_t nb = 0; nb < Nb; nb++) {
             const int64_t ix = hb[nb] / plane, rem = hb[nb] % plane, iy = rem / P, iz = rem % P;
@@ -1000,12 +1000,20 @@ template <typename Real> struct Engine : EngineBase {
       visit([&](int64_t, int64_t pi, int k) { pen[(size_t)pi].x |= 1u << k; });
       int64_t nrec = 0;
       for (int64_t i = 0; i < npen; i++) { pen[(size_t)i].y = (uint32_t)nrec; nrec += __builtin_popcount(pen[(size_t)i].x); }
-      if (nrec >= ((int64_t)1 << 32)) return PF_OK;
+      if (nrec >= ((int64_t)1 << 27)) return PF_OK;
       std::vector<uint32_t> rec((size_t)std::max<int64_t>(nrec, 1), 0u);
       visit([&](int64_t nb, int64_t pi, int k) {
-         const uint2 e = pen[(size_t)pi];
-         const uint32_t slot = e.y + (uint32_t)__builtin_popcount(e.x & ((1u << k) - 1u));
-         rec[slot] = (uint32_t)(hadj[nb] & 63u) | (hl[nb] >= 0 ? (0x40u | ((uint32_t)newli[hl[nb]] << 8)) : 0u);
+         uint4 &e = pen[(size_t)pi];
+         const uint32_t jn = (uint32_t)__builtin_popcount(e.x & ((1u << k) - 1u));
+         const uint32_t adj = (uint32_t)(hadj[nb] & 63u);
+         rec[(e.y & 0x7ffffffu) + jn] = adj | (hl[nb] >= 0 ? (0x40u | ((uint32_t)newli[hl[nb]] << 8)) : 0u);
+         if (jn < 5) { // the entry itself carries the first five nodes: adjacency bits, lossy flags, the first lossy one's place
+            e.z |= adj << (6 * jn);
+            if (hl[nb] >= 0) {
+               if ((e.w & 31u) == 0u) { e.w |= (uint32_t)newli[hl[nb]] << 8; e.y |= (uint32_t)k << 27; }
+               e.w |= 1u << jn;
+            }
+         }
       });
       int rc;
       if ((rc = upload(&wl_pen, pen.data(), npen))) return rc;

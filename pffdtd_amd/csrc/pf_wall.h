@@ -15,18 +15,24 @@
 //     generic: air (+ ABC loss by its coordinates), ghost (mirrored in registers: normal axis; by a wave shuffle: lane axis;
 //     by taking the other march plane: march axis), rigid boundary node, frequency-dependent boundary node.  Lane-axis
 //     neighbours come from the DPP wave shifts, so lanes 0 / 63 are halo (stage 1 invalid), lanes 1 / 62 are stage-1-only.
-//   * nodes: per pencil a 32-bit mask of its node cells and the index of their records (adjacency bits, position in the
-//     frequency-dependent arrays).  The wave walks the union of its lanes' masks (box rooms: two turns, one for the rigid
-//     layer, one for the lossy layer, every lane busy), so the branch ODEs run dense.
+//   * nodes: per pencil a 16-byte entry -- a mask of its node cells, the adjacency bits and frequency-dependent flags of its
+//     first five nodes, the position of its first frequency-dependent node in the lossy arrays -- plus a record list for
+//     whatever does not fit (edges, corners).  The wave walks the union of its lanes' masks (box rooms: two turns, one for
+//     the rigid layer, one for the lossy layer, every lane busy), so the branch ODEs run dense.
+//   * software pipeline: the loads of march step m+1 (u^n, u^{n-1}, the entry of m+2, the branch state of the first
+//     frequency-dependent node of pencil m+1) are issued at the top of step m -- a wave's march is a chain of dependent
+//     steps and only two or three waves fit a SIMD, so nothing else hides the latency (first version, everything loaded
+//     where it was needed: 9 dependent round trips per step, 5x slower).  That node's state stays in registers between its
+//     stage 1 (step m) and its stage 2 (step m+1) and is stored once.
 //   * everything a region needs beyond its own cells (one cell of halo in every direction, incl. the branch state of the
 //     nodes there) is RECOMPUTED from u^n / u^{n-1}, never read from the grids being written: the regions are independent
 //     of each other, of the box kernel and of the launch order.  For that the branch state is double-buffered (read
 //     sv_in / sg_in, write sv_out / sg_out; the engine swaps after the pair) and the node values of the two steps go to
 //     buffers nobody reads during the pair (o1, o2; x2 = u^{n-1} of the nodes is only read).
-//   * the owner's stage 2 reads the state its own stage 1 stored one march step earlier (same lane, same address: L2).
 //
-// Arithmetic: upd7 / upd_rigid / abc_loss / fd_core of pf_kernels.h, neighbours in FILE order whatever the pencil's
-// orientation -- bit-identical to the single-step kernels and to cpu_engine.h:175-194,225-229,234-257,290-301,363-405.
+// Arithmetic: upd7 / upd_rigid / abc_loss of pf_kernels.h and the branch ODEs in fd_core's order, neighbours in FILE order
+// whatever the pencil's orientation -- bit-identical to the single-step kernels and to
+// cpu_engine.h:175-194,225-229,234-257,290-301,363-405.
 #pragma once
 #include <type_traits>
 #include "pf_kernels.h"
@@ -50,6 +56,10 @@ struct WallRegion {
    int64_t pen_off;     // the region's pencil table: entry (m - (m0-1)) * nlp + (lc - (l0-2))
 };
 
+// pencil entry: .x bit k = pencil cell k is a boundary node; .y = index of its first record | pencil cell of its first
+// frequency-dependent node << 27; .z = adjacency bits of its first five nodes (6 each); .w = frequency-dependent flags of
+// those five | position of the first frequency-dependent one in the lossy arrays << 8
+// record (all nodes of a pencil, in pencil order): adjacency bits | 0x40 frequency-dependent | position in the lossy arrays << 8
 template <typename Real> struct WallParams {
    const Real *A, *B;       // u^{n-1}, u^n
    Real *C, *D;             // u^{n+1}, u^{n+2}
@@ -57,8 +67,8 @@ template <typename Real> struct WallParams {
    int32_t Nx, Ny, Nz, P, first, last;
    int32_t nreg;
    WallRegion reg[WALL_MAXREG];
-   const uint2 *pen;        // per pencil: .x bit k = pencil cell k is a boundary node, .y = index of its first record
-   const uint32_t *rec;     // per node: adjacency bits (6) | 0x40 frequency-dependent | position in the lossy arrays << 8
+   const uint4 *pen;
+   const uint32_t *rec;
    const Real *sv_in, *sg_in;
    Real *sv_out, *sg_out;   // branch state vh1 / gh1 before and after the pair (64-node blocks, st_idx)
    const Real *x2, *x1;     // node values u^{n-1} (step 1) and u^n (step 2): the u2b of cpu_engine.h:290-301
@@ -82,6 +92,38 @@ template <typename Real, int N> __device__ __forceinline__ Real wall_sel(const R
       r = (k == i) ? t : r;
    }
    return r;
+}
+
+// The branch ODEs of one node with its state in registers (fd_core's arithmetic, cpu_engine.h:363-405).  UNI: every active
+// lane has the same material -- the coefficients are then scalar loads.
+template <typename Real, bool UNI>
+__device__ __forceinline__ Real fd_regs(Real p, Real u2, Real sf, int32_t k, Real (&v1)[12], Real (&g1)[12], const MatQuadT<Real> *__restrict__ mq,
+                                        const Real *__restrict__ beta, const int8_t *__restrict__ Mb, Real lo2) {
+   const int32_t kk = UNI ? __builtin_amdgcn_readfirstlane(k) : k;
+   const int M = Mb[kk];
+   const Real two = 2.0, one = 1.0;
+   const Real g = lo2 * sf * beta[kk];
+   const Real fac = two * lo2 * sf / (one + g);
+   Real u = p;
+   u = (u + g * u2) / (one + g);
+#pragma unroll
+   for (int m = 0; m < 12; m++) {
+      if (m < M) {
+         const MatQuadT<Real> q = mq[kk * 12 + m];
+         u -= fac * (two * q.bDh * v1[m] - q.bFh * g1[m]);
+      }
+   }
+   const Real du = u - u2;
+#pragma unroll
+   for (int m = 0; m < 12; m++) {
+      if (m < M) {
+         const MatQuadT<Real> q = mq[kk * 12 + m];
+         const Real v0 = q.b * du + q.bd * v1[m] - two * q.bFh * g1[m];
+         g1[m] = g1[m] + (v0 + v1[m]) / two;
+         v1[m] = v0;
+      }
+   }
+   return u;
 }
 
 template <typename Real, int DP, bool VEC>
@@ -149,10 +191,11 @@ __global__ __launch_bounds__(64) void k_wall2(WallParams<Real> wp, Real a1, Real
             if (k == R.kg) b[k] = (k == 0) ? b[2] : b[k >= 2 ? k - 2 : 0];
       }
    };
-   auto load_pen = [&](int m) __attribute__((always_inline)) {
-      uint2 p = wp.pen[R.pen_off + (int64_t)(m - (R.m0 - 1)) * R.nlp + (WALL_LT * j + lane)];
-      if (!eval_lane) p.x = 0u;
-      return p;
+   auto load_ent = [&](int m) __attribute__((always_inline)) { // march steps R.m0-1 .. R.m1 have entries
+      uint4 e = make_uint4(0u, 0u, 0u, 0u);
+      if (m <= R.m1) e = wp.pen[R.pen_off + (int64_t)(m - (R.m0 - 1)) * R.nlp + (WALL_LT * j + lane)];
+      if (!eval_lane) { e.x = 0u; e.w = 0u; }
+      return e;
    };
    auto store_pencil = [&](Real *G, int m, const Real(&v)[DP]) __attribute__((always_inline)) {
       if (!own_lane) return;
@@ -173,12 +216,25 @@ __global__ __launch_bounds__(64) void k_wall2(WallParams<Real> wp, Real a1, Real
             if (k >= R.ko0 && k < R.ko1) pl[(int64_t)k * sn] = v[k];
       }
    };
+   // the branch state and parameters of a pencil's first frequency-dependent node, ahead of its stage 1
+   auto fd_fetch = [&](const uint4 E, Real(&v)[12], Real(&g)[12], Real &sf, Real &u2, Real &x1v, int32_t &k) __attribute__((always_inline)) {
+      if ((E.w & 31u) != 0u) {
+         const int32_t li = (int32_t)(E.w >> 8);
+#pragma unroll
+         for (int m = 0; m < 12; m++)
+            if (m < wp.mmax) { v[m] = wp.sv_in[st_idx(m, li)]; g[m] = wp.sg_in[st_idx(m, li)]; }
+         sf = wp.ssaf[li];
+         k = wp.mat[li];
+         u2 = wp.x2[li];
+         x1v = wp.x1[li];
+      }
+   };
 
    // One update of the pencil cells 1 .. DP-2 at march coordinate m: Out = f(Cur; Prv, Nxt = the march planes before / after;
    // Old = the value two steps back).  STAGE 1: u^n -> u^{n+1} (halo cells included, their nodes read-only); STAGE 2: owned
-   // cells only.
-   auto update = [&](auto stage, int m, const Real(&Prv)[DP], const Real(&Cur)[DP], const Real(&Nxt)[DP], const Real(&Old)[DP], const uint2 pen,
-                     Real(&Out)[DP], bool own_m) __attribute__((always_inline)) {
+   // cells only.  Fv / Fg / Fsf / Fu2 / Fk: state (updated in place) and parameters of the pencil's first frequency-dependent node.
+   auto update = [&](auto stage, int m, const Real(&Prv)[DP], const Real(&Cur)[DP], const Real(&Nxt)[DP], const Real(&Old)[DP], const uint4 E,
+                     Real(&Out)[DP], bool own_m, Real(&Fv)[12], Real(&Fg)[12], Real Fsf, Real Fu2, int32_t Fk) __attribute__((always_inline)) {
       constexpr int STAGE = decltype(stage)::value;
       const int qm = mx ? (((wp.first && m == 1) || (wp.last && m == wp.Nx - 2)) ? 1 : 0) : ((m == 1 || m == wp.Ny - 2) ? 1 : 0);
 #pragma unroll
@@ -204,12 +260,22 @@ __global__ __launch_bounds__(64) void k_wall2(WallParams<Real> wp, Real a1, Real
       uint32_t ub = 0;
 #pragma unroll
       for (int k = 1; k < DP - 1; k++)
-         if (__ballot((pen.x >> k) & 1u) != 0ull) ub |= 1u << k;
+         if (__ballot((E.x >> k) & 1u) != 0ull) ub |= 1u << k;
+      const int k0 = (int)(E.y >> 27);                             // pencil cell of the first frequency-dependent node
       while (ub) {
          const int k = __ffs(ub) - 1;
          ub &= ub - 1u;
-         const bool has = ((pen.x >> k) & 1u) != 0u;
-         const uint32_t rec = has ? wp.rec[pen.y + __popc(pen.x & ((1u << k) - 1u))] : 0u;
+         const bool has = ((E.x >> k) & 1u) != 0u;
+         const int jn = __popc(E.x & ((1u << k) - 1u));            // which node of the pencil
+         const bool inl = jn < 5;
+         const bool lossy_inl = inl && ((E.w >> jn) & 1u) != 0u;
+         const bool prim = has && lossy_inl && k == k0;            // the one whose state is in registers
+         const bool need_rec = has && (!inl || (lossy_inl && !prim));
+         uint32_t rec = 0u;
+         if (__ballot(need_rec) != 0ull) {
+            if (need_rec) rec = wp.rec[(E.y & 0x7ffffffu) + (uint32_t)jn];
+         }
+         const uint32_t adj = inl ? ((E.z >> (6 * jn)) & 63u) : (rec & 63u);
          const Real cc = wall_sel<Real, DP>(Cur, k), nm = wall_sel<Real, DP>(Cur, k - 1), np_ = wall_sel<Real, DP>(Cur, k + 1);
          const Real mp = wall_sel<Real, DP>(Nxt, k), mm = wall_sel<Real, DP>(Prv, k), old = wall_sel<Real, DP>(Old, k);
          const Real lm = lane_from_lower<true>(cc), lp = lane_from_upper<true>(cc);
@@ -218,11 +284,30 @@ __global__ __launch_bounds__(64) void k_wall2(WallParams<Real> wp, Real a1, Real
          else {
             nb[0] = mode1 ? mp : np_; nb[1] = mode1 ? mm : nm; nb[2] = mode1 ? np_ : mp; nb[3] = mode1 ? nm : mm; nb[4] = lp; nb[5] = lm;
          }
-         Real p = upd_rigid<false, 6>(a2, wp.sl2, rec & 63u, cc, old, nb); // (cpu_engine.h:234-257)
+         Real p = upd_rigid<false, 6>(a2, wp.sl2, adj, cc, old, nb); // (cpu_engine.h:234-257)
          const bool owner = own_m && own_lane && k >= R.ko0 && k < R.ko1;
-         const bool fd = has && (rec & 64u) != 0u && (STAGE == 1 || owner);
-         if (__ballot(fd) != 0ull) {
-            if (fd) { // (cpu_engine.h:290-301, 363-405)
+         // (cpu_engine.h:290-301, 363-405) the pencil's first frequency-dependent node: state in registers
+         const bool fdp = prim && (STAGE == 1 || owner);
+         if (__ballot(fdp) != 0ull) {
+            if (fdp) {
+               const int32_t ku = __builtin_amdgcn_readfirstlane(Fk);
+               if (__ballot(Fk != ku) == 0ull) p = fd_regs<Real, true>(p, Fu2, Fsf, Fk, Fv, Fg, wp.mq, wp.beta, wp.Mb, wp.lo2);
+               else p = fd_regs<Real, false>(p, Fu2, Fsf, Fk, Fv, Fg, wp.mq, wp.beta, wp.Mb, wp.lo2);
+               if (owner) {
+                  const int32_t li = (int32_t)(E.w >> 8);
+                  (STAGE == 1 ? wp.o1 : wp.o2)[li] = p;
+                  if (STAGE == 2) {
+#pragma unroll
+                     for (int q = 0; q < 12; q++)
+                        if (q < wp.mmax) { wp.sv_out[st_idx(q, li)] = Fv[q]; wp.sg_out[st_idx(q, li)] = Fg[q]; }
+                  }
+               }
+            }
+         }
+         // any further frequency-dependent node of the pencil (edges, corners): through memory
+         const bool fds = has && !prim && (inl ? lossy_inl : (rec & 64u) != 0u) && (STAGE == 1 || owner);
+         if (__ballot(fds) != 0ull) {
+            if (fds) {
                const int32_t li = (int32_t)(rec >> 8);
                const Real u2 = STAGE == 1 ? wp.x2[li] : wp.x1[li];
                p = fd_core<Real>(p, u2, li, STAGE == 1 ? wp.sv_in : wp.sv_out, STAGE == 1 ? wp.sg_in : wp.sg_out, wp.sv_out, wp.sg_out, owner, wp.ssaf,
@@ -247,19 +332,31 @@ __global__ __launch_bounds__(64) void k_wall2(WallParams<Real> wp, Real a1, Real
       }
    };
 
-   Real Bm[DP], Bc[DP], Bn[DP], Ac[DP], Vm[DP], Vc[DP], Vn[DP];
+   Real Bm[DP], Bc[DP], Bn[DP], Bq[DP], Ac[DP], Aq[DP], Vm[DP], Vc[DP], Vn[DP];
+   Real F1v[12], F1g[12], Fqv[12], Fqg[12], F2v[12], F2g[12];
+   Real F1sf = 0, F1u2 = 0, F1x1 = 0, Fqsf = 0, Fqu2 = 0, Fqx1 = 0, F2sf = 0, F2u2 = 0;
+   int32_t F1k = 0, Fqk = 0, F2k = 0;
+#pragma unroll
+   for (int q = 0; q < 12; q++) { F1v[q] = F1g[q] = Fqv[q] = Fqg[q] = F2v[q] = F2g[q] = Real(0); }
+   uint4 Ep = make_uint4(0u, 0u, 0u, 0u), Ec = load_ent(ms - 1), En = load_ent(ms), Eq;
    load_pencil(wp.B, ms - 2, Bm, true);
    load_pencil(wp.B, ms - 1, Bc, true);
    load_pencil(wp.B, ms, Bn, true);
    load_pencil(wp.A, ms - 1, Ac, false);
+   fd_fetch(Ec, F1v, F1g, F1sf, F1u2, F1x1, F1k);
 #pragma unroll
-   for (int k = 0; k < DP; k++) { Vm[k] = Real(0); Vc[k] = Real(0); Vn[k] = Real(0); }
-   uint2 pen_p = make_uint2(0u, 0u);
+   for (int k = 0; k < DP; k++) { Vm[k] = Real(0); Vc[k] = Real(0); Vn[k] = Real(0); Bq[k] = Real(0); Aq[k] = Real(0); }
    for (int m = ms - 1; m <= me; m++) {
+      // everything march step m+1 needs goes on its way now
+      Eq = load_ent(m + 2);
+      if (m < me) {
+         load_pencil(wp.B, m + 2, Bq, true);
+         load_pencil(wp.A, m + 1, Aq, false);
+         fd_fetch(En, Fqv, Fqg, Fqsf, Fqu2, Fqx1, Fqk);
+      }
       // stage 1: u^{n+1}(m)
-      const uint2 pen_c = load_pen(m);
       const bool own_m = m >= ms && m < me;
-      update(std::integral_constant<int, 1>(), m, Bm, Bc, Bn, Ac, pen_c, Vn, own_m);
+      update(std::integral_constant<int, 1>(), m, Bm, Bc, Bn, Ac, Ec, Vn, own_m, F1v, F1g, F1sf, F1u2, F1k);
       if (own_m) store_pencil(wp.C, m, Vn);
       // stage 2: u^{n+2}(m-1) from u^{n+1}(m-2 .. m); a ghost plane of the march axis is the plane two further in
       if (m - 1 >= ms) {
@@ -270,16 +367,16 @@ __global__ __launch_bounds__(64) void k_wall2(WallParams<Real> wp, Real a1, Real
          Real Pv[DP], Nv[DP];
 #pragma unroll
          for (int k = 0; k < DP; k++) { Pv[k] = sub_lo ? Vn[k] : Vm[k]; Nv[k] = sub_hi ? Vm[k] : Vn[k]; }
-         update(std::integral_constant<int, 2>(), m - 1, Pv, Vc, Nv, Bm, pen_p, W, true);
+         update(std::integral_constant<int, 2>(), m - 1, Pv, Vc, Nv, Bm, Ep, W, true, F2v, F2g, F2sf, F2u2, F2k);
          store_pencil(wp.D, m - 1, W);
       }
 #pragma unroll
-      for (int k = 0; k < DP; k++) { Vm[k] = Vc[k]; Vc[k] = Vn[k]; Bm[k] = Bc[k]; Bc[k] = Bn[k]; }
-      pen_p = pen_c;
-      if (m < me) {
-         load_pencil(wp.B, m + 2, Bn, true);
-         load_pencil(wp.A, m + 1, Ac, false);
-      }
+      for (int k = 0; k < DP; k++) { Vm[k] = Vc[k]; Vc[k] = Vn[k]; Bm[k] = Bc[k]; Bc[k] = Bn[k]; Bn[k] = Bq[k]; Ac[k] = Aq[k]; }
+#pragma unroll
+      for (int q = 0; q < 12; q++) { F2v[q] = F1v[q]; F2g[q] = F1g[q]; F1v[q] = Fqv[q]; F1g[q] = Fqg[q]; }
+      F2sf = F1sf; F2u2 = F1x1; F2k = F1k;
+      F1sf = Fqsf; F1u2 = Fqu2; F1x1 = Fqx1; F1k = Fqk;
+      Ep = Ec; Ec = En; En = Eq;
    }
 }
 
