@@ -244,7 +244,8 @@ template <typename Real> struct Engine : EngineBase {
    bool wl_on = false;
    pf::WallRegion wl_sreg[4], wl_vreg[2];                 // regions normal to x / y (lanes along z), normal to z (lanes along y)
    int wl_nsreg = 0, wl_nvreg = 0, wl_dpv = 0;            // wl_dpv: cells per pencil of the regions normal to z (12 | 20)
-   uint32_t wl_sblocks = 0, wl_vblocks = 0;
+   uint4 *wl_blk = nullptr;                               // block lists of the four launches: strided / vector pencils x alike (fast) / generic
+   uint32_t wl_nblk[4] = {0, 0, 0, 0}, wl_blk0[4] = {0, 0, 0, 0};
    uint4 *wl_pen = nullptr;                               // per pencil: node mask, first record, adjacency / flags of the first five nodes (pf_wall.h)
    uint32_t *wl_rec = nullptr;                            // per node of a pencil: adjacency bits | lossy flag | lossy position
    int32_t *wl_rest = nullptr;                            // boundary nodes no wall region owns (inside the box): the list kernel's
@@ -268,7 +269,7 @@ template <typename Real> struct Engine : EngineBase {
       auto F = [](void *p) { if (p) hipFree(p); };
       for (Real *g : own_list) F(g); // state grids this engine allocated (u0/u1 unless external, the temporal-blocking spares)
       own_list.clear();
-      F(wl_pen); F(wl_rec); F(wl_rest); F(vh1b); F(gh1b); F(d_lossy); F(mask); F(zs_map); F(zs_adj); F(zs_li); F(zs_rest); F(zs_fd); F(tb_clean); F(tb_dirty); F(tb_sample); F(sh_tiles); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
+      F(wl_pen); F(wl_rec); F(wl_rest); F(wl_blk); F(vh1b); F(gh1b); F(d_lossy); F(mask); F(zs_map); F(zs_adj); F(zs_li); F(zs_rest); F(zs_fd); F(tb_clean); F(tb_dirty); F(tb_sample); F(sh_tiles); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
       F(d_beta); F(d_insig); F(d_mq); F(ub[0]); F(ub[1]); F(ub[2]); F(u2ba); F(vh1); F(gh1); F(ring);
       if (h_ring) hipHostFree(h_ring);
       for (auto &p : air_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -893,7 +894,7 @@ template <typename Real> struct Engine : EngineBase {
    // cell), so that a wave's branch-state accesses are contiguous; the nodes inside the box follow in list order.
    void free_walls() {
       auto F = [](auto *&p) { if (p) hipFree((void *)p); p = nullptr; };
-      F(wl_pen); F(wl_rec); F(wl_rest); F(vh1b); F(gh1b);
+      F(wl_pen); F(wl_rec); F(wl_rest); F(wl_blk); F(vh1b); F(gh1b);
       wl_on = false; wl_nsreg = wl_nvreg = 0;
    }
    int init_walls() {
@@ -1038,21 +1039,52 @@ template <typename Real> struct Engine : EngineBase {
       if ((rc = dzalloc(&vh1b, round_up(Nbl, 64) * PF_MMB))) return rc;
       if ((rc = dzalloc(&gh1b, round_up(Nbl, 64) * PF_MMB))) return rc;
       wl_nsreg = 4; wl_nvreg = 2; wl_dpv = dpv;
-      uint32_t b0 = 0;
-      for (int i = 0; i < 4; i++) { reg[i].blk0 = b0; b0 += (uint32_t)reg[i].nlt * (uint32_t)cdiv(reg[i].m1 - reg[i].m0, reg[i].mchunk); wl_sreg[i] = reg[i]; }
-      wl_sblocks = b0;
-      b0 = 0;
-      for (int i = 4; i < 6; i++) { reg[i].blk0 = b0; b0 += (uint32_t)reg[i].nlt * (uint32_t)cdiv(reg[i].m1 - reg[i].m0, reg[i].mchunk); wl_vreg[i - 4] = reg[i]; }
-      wl_vblocks = b0;
+      for (int i = 0; i < 4; i++) wl_sreg[i] = reg[i];
+      for (int i = 4; i < 6; i++) wl_vreg[i - 4] = reg[i];
+      // Block lists.  A block (lane tile x march chunk of a region) whose pencils all have the same structure and that touches no
+      // ghost / ABC cell along its lane and march axes goes to the FAST launch with that structure attached; the others
+      // (edges, corners, the ends of a march) to the generic one.
+      std::vector<uint4> lists[4]; // 0 strided fast, 1 strided generic, 2 vector fast, 3 vector generic
+      int64_t nfast = 0, ngen = 0;
+      for (int i = 0; i < 6; i++) {
+         const pf::WallRegion &R = reg[i];
+         const int NL = R.mode == 2 ? (int)Ny : (int)Nz, NM = R.mode == 0 ? (int)Ny : (int)Nx;
+         const int nmc = (int)cdiv(R.m1 - R.m0, R.mchunk);
+         for (int c = 0; c < nmc; c++)
+            for (int jt = 0; jt < R.nlt; jt++) {
+               const int ms = R.m0 + c * R.mchunk, me = std::min(ms + R.mchunk, R.m1);
+               const int lc0 = R.l0 - 1 + pf::WALL_LT * jt, lc1 = std::min(R.l0 + pf::WALL_LT * jt + pf::WALL_LT, R.l1); // lanes 1 .. 62 within the region
+               bool fast = lc0 >= 2 && lc1 <= NL - 3 && ms - 1 >= 2 && me <= NM - 3 && !(op.debug & 0x8000000);
+               const uint4 ref = pen[(size_t)(R.pen_off + (int64_t)(ms - 1 - (R.m0 - 1)) * R.nlp + (lc0 - (R.l0 - 2)))];
+               if (__builtin_popcount(ref.x) > 5 || __builtin_popcount(ref.w & 31u) > 1) fast = false;
+               for (int m = ms - 1; m <= me && fast; m++) {
+                  const uint4 *row = pen.data() + (size_t)(R.pen_off + (int64_t)(m - (R.m0 - 1)) * R.nlp - (R.l0 - 2));
+                  for (int lc = lc0; lc <= lc1; lc++) {
+                     const uint4 &e = row[lc];
+                     if (e.x != ref.x || e.z != ref.z || (e.w & 31u) != (ref.w & 31u) || (e.y >> 27) != (ref.y >> 27)) { fast = false; break; }
+                  }
+               }
+               const uint32_t rl = (uint32_t)(i < 4 ? i : i - 4);
+               const uint4 b = make_uint4(rl | ((uint32_t)jt << 3) | ((uint32_t)c << 16), ref.x, ref.z, (ref.w & 31u) | ((ref.y >> 27) << 8));
+               lists[(i < 4 ? 0 : 2) + (fast ? 0 : 1)].push_back(b);
+               (fast ? nfast : ngen)++;
+            }
+      }
+      {
+         std::vector<uint4> all;
+         for (int q = 0; q < 4; q++) { wl_blk0[q] = (uint32_t)all.size(); wl_nblk[q] = (uint32_t)lists[q].size(); all.insert(all.end(), lists[q].begin(), lists[q].end()); }
+         if ((rc = upload(&wl_blk, all.data(), (int64_t)all.size()))) return rc;
+      }
       wl_on = true;
       if (getenv("PFFDTD_VERBOSE") && atoi(getenv("PFFDTD_VERBOSE")) > 0)
-         fprintf(stderr, "pffdtd_hip: wall regions: box x [%d,%d) y [%d,%d) z [%d,%d), %ld pencils, %ld node records, %ld of %ld boundary nodes left to the list kernel, column pencils of %d cells from column %d\n",
-                 tbx0, tbx1, tby0, tby1, tbz0, tbz1, (long)npen, (long)nrec, (long)wl_nrest, (long)Nb, dpv, zb);
+         fprintf(stderr, "pffdtd_hip: wall regions: box x [%d,%d) y [%d,%d) z [%d,%d), %ld pencils, %ld node records, %ld of %ld boundary nodes left to the list kernel, column pencils of %d cells from column %d; %ld blocks alike, %ld generic\n",
+                 tbx0, tbx1, tby0, tby1, tbz0, tbz1, (long)npen, (long)nrec, (long)wl_nrest, (long)Nb, dpv, zb, (long)nfast, (long)ngen);
       return PF_OK;
    }
    // both steps of the wall regions: A = u^{n-1}, B = u^n -> C = u^{n+1}, D = u^{n+2}; branch state vh1 / gh1 -> vh1b / gh1b;
    // node values: P2 = u^{n-1} and P1 = u^n are read, P0 <- u^{n+1}, P1 <- u^{n+2}
-   void launch_walls(hipStream_t s, const Real *A, const Real *B, Real *C, Real *D, Real *P0, Real *P1, const Real *P2) {
+   // (sg: the stream of the generic blocks -- edges, corners: few waves, each a long chain of dependent steps)
+   void launch_walls(hipStream_t s, hipStream_t sg, const Real *A, const Real *B, Real *C, Real *D, Real *P0, Real *P1, const Real *P2) {
       pf::WallParams<Real> wp{};
       wp.A = A; wp.B = B; wp.C = C; wp.D = D;
       wp.plane = plane; wp.Nx = (int)Nx; wp.Ny = (int)Ny; wp.Nz = (int)Nz; wp.P = (int)P; wp.first = op.slab_first; wp.last = op.slab_last;
@@ -1060,17 +1092,24 @@ template <typename Real> struct Engine : EngineBase {
       wp.sv_in = vh1; wp.sg_in = gh1; wp.sv_out = vh1b; wp.sg_out = gh1b;
       wp.x2 = P2; wp.x1 = P1; wp.o1 = P0; wp.o2 = P1;
       wp.ssaf = d_ssaf; wp.mat = d_mat; wp.Mb = d_Mb; wp.mq = d_mq; wp.beta = d_beta;
-      wp.lo2 = lo2; wp.sl2 = sl2; wp.l = l; wp.mmax = mb_max;
-      if (wl_nsreg > 0 && wl_sblocks > 0) {
-         wp.nreg = wl_nsreg;
-         for (int i = 0; i < wl_nsreg; i++) wp.reg[i] = wl_sreg[i];
-         hipLaunchKernelGGL((pf::k_wall2<Real, 8, false>), dim3(wl_sblocks), dim3(64), 0, s, wp, a1, a2);
-      }
-      if (wl_nvreg > 0 && wl_vblocks > 0) {
-         wp.nreg = wl_nvreg;
-         for (int i = 0; i < wl_nvreg; i++) wp.reg[i] = wl_vreg[i];
-         if (wl_dpv == 12) hipLaunchKernelGGL((pf::k_wall2<Real, 12, true>), dim3(wl_vblocks), dim3(64), 0, s, wp, a1, a2);
-         else if constexpr (sizeof(Real) == 4) hipLaunchKernelGGL((pf::k_wall2<Real, 20, true>), dim3(wl_vblocks), dim3(64), 0, s, wp, a1, a2);
+      wp.lo2 = lo2; wp.sl2 = sl2; wp.l = l; wp.mmax = mb_max; wp.nmat = sd.Nm;
+      wp.nreg = wl_nsreg;
+      for (int i = 0; i < wl_nsreg; i++) wp.reg[i] = wl_sreg[i];
+      if (wl_nblk[0]) { wp.blk = wl_blk + wl_blk0[0]; hipLaunchKernelGGL((pf::k_wall2<Real, 8, false, true>), dim3(wl_nblk[0]), dim3(64), 0, s, wp, a1, a2); }
+      if (wl_nblk[1]) { wp.blk = wl_blk + wl_blk0[1]; hipLaunchKernelGGL((pf::k_wall2<Real, 8, false, false>), dim3(wl_nblk[1]), dim3(64), 0, sg, wp, a1, a2); }
+      wp.nreg = wl_nvreg;
+      for (int i = 0; i < wl_nvreg; i++) wp.reg[i] = wl_vreg[i];
+      for (int q = 2; q < 4; q++) {
+         if (!wl_nblk[q]) continue;
+         wp.blk = wl_blk + wl_blk0[q];
+         const dim3 g(wl_nblk[q]), b(64);
+         if (wl_dpv == 12) {
+            if (q == 2) hipLaunchKernelGGL((pf::k_wall2<Real, 12, true, true>), g, b, 0, s, wp, a1, a2);
+            else hipLaunchKernelGGL((pf::k_wall2<Real, 12, true, false>), g, b, 0, sg, wp, a1, a2);
+         } else if constexpr (sizeof(Real) == 4) {
+            if (q == 2) hipLaunchKernelGGL((pf::k_wall2<Real, 20, true, true>), g, b, 0, s, wp, a1, a2);
+            else hipLaunchKernelGGL((pf::k_wall2<Real, 20, true, false>), g, b, 0, sg, wp, a1, a2);
+         }
       }
    }
    // steps n and n+1 with the shell in pairs as well.  Order: box (both steps), then the first step of what no wall region
@@ -1081,19 +1120,28 @@ template <typename Real> struct Engine : EngineBase {
       Real *A = u0, *B = u1, *C = bufC, *D = bufD;
       Real *P0 = ub[0], *P1 = ub[1], *P2 = ub[2];
       auto get_ev = [&]() { std::pair<hipEvent_t, hipEvent_t> e{}; if (!ev_pool.empty()) { e = ev_pool.back(); ev_pool.pop_back(); } else { hipEventCreate(&e.first); hipEventCreate(&e.second); } return e; };
-      std::pair<hipEvent_t, hipEvent_t> ev{}, ev2{}, evt{}, eva{};
-      if (op.timing) { ev = get_ev(); ev2 = get_ev(); evt = get_ev(); eva = get_ev(); hipEventRecord(ev.first, s); hipEventRecord(evt.first, s); }
-      launch_tb2(s, A, B, C, D);
-      if (op.timing) { hipEventRecord(evt.second, s); tb2_ev.push_back(evt); hipEventRecord(eva.first, s); }
+      std::pair<hipEvent_t, hipEvent_t> ev{}, ev2{}, evt{};
+      if (op.timing) { ev = get_ev(); ev2 = get_ev(); evt = get_ev(); hipEventRecord(ev.first, s); }
+      // The wall regions read u^{n-1}, u^n and the old branch state only and write cells the box kernel does not: any order will do.
+      // The generic blocks (edges, corners: a few hundred waves, each a long chain of dependent steps) go to the second stream
+      // and run beside the alike blocks' launches, which are issue-bound; beside the bandwidth-bound box kernel they crawl
+      // (measured: 0.47 -> 3.6 ms), so that one comes after.  debug 0x4000000: everything on the main stream.
+      const bool beside = !(op.debug & 0x4000000);
+      hipStream_t sw = beside ? s_edge : s_main;
+      if (beside) { HIPCHK(hipEventRecord(ev_pre, s_main)); HIPCHK(hipStreamWaitEvent(s_edge, ev_pre, 0)); }
       u0_src = A; u1 = B; u0 = C;
-      launch_dirty_tiles(s);
+      launch_dirty_tiles(sw);
       bnd_sel = wl_rest; bs_vout = vh1b; bs_gout = gh1b;
-      launch_rigid(s, {0, wl_nrest});
-      launch_io(s, n, true, {0, Ns});
+      launch_rigid(sw, {0, wl_nrest});
+      launch_walls(s, sw, A, B, C, D, P0, P1, P2);
+      if (op.timing) hipEventRecord(evt.first, s);
+      launch_tb2(s, A, B, C, D);
+      if (op.timing) { hipEventRecord(evt.second, s); tb2_ev.push_back(evt); }
+      if (beside) { HIPCHK(hipEventRecord(ev_edge, s_edge)); HIPCHK(hipStreamWaitEvent(s_main, ev_edge, 0)); }
+      launch_io(s, n, true, {0, Ns}); // (receivers read u^n; the source goes into u^{n+1}, which only the second step below reads)
       if (ring_fill == 0) ring_n0 = n;
       ring_fill++; steps_done++;
-      launch_walls(s, A, B, C, D, P0, P1, P2);
-      if (op.timing) { hipEventRecord(eva.second, s); air_ev.push_back(eva); hipEventRecord(ev.second, s); step_ev.push_back(ev); hipEventRecord(ev2.first, s); }
+      if (op.timing) { hipEventRecord(ev.second, s); step_ev.push_back(ev); hipEventRecord(ev2.first, s); }
       std::swap(vh1, vh1b); std::swap(gh1, gh1b); // the state after the pair (the nodes inside the box: after its first step)
       u0_src = B; u1 = C; u0 = D;
       launch_dirty_tiles(s);
@@ -1575,7 +1623,7 @@ template <typename Real> struct Engine : EngineBase {
             launch_tb2(s_main, U0, U1, bufC, bufD);
             bnd_sel = wl_rest;
             u0_src = U0; u1 = U1; u0 = bufC; launch_dirty_tiles(s_main); launch_rigid(s_main, {0, wl_nrest});
-            launch_walls(s_main, U0, U1, bufC, bufD, ub[0], ub[1], ub[2]);
+            launch_walls(s_main, s_main, U0, U1, bufC, bufD, ub[0], ub[1], ub[2]);
             u0_src = U1; u1 = bufC; u0 = bufD; launch_dirty_tiles(s_main); launch_rigid(s_main, {0, wl_nrest});
             bnd_sel = nullptr;
             u0_src = nullptr; u0 = U0; u1 = U1;

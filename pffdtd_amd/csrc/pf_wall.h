@@ -39,8 +39,9 @@
 
 namespace pf {
 
-constexpr int WALL_MAXREG = 4;
+constexpr int WALL_MAXREG = 6;
 constexpr int WALL_LT = 60; // owned lanes per tile (lanes 2 .. 61)
+#define PF_WALL_MAXMAT 64     // (= PF_MNM, fdtd_data.h:35)
 
 struct WallRegion {
    int32_t mode;        // pencils along 0: x (lanes z, march y), 1: y (lanes z, march x), 2: z (lanes y, march x; vector loads)
@@ -69,6 +70,8 @@ template <typename Real> struct WallParams {
    WallRegion reg[WALL_MAXREG];
    const uint4 *pen;
    const uint32_t *rec;
+   const uint4 *blk;        // the launch's blocks: .x = region | lane tile << 3 | march chunk << 16; FAST: .y / .z = node mask / adjacency words
+                            // common to the block's pencils, .w = lossy flags | pencil cell of the frequency-dependent node << 8
    const Real *sv_in, *sg_in;
    Real *sv_out, *sg_out;   // branch state vh1 / gh1 before and after the pair (64-node blocks, st_idx)
    const Real *x2, *x1;     // node values u^{n-1} (step 1) and u^n (step 2): the u2b of cpu_engine.h:290-301
@@ -78,7 +81,7 @@ template <typename Real> struct WallParams {
    const MatQuadT<Real> *mq;
    const Real *beta;
    Real lo2, sl2, l;
-   int32_t mmax;
+   int32_t mmax, nmat;
 };
 
 // (each element passes through an empty asm: otherwise the compiler turns the chain of selects over array elements into ONE
@@ -94,22 +97,26 @@ template <typename Real, int N> __device__ __forceinline__ Real wall_sel(const R
    return r;
 }
 
-// The branch ODEs of one node with its state in registers (fd_core's arithmetic, cpu_engine.h:363-405).  UNI: every active
-// lane has the same material -- the coefficients are then scalar loads.
-template <typename Real, bool UNI>
-__device__ __forceinline__ Real fd_regs(Real p, Real u2, Real sf, int32_t k, Real (&v1)[12], Real (&g1)[12], const MatQuadT<Real> *__restrict__ mq,
-                                        const Real *__restrict__ beta, const int8_t *__restrict__ Mb, Real lo2) {
-   const int32_t kk = UNI ? __builtin_amdgcn_readfirstlane(k) : k;
-   const int M = Mb[kk];
+// The branch ODEs of one node with its state in registers (fd_core's arithmetic, cpu_engine.h:363-405).  The materials'
+// coefficients come from a copy in LDS (scalar loads of them serialised: two dozen dependent waits per node).
+template <typename Real> struct WallLds {
+   MatQuadT<Real> mq[PF_WALL_MAXMAT * 12];
+   Real beta[PF_WALL_MAXMAT];
+   int32_t M[PF_WALL_MAXMAT];
+};
+template <typename Real>
+__device__ __forceinline__ Real fd_regs(Real p, Real u2, Real sf, int32_t k, const Real (&v1)[12], const Real (&g1)[12], Real (&v1o)[12], Real (&g1o)[12],
+                                        const WallLds<Real> &L, Real lo2) {
+   const int M = L.M[k];
    const Real two = 2.0, one = 1.0;
-   const Real g = lo2 * sf * beta[kk];
+   const Real g = lo2 * sf * L.beta[k];
    const Real fac = two * lo2 * sf / (one + g);
    Real u = p;
    u = (u + g * u2) / (one + g);
 #pragma unroll
    for (int m = 0; m < 12; m++) {
       if (m < M) {
-         const MatQuadT<Real> q = mq[kk * 12 + m];
+         const MatQuadT<Real> q = L.mq[k * 12 + m];
          u -= fac * (two * q.bDh * v1[m] - q.bFh * g1[m]);
       }
    }
@@ -117,103 +124,110 @@ __device__ __forceinline__ Real fd_regs(Real p, Real u2, Real sf, int32_t k, Rea
 #pragma unroll
    for (int m = 0; m < 12; m++) {
       if (m < M) {
-         const MatQuadT<Real> q = mq[kk * 12 + m];
+         const MatQuadT<Real> q = L.mq[k * 12 + m];
          const Real v0 = q.b * du + q.bd * v1[m] - two * q.bFh * g1[m];
-         g1[m] = g1[m] + (v0 + v1[m]) / two;
-         v1[m] = v0;
-      }
+         g1o[m] = g1[m] + (v0 + v1[m]) / two;
+         v1o[m] = v0;
+      } else { g1o[m] = g1[m]; v1o[m] = v1[m]; }
    }
    return u;
 }
 
-template <typename Real, int DP, bool VEC>
-__global__ __launch_bounds__(64) void k_wall2(WallParams<Real> wp, Real a1, Real a2) {
+// One block = one lane tile x one march chunk of a region.  MODE = the region's orientation (WallRegion::mode).
+// FAST: the host found every pencil the block evaluates (all lanes, all march steps) to have the SAME structure -- the same node
+// cells with the same adjacency, at most one frequency-dependent node -- and no ghost or ABC cell along the lane and march
+// axes: walls away from edges and corners, the bulk of the work.  The structure then arrives with the block (ds*) and the
+// per-lane node decoding, the node loop, the lane shuffles and the march-axis mirrors are compiled out.
+template <typename Real, int DP, int MODE, bool FAST>
+__device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const WallRegion &R, const int j, const int c, const Real a1, const Real a2,
+                                          const WallLds<Real> *ldsp, const uint32_t dsx, const uint32_t dsz, const uint32_t dsw) {
+   constexpr bool VEC = MODE == 2;
    typedef typename VecOf<Real>::type vec;
    constexpr int V = VecOf<Real>::V;
    static_assert(!VEC || DP % V == 0, "vector pencils hold whole vectors");
-   int r = 0;
-#pragma unroll
-   for (int i = 1; i < WALL_MAXREG; i++)
-      if (i < wp.nreg && blockIdx.x >= wp.reg[i].blk0) r = i;
-   const WallRegion R = wp.reg[r];
-   const uint32_t bl = blockIdx.x - R.blk0;
-   const int j = (int)(bl % (uint32_t)R.nlt), c = (int)(bl / (uint32_t)R.nlt);
    const int lane = threadIdx.x;
-   const bool mode1 = !VEC && R.mode == 1;
-   const bool mx = VEC || mode1;                                   // the march axis is x
+   constexpr bool mx = MODE != 0;                                  // the march axis is x
    const int NL = VEC ? wp.Ny : wp.Nz;                             // extent of the lane axis
    const int NM = mx ? wp.Nx : wp.Ny;                              // ... of the march axis
-   const int NN = VEC ? wp.Nz : (mode1 ? wp.Ny : wp.Nx);           // ... of the pencil axis
+   const int NN = VEC ? wp.Nz : (MODE == 1 ? wp.Ny : wp.Nx);       // ... of the pencil axis
    const bool mg_lo = mx ? (wp.first != 0) : true, mg_hi = mx ? (wp.last != 0) : true; // ghost planes at the ends of the march axis?
-   const bool ng_lo = (!VEC && !mode1) ? (wp.first != 0) : true, ng_hi = (!VEC && !mode1) ? (wp.last != 0) : true;
+   const bool ng_lo = MODE == 0 ? (wp.first != 0) : true, ng_hi = MODE == 0 ? (wp.last != 0) : true;
    const int64_t sl = VEC ? (int64_t)wp.P : 1, sm = mx ? wp.plane : (int64_t)wp.P;
-   const int64_t sn = VEC ? 1 : (mode1 ? (int64_t)wp.P : wp.plane);
+   const int64_t sn = VEC ? 1 : (MODE == 1 ? (int64_t)wp.P : wp.plane);
    const int lc = R.l0 - 2 + WALL_LT * j + lane;                   // this lane's coordinate on the lane axis
    int lsrc = min(max(lc, 0), NL - 1);                             // where its u^n comes from: ghost cells mirror
    if (lsrc == 0) lsrc = 2;
    else if (lsrc == NL - 1) lsrc = NL - 3;
    const bool lg_lo = lc == 0, lg_hi = lc == NL - 1;
-   const bool tile_lg = __ballot(lg_lo || lg_hi) != 0ull;
+   const bool tile_lg = !FAST && __ballot(lg_lo || lg_hi) != 0ull;
    const bool own_lane = lane >= 2 && lane <= 61 && lc < R.l1;
    const bool eval_lane = lane >= 1 && lane <= 62 && lc <= R.l1;   // stage 1 is valid (and needed) here
    const int ms = R.m0 + c * R.mchunk, me = min(ms + R.mchunk, R.m1);
    if (ms >= me) return;
+   const WallLds<Real> &lds = *ldsp;
+   // Wave-uniform values the loop body branches on.  They are made opaque once per march step (below): left alone, the compiler
+   // hoists every uniform predicate derived from them out of the march loop, runs out of scalar registers and spills them into
+   // vector-register lanes -- 300-500 v_readlane / v_writelane per step, a fifth of the vector instructions.
+   int rkg = R.kg, rko0 = R.ko0, rko1 = R.ko1, rkb0 = R.kb0, rkb1 = R.kb1, rnbase = R.nbase;
+   uint32_t usx = dsx, usz = dsz, usw = dsw;
    auto msrc = [&](int m) __attribute__((always_inline)) {
       m = min(max(m, 0), NM - 1);
+      if (FAST) return m;
       if (m == 0 && mg_lo) return 2;
       if (m == NM - 1 && mg_hi) return NM - 3;
       return m;
    };
-   const int64_t lbase = (int64_t)lsrc * sl + (int64_t)R.nbase * sn;
+   const int64_t lbase = (int64_t)lsrc * sl + (int64_t)rnbase * sn;
    const int ql = (lc == 1 || lc == NL - 2) ? 1 : 0;
+   const bool tile_ql = !FAST && __ballot(ql != 0) != 0ull;
 
-   auto load_pencil = [&](const Real *G, int m, Real(&b)[DP], bool mirror) __attribute__((always_inline)) {
+   // Loads are unconditional (a cell outside [kb0, kb1) re-reads the nearest one inside) and nothing touches what they return
+   // before the end of the march step: the mirror of the ghost cell and the masking of the entries happen at the rotation.
+   auto load_pencil = [&](const Real *G, int m, Real(&b)[DP]) __attribute__((always_inline)) {
       const Real *pl = G + (int64_t)msrc(m) * sm + lbase;
       if constexpr (VEC) {
 #pragma unroll
          for (int v = 0; v < DP / V; v++) {
-            if ((v + 1) * V > R.kb0 && v * V < R.kb1) {
-               const vec t = *(const vec *)(pl + v * V);
+            const vec t = *(const vec *)(pl + v * V);
 #pragma unroll
-               for (int i = 0; i < V; i++) b[v * V + i] = t[i];
-            } else {
-#pragma unroll
-               for (int i = 0; i < V; i++) b[v * V + i] = Real(0);
-            }
+            for (int i = 0; i < V; i++) b[v * V + i] = t[i];
          }
       } else {
 #pragma unroll
-         for (int k = 0; k < DP; k++) b[k] = (k >= R.kb0 && k < R.kb1 && k != R.kg) ? pl[(int64_t)k * sn] : Real(0);
-      }
-      if (mirror) {
-#pragma unroll
-         for (int k = 0; k < DP; k++)
-            if (k == R.kg) b[k] = (k == 0) ? b[2] : b[k >= 2 ? k - 2 : 0];
+         for (int k = 0; k < DP; k++) b[k] = pl[(int64_t)min(max(k, rkb0), rkb1 - 1) * sn];
       }
    };
+   auto mirror = [&](Real(&b)[DP]) __attribute__((always_inline)) { // the ghost cell of a pencil = the cell two inside
+#pragma unroll
+      for (int k = 0; k < DP; k++)
+         if (k == rkg) b[k] = (k == 0) ? b[2] : b[k >= 2 ? k - 2 : 0];
+   };
    auto load_ent = [&](int m) __attribute__((always_inline)) { // march steps R.m0-1 .. R.m1 have entries
-      uint4 e = make_uint4(0u, 0u, 0u, 0u);
-      if (m <= R.m1) e = wp.pen[R.pen_off + (int64_t)(m - (R.m0 - 1)) * R.nlp + (WALL_LT * j + lane)];
-      if (!eval_lane) { e.x = 0u; e.w = 0u; }
+      const uint4 *e = wp.pen + (R.pen_off + (int64_t)(min(m, R.m1) - (R.m0 - 1)) * R.nlp + (WALL_LT * j + lane));
+      if (FAST) return make_uint4(0u, 0u, 0u, e->w); // (only the place of the frequency-dependent node differs from lane to lane)
+      return *e;
+   };
+   auto mask_ent = [&](uint4 e, int m) __attribute__((always_inline)) {
+      if (!eval_lane || m > R.m1) { e.x = 0u; e.w = 0u; }
       return e;
    };
    auto store_pencil = [&](Real *G, int m, const Real(&v)[DP]) __attribute__((always_inline)) {
       if (!own_lane) return;
-      Real *pl = G + (int64_t)m * sm + (int64_t)lc * sl + (int64_t)R.nbase * sn;
+      Real *pl = G + (int64_t)m * sm + (int64_t)lc * sl + (int64_t)rnbase * sn;
       if constexpr (VEC) {
 #pragma unroll
          for (int q = 0; q < DP / V; q++) {
-            if ((q + 1) * V > R.ko0 && q * V < R.ko1) {
+            if ((q + 1) * V > rko0 && q * V < rko1) {
                vec t;
 #pragma unroll
-               for (int i = 0; i < V; i++) t[i] = (R.kg > 0 && q * V + i > R.kg) ? Real(0) : v[q * V + i]; // (pad columns beyond the ghost column)
+               for (int i = 0; i < V; i++) t[i] = (rkg > 0 && q * V + i > rkg) ? Real(0) : v[q * V + i]; // (pad columns beyond the ghost column)
                *(vec *)(pl + q * V) = t;
             }
          }
       } else {
 #pragma unroll
          for (int k = 0; k < DP; k++)
-            if (k >= R.ko0 && k < R.ko1) pl[(int64_t)k * sn] = v[k];
+            if (k >= rko0 && k < rko1) pl[(int64_t)k * sn] = v[k];
       }
    };
    // the branch state and parameters of a pencil's first frequency-dependent node, ahead of its stage 1
@@ -229,99 +243,123 @@ __global__ __launch_bounds__(64) void k_wall2(WallParams<Real> wp, Real a1, Real
          x1v = wp.x1[li];
       }
    };
+   // neighbours in file order (+x -x +y -y +z -z) from the pencil (np, nm), march (mp, mm) and lane (lp, lm) axes
+   auto air = [&](Real cc, Real old, Real np_, Real nm, Real mp, Real mm, Real lp, Real lm) __attribute__((always_inline)) {
+      if (MODE == 2) return upd7<false>(a1, a2, cc, old, mp, mm, lp, lm, np_, nm);
+      if (MODE == 1) return upd7<false>(a1, a2, cc, old, mp, mm, np_, nm, lp, lm);
+      return upd7<false>(a1, a2, cc, old, np_, nm, mp, mm, lp, lm);
+   };
+   auto rigid = [&](uint32_t adj, Real cc, Real old, Real np_, Real nm, Real mp, Real mm, Real lp, Real lm) __attribute__((always_inline)) {
+      Real nb[6];
+      if (MODE == 2) { nb[0] = mp; nb[1] = mm; nb[2] = lp; nb[3] = lm; nb[4] = np_; nb[5] = nm; }
+      else if (MODE == 1) { nb[0] = mp; nb[1] = mm; nb[2] = np_; nb[3] = nm; nb[4] = lp; nb[5] = lm; }
+      else { nb[0] = np_; nb[1] = nm; nb[2] = mp; nb[3] = mm; nb[4] = lp; nb[5] = lm; }
+      return upd_rigid<false, 6>(a2, wp.sl2, adj, cc, old, nb); // (cpu_engine.h:234-257)
+   };
 
    // One update of the pencil cells 1 .. DP-2 at march coordinate m: Out = f(Cur; Prv, Nxt = the march planes before / after;
    // Old = the value two steps back).  STAGE 1: u^n -> u^{n+1} (halo cells included, their nodes read-only); STAGE 2: owned
-   // cells only.  Fv / Fg / Fsf / Fu2 / Fk: state (updated in place) and parameters of the pencil's first frequency-dependent node.
+   // cells only.  Fv / Fg / Fsf / Fu2 / Fk: branch state and parameters of the pencil's first frequency-dependent node; its new
+   // state goes to Fvo / Fgo (may be Fv / Fg), its new value to nval, and st says whether this lane owns it -- NOTHING is stored
+   // here (the caller stores after it has consumed the loads in flight: gfx9 counts stores and loads in one in-order counter).
    auto update = [&](auto stage, int m, const Real(&Prv)[DP], const Real(&Cur)[DP], const Real(&Nxt)[DP], const Real(&Old)[DP], const uint4 E,
-                     Real(&Out)[DP], bool own_m, Real(&Fv)[12], Real(&Fg)[12], Real Fsf, Real Fu2, int32_t Fk) __attribute__((always_inline)) {
+                     Real(&Out)[DP], bool own_m, const Real(&Fv)[12], const Real(&Fg)[12], Real(&Fvo)[12], Real(&Fgo)[12], Real Fsf, Real Fu2,
+                     int32_t Fk, Real &nval, bool &st) __attribute__((always_inline)) {
       constexpr int STAGE = decltype(stage)::value;
-      const int qm = mx ? (((wp.first && m == 1) || (wp.last && m == wp.Nx - 2)) ? 1 : 0) : ((m == 1 || m == wp.Ny - 2) ? 1 : 0);
+      const int qm = FAST ? 0 : (mx ? (((wp.first && m == 1) || (wp.last && m == wp.Nx - 2)) ? 1 : 0) : ((m == 1 || m == wp.Ny - 2) ? 1 : 0));
+      st = false;
+      // Do all the pencils of the wave look alike (same node cells, same adjacency, at most one frequency-dependent node, all
+      // within the entry)?  Walls away from edges and corners: then the structure is decoded once, in scalar registers.
+      const uint32_t sx = FAST ? usx : __builtin_amdgcn_readlane(E.x, 1), sz = FAST ? usz : __builtin_amdgcn_readlane(E.z, 1);
+      const uint32_t sw5 = FAST ? (usw & 31u) : (__builtin_amdgcn_readlane(E.w, 1) & 31u), sk0 = FAST ? (usw >> 8) : (__builtin_amdgcn_readlane(E.y, 1) >> 27);
+      bool alike = true;
+      if (!FAST) {
+         const bool differs = eval_lane && (E.x != sx || E.z != sz || (E.w & 31u) != sw5 || (E.y >> 27) != sk0);
+         alike = __ballot(differs) == 0ull && __popc(sx) <= 5 && __popc(sw5) <= 1;
+      }
+      Real pfd = Real(0);
 #pragma unroll
       for (int k = 1; k < DP - 1; k++) {
          const Real cc = Cur[k];
          const Real lm = lane_from_lower<true>(cc), lp = lane_from_upper<true>(cc);
-         const Real np_ = Cur[k + 1], nm = Cur[k - 1], mp = Nxt[k], mm = Prv[k];
-         Real p;
-         if (VEC) p = upd7<false>(a1, a2, cc, Old[k], mp, mm, lp, lm, np_, nm);           // x = march, y = lanes, z = pencil
-         else {                                                                            // z = lanes; x, y = march / pencil
-            const Real xp = mode1 ? mp : np_, xm = mode1 ? mm : nm, yp = mode1 ? np_ : mp, ym = mode1 ? nm : mm;
-            p = upd7<false>(a1, a2, cc, Old[k], xp, xm, yp, ym, lp, lm);
+         Real p = Real(0);
+         const int nk = rnbase + k;
+         const bool node_all = alike && ((sx >> k) & 1u);          // a boundary node in every pencil of the wave
+         if (!node_all) {
+            p = air(cc, Old[k], Cur[k + 1], Cur[k - 1], Nxt[k], Prv[k], lp, lm);
+            const int qnm = (((ng_lo && nk == 1) || (ng_hi && nk == NN - 2)) ? 1 : 0) + qm;
+            if (qnm > 0 || tile_ql) {
+               const int Q = qnm + (FAST ? 0 : ql);
+               if (Q > 0) p = abc_loss<false>(p, Old[k], wp.l * (Real)Q); // (cpu_engine.h:225-229)
+            }
          }
-         const int nk = R.nbase + k;
-         const int qn = ((ng_lo && nk == 1) || (ng_hi && nk == NN - 2)) ? 1 : 0;
-         const int Q = qn + qm + ql;
-         if (__ballot(Q > 0) != 0ull) {
-            if (Q > 0) p = abc_loss<false>(p, Old[k], wp.l * (Real)Q); // (cpu_engine.h:225-229)
+         if (node_all) {
+            const uint32_t jn = __popc(sx & ((1u << k) - 1u));
+            p = rigid((sz >> (6 * jn)) & 63u, cc, Old[k], Cur[k + 1], Cur[k - 1], Nxt[k], Prv[k], lp, lm);
+            if (sw5 != 0u && (uint32_t)k == sk0) pfd = p;
          }
          Out[k] = p;
       }
-      // boundary nodes: the union of the lanes' node masks, one pencil cell per turn
-      uint32_t ub = 0;
+      if (alike) {
+         if (sw5 != 0u) { // (cpu_engine.h:290-301, 363-405) the pencils' frequency-dependent node: state in registers
+            const bool owner = own_m && own_lane && (int)sk0 >= rko0 && (int)sk0 < rko1;
+            if (eval_lane && (STAGE == 1 || owner)) {
+               pfd = fd_regs<Real>(pfd, Fu2, Fsf, Fk, Fv, Fg, Fvo, Fgo, lds, wp.lo2);
+               st = owner;
+               nval = pfd;
+            }
 #pragma unroll
-      for (int k = 1; k < DP - 1; k++)
-         if (__ballot((E.x >> k) & 1u) != 0ull) ub |= 1u << k;
-      const int k0 = (int)(E.y >> 27);                             // pencil cell of the first frequency-dependent node
-      while (ub) {
-         const int k = __ffs(ub) - 1;
-         ub &= ub - 1u;
-         const bool has = ((E.x >> k) & 1u) != 0u;
-         const int jn = __popc(E.x & ((1u << k) - 1u));            // which node of the pencil
-         const bool inl = jn < 5;
-         const bool lossy_inl = inl && ((E.w >> jn) & 1u) != 0u;
-         const bool prim = has && lossy_inl && k == k0;            // the one whose state is in registers
-         const bool need_rec = has && (!inl || (lossy_inl && !prim));
-         uint32_t rec = 0u;
-         if (__ballot(need_rec) != 0ull) {
-            if (need_rec) rec = wp.rec[(E.y & 0x7ffffffu) + (uint32_t)jn];
+            for (int k = 1; k < DP - 1; k++)
+               if ((uint32_t)k == sk0) Out[k] = pfd;
          }
-         const uint32_t adj = inl ? ((E.z >> (6 * jn)) & 63u) : (rec & 63u);
-         const Real cc = wall_sel<Real, DP>(Cur, k), nm = wall_sel<Real, DP>(Cur, k - 1), np_ = wall_sel<Real, DP>(Cur, k + 1);
-         const Real mp = wall_sel<Real, DP>(Nxt, k), mm = wall_sel<Real, DP>(Prv, k), old = wall_sel<Real, DP>(Old, k);
-         const Real lm = lane_from_lower<true>(cc), lp = lane_from_upper<true>(cc);
-         Real nb[6];
-         if (VEC) { nb[0] = mp; nb[1] = mm; nb[2] = lp; nb[3] = lm; nb[4] = np_; nb[5] = nm; }
-         else {
-            nb[0] = mode1 ? mp : np_; nb[1] = mode1 ? mm : nm; nb[2] = mode1 ? np_ : mp; nb[3] = mode1 ? nm : mm; nb[4] = lp; nb[5] = lm;
-         }
-         Real p = upd_rigid<false, 6>(a2, wp.sl2, adj, cc, old, nb); // (cpu_engine.h:234-257)
-         const bool owner = own_m && own_lane && k >= R.ko0 && k < R.ko1;
-         // (cpu_engine.h:290-301, 363-405) the pencil's first frequency-dependent node: state in registers
-         const bool fdp = prim && (STAGE == 1 || owner);
-         if (__ballot(fdp) != 0ull) {
-            if (fdp) {
-               const int32_t ku = __builtin_amdgcn_readfirstlane(Fk);
-               if (__ballot(Fk != ku) == 0ull) p = fd_regs<Real, true>(p, Fu2, Fsf, Fk, Fv, Fg, wp.mq, wp.beta, wp.Mb, wp.lo2);
-               else p = fd_regs<Real, false>(p, Fu2, Fsf, Fk, Fv, Fg, wp.mq, wp.beta, wp.Mb, wp.lo2);
-               if (owner) {
-                  const int32_t li = (int32_t)(E.w >> 8);
-                  (STAGE == 1 ? wp.o1 : wp.o2)[li] = p;
-                  if (STAGE == 2) {
+      } else if (!FAST) {
+         // edges, corners, tiles that straddle them: the union of the lanes' node masks, one pencil cell per turn
+         uint32_t ub = 0;
 #pragma unroll
-                     for (int q = 0; q < 12; q++)
-                        if (q < wp.mmax) { wp.sv_out[st_idx(q, li)] = Fv[q]; wp.sg_out[st_idx(q, li)] = Fg[q]; }
-                  }
+         for (int k = 1; k < DP - 1; k++)
+            if (__ballot((E.x >> k) & 1u) != 0ull) ub |= 1u << k;
+         const int k0 = (int)(E.y >> 27);                          // pencil cell of the first frequency-dependent node
+         while (ub) {
+            const int k = __ffs(ub) - 1;
+            ub &= ub - 1u;
+            const bool has = ((E.x >> k) & 1u) != 0u;
+            const int jn = __popc(E.x & ((1u << k) - 1u));         // which node of the pencil
+            const bool inl = jn < 5;
+            const bool lossy_inl = inl && ((E.w >> jn) & 1u) != 0u;
+            const bool prim = has && lossy_inl && k == k0;         // the one whose state is in registers
+            const bool need_rec = has && (!inl || (lossy_inl && !prim));
+            uint32_t rec = 0u;
+            if (__ballot(need_rec) != 0ull) {
+               if (need_rec) rec = wp.rec[(E.y & 0x7ffffffu) + (uint32_t)jn];
+            }
+            const uint32_t adj = inl ? ((E.z >> (6 * jn)) & 63u) : (rec & 63u);
+            const Real cc = wall_sel<Real, DP>(Cur, k), nm = wall_sel<Real, DP>(Cur, k - 1), np_ = wall_sel<Real, DP>(Cur, k + 1);
+            const Real mp = wall_sel<Real, DP>(Nxt, k), mm = wall_sel<Real, DP>(Prv, k), old = wall_sel<Real, DP>(Old, k);
+            const Real lm = lane_from_lower<true>(cc), lp = lane_from_upper<true>(cc);
+            Real p = rigid(adj, cc, old, np_, nm, mp, mm, lp, lm);
+            const bool owner = own_m && own_lane && k >= rko0 && k < rko1;
+            if (prim && (STAGE == 1 || owner)) {
+               p = fd_regs<Real>(p, Fu2, Fsf, Fk, Fv, Fg, Fvo, Fgo, lds, wp.lo2);
+               st = owner;
+               nval = p;
+            }
+            // any further frequency-dependent node of the pencil: through memory, stored right here
+            const bool fds = has && !prim && (inl ? lossy_inl : (rec & 64u) != 0u) && (STAGE == 1 || owner);
+            if (__ballot(fds) != 0ull) {
+               if (fds) {
+                  const int32_t li = (int32_t)(rec >> 8);
+                  const Real u2 = STAGE == 1 ? wp.x2[li] : wp.x1[li];
+                  p = fd_core<Real>(p, u2, li, STAGE == 1 ? wp.sv_in : wp.sv_out, STAGE == 1 ? wp.sg_in : wp.sg_out, wp.sv_out, wp.sg_out, owner, wp.ssaf,
+                                    wp.mat, wp.Mb, wp.mq, wp.beta, wp.lo2, wp.mmax);
+                  if (owner) (STAGE == 1 ? wp.o1 : wp.o2)[li] = p;
                }
             }
-         }
-         // any further frequency-dependent node of the pencil (edges, corners): through memory
-         const bool fds = has && !prim && (inl ? lossy_inl : (rec & 64u) != 0u) && (STAGE == 1 || owner);
-         if (__ballot(fds) != 0ull) {
-            if (fds) {
-               const int32_t li = (int32_t)(rec >> 8);
-               const Real u2 = STAGE == 1 ? wp.x2[li] : wp.x1[li];
-               p = fd_core<Real>(p, u2, li, STAGE == 1 ? wp.sv_in : wp.sv_out, STAGE == 1 ? wp.sg_in : wp.sg_out, wp.sv_out, wp.sg_out, owner, wp.ssaf,
-                                 wp.mat, wp.Mb, wp.mq, wp.beta, wp.lo2, wp.mmax);
-               if (owner) (STAGE == 1 ? wp.o1 : wp.o2)[li] = p;
-            }
-         }
 #pragma unroll
-         for (int i = 1; i < DP - 1; i++) Out[i] = (has && k == i) ? p : Out[i];
+            for (int i = 1; i < DP - 1; i++) Out[i] = (has && k == i) ? p : Out[i];
+         }
       }
       // ghost cells of the new field: mirror along the pencil, then along the lanes
-#pragma unroll
-      for (int k = 0; k < DP; k++)
-         if (k == R.kg) Out[k] = (k == 0) ? Out[2] : Out[k >= 2 ? k - 2 : 0];
+      mirror(Out);
       if (STAGE == 1 && tile_lg) {
 #pragma unroll
          for (int k = 0; k < DP; k++) {
@@ -332,52 +370,99 @@ __global__ __launch_bounds__(64) void k_wall2(WallParams<Real> wp, Real a1, Real
       }
    };
 
-   Real Bm[DP], Bc[DP], Bn[DP], Bq[DP], Ac[DP], Aq[DP], Vm[DP], Vc[DP], Vn[DP];
+   Real Bm[DP], Bc[DP], Bn[DP], Bq[DP], Ac[DP], Aq[DP], Vm[DP], Vc[DP], Vn[DP], W[DP];
    Real F1v[12], F1g[12], Fqv[12], Fqg[12], F2v[12], F2g[12];
    Real F1sf = 0, F1u2 = 0, F1x1 = 0, Fqsf = 0, Fqu2 = 0, Fqx1 = 0, F2sf = 0, F2u2 = 0;
    int32_t F1k = 0, Fqk = 0, F2k = 0;
 #pragma unroll
    for (int q = 0; q < 12; q++) { F1v[q] = F1g[q] = Fqv[q] = Fqg[q] = F2v[q] = F2g[q] = Real(0); }
-   uint4 Ep = make_uint4(0u, 0u, 0u, 0u), Ec = load_ent(ms - 1), En = load_ent(ms), Eq;
-   load_pencil(wp.B, ms - 2, Bm, true);
-   load_pencil(wp.B, ms - 1, Bc, true);
-   load_pencil(wp.B, ms, Bn, true);
-   load_pencil(wp.A, ms - 1, Ac, false);
+   uint4 Ep = make_uint4(0u, 0u, 0u, 0u), Ec = mask_ent(load_ent(ms - 1), ms - 1), En = mask_ent(load_ent(ms), ms), Eq;
+   load_pencil(wp.B, ms - 2, Bm);
+   load_pencil(wp.B, ms - 1, Bc);
+   load_pencil(wp.B, ms, Bn);
+   load_pencil(wp.A, ms - 1, Ac);
+   mirror(Bm); mirror(Bc); mirror(Bn);
    fd_fetch(Ec, F1v, F1g, F1sf, F1u2, F1x1, F1k);
 #pragma unroll
-   for (int k = 0; k < DP; k++) { Vm[k] = Real(0); Vc[k] = Real(0); Vn[k] = Real(0); Bq[k] = Real(0); Aq[k] = Real(0); }
+   for (int k = 0; k < DP; k++) { Vm[k] = Real(0); Vc[k] = Real(0); Vn[k] = Real(0); W[k] = Real(0); }
+   // before the loop: what march step ms-1 needs next
+   Eq = load_ent(ms + 1);
+   load_pencil(wp.B, ms + 1, Bq);
+   load_pencil(wp.A, ms, Aq);
+   fd_fetch(En, Fqv, Fqg, Fqsf, Fqu2, Fqx1, Fqk);
    for (int m = ms - 1; m <= me; m++) {
-      // everything march step m+1 needs goes on its way now
-      Eq = load_ent(m + 2);
-      if (m < me) {
-         load_pencil(wp.B, m + 2, Bq, true);
-         load_pencil(wp.A, m + 1, Aq, false);
-         fd_fetch(En, Fqv, Fqg, Fqsf, Fqu2, Fqx1, Fqk);
-      }
+      rkg = R.kg; rko0 = R.ko0; rko1 = R.ko1; rkb0 = R.kb0; rkb1 = R.kb1; rnbase = R.nbase; usx = dsx; usz = dsz; usw = dsw;
+      asm volatile("" : "+s"(rkg), "+s"(rko0), "+s"(rko1), "+s"(rkb0), "+s"(rkb1), "+s"(rnbase), "+s"(usx), "+s"(usz), "+s"(usw));
       // stage 1: u^{n+1}(m)
       const bool own_m = m >= ms && m < me;
-      update(std::integral_constant<int, 1>(), m, Bm, Bc, Bn, Ac, Ec, Vn, own_m, F1v, F1g, F1sf, F1u2, F1k);
-      if (own_m) store_pencil(wp.C, m, Vn);
+      Real nv1 = Real(0), nv2 = Real(0);
+      bool st1 = false, st2 = false;
+      update(std::integral_constant<int, 1>(), m, Bm, Bc, Bn, Ac, Ec, Vn, own_m, F1v, F1g, F1v, F1g, F1sf, F1u2, F1k, nv1, st1);
       // stage 2: u^{n+2}(m-1) from u^{n+1}(m-2 .. m); a ghost plane of the march axis is the plane two further in
-      if (m - 1 >= ms) {
-         Real W[DP];
+      const bool do2 = m - 1 >= ms;
+      if (do2) {
+         if (!mx && !FAST) {
+            const bool sub_hi = m == NM - 1 && mg_hi, sub_lo = m - 2 == 0 && mg_lo;
+            Real Pv[DP], Nv[DP];
 #pragma unroll
-         for (int k = 0; k < DP; k++) W[k] = Real(0);
-         const bool sub_hi = !mx && m == NM - 1 && mg_hi, sub_lo = !mx && m - 2 == 0 && mg_lo;
-         Real Pv[DP], Nv[DP];
-#pragma unroll
-         for (int k = 0; k < DP; k++) { Pv[k] = sub_lo ? Vn[k] : Vm[k]; Nv[k] = sub_hi ? Vm[k] : Vn[k]; }
-         update(std::integral_constant<int, 2>(), m - 1, Pv, Vc, Nv, Bm, Ep, W, true, F2v, F2g, F2sf, F2u2, F2k);
-         store_pencil(wp.D, m - 1, W);
+            for (int k = 0; k < DP; k++) { Pv[k] = sub_lo ? Vn[k] : Vm[k]; Nv[k] = sub_hi ? Vm[k] : Vn[k]; }
+            update(std::integral_constant<int, 2>(), m - 1, Pv, Vc, Nv, Bm, Ep, W, true, F2v, F2g, F2v, F2g, F2sf, F2u2, F2k, nv2, st2);
+         } else update(std::integral_constant<int, 2>(), m - 1, Vm, Vc, Vn, Bm, Ep, W, true, F2v, F2g, F2v, F2g, F2sf, F2u2, F2k, nv2, st2);
       }
+      const int32_t li1 = (int32_t)(Ec.w >> 8), li2 = (int32_t)(Ep.w >> 8);
+      // Rotate.  What was loaded a march step ago is touched HERE, before anything is stored: gfx9 counts loads and stores in one
+      // in-order counter, so a wait for those loads placed after this step's stores would wait for the stores as well (and
+      // without the touch the copies below are mere renamings: the first real use, and the wait, would be in the next step).
 #pragma unroll
       for (int k = 0; k < DP; k++) { Vm[k] = Vc[k]; Vc[k] = Vn[k]; Bm[k] = Bc[k]; Bc[k] = Bn[k]; Bn[k] = Bq[k]; Ac[k] = Aq[k]; }
+#pragma unroll
+      for (int k = 0; k < DP; k++) { asm volatile("" : "+v"(Bn[k])); asm volatile("" : "+v"(Ac[k])); }
+#pragma unroll
+      for (int q = 0; q < 12; q++) { asm volatile("" : "+v"(Fqv[q])); asm volatile("" : "+v"(Fqg[q])); }
+      asm volatile("" : "+v"(Fqsf), "+v"(Fqu2), "+v"(Fqx1), "+v"(Fqk), "+v"(Eq.x), "+v"(Eq.y), "+v"(Eq.z), "+v"(Eq.w) : : "memory");
+      mirror(Bn);
+      // the stores of this march step ...
+      if (own_m) store_pencil(wp.C, m, Vc);
+      if (do2) store_pencil(wp.D, m - 1, W);
+      if (st1) wp.o1[li1] = nv1;
+      if (st2) {
+         wp.o2[li2] = nv2;
+#pragma unroll
+         for (int q = 0; q < 12; q++)
+            if (q < wp.mmax) { wp.sv_out[st_idx(q, li2)] = F2v[q]; wp.sg_out[st_idx(q, li2)] = F2g[q]; }
+      }
+      asm volatile("" : : : "memory");
 #pragma unroll
       for (int q = 0; q < 12; q++) { F2v[q] = F1v[q]; F2g[q] = F1g[q]; F1v[q] = Fqv[q]; F1g[q] = Fqg[q]; }
       F2sf = F1sf; F2u2 = F1x1; F2k = F1k;
       F1sf = Fqsf; F1u2 = Fqu2; F1x1 = Fqx1; F1k = Fqk;
-      Ep = Ec; Ec = En; En = Eq;
+      Ep = Ec; Ec = En; En = mask_ent(Eq, m + 2);
+      // ... and the loads of the one after the next
+      if (m + 1 <= me) {
+         Eq = load_ent(m + 3);
+         if (m + 1 < me) {
+            load_pencil(wp.B, m + 3, Bq);
+            load_pencil(wp.A, m + 2, Aq);
+            fd_fetch(En, Fqv, Fqg, Fqsf, Fqu2, Fqx1, Fqk);
+         }
+      }
    }
+}
+
+// One launch = a list of blocks (WallParams::blk: region | lane tile << 3 | march chunk << 16, and for FAST launches the common
+// structure of the block's pencils).  !VEC: regions normal to x and y (lanes along z); VEC: regions normal to z.
+template <typename Real, int DP, bool VEC, bool FAST>
+__global__ __launch_bounds__(64) void k_wall2(WallParams<Real> wp, Real a1, Real a2) {
+   const uint4 bd = wp.blk[blockIdx.x];
+   const WallRegion R = wp.reg[bd.x & 7u];
+   const int j = (int)((bd.x >> 3) & 0x1fffu), c = (int)(bd.x >> 16);
+   __shared__ WallLds<Real> lds;
+   for (int i = threadIdx.x; i < wp.nmat * 12; i += 64) lds.mq[i] = wp.mq[i];
+   for (int i = threadIdx.x; i < wp.nmat; i += 64) { lds.beta[i] = wp.beta[i]; lds.M[i] = wp.Mb[i]; }
+   __syncthreads();
+   if constexpr (VEC) wall_body<Real, DP, 2, FAST>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
+   else if (R.mode == 1) wall_body<Real, DP, 1, FAST>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
+   else wall_body<Real, DP, 0, FAST>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
 }
 
 } // namespace pf
