@@ -120,11 +120,13 @@ def fill_engine_grids(torch, eng_view, nplanes, plane_elems, real_bytes, device,
         torch.cuda.synchronize()
 
 
-def roofline_block(args, sd, tm, K, real_bytes, interior_planes):
-    """`roofline` of the bench line from an engine's timing record (collected in a region with per-launch events on)."""
+def roofline_block(args, sd, tm, K, real_bytes, interior_planes, interior_per_plane=None):
+    """`roofline` of the bench line from an engine's timing record (collected in a region with per-launch events on).
+    interior_per_plane: interior cells of one stored plane (default: the file's (Ny-2)(Nz-2); a chain cut along file z
+    stores planes of Ny x Nx)."""
     bpv = 3 * real_bytes + 0.125  # u1 read, u0 read + write, one mask bit (SURVEY 8d)
     T = "float" if real_bytes == 4 else "double"
-    upd = interior_planes * (sd.Ny - 2) * (sd.Nz - 2)
+    upd = interior_planes * (interior_per_plane if interior_per_plane is not None else (sd.Ny - 2) * (sd.Nz - 2))
     air_ms_per_step = tm["air_ms_total"] / max(tm["steps"] if tm["steps"] else K, 1)
     if tm.get("tb2_launches", 0) > 0:
         # temporal blocking: the dominant kernel advances `tb2_cells` cells by TWO steps per launch; its algorithmic
@@ -152,6 +154,14 @@ def roofline_block(args, sd, tm, K, real_bytes, interior_planes):
           "autotune_ms_per_step": {k: round(v, 4) for k, v in zip(("lean", "barrier_free", "blocked_pair"), tm.get("tune_ms", [0, 0, 0]))},
           "grid_placement": {"candidates": tm.get("place_candidates", 0),
                              "kernel_ms_as_allocated_chosen_slowest": [round(v, 4) for v in tm.get("place_ms", [0, 0, 0])]}}
+    if tm.get("tb2_launches", 0) > 0 and kernel_ms > 0:
+        # what a two-steps-per-pass kernel MUST move: u^{n-1}, u^n read once, u^{n+1}, u^{n+2} written once = 4 values per cell
+        # and launch -- a fraction of a hardware limit (<= 1 by construction), unlike `frac` above
+        comp = tm["tb2_cells"] * 4 * real_bytes
+        rl["blocked_compulsory_GB_per_launch"] = round(comp / 1e9, 3)
+        rl["frac_of_blocked_compulsory"] = round(comp / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        wb = tm.get("wall_blocks", [0, 0])
+        rl["shell"] = ("wall regions in pairs (k_wall2): %d blocks of alike pencils, %d generic" % (wb[0], wb[1])) if sum(wb) else "single steps"
     return rl, bpv, kernel_ms, units
 
 
@@ -160,7 +170,7 @@ def add_traffic(rl, res, sd, kernel_ms, units, bpv):
     FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 x2 read correction applied; tools/collect_n1_profile.sh) -- counters
     cannot be read from inside the process.  Only quoted when the committed profile is of the very kernel instantiation this
     run launched, advancing the same number of voxel updates per launch on the same scene; otherwise null."""
-    for tag in ("r03", "r02"):
+    for tag in ("r04", "r03", "r02"):
         tfile, pfile = ROOT / "profiles" / f"{tag}_bench_n1_hbm_traffic.json", ROOT / "profiles" / f"{tag}_bench_n1.json"
         if tfile.exists():
             break
@@ -193,6 +203,13 @@ def base_result(args, sd, world, K, W, R, regions, el, real_bytes, lossy, parall
     gvox = sd.Npts * K / el / 1e9
     bpv = 3 * real_bytes + 0.125
     n = args.size
+    # which BASELINE.json configuration is this?  (configs[3]: shoebox 1024^3 7-pt fp32; configs[4]: 1536^3 13-pt folded FCC fp64)
+    if not args.fcc and real_bytes == 4 and n == 1024 and not (args.nx or args.ny):
+        which = "BASELINE.json configs[3]" + ("" if lossy and args.mb == 11 else ", wall variant")
+    elif args.fcc and real_bytes == 8 and n == 1536:
+        which = "BASELINE.json configs[4] on this many GPUs" + ("" if lossy and args.mb == 11 else ", wall variant")
+    else:
+        which = "an experiment, no BASELINE.json configuration"
     return {
         "metric": "Gvoxel-updates/s", "value": round(gvox, 3), "unit": "Gvoxel-updates/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(el / K * 1e3, 4),
@@ -202,7 +219,7 @@ def base_result(args, sd, world, K, W, R, regions, el, real_bytes, lossy, parall
         "config": {"workload": f"shoebox {n}^3 {'13-pt folded FCC' if args.fcc else '7-pt Cartesian'} "
                                f"{'fp32' if real_bytes == 4 else 'fp64'}, "
                                f"{'Mb=%d freq-dependent walls' % args.mb if lossy else 'rigid walls'} "
-                               "(BASELINE.json configs[3])",
+                               f"({which})",
                    "grid": [sd.Nx, sd.Ny, sd.Nz], "Nb": sd.Nb, "Nbl": sd.Nbl, "Nba": sd.Nba,
                    "numerics": {0: "cpu-exact", 1: "fma", 2: "safeguarded"}.get(args.numerics, str(args.numerics)),
                    "parallelism": parallelism, "air_variant": args.variant},
@@ -264,7 +281,8 @@ def run_chain(args):
                    + (f"; VIRTUAL: the {N} slabs share {ndev} device(s) -- control-flow run, not a scaling figure" if virt else ""))
     res = base_result(args, sd, N, K, W, R, regions, el, real_bytes, lossy, parallelism)
     g0 = max(range(N), key=lambda g: slabs[g]["x1"] - slabs[g]["x0"])
-    rl, bpv, kernel_ms, units = roofline_block(args, sd, tms[g0], K, real_bytes, slabs[g0]["x1"] - slabs[g0]["x0"])
+    (_, ly, lz), _, _ = slabs[g0]["engine"].layout()  # stored rows x columns of a plane (exchanged axes: Ny x Nx)
+    rl, bpv, kernel_ms, units = roofline_block(args, sd, tms[g0], K, real_bytes, slabs[g0]["x1"] - slabs[g0]["x0"], (ly - 2) * (lz - 2))
     rl["slab"] = g0
     res["roofline"] = rl
     res["exchange_verified"] = info["exchange_verified"]

@@ -100,7 +100,9 @@ typedef struct pf_opts {
    int32_t debug;         /* test switches, 0 in production: 0x100 / 0x200 / 0x400 force 32- / 16- / 64-lane row segments; 0x4000 single
                              steps only (no blocked pairs); 0x8000 no creation-time measurement (static rules choose the kernel);
                              0x20000000 the boundary-list kernel visits every node (none left to the column-strip kernel); 0x1000 /
-                             0x2000 store the grid with the file's x and z axes exchanged / never (default: decided per scene) */
+                             0x2000 store the grid with the file's x and z axes exchanged / never (default: decided per scene);
+                             0x10000000 blocked pairs keep the single-step shell (no wall regions); 0x8000000 wall regions: every block
+                             generic; 0x4000000 all their launches on one stream; 0x2000000 wide column strips cut in two */
    int32_t energy;        /* 1 = keep what the energy diagnostic needs (explicit Laplacian grid, unfused kernel
                              sequence); then use pf_engine_energy_cfg + pf_engine_run_energy */
    int32_t multi_flags;   /* pf_run_sim_devices / pf_multi_create only: PF_MULTI_* */
@@ -140,6 +142,8 @@ typedef struct pf_timing {
    int64_t tb2_dirty_tiles; /* blocked pairs: tiles of the box that step singly (geometry or a source inside) */
    int64_t place_candidates;/* blocked pairs: grid placements timed at creation (0: none), and the two-steps-per-pass kernel's */
    double  place_ms[3];     /*   ms per launch on the first (as allocated), the chosen (fastest) and the slowest of them */
+   int64_t wall_blocks[2];  /* blocked pairs with the shell in pairs too (wall regions, pf_wall.h): blocks of the launches whose pencils
+                               are all alike / generic blocks (edges, corners); 0, 0: the shell takes single steps */
 } pf_timing;
 
 typedef struct pf_engine pf_engine;

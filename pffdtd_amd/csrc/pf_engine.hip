@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -49,7 +50,8 @@ extern "C" int pf__axis_exchange_pays(const pf_simdata *sd, int64_t *counts) {
    const int64_t fNx = sd->Nx, fNy = sd->Ny, fNz = sd->Nz;
    if (sd->Nb < 100000 || sd->Npts > ((int64_t)1 << 34) || fNx <= fNz) return 0; // (small scenes: nothing to gain; the bitmap below is Npts / 8 bytes)
    const int64_t NzNy = fNz * fNy;
-   std::vector<uint64_t> bits((size_t)(sd->Npts >> 6) + 1, 0);
+   std::vector<uint64_t> bits;
+   try { bits.assign((size_t)(sd->Npts >> 6) + 1, 0); } catch (const std::bad_alloc &) { return 0; } // (no room for the bitmap: file order; nothing may cross the C ABI)
    int64_t near_face = 0;
    for (int64_t i = 0; i < sd->Nb; i++) {
       const int64_t ii = sd->bn_ixyz[i];
@@ -242,10 +244,11 @@ template <typename Real> struct Engine : EngineBase {
    const int32_t *bnd_sel = nullptr;                      // launch_boundary visits bnd_sel[range] when set
    // wall regions (pf_wall.h): the shell of a blocked pair -- wall layers, ABC cells, ghost mirrors -- stepped in pairs too
    bool wl_on = false;
-   pf::WallRegion wl_sreg[4], wl_vreg[2];                 // regions normal to x / y (lanes along z), normal to z (lanes along y)
-   int wl_nsreg = 0, wl_nvreg = 0, wl_dpv = 0;            // wl_dpv: cells per pencil of the regions normal to z (12 | 20)
+   // launch groups: 0 = regions normal to x / y (lanes along z, pencils of 8 cells); 1 / 2 / 3 = regions normal to z (lanes along
+   // y) with vector pencils of 12 / 16 / 20 cells.  Each has a list of alike blocks and one of generic blocks.
+   struct WlGroup { int nreg = 0; pf::WallRegion reg[pf::WALL_MAXREG]; uint32_t blk0[3] = {0, 0, 0}, nblk[3] = {0, 0, 0}; }; // lists: alike, generic, alike without nodes
+   WlGroup wl_grp[4];
    uint4 *wl_blk = nullptr;                               // block lists of the four launches: strided / vector pencils x alike (fast) / generic
-   uint32_t wl_nblk[4] = {0, 0, 0, 0}, wl_blk0[4] = {0, 0, 0, 0};
    uint4 *wl_pen = nullptr;                               // per pencil: node mask, first record, adjacency / flags of the first five nodes (pf_wall.h)
    uint32_t *wl_rec = nullptr;                            // per node of a pencil: adjacency bits | lossy flag | lossy position
    int32_t *wl_rest = nullptr;                            // boundary nodes no wall region owns (inside the box): the list kernel's
@@ -895,7 +898,8 @@ template <typename Real> struct Engine : EngineBase {
    void free_walls() {
       auto F = [](auto *&p) { if (p) hipFree((void *)p); p = nullptr; };
       F(wl_pen); F(wl_rec); F(wl_rest); F(wl_blk); F(vh1b); F(gh1b);
-      wl_on = false; wl_nsreg = wl_nvreg = 0;
+      wl_on = false;
+      for (auto &g : wl_grp) g = WlGroup{};
    }
    int init_walls() {
       wl_on = false;
@@ -906,23 +910,15 @@ template <typename Real> struct Engine : EngineBase {
       constexpr int DPS = 8, V = pf::VecOf<Real>::V;
       if (tbx0 + 2 > DPS || Nx - tbx1 + 2 > DPS || tby0 + 2 > DPS || Ny - tby1 + 2 > DPS) return PF_OK;
       if (Nx < 2 * DPS || Ny < 2 * DPS) return PF_OK;
-      int dpv = 0, zb = 0;
-      for (int dp : {12, 20}) {
-         if (dp == 20 && sizeof(Real) != 4) break; // (fp64: 20 doubles per pencil and seven pencils do not fit the registers)
-         const int z = std::min((tbz1 - 2) / 4 * 4, (int)P - dp);
-         if (tbz0 + 2 <= dp && z >= 0 && z + dp >= Nz && tbz1 - z >= 2 && z % V == 0) { dpv = dp; zb = z; break; }
-      }
-      if (!dpv) return PF_OK;
       for (int64_t i = 0; i < Ns; i++) { // sources stay two cells inside the box
          int64_t ix, iy, iz;
          decode(sd.in_ixyz[i], ix, iy, iz);
          if (ix < tbx0 + 1 || ix > tbx1 - 2 || iy < tby0 + 1 || iy > tby1 - 2 || iz < tbz0 + 1 || iz > tbz1 - 2) return PF_OK;
       }
-      pf::WallRegion reg[6];
-      int dps[6];
-      auto mk = [&](int i, int mode, int nbase, int kg, int ko0, int ko1, int dp, int l0, int l1, int m0, int m1) {
-         pf::WallRegion &R = reg[i];
-         R = pf::WallRegion{};
+      std::vector<pf::WallRegion> reg;
+      std::vector<int> dps, grp;
+      auto mk = [&](int group, int mode, int nbase, int kg, int ko0, int ko1, int dp, int l0, int l1, int m0, int m1) {
+         pf::WallRegion R{};
          R.mode = mode; R.nbase = nbase; R.kg = kg; R.ko0 = ko0; R.ko1 = ko1;
          R.kb0 = std::max(ko0 - 2, 0); R.kb1 = std::min(ko1 + 2, dp);
          R.l0 = l0; R.l1 = l1; R.m0 = m0; R.m1 = m1;
@@ -930,16 +926,49 @@ template <typename Real> struct Engine : EngineBase {
          R.mchunk = (int)cdiv(len, nmc);
          R.nlt = (int)cdiv(l1 - l0, pf::WALL_LT);
          R.nlp = R.nlt * pf::WALL_LT + 4;
-         dps[i] = dp;
+         reg.push_back(R); dps.push_back(dp); grp.push_back(group);
       };
       mk(0, 0, 0, 0, 1, tbx0, DPS, 1, (int)Nz - 1, 1, (int)Ny - 1);
-      mk(1, 0, (int)Nx - DPS, DPS - 1, tbx1 - ((int)Nx - DPS), DPS - 1, DPS, 1, (int)Nz - 1, 1, (int)Ny - 1);
-      mk(2, 1, 0, 0, 1, tby0, DPS, 1, (int)Nz - 1, tbx0, tbx1);
-      mk(3, 1, (int)Ny - DPS, DPS - 1, tby1 - ((int)Ny - DPS), DPS - 1, DPS, 1, (int)Nz - 1, tbx0, tbx1);
-      mk(4, 2, 0, 0, 1, tbz0, dpv, tby0, tby1, tbx0, tbx1);
-      mk(5, 2, zb, (int)Nz - 1 - zb, tbz1 - zb, (int)Nz - 1 - zb, dpv, tby0, tby1, tbx0, tbx1);
+      mk(0, 0, (int)Nx - DPS, DPS - 1, tbx1 - ((int)Nx - DPS), DPS - 1, DPS, 1, (int)Nz - 1, 1, (int)Ny - 1);
+      mk(0, 1, 0, 0, 1, tby0, DPS, 1, (int)Nz - 1, tbx0, tbx1);
+      mk(0, 1, (int)Ny - DPS, DPS - 1, tby1 - ((int)Ny - DPS), DPS - 1, DPS, 1, (int)Nz - 1, tbx0, tbx1);
+      // The column strips.  A strip of up to 10 columns is one region with pencils of 12 cells; a wider one (a sliver of the box went
+      // to it) has pencils of 20 cells (fp32; ~350 registers, one wave per SIMD).  Cutting such a strip in two -- the 7 columns next
+      // to the face with the wall layers, 12-cell pencils, and the rest, plain air, 16-cell pencils without any node code, two
+      // waves per SIMD each -- was measured and LOSES (1024^3: 0.54 + 0.31 ms against 0.59 ms per pair; the strips' cost is the
+      // 64 separate lines behind every load and store instruction, not the occupancy): only where the wide pencils do not fit (odd
+      // widths, fp64) or with debug 0x2000000 (tests).
+      int zb = 0;
+      bool zok = true;
+      const bool prefer_split = (op.debug & 0x2000000) != 0 || sizeof(Real) != 4;
+      { // low side
+         const bool split_ok = tbz0 >= 10 && tbz0 + 2 - 4 <= 16, wide_ok = sizeof(Real) == 4 && tbz0 + 2 <= 20;
+         if (tbz0 + 2 <= 12) mk(1, 2, 0, 0, 1, tbz0, 12, tby0, tby1, tbx0, tbx1);
+         else if (split_ok && (prefer_split || !wide_ok)) {
+            mk(1, 2, 0, 0, 1, 8, 12, tby0, tby1, tbx0, tbx1);
+            mk(2, 2, 4, -1, 8 - 4, tbz0 - 4, 16, tby0, tby1, tbx0, tbx1);
+         } else if (wide_ok) mk(3, 2, 0, 0, 1, tbz0, 20, tby0, tby1, tbx0, tbx1);
+         else zok = false;
+      }
+      { // high side
+         const int z1 = std::min((tbz1 - 2) / 4 * 4, (int)P - 12);
+         const int zw = (int)round_up(Nz - 12, 4), s0 = zw + 2;   // wall part: pencil from column zw, owned from s0
+         const int z2 = (tbz1 - 2) / 4 * 4;                      // the rest: pencil from column z2
+         const int z20 = std::min((tbz1 - 2) / 4 * 4, (int)P - 20);
+         const bool split_ok = zw >= 0 && zw + 12 <= P && s0 > tbz1 && s0 + 2 - z2 <= 16 && z2 + 16 <= P && (int)Nz - 1 - zw <= 11;
+         const bool wide_ok = sizeof(Real) == 4 && z20 >= 0 && z20 + 20 >= Nz && tbz1 - z20 >= 2;
+         if (z1 >= 0 && z1 + 12 >= Nz && tbz1 - z1 >= 2) { zb = z1; mk(1, 2, z1, (int)Nz - 1 - z1, tbz1 - z1, (int)Nz - 1 - z1, 12, tby0, tby1, tbx0, tbx1); }
+         else if (split_ok && (prefer_split || !wide_ok)) {
+            zb = zw;
+            mk(1, 2, zw, (int)Nz - 1 - zw, 2, (int)Nz - 1 - zw, 12, tby0, tby1, tbx0, tbx1);
+            mk(2, 2, z2, -1, tbz1 - z2, s0 - z2, 16, tby0, tby1, tbx0, tbx1);
+         } else if (wide_ok) { zb = z20; mk(3, 2, z20, (int)Nz - 1 - z20, tbz1 - z20, (int)Nz - 1 - z20, 20, tby0, tby1, tbx0, tbx1); }
+         else zok = false;
+      }
+      if (!zok) return PF_OK;
+      const int nregs = (int)reg.size();
       int64_t npen = 0;
-      for (int i = 0; i < 6; i++) { reg[i].pen_off = npen; npen += (int64_t)(reg[i].m1 - reg[i].m0 + 2) * reg[i].nlp; }
+      for (int i = 0; i < nregs; i++) { reg[i].pen_off = npen; npen += (int64_t)(reg[i].m1 - reg[i].m0 + 2) * reg[i].nlp; }
       if (npen >= ((int64_t)1 << 31)) return PF_OK;
       // a node's place in a region's frame
       auto frame = [&](const pf::WallRegion &R, int64_t ix, int64_t iy, int64_t iz, int &k, int &lc, int &m) {
@@ -956,27 +985,27 @@ template <typename Real> struct Engine : EngineBase {
          HIPCHK(hipMemcpy(hl.data(), d_lossy, Nb * sizeof(int32_t), hipMemcpyDeviceToHost));
       }
       // owners, and the new order of the frequency-dependent nodes
-      std::vector<int8_t> owner(Nb, 6);
+      std::vector<int8_t> owner(Nb, 8);
       struct Key { int32_t r, m, lc, k, li; };
       std::vector<Key> keys;
       keys.reserve((size_t)Nbl);
       std::vector<int32_t> rest;
       for (int64_t nb = 0; nb < Nb; nb++) {
          const int64_t ix = hb[nb] / plane, rem = hb[nb] % plane, iy = rem / P, iz = rem % P;
-         int r = 6, k = 0, lc = 0, m = 0;
-         for (int i = 0; i < 6; i++) {
+         int r = 8, k = 0, lc = 0, m = 0;
+         for (int i = 0; i < nregs; i++) {
             int kk, ll, mm;
             frame(reg[i], ix, iy, iz, kk, ll, mm);
             if (kk >= reg[i].ko0 && kk < reg[i].ko1 && ll >= reg[i].l0 && ll < reg[i].l1 && mm >= reg[i].m0 && mm < reg[i].m1) { r = i; k = kk; lc = ll; m = mm; break; }
          }
          owner[nb] = (int8_t)r;
-         if (r == 6) rest.push_back((int32_t)nb);
+         if (r == 8) rest.push_back((int32_t)nb);
          if (hl[nb] >= 0) keys.push_back({r, m, lc, k, hl[nb]});
       }
       if ((int64_t)keys.size() != Nbl) return PF_OK; // (a lossy node that is no boundary node: fuse_boundary excludes it)
       std::stable_sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
          if (a.r != b.r) return a.r < b.r;
-         if (a.r == 6) return a.li < b.li;
+         if (a.r == 8) return a.li < b.li;
          if (a.m != b.m) return a.m < b.m;
          if (a.lc != b.lc) return a.lc < b.lc;
          return a.k < b.k;
@@ -989,7 +1018,7 @@ template <typename Real> struct Engine : EngineBase {
       auto visit = [&](auto &&fn) {
          for (int64_t nb = 0; nb < Nb; nb++) {
             const int64_t ix = hb[nb] / plane, rem = hb[nb] % plane, iy = rem / P, iz = rem % P;
-            for (int i = 0; i < 6; i++) {
+            for (int i = 0; i < nregs; i++) {
                const pf::WallRegion &R = reg[i];
                int k, lc, m;
                frame(R, ix, iy, iz, k, lc, m);
@@ -1038,15 +1067,19 @@ template <typename Real> struct Engine : EngineBase {
       }
       if ((rc = dzalloc(&vh1b, round_up(Nbl, 64) * PF_MMB))) return rc;
       if ((rc = dzalloc(&gh1b, round_up(Nbl, 64) * PF_MMB))) return rc;
-      wl_nsreg = 4; wl_nvreg = 2; wl_dpv = dpv;
-      for (int i = 0; i < 4; i++) wl_sreg[i] = reg[i];
-      for (int i = 4; i < 6; i++) wl_vreg[i - 4] = reg[i];
+      std::vector<uint32_t> rloc((size_t)nregs); // a region's place in its launch group
+      for (int i = 0; i < nregs; i++) {
+         WlGroup &g = wl_grp[grp[i]];
+         if (g.nreg >= pf::WALL_MAXREG) return PF_OK;
+         rloc[i] = (uint32_t)g.nreg;
+         g.reg[g.nreg++] = reg[i];
+      }
       // Block lists.  A block (lane tile x march chunk of a region) whose pencils all have the same structure and that touches no
       // ghost / ABC cell along its lane and march axes goes to the FAST launch with that structure attached; the others
       // (edges, corners, the ends of a march) to the generic one.
-      std::vector<uint4> lists[4]; // 0 strided fast, 1 strided generic, 2 vector fast, 3 vector generic
+      std::vector<uint4> lists[12]; // group g: 3 g alike, 3 g + 1 generic, 3 g + 2 alike and free of nodes
       int64_t nfast = 0, ngen = 0;
-      for (int i = 0; i < 6; i++) {
+      for (int i = 0; i < nregs; i++) {
          const pf::WallRegion &R = reg[i];
          const int NL = R.mode == 2 ? (int)Ny : (int)Nz, NM = R.mode == 0 ? (int)Ny : (int)Nx;
          const int nmc = (int)cdiv(R.m1 - R.m0, R.mchunk);
@@ -1064,21 +1097,21 @@ template <typename Real> struct Engine : EngineBase {
                      if (e.x != ref.x || e.z != ref.z || (e.w & 31u) != (ref.w & 31u) || (e.y >> 27) != (ref.y >> 27)) { fast = false; break; }
                   }
                }
-               const uint32_t rl = (uint32_t)(i < 4 ? i : i - 4);
+               const uint32_t rl = rloc[i];
                const uint4 b = make_uint4(rl | ((uint32_t)jt << 3) | ((uint32_t)c << 16), ref.x, ref.z, (ref.w & 31u) | ((ref.y >> 27) << 8));
-               lists[(i < 4 ? 0 : 2) + (fast ? 0 : 1)].push_back(b);
+               lists[3 * grp[i] + (fast ? (ref.x == 0u && R.mode == 2 ? 2 : 0) : 1)].push_back(b);
                (fast ? nfast : ngen)++;
             }
       }
       {
          std::vector<uint4> all;
-         for (int q = 0; q < 4; q++) { wl_blk0[q] = (uint32_t)all.size(); wl_nblk[q] = (uint32_t)lists[q].size(); all.insert(all.end(), lists[q].begin(), lists[q].end()); }
+         for (int q = 0; q < 12; q++) { wl_grp[q / 3].blk0[q % 3] = (uint32_t)all.size(); wl_grp[q / 3].nblk[q % 3] = (uint32_t)lists[q].size(); all.insert(all.end(), lists[q].begin(), lists[q].end()); }
          if ((rc = upload(&wl_blk, all.data(), (int64_t)all.size()))) return rc;
       }
       wl_on = true;
       if (getenv("PFFDTD_VERBOSE") && atoi(getenv("PFFDTD_VERBOSE")) > 0)
          fprintf(stderr, "pffdtd_hip: wall regions: box x [%d,%d) y [%d,%d) z [%d,%d), %ld pencils, %ld node records, %ld of %ld boundary nodes left to the list kernel, column pencils of %d cells from column %d; %ld blocks alike, %ld generic\n",
-                 tbx0, tbx1, tby0, tby1, tbz0, tbz1, (long)npen, (long)nrec, (long)wl_nrest, (long)Nb, dpv, zb, (long)nfast, (long)ngen);
+                 tbx0, tbx1, tby0, tby1, tbz0, tbz1, (long)npen, (long)nrec, (long)wl_nrest, (long)Nb, dps.back(), zb, (long)nfast, (long)ngen);
       return PF_OK;
    }
    // both steps of the wall regions: A = u^{n-1}, B = u^n -> C = u^{n+1}, D = u^{n+2}; branch state vh1 / gh1 -> vh1b / gh1b;
@@ -1093,22 +1126,23 @@ template <typename Real> struct Engine : EngineBase {
       wp.x2 = P2; wp.x1 = P1; wp.o1 = P0; wp.o2 = P1;
       wp.ssaf = d_ssaf; wp.mat = d_mat; wp.Mb = d_Mb; wp.mq = d_mq; wp.beta = d_beta;
       wp.lo2 = lo2; wp.sl2 = sl2; wp.l = l; wp.mmax = mb_max; wp.nmat = sd.Nm;
-      wp.nreg = wl_nsreg;
-      for (int i = 0; i < wl_nsreg; i++) wp.reg[i] = wl_sreg[i];
-      if (wl_nblk[0]) { wp.blk = wl_blk + wl_blk0[0]; hipLaunchKernelGGL((pf::k_wall2<Real, 8, false, true>), dim3(wl_nblk[0]), dim3(64), 0, s, wp, a1, a2); }
-      if (wl_nblk[1]) { wp.blk = wl_blk + wl_blk0[1]; hipLaunchKernelGGL((pf::k_wall2<Real, 8, false, false>), dim3(wl_nblk[1]), dim3(64), 0, sg, wp, a1, a2); }
-      wp.nreg = wl_nvreg;
-      for (int i = 0; i < wl_nvreg; i++) wp.reg[i] = wl_vreg[i];
-      for (int q = 2; q < 4; q++) {
-         if (!wl_nblk[q]) continue;
-         wp.blk = wl_blk + wl_blk0[q];
-         const dim3 g(wl_nblk[q]), b(64);
-         if (wl_dpv == 12) {
-            if (q == 2) hipLaunchKernelGGL((pf::k_wall2<Real, 12, true, true>), g, b, 0, s, wp, a1, a2);
-            else hipLaunchKernelGGL((pf::k_wall2<Real, 12, true, false>), g, b, 0, sg, wp, a1, a2);
-         } else if constexpr (sizeof(Real) == 4) {
-            if (q == 2) hipLaunchKernelGGL((pf::k_wall2<Real, 20, true, true>), g, b, 0, s, wp, a1, a2);
-            else hipLaunchKernelGGL((pf::k_wall2<Real, 20, true, false>), g, b, 0, sg, wp, a1, a2);
+      for (int gi = 0; gi < 4; gi++) {
+         const WlGroup &g = wl_grp[gi];
+         wp.nreg = g.nreg;
+         for (int i = 0; i < g.nreg; i++) wp.reg[i] = g.reg[i];
+         for (int q = 0; q < 3; q++) { // alike blocks, generic blocks, alike blocks without nodes (column strips only)
+            if (!g.nblk[q]) continue;
+            wp.blk = wl_blk + g.blk0[q];
+            const dim3 gd(g.nblk[q]), b(64);
+            hipStream_t st = q == 1 ? sg : s;
+#define PF_WALL(DP, VEC) do { if (q == 0) hipLaunchKernelGGL((pf::k_wall2<Real, DP, VEC, true>), gd, b, 0, st, wp, a1, a2); \
+                              else if (q == 1) hipLaunchKernelGGL((pf::k_wall2<Real, DP, VEC, false>), gd, b, 0, st, wp, a1, a2); \
+                              else if constexpr (VEC) hipLaunchKernelGGL((pf::k_wall2<Real, DP, VEC, true, false>), gd, b, 0, st, wp, a1, a2); } while (0)
+            if (gi == 0) PF_WALL(8, false);
+            else if (gi == 1) PF_WALL(12, true);
+            else if (gi == 2) PF_WALL(16, true);
+            else if constexpr (sizeof(Real) == 4) PF_WALL(20, true);
+#undef PF_WALL
          }
       }
    }
@@ -2378,6 +2412,9 @@ template <typename Real> struct Engine : EngineBase {
          tm.place_ms[1] = *std::min_element(place_ms.begin(), place_ms.end());
          tm.place_ms[2] = *std::max_element(place_ms.begin(), place_ms.end());
       }
+      tm.wall_blocks[0] = tm.wall_blocks[1] = 0;
+      if (wl_on)
+         for (const WlGroup &g : wl_grp) { tm.wall_blocks[0] += g.nblk[0] + g.nblk[2]; tm.wall_blocks[1] += g.nblk[1]; }
       if (t) *t = tm;
       if (reset) tm = pf_timing{};
       return PF_OK;

@@ -257,11 +257,13 @@ struct Rccl {
       cand.push_back("librccl.so");
       void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
       if (lib) where = "librccl.so.1 (already loaded)";
+      std::string last_err; // (dlerror() hands its message out once and clears it: read it right after the failing call)
       for (size_t i = 0; i < cand.size() && !lib; i++) {
          lib = dlopen(cand[i].c_str(), RTLD_NOW | RTLD_LOCAL);
          if (lib) where = cand[i];
+         else if (const char *de = dlerror()) last_err = de;
       }
-      if (!lib) { err = std::string("librccl not found (") + (dlerror() ? dlerror() : "dlopen failed") + "); PFFDTD_RCCL_LIB names it explicitly"; return false; }
+      if (!lib) { err = std::string("librccl not found (") + (last_err.empty() ? "dlopen failed" : last_err.c_str()) + "); PFFDTD_RCCL_LIB names it explicitly"; return false; }
 #define PF_SYM(field, name) field = (decltype(field))dlsym(lib, name); if (!field) { err = std::string("librccl: symbol ") + name + " missing"; dlclose(lib); return false; }
       PF_SYM(CommInitAll, "ncclCommInitAll") PF_SYM(CommDestroy, "ncclCommDestroy") PF_SYM(GroupStart, "ncclGroupStart")
       PF_SYM(GroupEnd, "ncclGroupEnd") PF_SYM(Send, "ncclSend") PF_SYM(Recv, "ncclRecv")
@@ -326,6 +328,7 @@ struct Shared {
    std::vector<int> rank;                                        // [g] peer rank of slab g in the clique
    // exchange self-check: the first `verify_n` exchanges after creation
    int64_t verify_n = 0;
+   int64_t drop_step = -1; // test hook (PFFDTD_TEST_DROP_EXCHANGE=n): slab 1 misses the planes of step n; the self-check then always covers that step
    std::vector<int64_t> steps_done;                              // [g]
    std::vector<uint64_t> sums;                                   // [g*4 + {send_lo, send_hi, recv_lo, recv_hi}]
    std::vector<std::vector<uint8_t>> hbuf;                       // [g] host staging for the checksums
@@ -386,7 +389,8 @@ void create_slab(Shared &S, int g) {
    // temporally blocked pairs need all four grids in the caller's hands (pf_engine_set_spares); worth it for slabs of
    // >= 96 planes (measured)
    const int flags = S.base.multi_flags;
-   const bool want_pairs = !(flags & PF_MULTI_NO_PAIRS) && ((flags & PF_MULTI_FORCE_PAIRS) || (S.along_z ? sl.sd.Nz : sl.sd.Nx) - 2 >= 96);
+   // (a chain cut along file z stores its grids with the axes exchanged, which steps singly: no pool, no placement search)
+   const bool want_pairs = !S.along_z && !(flags & PF_MULTI_NO_PAIRS) && ((flags & PF_MULTI_FORCE_PAIRS) || sl.sd.Nx - 2 >= 96);
    for (int k = 0; k < 2; k++) {
       void *p = nullptr;
       MCHK(g, hipMalloc(&p, gb));
@@ -488,6 +492,8 @@ int choose_transport(Shared &S, int requested) {
    ncclResult_t r = ncclSuccess;
    // RCCL greets with a version banner on STDOUT when NCCL_DEBUG asks for one; a host that prints machine-readable results
    // there (bench.py: one JSON line) must not find it in between: stdout points at stderr while the communicators are made
+   // (process-wide and not thread-safe: another thread of the host writing to stdout in this window lands on stderr; chains
+   // are created from one thread, before the time loop)
    fflush(stdout);
    const int saved_out = dup(1);
    if (saved_out >= 0) dup2(2, 1);
@@ -531,8 +537,7 @@ void phase_pull(Shared &S, int g, int64_t n) {
                                             : hipMemcpyPeerAsync(dst, d, src, S.dev[nb], S.plane_bytes, S.edge[g]);
       if (e != hipSuccess) S.set_error(PF_ERR_HIP, hipGetErrorString(e));
    };
-   static const int64_t drop = getenv("PFFDTD_TEST_DROP_EXCHANGE") ? atoll(getenv("PFFDTD_TEST_DROP_EXCHANGE")) : -1; // test hook: slab 1 misses the planes of that step, the self-check must notice
-   if (drop >= 0 && g == 1 && n == drop) return;
+   if (S.drop_step >= 0 && g == 1 && n == S.drop_step) return; // (test hook: the self-check must notice)
    if (g > 0) pull(g - 1, S.recv_lo[k][g], S.send_hi[k][g - 1]);         // left neighbour's last owned plane -> my plane 0
    if (g < S.G - 1) pull(g + 1, S.recv_hi[k][g], S.send_lo[k][g + 1]);   // right neighbour's first owned plane -> my last plane
 }
@@ -769,6 +774,10 @@ int pf_multi_create(pf_simdata *sd, int32_t nslabs, const int32_t *devices, cons
    S.plane_bytes = S.along_z ? pf_grid_bytes(1, sd->Ny, sd->Nx, sd->real_bytes) : pf_grid_bytes(1, sd->Ny, sd->Nz, sd->real_bytes);
    S.verify_n = S.base.verify_exchange > 0 ? S.base.verify_exchange : 0;
    if (const char *ev = getenv("PFFDTD_VERIFY_EXCHANGE")) S.verify_n = std::max(atoi(ev), 0);
+   if (const char *ev = getenv("PFFDTD_TEST_DROP_EXCHANGE")) { // fault injection for the tests: never without the check that must catch it
+      S.drop_step = atoll(ev);
+      if (S.drop_step >= 0) S.verify_n = std::max<int64_t>(S.verify_n, S.drop_step + 2);
+   }
    S.sums.assign((size_t)G * 4, 0);
    S.hbuf.resize(G);
    if (rc == PF_OK) rc = choose_transport(S, S.base.transport);

@@ -138,7 +138,8 @@ __device__ __forceinline__ Real fd_regs(Real p, Real u2, Real sf, int32_t k, con
 // cells with the same adjacency, at most one frequency-dependent node -- and no ghost or ABC cell along the lane and march
 // axes: walls away from edges and corners, the bulk of the work.  The structure then arrives with the block (ds*) and the
 // per-lane node decoding, the node loop, the lane shuffles and the march-axis mirrors are compiled out.
-template <typename Real, int DP, int MODE, bool FAST>
+// NODES = false (FAST only): none of the block's pencils holds a boundary node (the plain-air part of a wide column strip).
+template <typename Real, int DP, int MODE, bool FAST, bool NODES>
 __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const WallRegion &R, const int j, const int c, const Real a1, const Real a2,
                                           const WallLds<Real> *ldsp, const uint32_t dsx, const uint32_t dsz, const uint32_t dsw) {
    constexpr bool VEC = MODE == 2;
@@ -204,6 +205,7 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
    };
    auto load_ent = [&](int m) __attribute__((always_inline)) { // march steps R.m0-1 .. R.m1 have entries
       const uint4 *e = wp.pen + (R.pen_off + (int64_t)(min(m, R.m1) - (R.m0 - 1)) * R.nlp + (WALL_LT * j + lane));
+      if (FAST && !NODES) return make_uint4(0u, 0u, 0u, 0u);
       if (FAST) return make_uint4(0u, 0u, 0u, e->w); // (only the place of the frequency-dependent node differs from lane to lane)
       return *e;
    };
@@ -232,7 +234,7 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
    };
    // the branch state and parameters of a pencil's first frequency-dependent node, ahead of its stage 1
    auto fd_fetch = [&](const uint4 E, Real(&v)[12], Real(&g)[12], Real &sf, Real &u2, Real &x1v, int32_t &k) __attribute__((always_inline)) {
-      if ((E.w & 31u) != 0u) {
+      if (NODES && (E.w & 31u) != 0u) {
          const int32_t li = (int32_t)(E.w >> 8);
 #pragma unroll
          for (int m = 0; m < 12; m++)
@@ -270,8 +272,8 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
       st = false;
       // Do all the pencils of the wave look alike (same node cells, same adjacency, at most one frequency-dependent node, all
       // within the entry)?  Walls away from edges and corners: then the structure is decoded once, in scalar registers.
-      const uint32_t sx = FAST ? usx : __builtin_amdgcn_readlane(E.x, 1), sz = FAST ? usz : __builtin_amdgcn_readlane(E.z, 1);
-      const uint32_t sw5 = FAST ? (usw & 31u) : (__builtin_amdgcn_readlane(E.w, 1) & 31u), sk0 = FAST ? (usw >> 8) : (__builtin_amdgcn_readlane(E.y, 1) >> 27);
+      const uint32_t sx = !NODES ? 0u : FAST ? usx : __builtin_amdgcn_readlane(E.x, 1), sz = FAST ? usz : __builtin_amdgcn_readlane(E.z, 1);
+      const uint32_t sw5 = !NODES ? 0u : FAST ? (usw & 31u) : (__builtin_amdgcn_readlane(E.w, 1) & 31u), sk0 = FAST ? (usw >> 8) : (__builtin_amdgcn_readlane(E.y, 1) >> 27);
       bool alike = true;
       if (!FAST) {
          const bool differs = eval_lane && (E.x != sx || E.z != sz || (E.w & 31u) != sw5 || (E.y >> 27) != sk0);
@@ -451,18 +453,21 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
 
 // One launch = a list of blocks (WallParams::blk: region | lane tile << 3 | march chunk << 16, and for FAST launches the common
 // structure of the block's pencils).  !VEC: regions normal to x and y (lanes along z); VEC: regions normal to z.
-template <typename Real, int DP, bool VEC, bool FAST>
-__global__ __launch_bounds__(64) void k_wall2(WallParams<Real> wp, Real a1, Real a2) {
+template <typename Real, int DP, bool VEC, bool FAST, bool NODES = true>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FAST && DP * sizeof(Real) <= 64) ? 2 : 1))) void k_wall2(WallParams<Real> wp, Real a1, Real a2) {
+   static_assert(FAST || NODES, "generic blocks have everything");
    const uint4 bd = wp.blk[blockIdx.x];
    const WallRegion R = wp.reg[bd.x & 7u];
    const int j = (int)((bd.x >> 3) & 0x1fffu), c = (int)(bd.x >> 16);
    __shared__ WallLds<Real> lds;
-   for (int i = threadIdx.x; i < wp.nmat * 12; i += 64) lds.mq[i] = wp.mq[i];
-   for (int i = threadIdx.x; i < wp.nmat; i += 64) { lds.beta[i] = wp.beta[i]; lds.M[i] = wp.Mb[i]; }
-   __syncthreads();
-   if constexpr (VEC) wall_body<Real, DP, 2, FAST>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
-   else if (R.mode == 1) wall_body<Real, DP, 1, FAST>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
-   else wall_body<Real, DP, 0, FAST>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
+   if (NODES) {
+      for (int i = threadIdx.x; i < wp.nmat * 12; i += 64) lds.mq[i] = wp.mq[i];
+      for (int i = threadIdx.x; i < wp.nmat; i += 64) { lds.beta[i] = wp.beta[i]; lds.M[i] = wp.Mb[i]; }
+      __syncthreads();
+   }
+   if constexpr (VEC) wall_body<Real, DP, 2, FAST, NODES>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
+   else if (R.mode == 1) wall_body<Real, DP, 1, FAST, NODES>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
+   else wall_body<Real, DP, 0, FAST, NODES>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
 }
 
 } // namespace pf

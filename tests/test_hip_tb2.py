@@ -210,3 +210,76 @@ def test_fcc_blocked_pairs_with_live_abc_and_odd_sizes():
     _, base_g, _ = run(sim, 0, debug=0x4000)
     for a, b in zip(g, base_g):
         assert np.array_equal(a[1:-1, 1:-1, 1:-1], b[1:-1, 1:-1, 1:-1])
+
+
+# ---- wall regions (pf_wall.h): the shell of a blocked pair in pairs too --------------------------------------------------
+WALL_MODES = [(0, "default"), (0x8000000, "all_generic"), (0x4000000, "one_stream"), (0x2000000, "split_strips"), (0x10000000, "single_step_shell")]
+
+
+@pytest.mark.parametrize("prec", ["single", "double"])
+@pytest.mark.parametrize("dbg,label", WALL_MODES, ids=[m[1] for m in WALL_MODES])
+def test_wall_regions_give_the_oracles_bits(prec, dbg, label):
+    """k_wall2 steps the wall layers, ABC cells and ghost mirrors around the box twice per pass (branch state double-buffered,
+    blocks of alike pencils decoded in scalar registers, the others generically): receivers equal the oracle's, whole fields
+    the single-step engine's -- three materials mixed along the walls, 11 / 3 / 7 branches (generic mode: every 13th lossy node
+    rigid, so that no two neighbouring pencils look alike)."""
+    n = (38, 66, 280)
+    sim = synth.shoebox(*n, Nt=63, Nm=3, Mb=[11, 3, 7], rigid_every=13 if dbg == 0x8000000 else 0, src=[19, 30, 140],
+                        rcv=[[19, 33, 150], [5, 29, 141], [32, 31, 139], [18, 5, 142], [20, 60, 138]])  # next to four walls
+    ref = sim_data.SimData.from_sim(sim, prec)
+    ref.scale_input()
+    oracle.run_sim(ref)
+    assert (np.abs(ref.u_out[::8]).max(axis=1) > 0).all()
+    _, base_g, _ = run(sim, 25, prec=prec)
+    for chunk in (0, 6):
+        out, g, tm = run(sim, 40, prec=prec, readout_chunk=chunk, debug=dbg)
+        assert tm["tb2_launches"] > 0 and tm["steps"] == 63
+        if dbg == 0x10000000:
+            assert tm["wall_blocks"] == [0, 0]
+        elif dbg == 0x8000000:
+            assert tm["wall_blocks"][0] == 0 and tm["wall_blocks"][1] > 0
+        else:
+            assert tm["wall_blocks"][0] > 0 and tm["wall_blocks"][1] > 0, tm
+        assert np.array_equal(out, ref.u_out), (label, chunk)
+        for a, b in zip(g, base_g):
+            assert np.array_equal(a[1:-1, 1:-1, 1:-1], b[1:-1, 1:-1, 1:-1]), (label, chunk)
+
+
+@pytest.mark.parametrize("n,wall", [((37, 67, 283), 3), ((41, 75, 291), 5), ((36, 64, 325), 3), ((40, 70, 571), 4)],
+                         ids=["odd", "deep_walls", "sliver", "two_tiles"])
+def test_wall_regions_from_random_fields(n, wall):
+    """Every cell live from step 0 (seeded random u^{n-1}, u^n): ghost mirrors on all three axes, ABC faces / edges / corners,
+    both wall layers on every face, odd sizes.  Pairs with wall regions against the single-step engine, all cells."""
+    sim = scene([n[0] // 2, n[1] // 2 - 3, n[2] // 2 + 5], Nt=10, n=n, wall=wall)
+    rng = np.random.default_rng(17)
+    init = [(rng.standard_normal(n) * 1e-2).astype(np.float32) for _ in range(2)]
+    fields = {}
+    for variant, dbg in ((25, 0), (40, 0), (40, 0x8000000)):
+        sd = sim_data.SimData.from_sim(sim, "single", build_mask=False)
+        sd.scale_input()
+        eng = engine.HipEngine(sd, air_variant=variant, timing=True, debug=dbg)
+        for k in (0, 1):
+            eng.set_grid(k, init[k])
+        eng.run(0, sd.Nt)
+        tm = eng.timing()
+        fields[(variant, dbg)] = (sd.u_out.copy(), eng.get_grid(0).copy(), eng.get_grid(1).copy())
+        eng.close()
+        if variant == 40:
+            assert sum(tm["wall_blocks"]) > 0
+    base = fields[(25, 0)]
+    for key, f in fields.items():
+        assert np.array_equal(f[0], base[0]), key
+        for a, b in zip(f[1:], base[1:]):
+            assert np.array_equal(a[1:-1, 1:-1, 1:-1], b[1:-1, 1:-1, 1:-1]), key
+
+
+def test_wall_regions_step_aside_for_a_source_in_the_shell():
+    """A source within a cell of the shell is added between the two steps, which a region that keeps u^{n+1} in registers cannot
+    see: such scenes keep the single-step shell (and the oracle's bits)."""
+    sim = scene([18, 8, 12], Nt=12)
+    ref = sim_data.SimData.from_sim(sim, "single")
+    ref.scale_input()
+    oracle.run_sim(ref)
+    out, _, tm = run(sim, 40)
+    assert tm["tb2_launches"] > 0 and tm["wall_blocks"] == [0, 0]
+    assert np.array_equal(out, ref.u_out)
