@@ -684,9 +684,13 @@ template <typename Real> struct Engine : EngineBase {
          const int z1full = (int)((Nz - mz1) / 4 * 4);
          if (tbz1 < z1full) {
             const int rem = z1full - tbz1;
+            // (the shift that lets both strips become wall regions with the fewest pencils cut in two; else the most even one)
+            const bool ps = (op.debug & 0x2000000) != 0 || sizeof(Real) != 4;
             int best_sh = 0, best_need = 1 << 30;
             for (int sh = 0; sh <= rem; sh += 4) {
-               const int need = std::max(tbz0 + sh + 2, (int)Nz - ((tbz1 + sh - 2) / 4 * 4));
+               const int lo = wl_lo_option(tbz0 + sh, ps), hi = wl_hi_option(tbz1 + sh, ps);
+               int need = std::max(tbz0 + sh + 2, (int)Nz - ((tbz1 + sh - 2) / 4 * 4));
+               need += (lo && hi) ? ((lo == 2) + (hi == 2)) * 100 : 1000;
                if (need < best_need) { best_need = need; best_sh = sh; }
             }
             tbz0 += best_sh; tbz1 += best_sh;
@@ -895,6 +899,24 @@ template <typename Real> struct Engine : EngineBase {
    // round 2 runs (debug 0x10000000 forces that).
    // The frequency-dependent nodes are renumbered region by region in the order the lanes visit them (march, lane, pencil
    // cell), so that a wave's branch-state accesses are contiguous; the nodes inside the box follow in list order.
+   // How a column strip becomes wall regions (0: it does not fit): 1 = one region with 12-cell pencils (strips of up to 10
+   // columns), 3 = one region with 20-cell pencils (fp32), 2 = cut in two: the 7 columns next to the face, 12-cell pencils, and
+   // the rest, plain air, 16-cell pencils.  t0 / t1: first / one past the last column of the box.
+   int wl_lo_option(int t0, bool prefer_split) const {
+      const bool split_ok = t0 >= 10 && t0 + 2 - 4 <= 16, wide_ok = sizeof(Real) == 4 && t0 + 2 <= 20;
+      if (t0 + 2 <= 12) return 1;
+      if (split_ok && (prefer_split || !wide_ok)) return 2;
+      return wide_ok ? 3 : 0;
+   }
+   int wl_hi_option(int t1, bool prefer_split) const {
+      const int z1 = std::min((t1 - 2) / 4 * 4, (int)P - 12), zw = (int)round_up(Nz - 12, 4), s0 = zw + 4, z2 = (t1 - 2) / 4 * 4; // (s0: whole vectors are stored)
+      const int z20 = std::min((t1 - 2) / 4 * 4, (int)P - 20);
+      const bool split_ok = zw >= 0 && zw + 12 <= P && s0 > t1 && s0 + 2 - z2 <= 16 && z2 + 16 <= P && (int)Nz - 1 - zw <= 11;
+      const bool wide_ok = sizeof(Real) == 4 && z20 >= 0 && z20 + 20 >= Nz && t1 - z20 >= 2;
+      if (z1 >= 0 && z1 + 12 >= Nz && t1 - z1 >= 2) return 1;
+      if (split_ok && (prefer_split || !wide_ok)) return 2;
+      return wide_ok ? 3 : 0;
+   }
    void free_walls() {
       auto F = [](auto *&p) { if (p) hipFree((void *)p); p = nullptr; };
       F(wl_pen); F(wl_rec); F(wl_rest); F(wl_blk); F(vh1b); F(gh1b);
@@ -942,27 +964,26 @@ template <typename Real> struct Engine : EngineBase {
       bool zok = true;
       const bool prefer_split = (op.debug & 0x2000000) != 0 || sizeof(Real) != 4;
       { // low side
-         const bool split_ok = tbz0 >= 10 && tbz0 + 2 - 4 <= 16, wide_ok = sizeof(Real) == 4 && tbz0 + 2 <= 20;
-         if (tbz0 + 2 <= 12) mk(1, 2, 0, 0, 1, tbz0, 12, tby0, tby1, tbx0, tbx1);
-         else if (split_ok && (prefer_split || !wide_ok)) {
+         const int opt = wl_lo_option(tbz0, prefer_split);
+         if (opt == 1) mk(1, 2, 0, 0, 1, tbz0, 12, tby0, tby1, tbx0, tbx1);
+         else if (opt == 2) {
             mk(1, 2, 0, 0, 1, 8, 12, tby0, tby1, tbx0, tbx1);
             mk(2, 2, 4, -1, 8 - 4, tbz0 - 4, 16, tby0, tby1, tbx0, tbx1);
-         } else if (wide_ok) mk(3, 2, 0, 0, 1, tbz0, 20, tby0, tby1, tbx0, tbx1);
+         } else if (opt == 3) mk(3, 2, 0, 0, 1, tbz0, 20, tby0, tby1, tbx0, tbx1);
          else zok = false;
       }
       { // high side
          const int z1 = std::min((tbz1 - 2) / 4 * 4, (int)P - 12);
-         const int zw = (int)round_up(Nz - 12, 4), s0 = zw + 2;   // wall part: pencil from column zw, owned from s0
+         const int zw = (int)round_up(Nz - 12, 4), s0 = zw + 4;   // wall part: pencil from column zw, owned from s0 (whole vectors are stored)
          const int z2 = (tbz1 - 2) / 4 * 4;                      // the rest: pencil from column z2
          const int z20 = std::min((tbz1 - 2) / 4 * 4, (int)P - 20);
-         const bool split_ok = zw >= 0 && zw + 12 <= P && s0 > tbz1 && s0 + 2 - z2 <= 16 && z2 + 16 <= P && (int)Nz - 1 - zw <= 11;
-         const bool wide_ok = sizeof(Real) == 4 && z20 >= 0 && z20 + 20 >= Nz && tbz1 - z20 >= 2;
-         if (z1 >= 0 && z1 + 12 >= Nz && tbz1 - z1 >= 2) { zb = z1; mk(1, 2, z1, (int)Nz - 1 - z1, tbz1 - z1, (int)Nz - 1 - z1, 12, tby0, tby1, tbx0, tbx1); }
-         else if (split_ok && (prefer_split || !wide_ok)) {
+         const int opt = wl_hi_option(tbz1, prefer_split);
+         if (opt == 1) { zb = z1; mk(1, 2, z1, (int)Nz - 1 - z1, tbz1 - z1, (int)Nz - 1 - z1, 12, tby0, tby1, tbx0, tbx1); }
+         else if (opt == 2) {
             zb = zw;
-            mk(1, 2, zw, (int)Nz - 1 - zw, 2, (int)Nz - 1 - zw, 12, tby0, tby1, tbx0, tbx1);
+            mk(1, 2, zw, (int)Nz - 1 - zw, 4, (int)Nz - 1 - zw, 12, tby0, tby1, tbx0, tbx1);
             mk(2, 2, z2, -1, tbz1 - z2, s0 - z2, 16, tby0, tby1, tbx0, tbx1);
-         } else if (wide_ok) { zb = z20; mk(3, 2, z20, (int)Nz - 1 - z20, tbz1 - z20, (int)Nz - 1 - z20, 20, tby0, tby1, tbx0, tbx1); }
+         } else if (opt == 3) { zb = z20; mk(3, 2, z20, (int)Nz - 1 - z20, tbz1 - z20, (int)Nz - 1 - z20, 20, tby0, tby1, tbx0, tbx1); }
          else zok = false;
       }
       if (!zok) return PF_OK;
