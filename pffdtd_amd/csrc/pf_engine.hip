@@ -944,7 +944,9 @@ template <typename Real> struct Engine : EngineBase {
          R.mode = mode; R.nbase = nbase; R.kg = kg; R.ko0 = ko0; R.ko1 = ko1;
          R.kb0 = std::max(ko0 - 2, 0); R.kb1 = std::min(ko1 + 2, dp);
          R.l0 = l0; R.l1 = l1; R.m0 = m0; R.m1 = m1;
-         const int len = m1 - m0, nmc = (int)std::max<int64_t>(cdiv(len, 16), 1);
+         int want = 16;
+         if (const char *ev = getenv("PFFDTD_WALL_CHUNK")) want = std::max(atoi(ev), 2); // (experiments)
+         const int len = m1 - m0, nmc = (int)std::max<int64_t>(cdiv(len, want), 1);
          R.mchunk = (int)cdiv(len, nmc);
          R.nlt = (int)cdiv(l1 - l0, pf::WALL_LT);
          R.nlp = R.nlt * pf::WALL_LT + 4;
