@@ -231,7 +231,9 @@ def base_result(args, sd, world, K, W, R, regions, el, real_bytes, lossy, parall
 # ------------------------------------------------------------------------------------------------------------------
 # N > 1 from ONE plain process: the C seam's chain object (pf_multi_*), one host thread per slab
 # ------------------------------------------------------------------------------------------------------------------
-def run_chain(args):
+def run_chain(args, only=None):
+    """only = (r, N): the cost model of rank r of an N-rank chain on ONE device -- the chain is cut as usual, slab r alone is
+    instantiated (pf_opts.only_slab) and exchanges its own edge planes with itself through the chosen transport."""
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     from pffdtd_amd import engine
@@ -239,15 +241,20 @@ def run_chain(args):
     if not torch.cuda.is_available() or ndev == 0:
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
     N, K, W, R = args.gpus, args.steps, args.warmup, max(args.repeats, 1)
-    devices = list(range(N)) if ndev >= N else [i % ndev for i in range(N)]
+    if only:
+        N = only[1]
+    devices = [0] * N if only else (list(range(N)) if ndev >= N else [i % ndev for i in range(N)])
     lossy = not args.rigid
     real_bytes = 4 if args.precision == "single" else 8
     sd = build_scene(args.size, (R + 1) * K + W, args.precision, args.fcc, lossy, args.mb, args.nx, args.ny)
     transport = {"auto": engine.PF_TRANSPORT_AUTO, "peer": engine.PF_TRANSPORT_PEER, "rccl": engine.PF_TRANSPORT_RCCL}[args.transport]
+    if only:
+        transport = engine.PF_TRANSPORT_RCCL if args.emulate_transport == "rccl" else engine.PF_TRANSPORT_PEER
     m = engine.HipMulti(sd, devices, numerics=args.numerics, air_variant=args.variant, air_chunk=args.chunk, debug=args.debug,
-                        transport=transport, verify_exchange=min(W, 4))
-    slabs = [m.slab(g) for g in range(N)]
-    for g, sl in enumerate(slabs):
+                        transport=transport, verify_exchange=0 if only else min(W, 4), only_slab=(only[0] + 1) if only else 0)
+    live = [only[0]] if only else list(range(N))
+    slabs = [m.slab(g) for g in live]
+    for g, sl in zip(live, slabs):
         (nloc, ny, _), pitch, _ = sl["engine"].layout()
         fill_engine_grids(torch, sl["engine"], nloc, ny * pitch, real_bytes, sl["device"], 1234 + g)
 
@@ -267,7 +274,7 @@ def run_chain(args):
     regions = [timed_region(W + r * K) for r in range(R)]
     el = sorted(regions)[len(regions) // 2]
     info = m.info()
-    if not np.isfinite(sd.u_out[:, :W + R * K]).all():
+    if not only and not np.isfinite(sd.u_out[:, :W + R * K]).all():
         raise SystemExit("bench: non-finite receiver samples")
     # kernel durations: one more region with per-launch events on
     for sl in slabs:
@@ -280,12 +287,18 @@ def run_chain(args):
                    "on the edge stream while the interior planes run"
                    + (f"; VIRTUAL: the {N} slabs share {ndev} device(s) -- control-flow run, not a scaling figure" if virt else ""))
     res = base_result(args, sd, N, K, W, R, regions, el, real_bytes, lossy, parallelism)
-    g0 = max(range(N), key=lambda g: slabs[g]["x1"] - slabs[g]["x0"])
+    if only:
+        parallelism = (f"COST MODEL of rank {only[0]} of a z-slab x{N} chain on one device: slab {only[0]} alone exists (pf_opts.only_slab) and "
+                       f"exchanges its own edge planes with itself by {info['transport_name']}; value = what an {N}-rank chain of such ranks would do")
+        res = base_result(args, sd, N, K, W, R, regions, el, real_bytes, lossy, parallelism)
+        res["emulated_slab"] = {"rank": only[0], "of": N, "planes": [slabs[0]["x0"], slabs[0]["x1"]], "pairs": slabs[0]["paired"],
+                                "ms_per_step": round(el / K * 1e3, 4), "ideal_ms_per_step_note": "single-domain ms/step / N"}
+    g0 = max(range(len(slabs)), key=lambda g: slabs[g]["x1"] - slabs[g]["x0"])
     (_, ly, lz), _, _ = slabs[g0]["engine"].layout()  # stored rows x columns of a plane (exchanged axes: Ny x Nx)
     rl, bpv, kernel_ms, units = roofline_block(args, sd, tms[g0], K, real_bytes, slabs[g0]["x1"] - slabs[g0]["x0"], (ly - 2) * (lz - 2))
     rl["slab"] = g0
     res["roofline"] = rl
-    res["exchange_verified"] = info["exchange_verified"]
+    res["exchange_verified"] = None if only else info["exchange_verified"]
     res["exchange"] = {"backend": info["transport_name"], "ranks": N, "checked_steps": info["exchanges_checked"],
                        "nonzero_planes": info["exchange_nonzero"], "plane_bytes": info["plane_bytes"],
                        "what": "position-weighted bit-pattern checksums of the received ghost planes == the senders' planes, every slab"}
@@ -322,7 +335,11 @@ def main():
     ap.add_argument("--emulate-slab", default="", help="debug: 'r/N' = run only slab r of an N-way split on this GPU, the exchange\n                    replaced by device copies of the same planes (per-rank cost model; physics is wrong)")
     ap.add_argument("--emulate-transport", default="copy", choices=["copy", "rccl"],
                     help="with --emulate-slab: 'rccl' sends the planes to this same rank through RCCL (real launch cost)")
+    ap.add_argument("--emulate-via", default="chain", choices=["chain", "torch"],
+                    help="with --emulate-slab: through the C chain object (pf_opts.only_slab; default) or the torch.distributed runner")
     args = ap.parse_args()
+    if args.emulate_slab and args.emulate_via == "chain":
+        return run_chain(args, only=tuple(int(v) for v in args.emulate_slab.split("/")))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

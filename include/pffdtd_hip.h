@@ -108,7 +108,10 @@ typedef struct pf_opts {
    int32_t multi_flags;   /* pf_run_sim_devices / pf_multi_create only: PF_MULTI_* */
    int32_t transport;     /* pf_run_sim_devices / pf_multi_create only: PF_TRANSPORT_* (how ghost planes travel between devices) */
    int32_t verify_exchange; /* same: the first n exchanges are checksummed on both sides (pf_multi_info.exchange_verified) */
-   int32_t reserved[2];
+   int32_t only_slab;     /* pf_multi_create only: 1 + g = cost model of ONE rank -- the chain is cut as usual but slab g alone is
+                             instantiated and receives its own edge planes as ghost planes, through the chosen transport (the
+                             physics is wrong, the work and the launches are a rank's); 0 = the whole chain */
+   int32_t reserved[1];
 } pf_opts;
 
 #define PF_TRANSPORT_AUTO 0 /* peer copies where hipDeviceCanAccessPeer says yes for every neighbouring pair, else RCCL */

@@ -302,6 +302,7 @@ enum { TR_PEER = PF_TRANSPORT_PEER, TR_RCCL = PF_TRANSPORT_RCCL };
 
 struct Shared {
    int G = 1;
+   int only = -1;                                                // >= 0: the one slab that exists (pf_opts.only_slab: cost model of a rank)
    std::vector<Slab> slabs;
    std::vector<int64_t> cuts;
    std::vector<int> dev;
@@ -500,7 +501,7 @@ int choose_transport(Shared &S, int requested) {
    if (S.rccl_self) {
       // virtual slabs: slab g's communicator has ONE rank (the device); its exchange sends the neighbour's plane -- same
       // device, directly addressable -- to itself.  Group semantics, stream ordering and error paths as on a real chain.
-      for (int g = 0; g < S.G && r == ncclSuccess; g++) { const int d = S.dev[g]; r = g_rccl.CommInitAll(&S.comm[g], 1, &d); }
+      for (int g = 0; g < S.G && r == ncclSuccess; g++) { if (S.only >= 0 && g != S.only) continue; const int d = S.dev[g]; r = g_rccl.CommInitAll(&S.comm[g], 1, &d); }
    } else {
       for (int g = 0; g < S.G; g++) S.rank[g] = g;
       r = g_rccl.CommInitAll(S.comm.data(), S.G, S.dev.data()); // one clique over the chain's devices, rank g = slab g
@@ -538,6 +539,11 @@ void phase_pull(Shared &S, int g, int64_t n) {
       if (e != hipSuccess) S.set_error(PF_ERR_HIP, hipGetErrorString(e));
    };
    if (S.drop_step >= 0 && g == 1 && n == S.drop_step) return; // (test hook: the self-check must notice)
+   if (S.only >= 0) { // (cost model of one rank: its own edge planes stand in for the neighbours')
+      if (g > 0) pull(g, S.recv_lo[k][g], S.send_hi[k][g]);
+      if (g < S.G - 1) pull(g, S.recv_hi[k][g], S.send_lo[k][g]);
+      return;
+   }
    if (g > 0) pull(g - 1, S.recv_lo[k][g], S.send_hi[k][g - 1]);         // left neighbour's last owned plane -> my plane 0
    if (g < S.G - 1) pull(g + 1, S.recv_hi[k][g], S.send_lo[k][g + 1]);   // right neighbour's first owned plane -> my last plane
 }
@@ -550,11 +556,12 @@ void phase_rccl(Shared &S, int g, int64_t n, bool grouped) {
    const size_t nb = S.plane_bytes;
    if (S.rccl_self) {
       // 1-rank communicator: the neighbour's plane goes through RCCL to myself (after the neighbour's edge event)
-      for (int q : {g - 1, g + 1})
+      const int ql = S.only >= 0 ? g : g - 1, qh = S.only >= 0 ? g : g + 1; // (cost model of one rank: its own planes)
+      for (int q : {ql, qh})
          if (q >= 0 && q < S.G && hipStreamWaitEvent(S.edge[g], S.ev[k][q], 0) != hipSuccess) { S.set_error(PF_ERR_HIP, "hipStreamWaitEvent failed"); return; }
       if (!grouped) NCHK(g, g_rccl.GroupStart());
-      if (g > 0) { NCHK(g, g_rccl.Send(S.send_hi[k][g - 1], nb, ncclInt8, 0, S.comm[g], S.edge[g])); NCHK(g, g_rccl.Recv(S.recv_lo[k][g], nb, ncclInt8, 0, S.comm[g], S.edge[g])); }
-      if (g < S.G - 1) { NCHK(g, g_rccl.Send(S.send_lo[k][g + 1], nb, ncclInt8, 0, S.comm[g], S.edge[g])); NCHK(g, g_rccl.Recv(S.recv_hi[k][g], nb, ncclInt8, 0, S.comm[g], S.edge[g])); }
+      if (g > 0) { NCHK(g, g_rccl.Send(S.send_hi[k][ql], nb, ncclInt8, 0, S.comm[g], S.edge[g])); NCHK(g, g_rccl.Recv(S.recv_lo[k][g], nb, ncclInt8, 0, S.comm[g], S.edge[g])); }
+      if (g < S.G - 1) { NCHK(g, g_rccl.Send(S.send_lo[k][qh], nb, ncclInt8, 0, S.comm[g], S.edge[g])); NCHK(g, g_rccl.Recv(S.recv_hi[k][g], nb, ncclInt8, 0, S.comm[g], S.edge[g])); }
       if (!grouped) NCHK(g, g_rccl.GroupEnd());
       return;
    }
@@ -691,7 +698,7 @@ void post(pf_multi *m, int kind, int64_t n0, int64_t ns) {
 }
 void wait_done(pf_multi *m) {
    std::unique_lock<std::mutex> lk(m->mu);
-   m->cv_done.wait(lk, [&] { return m->done == m->S.G; });
+   m->cv_done.wait(lk, [&] { return m->done == (m->S.only >= 0 ? 1 : m->S.G); });
 }
 
 void scatter_outputs(pf_multi *m) { // receivers: every slab filled its own rows (gpu_engine.h:1066-1075)
@@ -774,6 +781,12 @@ int pf_multi_create(pf_simdata *sd, int32_t nslabs, const int32_t *devices, cons
    S.plane_bytes = S.along_z ? pf_grid_bytes(1, sd->Ny, sd->Nx, sd->real_bytes) : pf_grid_bytes(1, sd->Ny, sd->Nz, sd->real_bytes);
    S.verify_n = S.base.verify_exchange > 0 ? S.base.verify_exchange : 0;
    if (const char *ev = getenv("PFFDTD_VERIFY_EXCHANGE")) S.verify_n = std::max(atoi(ev), 0);
+   if (S.base.only_slab > 0) {
+      if (S.base.only_slab > G) { delete m; return fail("pf_opts.only_slab: no such slab"); }
+      S.only = S.base.only_slab - 1;
+      S.verify_n = 0; // (nothing to compare with)
+      for (int g = 0; g < G; g++) if (S.dev[g] != S.dev[S.only]) { delete m; return fail("pf_opts.only_slab: name one device for every slab"); }
+   }
    if (const char *ev = getenv("PFFDTD_TEST_DROP_EXCHANGE")) { // fault injection for the tests: never without the check that must catch it
       S.drop_step = atoll(ev);
       if (S.drop_step >= 0) S.verify_n = std::max<int64_t>(S.verify_n, S.drop_step + 2);
@@ -782,13 +795,13 @@ int pf_multi_create(pf_simdata *sd, int32_t nslabs, const int32_t *devices, cons
    S.hbuf.resize(G);
    if (rc == PF_OK) rc = choose_transport(S, S.base.transport);
    if (rc != PF_OK) { delete m; return rc; }
-   S.bar.n = G;
-   m->one_thread = (S.base.multi_flags & PF_MULTI_ONE_THREAD) != 0;
+   S.bar.n = S.only >= 0 ? 1 : G;
+   m->one_thread = (S.base.multi_flags & PF_MULTI_ONE_THREAD) != 0 && S.only < 0;
    if (m->one_thread) {
       // the reference's arrangement (one host thread drives every GPU, gpu_engine.h:993-1145): kept for debugging
       for (int g = 0; g < G && !S.err.load(); g++) create_slab(S, g);
    } else {
-      for (int g = 0; g < G; g++) m->th.emplace_back(worker, m, g);
+      for (int g = 0; g < G; g++) if (S.only < 0 || g == S.only) m->th.emplace_back(worker, m, g);
       wait_done(m);
    }
    m->created = true;

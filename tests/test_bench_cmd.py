@@ -43,3 +43,22 @@ def test_default_command_line_single_gpu_line_has_the_contract_fields():
     assert res["n_gpus"] == 1 and res["selfcheck"]["family_agreement"] is True and res["selfcheck"]["max_abs_sample"] > 0
     assert res["roofline"]["bound"] == "hbm" and 0 < res["roofline"]["frac"] < 1.5
     assert res["cpu_baseline"]["kind"] == "port" and res["cpu_baseline"]["cores"] >= 1
+
+
+def test_plain_command_line_with_eight_virtual_gpus():
+    """The driver's N = 8 command on this 1-GPU box: eight virtual slabs through the C chain, exchange checksummed."""
+    res = _bench("--gpus", "8", "--steps", "6", "--warmup", "3", "--repeats", "2")
+    assert res["n_gpus"] == 8 and len(res["slabs"]) == 8 and res["virtual_slabs"] is True
+    assert res["exchange_verified"] is True and res["exchange"]["checked_steps"] == 3 and res["exchange"]["nonzero_planes"]
+    assert [s["planes"][1] for s in res["slabs"][:-1]] == [s["planes"][0] for s in res["slabs"][1:]]
+    assert res["slabs"][0]["planes"][0] == 0 and res["slabs"][-1]["planes"][1] == 1024 and res["value"] > 0
+
+
+@pytest.mark.parametrize("transport", ["copy", "rccl"])
+def test_cost_model_of_one_rank_through_the_chain(transport):
+    """--emulate-slab r/N: slab r of an N-rank chain alone on the device (pf_opts.only_slab), its own edge planes as ghost planes."""
+    res = _bench("--emulate-slab", "3/8", "--emulate-transport", transport, "--steps", "6", "--warmup", "4", "--repeats", "2")
+    em = res["emulated_slab"]
+    assert em["rank"] == 3 and em["of"] == 8 and 120 <= em["planes"][1] - em["planes"][0] <= 136 and em["ms_per_step"] > 0
+    assert ("rccl" in res["exchange"]["backend"]) == (transport == "rccl")
+    assert res["n_gpus"] == 8 and "COST MODEL" in res["config"]["parallelism"]
