@@ -634,7 +634,8 @@ template <typename Real> struct Engine : EngineBase {
       // 7-point: the fused single-step kernels carry the shell; 13-point: folded grids with the flips in memory and the ABC
       // loss in the interior kernel (the automatic 13-point arrangement)
       if (fcc ? !(fold && abck) : !(lean || vg)) return PF_OK;
-      if (!(vbase == 0 || vbase == 40 || vbase == 41) || sg || !use_dpp) return PF_OK; // (the blocked kernels exist in the CPU-exact arithmetic only)
+      if (!(vbase == 0 || vbase == 40 || vbase == 41) || !use_dpp) return PF_OK;
+      if (sg && fcc) return PF_OK; // (GPU-safeguarded arithmetic: the 7-point pair kernels have it, round 4; the 13-point ones do not)
       if (Nb > 0 && !boundary_fused()) return PF_OK;
       // Margins of the box: three cells off every grid face (the ABC cells sit at index 1 and the box must stay two cells
       // away from anything that is not a plain air update), deeper where a wall layer hugs the face -- a face whose plane at
@@ -1737,6 +1738,13 @@ template <typename Real> struct Engine : EngineBase {
          else pf::launch_tb2_fcc<Real>(s, tp, a1, a2, tb_lw, (uint32_t)tb_nclean);
          return;
       }
+      if (sg) { // the reference GPU engine's arithmetic (towards-zero pairwise sums, two FMAs)
+         if (tb_lw == 32) hipLaunchKernelGGL((pf::k_tb2_reg<Real, 3, 4, false, 32, false, true>), g, b, 0, s, tp, a1, a2);
+         else if (tb_lw == 16) hipLaunchKernelGGL((pf::k_tb2_reg<Real, 3, 4, false, 16, false, true>), g, b, 0, s, tp, a1, a2);
+         else if (tb2_probe) hipLaunchKernelGGL((pf::k_tb2_reg<Real, 3, 4, false, 64, true, true>), g, b, 0, s, tp, a1, a2);
+         else hipLaunchKernelGGL((pf::k_tb2_reg<Real, 3, 4, false, 64, false, true>), g, b, 0, s, tp, a1, a2);
+         return;
+      }
       if (tb_lw == 32) hipLaunchKernelGGL((pf::k_tb2_reg<Real, 3, 4, false, 32>), g, b, 0, s, tp, a1, a2);
       else if (tb_lw == 16) hipLaunchKernelGGL((pf::k_tb2_reg<Real, 3, 4, false, 16>), g, b, 0, s, tp, a1, a2);
       else if (tb2_probe) hipLaunchKernelGGL((pf::k_tb2_reg<Real, 3, 4, false, 64, true>), g, b, 0, s, tp, a1, a2);
@@ -1750,6 +1758,12 @@ template <typename Real> struct Engine : EngineBase {
       tp.tiles = tb_dirty; tp.mask = mask;
       tp.xsub = tb_ndirty <= 256 ? std::min(4, std::max(tb_chunk / 4, 1)) : 1; // few tiles: shorter marches, more workgroups
       const dim3 g((uint32_t)tb_ndirty * (uint32_t)tp.xsub), b(256);
+      if (sg) {
+         if (tb_lw == 32) hipLaunchKernelGGL((pf::k_tb1_tile<Real, 3, 4, 32, true>), g, b, 0, s, tp, a1, a2);
+         else if (tb_lw == 16) hipLaunchKernelGGL((pf::k_tb1_tile<Real, 3, 4, 16, true>), g, b, 0, s, tp, a1, a2);
+         else hipLaunchKernelGGL((pf::k_tb1_tile<Real, 3, 4, 64, true>), g, b, 0, s, tp, a1, a2);
+         return;
+      }
       if (tb_lw == 32) hipLaunchKernelGGL((pf::k_tb1_tile<Real, 3, 4, 32>), g, b, 0, s, tp, a1, a2);
       else if (tb_lw == 16) hipLaunchKernelGGL((pf::k_tb1_tile<Real, 3, 4, 16>), g, b, 0, s, tp, a1, a2);
       else hipLaunchKernelGGL((pf::k_tb1_tile<Real, 3, 4, 64>), g, b, 0, s, tp, a1, a2);
@@ -1818,8 +1832,9 @@ template <typename Real> struct Engine : EngineBase {
          }
          const int64_t nthreads = (int64_t)(zp.zl / V + (P - zp.zr) / V) * (Ny - 2);
          const int xchunk = 16;
-         hipLaunchKernelGGL(pf::k_air_zstrip<Real>, dim3((unsigned)cdiv(nthreads, 256), (unsigned)cdiv(xe - xb, xchunk)), dim3(256), 0, s, zp,
-                            a1, a2, l, xchunk);
+         const dim3 gz((unsigned)cdiv(nthreads, 256), (unsigned)cdiv(xe - xb, xchunk));
+         if (sg) hipLaunchKernelGGL((pf::k_air_zstrip<Real, true>), gz, dim3(256), 0, s, zp, a1, a2, l, xchunk);
+         else hipLaunchKernelGGL((pf::k_air_zstrip<Real, false>), gz, dim3(256), 0, s, zp, a1, a2, l, xchunk);
       }
       launch_dirty_tiles(s); // ... and the tiles of the box that hold geometry or a source
    }

@@ -33,7 +33,8 @@ struct Tb2Params {
 // ---------------------------------------------------------------------------------------------------------------
 // PROBE: the same code under another name, for the creation-time measurements (grid placement search, path choice): per-kernel
 // profiler statistics of k_tb2_reg<..., false> then hold the launches of the time loop only.
-template <typename Real, int R, int WY, bool NTA = true, int LW = 64, bool PROBE = false>
+// SG: the reference GPU engine's arithmetic (pf_kernels.h: upd7<true>) instead of the C CPU engine's.
+template <typename Real, int R, int WY, bool NTA = true, int LW = 64, bool PROBE = false, bool SG = false>
 __global__ __launch_bounds__(64 * WY) void k_tb2_reg(Tb2Params tp, Real a1, Real a2) {
    typedef typename VecOf<Real>::type vec;
    // LW lanes span a row segment of LW*V columns whose first and last lane are z halo (their u^{n+1} values feed their
@@ -92,9 +93,7 @@ __global__ __launch_bounds__(64 * WY) void k_tb2_reg(Tb2Params tp, Real a1, Real
       for (int i = 0; i < V; i++) {
          const Real zp = (i == V - 1) ? rt : c[i < V - 1 ? i + 1 : V - 1];
          const Real zm = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
-         Real p = a1 * c[i] - old[i];
-         p = p + a2 * xp[i]; p = p + a2 * xm[i]; p = p + a2 * yp[i]; p = p + a2 * ym[i]; p = p + a2 * zp; p = p + a2 * zm;
-         o[i] = p;
+         o[i] = upd7<SG>(a1, a2, c[i], old[i], xp[i], xm[i], yp[i], ym[i], zp, zm);
       }
       return o;
    };
@@ -411,7 +410,7 @@ template <typename Real> void launch_tb2_fcc(hipStream_t s, const Tb2Params &tp,
 // Cells whose skip-mask bit is set (boundary nodes) are not written: the boundary pass writes them afterwards.
 // Inside the box of tiles there are no ghost cells and no ABC cells, so none of that is handled here.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename Real, int R, int WY, int LW = 64>
+template <typename Real, int R, int WY, int LW = 64, bool SG = false>
 __global__ __launch_bounds__(64 * WY) void k_tb1_tile(Tb2Params tp, Real a1, Real a2) {
    typedef typename VecOf<Real>::type vec;
    static_assert(LW == 64 || LW == 32 || LW == 16, "row segments are 64, 32 or 16 lanes wide");
@@ -470,9 +469,7 @@ __global__ __launch_bounds__(64 * WY) void k_tb1_tile(Tb2Params tp, Real a1, Rea
          for (int i = 0; i < V; i++) {
             const Real zp = (i == V - 1) ? rt : c[i < V - 1 ? i + 1 : V - 1];
             const Real zm = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
-            Real p = a1 * c[i] - old[i];
-            p = p + a2 * Bn[r + 1][i]; p = p + a2 * Bp[r][i]; p = p + a2 * Bc[r + 2][i]; p = p + a2 * Bc[r][i]; p = p + a2 * zp; p = p + a2 * zm;
-            o[i] = p;
+            o[i] = upd7<SG>(a1, a2, c[i], old[i], Bn[r + 1][i], Bp[r][i], Bc[r + 2][i], Bc[r][i], zp, zm);
          }
          if (core_col && core_row[r]) {
             if ((bits & ((1u << V) - 1u)) == 0u) __builtin_nontemporal_store(o, (vec *)(pc + off[r + 1]));
@@ -517,7 +514,7 @@ template <typename Real> struct ZStripParams {
    Real sl2;
 };
 
-template <typename Real>
+template <typename Real, bool SG = false>
 __global__ __launch_bounds__(256) void k_air_zstrip(ZStripParams<Real> zp, Real a1, Real a2, Real l, int xchunk) {
    // thread = one 16-byte vector of one row; it marches xchunk planes with the x neighbours in registers, so every
    // 128-byte line of u1 / u0s next to the strip is fetched once (a thread-per-cell version re-fetched the x neighbours
@@ -573,27 +570,16 @@ __global__ __launch_bounds__(256) void k_air_zstrip(ZStripParams<Real> zp, Real 
       for (int i = 0; i < V; i++) {
          const Real zpv = (i == V - 1) ? rt : c[i < V - 1 ? i + 1 : V - 1];
          const Real zmv = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
-         Real p = a1 * c[i] - old[i];
-         p = p + a2 * cp[i]; p = p + a2 * cm[i]; p = p + a2 * yp[i]; p = p + a2 * ym[i]; p = p + a2 * zpv; p = p + a2 * zmv;
+         Real p = upd7<SG>(a1, a2, c[i], old[i], cp[i], cm[i], yp[i], ym[i], zpv, zmv);
          const int Q = qxy + ((z0 + i == 1 || z0 + i == Nz - 2) ? 1 : 0);
-         if (Q > 0) { // ABC loss (cpu_engine.h:225-229), double literal of :228
-            const Real lQ = l * (Real)Q;
-            const Real num = p + lQ * old[i];
-            p = (Real)((double)num / (1.0 + (double)lQ));
-         }
+         if (Q > 0) p = abc_loss<SG>(p, old[i], l * (Real)Q); // (cpu_engine.h:225-229 incl. the double literal of :228; SG: gpu_engine.h:351-365)
          if ((bits >> i) & 1u) {
             p = old[i]; // ghost / pad column, or a boundary node that the list kernel updates
             const int32_t nb = ((zrec >> i) & 1u) ? (int32_t)((zrec >> 4) + __popc(zrec & ((1u << i) - 1u))) : -1;
             if (nb >= 0) { // boundary node (its number in strip order): rigid update from the registers (k_boundary's expression), then the FD branches
                const uint32_t adj = zp.adjv[nb];
                const Real nbk[6] = {cp[i], cm[i], yp[i], ym[i], zpv, zmv};
-               const Real two = 2.0, b1 = two - zp.sl2 * (Real)__popc(adj);
-               p = b1 * c[i] - old[i];
-#pragma unroll
-               for (int k = 0; k < 6; k++) {
-                  const Real w = a2 * (Real)((adj >> k) & 1u);
-                  p = p + w * nbk[k];
-               }
+               p = upd_rigid<SG, 6>(a2, zp.sl2, adj, c[i], old[i], nbk);
                const int32_t li = zp.lossy[nb];
                if (li >= 0) zp.u0b[li] = p;
             }

@@ -284,3 +284,31 @@ def test_wall_regions_step_aside_for_a_source_in_the_shell():
     out, _, tm = run(sim, 40)
     assert tm["tb2_launches"] > 0 and tm["wall_blocks"] == [0, 0]
     assert np.array_equal(out, ref.u_out)
+
+
+@pytest.mark.parametrize("prec", ["single", "double"])
+@pytest.mark.parametrize("src,kw", [(None, {}), ([18, 8, 12], dict(n=(37, 67, 283)))], ids=["centre", "corner_odd"])
+def test_blocked_pairs_in_the_gpu_safeguarded_arithmetic(prec, src, kw):
+    """PF_NUM_GPU_SAFEGUARDED in the pair kernels (round 4: k_tb2_reg, k_tb1_tile, k_air_zstrip with the towards-zero pairwise sums
+    and the two FMAs of gpu_engine.h:220-242, 288-314): forced pairs give the bits of the oracle's restatement of that
+    arithmetic, and differ from the CPU-exact mode only in the roundings."""
+    sim = scene(src, Nt=31, **kw)
+    sd = sim_data.SimData.from_sim(sim, prec)
+    sd.scale_input()
+    e = oracle.Engine(sd, safeguarded=True)
+    for n in range(sd.Nt):
+        e.step(n)
+    ref_out, ref_u1 = sd.u_out.copy(), e.grid(1).copy()
+    e.close()
+    exact = sim_data.SimData.from_sim(sim, prec)
+    exact.scale_input()
+    oracle.run_sim(exact)
+    for variant in (41, 40):
+        out, g, tm = run(sim, variant, prec=prec, numerics=engine.PF_NUM_GPU_SAFEGUARDED)
+        assert np.array_equal(out, ref_out), variant
+        assert np.array_equal(g[1][1:-1, 1:-1, 1:-1], ref_u1[1:-1, 1:-1, 1:-1]), variant
+        if variant == 40:
+            assert tm["tb2_launches"] > 0 and tm["wall_blocks"] == [0, 0]  # (the wall regions exist in the CPU-exact arithmetic only)
+    peak = np.abs(exact.u_out).max()
+    d = np.abs(ref_out - exact.u_out).max()
+    assert 0 < d <= (3e-5 if prec == "single" else 1e-12) * peak
