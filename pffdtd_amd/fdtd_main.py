@@ -5,22 +5,23 @@
 Same flow: load_sim_data -> scale_input -> run_sim -> rescale_output -> write_outputs -> print_last_samples,
 reading the four input .h5 files from the current directory and writing sim_outs.h5 there.
 
-`--gpus N` is the counterpart of the reference GPU binary driving every visible device from one thread
-(gpu_engine.h:680-690, 993-1145): here the command re-launches itself as N processes (one per GPU,
-`torch.distributed.run`), each cuts its Z-slab out of the folder's lists (`pffdtd_amd/slab.py` =
-gpu_engine.h:516-662), steps it with the split-phase engine and exchanges one plane per side and step over RCCL;
-rank 0 gathers the receiver rows and writes `sim_outs.h5`.  Unlike the reference (gpu_engine.h:688) the lists need
+`--gpus N` is the counterpart of the reference GPU binary driving every visible device from one process
+(gpu_engine.h:680-690, 993-1145): ONE process, the C library's chain object (pf_multi_*, csrc/pf_multi.hip: the grid cut
+into Z-slabs like gpu_engine.h:516-662, one host thread per slab, ghost planes by peer copies or native RCCL on the edge
+stream) on devices 0 .. N-1 -- round 4: the one N > 1 driver of the product.  `--devices 0,1,2,3` names the chain
+explicitly; a device id may repeat (several slabs on one GPU).  Unlike the reference (gpu_engine.h:688) the lists need
 not be sorted: the slabs are cut by plane tests and every engine sorts its own lists.
-It can also be started under `python -m torch.distributed.run --nproc-per-node N -m pffdtd_amd.fdtd_main ...` directly.
 
-`--devices 0,1,2,3` is the in-process alternative, closest to the reference binary: ONE process, the C library's own
-multi-device `run_sim` (pf_run_sim_devices, csrc/pf_multi.hip: one host thread per slab, ghost planes pulled with peer
-copies), no torch and no RCCL involved; a device id may repeat (several slabs on one GPU).
+Under an external launcher (`python -m torch.distributed.run --nproc-per-node N -m pffdtd_amd.fdtd_main ...`: one process
+per GPU, WORLD_SIZE set) each rank cuts its own slab (`pffdtd_amd/slab.py`), steps it with the split-phase engine and
+exchanges over RCCL through torch.distributed; rank 0 gathers the receiver rows and writes `sim_outs.h5`.
+
+`--progress [K]` prints the reference's progress fields (fdtd_common.h:106-190: T / I / TPW / IPW / TA / IA / TB / IB Mvox/s
+and the air share, "I" = over the last K steps, default 200) as one plain line per report -- the reference redraws six
+lines per STEP, which would cost a device synchronisation per step here.
 """
 import argparse
 import os
-import subprocess
-import sys
 import time
 from pathlib import Path
 
@@ -44,6 +45,48 @@ def _finish(sd, data_dir):
     print(f"--Date and time: {time.ctime()}")
 
 
+def _progress(sd, n, nt, t_all, t_chunk, k, air_all, air_chunk, bn_all, bn_chunk, workers):
+    """one report in the reference's vocabulary (fdtd_common.h:106-190)"""
+    def hms(sec):
+        sec = int(sec)
+        return f"{sec // 3600:02d}:{sec % 3600 // 60:02d}:{sec % 60:02d}"
+    mv = lambda cells, t: 1e-6 * cells / max(t, 1e-12)
+    print(f"Running [{100.0 * n / nt:.1f}%] [{hms(t_all)}<{hms(t_all * nt / max(n, 1))}] "
+          f"T: {mv(sd.Npts * n, t_all):06.1f} - I: {mv(sd.Npts * k, t_chunk):06.1f} | "
+          f"TPW: {mv(sd.Npts * n, t_all) / workers:06.1f} - IPW: {mv(sd.Npts * k, t_chunk) / workers:06.1f} | "
+          f"TA: {mv(sd.Npts * n, air_all):06.1f} - IA: {mv(sd.Npts * k, air_chunk):06.1f} | "
+          f"TB: {mv(sd.Nb * n, bn_all):06.1f} - IB: {mv(sd.Nb * k, bn_chunk):06.1f} | "
+          f"T: {100.0 * air_all / max(t_all, 1e-12):02.1f}% - I: {100.0 * air_chunk / max(t_chunk, 1e-12):02.1f}%", flush=True)
+
+
+def _run_chain(a, sd, m):
+    """all Nt steps of a chain object, in one go or in chunks with progress reports; returns (seconds, timing of the busiest slab)"""
+    live = range(m.nslabs)
+    t0 = time.perf_counter()
+    if not a.progress:
+        m.run(0, sd.Nt)
+        el = time.perf_counter() - t0
+        tms = [m.slab(g)["engine"].timing() for g in live]
+        return el, {"air_ms_total": max(t["air_ms_total"] for t in tms), "step_ms_total": max(t["step_ms_total"] for t in tms)}
+    air_all = step_all = 0.0
+    n = 0
+    while n < sd.Nt:
+        k = min(a.progress, sd.Nt - n)
+        tc = time.perf_counter()
+        m.run(n, k)
+        now = time.perf_counter()
+        n += k
+        tms = [m.slab(g)["engine"].timing(reset=True) for g in live]
+        air = max(t["air_ms_total"] for t in tms) * 1e-3
+        step = max(t["step_ms_total"] for t in tms) * 1e-3
+        if step <= 0:
+            step = now - tc  # (slab engines time their interior launches only)
+        air_all += air
+        step_all += step
+        _progress(sd, n, sd.Nt, now - t0, now - tc, k, air_all, air, max(step_all - air_all, 1e-12), max(step - air, 1e-12), m.nslabs)
+    return time.perf_counter() - t0, {"air_ms_total": air_all * 1e3, "step_ms_total": step_all * 1e3}
+
+
 def run_single(a):
     """One device.  Rooms (scenes the library stores with the x and z axes exchanged) run as TWO slabs on it, like pf_run_sim:
     the halves' kernels overlap (CTK church 313 against 288 Gvox/s); box rooms as one domain."""
@@ -53,14 +96,10 @@ def run_single(a):
     from .dist import scene_prefers_exchanged_axes
     two = sd.Nz >= 64 and os.environ.get("PFFDTD_SLABS_PER_DEVICE", "") != "1" and scene_prefers_exchanged_axes(sd)
     m = engine.HipMulti(sd, [a.gpu] * (2 if two else 1), timing=1)
-    t0 = time.perf_counter()
-    m.run(0, sd.Nt)
-    el = time.perf_counter() - t0
-    tms = [m.slab(g)["engine"].timing() for g in range(m.nslabs)]
     if two:
         print(f"--2 slabs on device {a.gpu}, cut along file z: {[(m.slab(g)['x0'], m.slab(g)['x1']) for g in range(2)]}")
     # sub-timers: the busier slab's HIP-event sums (two slabs run side by side on the device)
-    tm = {"air_ms_total": max(t["air_ms_total"] for t in tms), "step_ms_total": max(t["step_ms_total"] for t in tms)}
+    el, tm = _run_chain(a, sd, m)
     if tm["step_ms_total"] <= 0:  # (slab engines time their interior launches only)
         tm["step_ms_total"] = el * 1e3
     m.close()
@@ -69,15 +108,24 @@ def run_single(a):
 
 
 def run_devices(a, devices):
-    """`--devices`: the C seam's multi-device run_sim in this process"""
+    """`--gpus N` / `--devices`: the C library's chain object in this process (what pf_run_sim_devices does inside)"""
     print(f"--Date and time: {time.ctime()}")
     sd = sim_data.SimData.from_folder(Path(a.data_dir), a.precision, build_mask=False)
+    if len(devices) >= sd.Nx:
+        raise SystemExit(f"need ngpus < Nx (got {len(devices)}, Nx={sd.Nx})")  # gpu_engine.h:682
     sd.scale_input()
-    print(f"--{len(devices)} slabs on devices {devices}: planes {engine.slab_partition(sd, len(devices))}")
-    t0 = time.perf_counter()
-    engine.run_sim_devices(sd, devices)
-    el = time.perf_counter() - t0
-    print(f"Combined (total): {el:.6f}s, {sd.Npts * sd.Nt / 1e6 / el:.2f} Mvox/s")  # incl. engine creation on every device
+    m = engine.HipMulti(sd, devices, timing=1, verify_exchange=2)
+    info = m.info()
+    spans = [(m.slab(g)["x0"], m.slab(g)["x1"]) for g in range(m.nslabs)]
+    print(f"--{len(devices)} slabs on devices {devices}, cut along file {'z' if info['cut_along_z'] else 'x'}: planes {spans}, ghost planes by {info['transport_name']}")
+    el, tm = _run_chain(a, sd, m)
+    if tm["step_ms_total"] <= 0:
+        tm["step_ms_total"] = el * 1e3
+    info = m.info()
+    m.close()
+    if info["exchange_verified"] is False:
+        raise SystemExit("slab exchange self-check failed: a ghost plane does not hold what the neighbour sent")
+    _summary(sd, tm, el)
     _finish(sd, a.data_dir)
 
 
@@ -135,9 +183,10 @@ def main():
     p.add_argument("--precision", default="single", choices=["single", "double"])
     p.add_argument("--data_dir", default=".", help="folder with the input .h5 files (the reference uses the CWD)")
     p.add_argument("--gpu", type=int, default=0, help="device of a single-GPU run")
-    p.add_argument("--gpus", type=int, default=1, help="number of GPUs (one process each, Z-slabs)")
-    p.add_argument("--master_port", type=int, default=29541)
-    p.add_argument("--devices", default="", help="comma-separated device chain for the in-process multi-device run, e.g. 0,1,2,3")
+    p.add_argument("--gpus", type=int, default=1, help="number of GPUs: Z-slabs on devices 0 .. N-1, driven from this one process")
+    p.add_argument("--devices", default="", help="comma-separated device chain instead of 0 .. N-1, e.g. 0,1,2,3 (ids may repeat)")
+    p.add_argument("--progress", type=int, nargs="?", const=200, default=0, metavar="K",
+                   help="report the reference's progress fields (fdtd_common.h:106-190) every K steps (default 200)")
     a = p.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.devices:
@@ -147,14 +196,10 @@ def main():
             raise SystemExit(f"--gpus {a.gpus} != WORLD_SIZE {world}")
         return run_rank(a, world)
     if a.gpus > 1:
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(a.master_port), "-m", "pffdtd_amd.fdtd_main",
-               "--precision", a.precision, "--data_dir", str(Path(a.data_dir).resolve()), "--gpus", str(a.gpus),
-               "--gpu", str(a.gpu)]
-        env = dict(os.environ)
-        root = str(Path(__file__).resolve().parent.parent)
-        env["PYTHONPATH"] = root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
-        raise SystemExit(subprocess.call(cmd, env=env))
+        ndev = engine.device_count()
+        if ndev < a.gpus:
+            raise SystemExit(f"--gpus {a.gpus}: only {ndev} device(s) visible (name a chain with repeats by --devices for virtual slabs)")
+        return run_devices(a, list(range(a.gpus)))
     run_single(a)
 
 
