@@ -102,7 +102,8 @@ typedef struct pf_opts {
                              0x20000000 the boundary-list kernel visits every node (none left to the column-strip kernel); 0x1000 /
                              0x2000 store the grid with the file's x and z axes exchanged / never (default: decided per scene);
                              0x10000000 blocked pairs keep the single-step shell (no wall regions); 0x8000000 wall regions: every block
-                             generic; 0x4000000 all their launches on one stream; 0x2000000 wide column strips cut in two */
+                             generic; 0x4000000 all their launches on one stream; 0x2000000 wide column strips cut in two;
+                             0x800000 replay the single-step loop from a hipGraph (six steps per graph; no faster on this stack) */
    int32_t energy;        /* 1 = keep what the energy diagnostic needs (explicit Laplacian grid, unfused kernel
                              sequence); then use pf_engine_energy_cfg + pf_engine_run_energy */
    int32_t multi_flags;   /* pf_run_sim_devices / pf_multi_create only: PF_MULTI_* */
@@ -111,7 +112,8 @@ typedef struct pf_opts {
    int32_t only_slab;     /* pf_multi_create only: 1 + g = cost model of ONE rank -- the chain is cut as usual but slab g alone is
                              instantiated and receives its own edge planes as ghost planes, through the chosen transport (the
                              physics is wrong, the work and the launches are a rank's); 0 = the whole chain */
-   int32_t reserved[1];
+   int32_t test_drop_exchange; /* tests only, pf_multi_create: 1 + n = slab 1 misses the ghost planes of step n (the exchange self-check, which
+                             then always covers that step, must notice) */
 } pf_opts;
 
 #define PF_TRANSPORT_AUTO 0 /* peer copies where hipDeviceCanAccessPeer says yes for every neighbouring pair, else RCCL */

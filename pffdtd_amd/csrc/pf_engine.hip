@@ -607,10 +607,8 @@ template <typename Real> struct Engine : EngineBase {
       // hipGraph replay of the step loop (six steps per graph): measured on MI355X / ROCm 7.2 it does not beat plain
       // launches even on launch-bound grids (234x154x85: 0.0503 vs 0.0473 ms/step, 256^3: 0.0951 vs 0.0921) -- the gaps
       // between dependent kernels are the same inside a graph, and the counter-tick node adds one -- so it is opt-in
-      // (PFFDTD_GRAPH=1), kept bit-identical by the tests.
-      graph_ok = false;
-      if (const char *ev = getenv("PFFDTD_GRAPH"))
-         graph_ok = ev[0] == '1' && op.slab_first && op.slab_last && !tb2 && !op.timing && !op.energy;
+      // (debug 0x800000), kept bit-identical by the tests.
+      graph_ok = (op.debug & 0x800000) && op.slab_first && op.slab_last && !tb2 && !op.timing && !op.energy;
       if (getenv("PFFDTD_VERBOSE") && atoi(getenv("PFFDTD_VERBOSE")) > 0)
          fprintf(stderr, "pffdtd_hip: engine on device %d, %ldx%ldx%ld %s %s, interior path: %s%s, numerics: %s, %d-lane row segments\n", op.device, (long)Nx, (long)Ny, (long)Nz,
                  fcc ? "13-point" : "7-point", sizeof(Real) == 4 ? "fp32" : "fp64",
@@ -770,9 +768,8 @@ template <typename Real> struct Engine : EngineBase {
          if ((rc = upload(&tb_dirty, di.data(), tb_ndirty))) return rc;
          { // The placement search times the pair kernel on a SAMPLE of the clean tiles: every k-th x chunk, whole chunks in the
            // launch's own order (the effect it looks for is a property of how the four grids' pages lie relative to each
-           // other, the same all along x), so a candidate costs 1/k of a launch.  PFFDTD_PLACE_SAMPLE=k (default 4, 1 = all).
+           // other, the same all along x), so a candidate costs 1/k of a launch (k = 4).
             int k = 4;
-            if (const char *ev = getenv("PFFDTD_PLACE_SAMPLE")) k = std::min(std::max(atoi(ev), 1), 16);
             if (tb_nxc < 8 * k) k = std::max(tb_nxc / 8, 1);
             std::vector<int32_t> sm;
             int64_t svol = 0;
@@ -945,8 +942,7 @@ template <typename Real> struct Engine : EngineBase {
          R.mode = mode; R.nbase = nbase; R.kg = kg; R.ko0 = ko0; R.ko1 = ko1;
          R.kb0 = std::max(ko0 - 2, 0); R.kb1 = std::min(ko1 + 2, dp);
          R.l0 = l0; R.l1 = l1; R.m0 = m0; R.m1 = m1;
-         int want = 16;
-         if (const char *ev = getenv("PFFDTD_WALL_CHUNK")) want = std::max(atoi(ev), 2); // (experiments)
+         const int want = 16; // march steps per block: 8 and 16 equal, 24-32 1-2 % slower, 48-64 7 % (1024^3, measured)
          const int len = m1 - m0, nmc = (int)std::max<int64_t>(cdiv(len, want), 1);
          R.mchunk = (int)cdiv(len, nmc);
          R.nlt = (int)cdiv(l1 - l0, pf::WALL_LT);
@@ -1437,7 +1433,6 @@ template <typename Real> struct Engine : EngineBase {
    }
    int place_evals() const {
       int evals = 48;
-      if (const char *ev = getenv("PFFDTD_PLACE_EVALS")) evals = std::min(std::max(atoi(ev), 1), 64);
       return evals;
    }
    // the single-step paths stream two grids (u^n read, u^{n-1} read and overwritten): the same question with a smaller answer
@@ -1503,7 +1498,6 @@ template <typename Real> struct Engine : EngineBase {
    int sample_placement_single() {
       if (!own_grids || !place_single_ok()) return PF_OK;
       int extra = 4;
-      if (const char *ev = getenv("PFFDTD_PLACE_EXTRA")) extra = std::min(std::max(atoi(ev), 0), 12);
       extra = pool_extra(extra, 2);
       if (extra == 0) return PF_OK;
       std::vector<Real *> pool = {u0, u1};
@@ -1526,7 +1520,6 @@ template <typename Real> struct Engine : EngineBase {
    int sample_placement() {
       if (!tb2 || tb2_slab || !bufC || !bufD || (op.debug & 0x8000) || vbase == 41) return PF_OK;
       int extra = 4;
-      if (const char *ev = getenv("PFFDTD_PLACE_EXTRA")) extra = std::min(std::max(atoi(ev), 0), 12);
       extra = pool_extra(extra, 4);
       if (extra == 0 && !own_grids) return PF_OK;
       std::vector<Real *> pool;

@@ -329,7 +329,7 @@ struct Shared {
    std::vector<int> rank;                                        // [g] peer rank of slab g in the clique
    // exchange self-check: the first `verify_n` exchanges after creation
    int64_t verify_n = 0;
-   int64_t drop_step = -1; // test hook (PFFDTD_TEST_DROP_EXCHANGE=n): slab 1 misses the planes of step n; the self-check then always covers that step
+   int64_t drop_step = -1; // test hook (pf_opts.test_drop_exchange): slab 1 misses the planes of that step; the self-check then always covers it
    std::vector<int64_t> steps_done;                              // [g]
    std::vector<uint64_t> sums;                                   // [g*4 + {send_lo, send_hi, recv_lo, recv_hi}]
    std::vector<std::vector<uint8_t>> hbuf;                       // [g] host staging for the checksums
@@ -408,7 +408,6 @@ void create_slab(Shared &S, int g) {
       // rejected candidates are freed before the next one starts.
       std::vector<void *> pool = {S.grids[0][g], S.grids[1][g]};
       int extra = 6;
-      if (const char *ev = getenv("PFFDTD_PLACE_EXTRA")) extra = std::min(std::max(atoi(ev), 0), 12) + 2;
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
          const size_t reserve = std::max(2 * gb, total_b / 16);
@@ -787,9 +786,9 @@ int pf_multi_create(pf_simdata *sd, int32_t nslabs, const int32_t *devices, cons
       S.verify_n = 0; // (nothing to compare with)
       for (int g = 0; g < G; g++) if (S.dev[g] != S.dev[S.only]) { delete m; return fail("pf_opts.only_slab: name one device for every slab"); }
    }
-   if (const char *ev = getenv("PFFDTD_TEST_DROP_EXCHANGE")) { // fault injection for the tests: never without the check that must catch it
-      S.drop_step = atoll(ev);
-      if (S.drop_step >= 0) S.verify_n = std::max<int64_t>(S.verify_n, S.drop_step + 2);
+   if (S.base.test_drop_exchange > 0) { // fault injection for the tests: never without the check that must catch it
+      S.drop_step = S.base.test_drop_exchange - 1;
+      S.verify_n = std::max<int64_t>(S.verify_n, S.drop_step + 2);
    }
    S.sums.assign((size_t)G * 4, 0);
    S.hbuf.resize(G);
@@ -939,10 +938,9 @@ double pf_run_sim(pf_simdata *sd) {
       // Rooms (scenes the chain cuts along file z) run as TWO slabs per device when only one device is in use: the halves' kernels
       // overlap -- one half's boundary pass runs beside the other's interior kernel -- which a single domain's dependent launches
       // cannot.  Measured on one MI355X, whole step: CTK church 313 against 288 Gvox/s as one domain (3, 4, 6 slabs: 280, 279,
-      // 199), Musikverein 354 against 341-345 (3, 4 slabs: 330, 351).  PFFDTD_SLABS_PER_DEVICE=1 switches it off.
+      // 199), Musikverein 354 against 341-345 (3, 4 slabs: 330, 351).  PFFDTD_DEVICES=0 (a chain of one named device) is one domain.
       int per_dev = 1;
       if (n == 1 && sd->Nz >= 64 && pf__axis_exchange_pays(sd, nullptr)) per_dev = 2;
-      if (const char *ev = getenv("PFFDTD_SLABS_PER_DEVICE")) per_dev = std::max(1, std::min(atoi(ev), 8));
       for (int i = 0; i < n; i++)
          for (int k = 0; k < per_dev; k++) devs.push_back(i);
    }

@@ -68,7 +68,7 @@ class HipSlabStepper:
             pool = list(self.grids)
             try:
                 with torch.cuda.device(self.device):
-                    for _ in range(int(os.environ.get("PFFDTD_PLACE_EXTRA", "4")) + 2):
+                    for _ in range(4 + 2):
                         pool.append(torch.zeros((self.nplanes, self.plane), dtype=self.tdtype, device=self.device))
                     torch.cuda.synchronize()
             except torch.OutOfMemoryError:  # no room for more: what fits

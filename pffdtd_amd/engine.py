@@ -25,7 +25,7 @@ class PfOpts(ctypes.Structure):
                 ("air_chunk", ctypes.c_int32), ("timing", ctypes.c_int32), ("ext_u0", ctypes.c_void_p),
                 ("ext_u1", ctypes.c_void_p), ("x_global0", ctypes.c_int32), ("debug", ctypes.c_int32),
                 ("energy", ctypes.c_int32), ("multi_flags", ctypes.c_int32), ("transport", ctypes.c_int32),
-                ("verify_exchange", ctypes.c_int32), ("only_slab", ctypes.c_int32), ("reserved", ctypes.c_int32 * 1)]
+                ("verify_exchange", ctypes.c_int32), ("only_slab", ctypes.c_int32), ("test_drop_exchange", ctypes.c_int32)]
 
 
 class PfTiming(ctypes.Structure):

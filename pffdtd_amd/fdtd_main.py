@@ -94,7 +94,7 @@ def run_single(a):
     sd = sim_data.SimData.from_folder(Path(a.data_dir), a.precision, build_mask=False)
     sd.scale_input()
     from .dist import scene_prefers_exchanged_axes
-    two = sd.Nz >= 64 and os.environ.get("PFFDTD_SLABS_PER_DEVICE", "") != "1" and scene_prefers_exchanged_axes(sd)
+    two = sd.Nz >= 64 and scene_prefers_exchanged_axes(sd)  # (`--devices 0` = one domain on device 0)
     m = engine.HipMulti(sd, [a.gpu] * (2 if two else 1), timing=1)
     if two:
         print(f"--2 slabs on device {a.gpu}, cut along file z: {[(m.slab(g)['x0'], m.slab(g)['x1']) for g in range(2)]}")

@@ -115,18 +115,18 @@ def test_long_run_ring_wraps_and_stays_bit_exact():
     assert np.array_equal(out, ref)
 
 
-def test_graph_replay_of_the_step_loop(monkeypatch):
-    """PFFDTD_GRAPH=1: six steps per hipGraph with the step index / ring column in device counters (opt-in: no faster
+def test_graph_replay_of_the_step_loop():
+    """pf_opts.debug 0x800000: six steps per hipGraph with the step index / ring column in device counters (opt-in: no faster
     than plain launches on this stack).  Unaligned step counts, several run() calls, a ring that wraps."""
     import cases
     import oracle
     from pffdtd_amd import engine
-    monkeypatch.setenv("PFFDTD_GRAPH", "1")
+    GRAPH = 0x800000  # pf_opts.debug: replay the step loop from a hipGraph
     for name, prec in (("cart_lossy", "single"), ("fcc2_lossy", "double"), ("cart_wall2", "single"), ("fcc1_outside", "single")):
         ref = cases.make_sd(name, prec)
         oracle.run_sim(ref)
         sd = cases.make_sd(name, prec)
-        eng = engine.HipEngine(sd, readout_chunk=16)
+        eng = engine.HipEngine(sd, readout_chunk=16, debug=GRAPH)
         eng.run(0, 3)
         eng.run(3, 25)
         eng.run(28, sd.Nt - 28)

@@ -169,14 +169,14 @@ def test_chain_object_pairs_through_both_transports(transport):
 
 
 def test_exchange_self_check_notices_a_missing_plane(tmp_path):
-    """PFFDTD_TEST_DROP_EXCHANGE=n makes slab 1 skip the pull of its ghost planes in step n: the run must fail, naming the check"""
-    code = ("import sys; sys.path[:0] = [%r, %r]; import cases; from pffdtd_amd import engine; "
-            "sd = cases.make_sd('cart_outside', 'single'); "
-            "engine.run_sim_devices(sd, [0, 0, 0], verify_exchange=int(sd.Nt))" % (str(ROOT), str(ROOT / "tests")))
-    r = subprocess.run([os.sys.executable, "-c", code], env={**os.environ, "PFFDTD_TEST_DROP_EXCHANGE": "40"}, capture_output=True, text=True)
-    assert r.returncode != 0 and "self-check failed" in r.stderr, r.stderr[-1500:]
-    r = subprocess.run([os.sys.executable, "-c", code], env=os.environ, capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-1500:]
+    """pf_opts.test_drop_exchange = 1 + n makes slab 1 skip the pull of its ghost planes in step n: the run must fail, naming the
+    check -- also when the caller asked for no check at all (the fault injection switches it on)"""
+    for ver in (70, 0):
+        sd = cases.make_sd("cart_outside", "single")
+        with pytest.raises(engine.PfError, match="self-check failed"):
+            engine.run_sim_devices(sd, [0, 0, 0], verify_exchange=ver, test_drop_exchange=41)
+    sd = cases.make_sd("cart_outside", "single")
+    engine.run_sim_devices(sd, [0, 0, 0], verify_exchange=int(sd.Nt))
 
 
 def test_transport_requests_are_validated():
@@ -229,7 +229,7 @@ def test_rooms_are_cut_along_file_z_by_themselves():
 
 def test_run_sim_runs_a_room_as_two_slabs_on_one_device(tmp_path):
     """pf_run_sim with ONE device in use: a room (cut along file z) is stepped as two slabs on that device -- their kernels overlap;
-    PFFDTD_SLABS_PER_DEVICE=1 keeps one domain; same bits either way"""
+    PFFDTD_DEVICES=0 (a chain of one named device) keeps one domain; same bits either way"""
     plates = [(8, 190, 8, 90, z, z + 1) for z in (10, 18, 26, 34, 42, 50, 58, 66)]
     kw = dict(Nx=200, Ny=100, Nz=76, Nt=24, wall=3, Nm=2, Mb=[3, 5], blocks=plates, src=[100, 50, 6], rcv=[[104, 52, 6], [96, 47, 7], [100, 56, 5]])
     sd = sim_data.SimData.from_sim(synth.shoebox(**kw), "single")
@@ -240,8 +240,8 @@ def test_run_sim_runs_a_room_as_two_slabs_on_one_device(tmp_path):
     code = ("import sys; sys.path[:0] = [%r]; import numpy as np; from pffdtd_amd import engine, sim_data, synth; "
             "sd = sim_data.SimData.from_sim(synth.shoebox(**%r), 'single'); sd.scale_input(); engine.run_sim(sd); np.save(%r, sd.u_out)"
             % (str(ROOT), kw, str(tmp_path / "u.npy")))
-    for extra, expect in (({}, "2 slabs cut along file z"), ({"PFFDTD_SLABS_PER_DEVICE": "1"}, None)):
-        r = subprocess.run([os.sys.executable, "-c", code], env={**os.environ, "PFFDTD_NGPUS": "1", "PFFDTD_VERBOSE": "1", **extra},
+    for extra, expect in (({"PFFDTD_NGPUS": "1"}, "2 slabs cut along file z"), ({"PFFDTD_DEVICES": "0"}, None)):
+        r = subprocess.run([os.sys.executable, "-c", code], env={**os.environ, "PFFDTD_VERBOSE": "1", **extra},
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         assert (expect in r.stderr) if expect else ("slabs" not in r.stderr), r.stderr[-1500:]
