@@ -106,34 +106,40 @@ template <typename Real> struct WallLds {
 };
 template <typename Real>
 __device__ __forceinline__ Real fd_regs(Real p, Real u2, Real sf, int32_t k, const Real (&v1)[12], const Real (&g1)[12], Real (&v1o)[12], Real (&g1o)[12],
-                                        const WallLds<Real> &L, Real lo2) {
+                                        const WallLds<Real> &L, Real lo2, int mmax) {
+   // mmax = the largest branch count of the scene (uniform).  Branches m >= the node's own count M are computed and thrown away
+   // (selects): a per-lane branch around every m put each LDS read of a coefficient and its wait into a block of its own --
+   // two dozen dependent LDS round trips per node, with one wave per SIMD nothing to hide them.
    const int M = L.M[k];
    const Real two = 2.0, one = 1.0;
    const Real g = lo2 * sf * L.beta[k];
+   MatQuadT<Real> q[12];
+#pragma unroll
+   for (int m = 0; m < 12; m++)
+      if (m < mmax) q[m] = L.mq[k * 12 + m];
    const Real fac = two * lo2 * sf / (one + g);
    Real u = p;
    u = (u + g * u2) / (one + g);
 #pragma unroll
    for (int m = 0; m < 12; m++) {
-      if (m < M) {
-         const MatQuadT<Real> q = L.mq[k * 12 + m];
-         u -= fac * (two * q.bDh * v1[m] - q.bFh * g1[m]);
+      if (m < mmax) {
+         const Real t = u - fac * (two * q[m].bDh * v1[m] - q[m].bFh * g1[m]);
+         u = (m < M) ? t : u;
       }
    }
    const Real du = u - u2;
 #pragma unroll
    for (int m = 0; m < 12; m++) {
-      if (m < M) {
-         const MatQuadT<Real> q = L.mq[k * 12 + m];
-         const Real v0 = q.b * du + q.bd * v1[m] - two * q.bFh * g1[m];
-         g1o[m] = g1[m] + (v0 + v1[m]) / two;
-         v1o[m] = v0;
+      if (m < mmax) {
+         const Real v0 = q[m].b * du + q[m].bd * v1[m] - two * q[m].bFh * g1[m];
+         const Real gn = g1[m] + (v0 + v1[m]) / two;
+         g1o[m] = (m < M) ? gn : g1[m];
+         v1o[m] = (m < M) ? v0 : v1[m];
       } else { g1o[m] = g1[m]; v1o[m] = v1[m]; }
    }
    return u;
 }
 
-// One block = one lane tile x one march chunk of a region.  MODE = the region's orientation (WallRegion::mode).
 // FAST: the host found every pencil the block evaluates (all lanes, all march steps) to have the SAME structure -- the same node
 // cells with the same adjacency, at most one frequency-dependent node -- and no ghost or ABC cell along the lane and march
 // axes: walls away from edges and corners, the bulk of the work.  The structure then arrives with the block (ds*) and the
@@ -306,7 +312,7 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
          if (sw5 != 0u) { // (cpu_engine.h:290-301, 363-405) the pencils' frequency-dependent node: state in registers
             const bool owner = own_m && own_lane && (int)sk0 >= rko0 && (int)sk0 < rko1;
             if (eval_lane && (STAGE == 1 || owner)) {
-               pfd = fd_regs<Real>(pfd, Fu2, Fsf, Fk, Fv, Fg, Fvo, Fgo, lds, wp.lo2);
+               pfd = fd_regs<Real>(pfd, Fu2, Fsf, Fk, Fv, Fg, Fvo, Fgo, lds, wp.lo2, wp.mmax);
                st = owner;
                nval = pfd;
             }
@@ -341,7 +347,7 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
             Real p = rigid(adj, cc, old, np_, nm, mp, mm, lp, lm);
             const bool owner = own_m && own_lane && k >= rko0 && k < rko1;
             if (prim && (STAGE == 1 || owner)) {
-               p = fd_regs<Real>(p, Fu2, Fsf, Fk, Fv, Fg, Fvo, Fgo, lds, wp.lo2);
+               p = fd_regs<Real>(p, Fu2, Fsf, Fk, Fv, Fg, Fvo, Fgo, lds, wp.lo2, wp.mmax);
                st = owner;
                nval = p;
             }
