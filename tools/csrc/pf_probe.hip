@@ -111,6 +111,11 @@ double pf_tb2_probe(const void *A, const void *B, void *C, void *D, int64_t Nx, 
       if (tye == 2404) { tp.nyt = (int)cdiv(Ny - 2 * margin, 16); hipLaunchKernelGGL((pf::k_tb2_lds<4, 4>), dim3(nblk()), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
       if (tye == 2204) { tp.nyt = (int)cdiv(Ny - 2 * margin, 8); hipLaunchKernelGGL((pf::k_tb2_lds<2, 4>), dim3(nblk()), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
       if (tye == 2208) { tp.nyt = (int)cdiv(Ny - 2 * margin, 16); hipLaunchKernelGGL((pf::k_tb2_lds<2, 8>), dim3(nblk()), dim3(512), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 1316) { tp.nyt = (int)cdiv(Ny - 2 * margin, 48); hipLaunchKernelGGL((pf::k_tb2_reg<float, 3, 16, false>), dim3(nblk()), dim3(1024), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 1216) { tp.nyt = (int)cdiv(Ny - 2 * margin, 32); hipLaunchKernelGGL((pf::k_tb2_reg<float, 2, 16, false>), dim3(nblk()), dim3(1024), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 1208) { tp.nyt = (int)cdiv(Ny - 2 * margin, 16); hipLaunchKernelGGL((pf::k_tb2_reg<float, 2, 8, false>), dim3(nblk()), dim3(512), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 1404) { tp.nyt = (int)cdiv(Ny - 2 * margin, 16); hipLaunchKernelGGL((pf::k_tb2_reg<float, 4, 4, false>), dim3(nblk()), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
+      if (tye == 1408) { tp.nyt = (int)cdiv(Ny - 2 * margin, 32); hipLaunchKernelGGL((pf::k_tb2_reg<float, 4, 8, false>), dim3(nblk()), dim3(512), 0, 0, tp, (float)a1, (float)a2); return true; }
       if (tye == 1308) { tp.nyt = (int)cdiv(Ny - 2 * margin, 24); hipLaunchKernelGGL((pf::k_tb2_reg<float, 3, 8, false>), dim3(nblk()), dim3(512), 0, 0, tp, (float)a1, (float)a2); return true; }
       if (tye == 1304) { tp.nyt = (int)cdiv(Ny - 2 * margin, 12); hipLaunchKernelGGL((pf::k_tb2_reg<float, 3, 4, false>), dim3(nblk()), dim3(256), 0, 0, tp, (float)a1, (float)a2); return true; }
       if (tye == 308) { tp.nyt = (int)cdiv(Ny - 2 * margin, 24); hipLaunchKernelGGL((pf::k_tb2_reg<float, 3, 8>), dim3((uint32_t)tp.nzt * tp.nyt * tp.nxc), dim3(512), 0, 0, tp, (float)a1, (float)a2); return true; }
