@@ -94,6 +94,12 @@ double pf_tb2_probe(const void *A, const void *B, void *C, void *D, int64_t Nx, 
    tp.nzt = (int)cdiv(Nz - 2 * margin, 248);
    hipEvent_t e0, e1;
    hipEventCreate(&e0); hipEventCreate(&e1);
+   // +100000: A,B (and C,D) interleaved row by row in one storage (the caller passes B = A + P, D = C + P); +200000: plane by plane
+   // (B = A + Ny*P).  Layout experiments for the number of concurrent DRAM streams; the column clamp is then off by a row, which
+   // only matters for the bits of the last columns, not for the time.
+   const int lay = tye / 100000; tye %= 100000;
+   if (lay == 1) { tp.P = (int)(2 * P); tp.plane = 2 * Ny * P; }
+   if (lay == 2) tp.plane = 2 * Ny * P;
    tp.band = tye >= 10000 ? 1 : 0; // +10000: banded tile order
    if (tye >= 10000) tye -= 10000;
    auto nblk = [&]() { const uint32_t T = (uint32_t)tp.nzt * tp.nyt; return tp.band ? 8 * ((T + 7) / 8) * (uint32_t)tp.nxc : T * (uint32_t)tp.nxc; };

@@ -18,11 +18,15 @@ L = build.load_probe()
 P = engine.grid_pitch(n, 4)
 gen = torch.Generator(device="cuda"); gen.manual_seed(7)
 g = [(torch.rand((n, n * P), generator=gen, device="cuda") * 2 - 1) * 1e-3 for _ in range(4)]
+S = [torch.cat([g[0], g[1]]), torch.cat([g[2], g[3]])]  # interleaved layouts (tye + 100000 rows, + 200000 planes): two storages
 m = 8
 cells = (n - 2 * m) ** 3
 for tye in tyes:
     for chunk in chunks:
-        ms = L.pf_tb2_probe(g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), g[3].data_ptr(), n, n, n, 0.5, 0.25, m, tye, chunk, reps)
+        lay = tye // 100000
+        off = 4 * (P if lay == 1 else n * P)
+        ptrs = [g[i].data_ptr() for i in range(4)] if lay == 0 else [S[0].data_ptr(), S[0].data_ptr() + off, S[1].data_ptr(), S[1].data_ptr() + off]
+        ms = L.pf_tb2_probe(*ptrs, n, n, n, 0.5, 0.25, m, tye, chunk, reps)
         if ms < 0:
             print("probe failed:", L.pf_probe_last_error().decode(), flush=True)
             continue
