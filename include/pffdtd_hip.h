@@ -103,7 +103,9 @@ typedef struct pf_opts {
                              0x2000 store the grid with the file's x and z axes exchanged / never (default: decided per scene);
                              0x10000000 blocked pairs keep the single-step shell (no wall regions); 0x8000000 wall regions: every block
                              generic; 0x4000000 all their launches on one stream; 0x2000000 wide column strips cut in two;
-                             0x800000 replay the single-step loop from a hipGraph (six steps per graph; no faster on this stack) */
+                             0x800000 replay the single-step loop from a hipGraph (six steps per graph; no faster on this stack);
+                             0x100000 boundary pass of a room in plain workgroup order; 0x200000 it fetches the neighbours inside
+                             the wall too */
    int32_t energy;        /* 1 = keep what the energy diagnostic needs (explicit Laplacian grid, unfused kernel
                              sequence); then use pf_engine_energy_cfg + pf_engine_run_energy */
    int32_t multi_flags;   /* pf_run_sim_devices / pf_multi_create only: PF_MULTI_* */

@@ -640,17 +640,23 @@ static __global__ void k_abc_loss(Real *__restrict__ u0, const int64_t *__restri
 // gather the NN neighbours of a boundary node in the adjacency-bit order (cpu_engine.h:241-246 / 262-273)
 // (axes exchanged in storage: sx = stride of the file's x axis = 1, sz = stride of its z axis = plane)
 template <typename Real, bool FCC>
-__device__ __forceinline__ void gather_nb(const Real *__restrict__ u1, int64_t ii, int64_t P, int64_t plane_, Real (&nb)[FCC ? 12 : 6], bool swz = false) {
+// need: bit k set = neighbour k is wanted.  A neighbour whose adjacency bit is clear enters the CPU-exact rigid update as
+// p + (a2*0)*u1 = p + (+-0) (upd_rigid), which leaves p as it is unless p is -0 -- and p never is: every sum of the time loop
+// has a +0 or a non-zero addend (the state starts as +0, and x + (-x) = +0), so the field holds no -0 and b1*c - old is never
+// -0.  Those neighbours (the cells INSIDE the wall) therefore need not be fetched: a third of a floor node's lines.  The
+// safeguarded arithmetic (products bit*u1, round-towards-zero tree) passes need = all ones.
+__device__ __forceinline__ void gather_nb(const Real *__restrict__ u1, int64_t ii, int64_t P, int64_t plane_, Real (&nb)[FCC ? 12 : 6], bool swz = false,
+                                          uint32_t need = 0xffffu) {
    const int64_t plane = swz ? 1 : plane_, one = swz ? plane_ : 1;
    if (!FCC) {
       const int64_t off[6] = {plane, -plane, P, -P, one, -one};
 #pragma unroll
-      for (int j = 0; j < 6; j++) nb[j] = u1[ii + off[j]];
+      for (int j = 0; j < 6; j++) nb[j] = ((need >> j) & 1u) ? u1[ii + off[j]] : (Real)0;
    } else {
       const int64_t off[12] = {plane + P, -plane - P, P + one, -P - one, plane + one, -plane - one,
                                plane - P, -plane + P, P - one, -P + one, plane - one, -plane + one};
 #pragma unroll
-      for (int j = 0; j < 12; j++) nb[j] = u1[ii + off[j]];
+      for (int j = 0; j < 12; j++) nb[j] = ((need >> j) & 1u) ? u1[ii + off[j]] : (Real)0;
    }
 }
 template <typename Real, bool FCC, bool SG>
@@ -768,10 +774,25 @@ static __global__ void k_boundary(const Real *__restrict__ u1, Real *u0, const i
                            const Real *gh1, Real *vh1o, Real *gh1o, // branch state before / after (the same arrays: in place)
                            Real lo2, int64_t mmax, int64_t begin, int64_t end,
                            const Real *u0_old, const int32_t *__restrict__ sel, int swz, // u0_old: where u^{n-1} lives (== u0 in place)
-                           const int32_t *__restrict__ fdsel = nullptr, int64_t nfd = 0, const int64_t *__restrict__ idx_l = nullptr) {
+                           const int32_t *__restrict__ fdsel = nullptr, int64_t nfd = 0, const int64_t *__restrict__ idx_l = nullptr,
+                           int flags = 0) {
+   // flags & 1: XCD-aware order of the workgroups over the list.  G = flags >> 4 > 0: inside every window of 8*G workgroups, XCD k
+   // (blocks k, k+8, ...) walks the k-th run of G consecutive pieces, so the rows of u^n a node row shares with the next one (all
+   // but the outermost of its 3 / 9 neighbour rows) are asked for by the same L2 a few workgroups later instead of by up to
+   // eight L2s, while all XCDs stay within 8*G pieces of each other (G = 0: one run per XCD over the whole list).
+   // flags & 2: fetch every neighbour (gather_nb).
    // fdsel: threads beyond the list do the branch ODEs of nfd lossy nodes whose RIGID update was done elsewhere (the column-strip
    // kernel left it in u0b[li]): k_fd_sel's work in the same launch -- one kernel, one wait for the index chains, fewer
-   const int64_t t = begin + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+   uint32_t blk = blockIdx.x;
+   if (flags & 1) {
+      const uint32_t G = (uint32_t)flags >> 4; // run length per XCD (workgroups); 0: one run per XCD over the whole list
+      if (G == 0) blk = xcd_swizzle(blockIdx.x, gridDim.x);
+      else {
+         const uint32_t win = 8u * G, full = (gridDim.x / win) * win;
+         if (blk < full) { const uint32_t r = blk % win; blk = blk - r + (r & 7u) * G + (r >> 3); }
+      }
+   }
+   const int64_t t = begin + blk * (int64_t)blockDim.x + threadIdx.x;
    if (t >= end) {
       const int64_t f = t - end;
       if (f < nfd) {
@@ -784,7 +805,7 @@ static __global__ void k_boundary(const Real *__restrict__ u1, Real *u0, const i
    const int64_t ii = idx[nb];
    const uint32_t adj = adjv[nb];
    Real v[FCC ? 12 : 6];
-   gather_nb<Real, FCC>(u1, ii, P, plane, v, swz != 0);
+   gather_nb<Real, FCC>(u1, ii, P, plane, v, swz != 0, (SG || (flags & 2)) ? 0xffffu : adj);
    Real p = upd_rigid<SG, FCC ? 12 : 6>(a2, sl2, adj, u1[ii], u0_old[ii], v);
    const int32_t li = lossy[nb];
    if (li >= 0) p = fd_node_update<Real>(p, li, u0b, u2b, ssaf, mat, Mb, mq, beta, vh1, gh1, vh1o, gh1o, lo2, mmax);
