@@ -1155,9 +1155,13 @@ template <typename Real> struct Engine : EngineBase {
             wp.blk = wl_blk + g.blk0[q];
             const dim3 gd(g.nblk[q]), b(64);
             hipStream_t st = q == 1 ? sg : s;
-#define PF_WALL(DP, VEC) do { if (q == 0) hipLaunchKernelGGL((pf::k_wall2<Real, DP, VEC, true>), gd, b, 0, st, wp, a1, a2); \
-                              else if (q == 1) hipLaunchKernelGGL((pf::k_wall2<Real, DP, VEC, false>), gd, b, 0, st, wp, a1, a2); \
-                              else if constexpr (VEC) hipLaunchKernelGGL((pf::k_wall2<Real, DP, VEC, true, false>), gd, b, 0, st, wp, a1, a2); } while (0)
+#define PF_WALL(DP, VEC) do { if (q == 2) { if constexpr (VEC) hipLaunchKernelGGL((pf::k_wall2<Real, DP, VEC, true, false>), gd, b, 0, st, wp, a1, a2); } \
+                              else if (mb_max <= 4) { \
+                                 if (q == 0) hipLaunchKernelGGL((pf::k_wall2<Real, DP, VEC, true, true, 4>), gd, b, 0, st, wp, a1, a2); \
+                                 else hipLaunchKernelGGL((pf::k_wall2<Real, DP, VEC, false, true, 4>), gd, b, 0, st, wp, a1, a2); \
+                              } else { \
+                                 if (q == 0) hipLaunchKernelGGL((pf::k_wall2<Real, DP, VEC, true, true, 12>), gd, b, 0, st, wp, a1, a2); \
+                                 else hipLaunchKernelGGL((pf::k_wall2<Real, DP, VEC, false, true, 12>), gd, b, 0, st, wp, a1, a2); } } while (0)
             if (gi == 0) PF_WALL(8, false);
             else if (gi == 1) PF_WALL(12, true);
             else if (gi == 2) PF_WALL(16, true);

@@ -104,9 +104,9 @@ template <typename Real> struct WallLds {
    Real beta[PF_WALL_MAXMAT];
    int32_t M[PF_WALL_MAXMAT];
 };
-template <typename Real>
+template <typename Real, int mmax>
 __device__ __forceinline__ Real fd_regs(Real p, Real u2, Real sf, int32_t k, const Real (&v1)[12], const Real (&g1)[12], Real (&v1o)[12], Real (&g1o)[12],
-                                        const WallLds<Real> &L, Real lo2, int mmax) {
+                                        const WallLds<Real> &L, Real lo2) {
    // mmax = the largest branch count of the scene (uniform).  Branches m >= the node's own count M are computed and thrown away
    // (selects): a per-lane branch around every m put each LDS read of a coefficient and its wait into a block of its own --
    // two dozen dependent LDS round trips per node, with one wave per SIMD nothing to hide them.
@@ -145,7 +145,7 @@ __device__ __forceinline__ Real fd_regs(Real p, Real u2, Real sf, int32_t k, con
 // axes: walls away from edges and corners, the bulk of the work.  The structure then arrives with the block (ds*) and the
 // per-lane node decoding, the node loop, the lane shuffles and the march-axis mirrors are compiled out.
 // NODES = false (FAST only): none of the block's pencils holds a boundary node (the plain-air part of a wide column strip).
-template <typename Real, int DP, int MODE, bool FAST, bool NODES>
+template <typename Real, int DP, int MODE, bool FAST, bool NODES, int MC>
 __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const WallRegion &R, const int j, const int c, const Real a1, const Real a2,
                                           const WallLds<Real> *ldsp, const uint32_t dsx, const uint32_t dsz, const uint32_t dsw) {
    constexpr bool VEC = MODE == 2;
@@ -205,9 +205,12 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
       }
    };
    auto mirror = [&](Real(&b)[DP]) __attribute__((always_inline)) { // the ghost cell of a pencil = the cell two inside
+      // (selects, not branches: a wave-uniform `if` per cell is a compare + branch around one move, three pencils per march step)
 #pragma unroll
-      for (int k = 0; k < DP; k++)
-         if (k == rkg) b[k] = (k == 0) ? b[2] : b[k >= 2 ? k - 2 : 0];
+      for (int k = DP - 1; k >= 0; k--) {
+         const Real src = (k == 0) ? b[2] : b[k >= 2 ? k - 2 : 0];
+         b[k] = (k == rkg) ? src : b[k];
+      }
    };
    auto load_ent = [&](int m) __attribute__((always_inline)) { // march steps R.m0-1 .. R.m1 have entries
       const uint4 *e = wp.pen + (R.pen_off + (int64_t)(min(m, R.m1) - (R.m0 - 1)) * R.nlp + (WALL_LT * j + lane));
@@ -244,7 +247,7 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
          const int32_t li = (int32_t)(E.w >> 8);
 #pragma unroll
          for (int m = 0; m < 12; m++)
-            if (m < wp.mmax) { v[m] = wp.sv_in[st_idx(m, li)]; g[m] = wp.sg_in[st_idx(m, li)]; }
+            if (m < MC) { v[m] = wp.sv_in[st_idx(m, li)]; g[m] = wp.sg_in[st_idx(m, li)]; }
          sf = wp.ssaf[li];
          k = wp.mat[li];
          u2 = wp.x2[li];
@@ -312,7 +315,7 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
          if (sw5 != 0u) { // (cpu_engine.h:290-301, 363-405) the pencils' frequency-dependent node: state in registers
             const bool owner = own_m && own_lane && (int)sk0 >= rko0 && (int)sk0 < rko1;
             if (eval_lane && (STAGE == 1 || owner)) {
-               pfd = fd_regs<Real>(pfd, Fu2, Fsf, Fk, Fv, Fg, Fvo, Fgo, lds, wp.lo2, wp.mmax);
+               pfd = fd_regs<Real, MC>(pfd, Fu2, Fsf, Fk, Fv, Fg, Fvo, Fgo, lds, wp.lo2);
                st = owner;
                nval = pfd;
             }
@@ -347,7 +350,7 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
             Real p = rigid(adj, cc, old, np_, nm, mp, mm, lp, lm);
             const bool owner = own_m && own_lane && k >= rko0 && k < rko1;
             if (prim && (STAGE == 1 || owner)) {
-               p = fd_regs<Real>(p, Fu2, Fsf, Fk, Fv, Fg, Fvo, Fgo, lds, wp.lo2, wp.mmax);
+               p = fd_regs<Real, MC>(p, Fu2, Fsf, Fk, Fv, Fg, Fvo, Fgo, lds, wp.lo2);
                st = owner;
                nval = p;
             }
@@ -437,7 +440,7 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
          wp.o2[li2] = nv2;
 #pragma unroll
          for (int q = 0; q < 12; q++)
-            if (q < wp.mmax) { wp.sv_out[st_idx(q, li2)] = F2v[q]; wp.sg_out[st_idx(q, li2)] = F2g[q]; }
+            if (q < MC) { wp.sv_out[st_idx(q, li2)] = F2v[q]; wp.sg_out[st_idx(q, li2)] = F2g[q]; }
       }
       asm volatile("" : : : "memory");
 #pragma unroll
@@ -459,7 +462,11 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
 
 // One launch = a list of blocks (WallParams::blk: region | lane tile << 3 | march chunk << 16, and for FAST launches the common
 // structure of the block's pencils).  !VEC: regions normal to x and y (lanes along z); VEC: regions normal to z.
-template <typename Real, int DP, bool VEC, bool FAST, bool NODES = true>
+// MC = how many branch states per node the kernel moves and evaluates, a compile-time bound of the scene's largest branch count
+// (4 or 12; the state arrays hold 12 slots per node, pf_kernels.h: st_idx): with the count itself, a kernel argument, as the
+// bound every branch m sat in a block of its own -- compare, jump, reload of the array pointers, wait -- 12 times per fetch, per
+// evaluation and per store.  Slots between the scene's count and MC are loaded and stored back unchanged.
+template <typename Real, int DP, bool VEC, bool FAST, bool NODES = true, int MC = 12>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FAST && DP * sizeof(Real) <= 64) ? 2 : 1))) void k_wall2(WallParams<Real> wp, Real a1, Real a2) {
    static_assert(FAST || NODES, "generic blocks have everything");
    const uint4 bd = wp.blk[blockIdx.x];
@@ -471,9 +478,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FAST && DP 
       for (int i = threadIdx.x; i < wp.nmat; i += 64) { lds.beta[i] = wp.beta[i]; lds.M[i] = wp.Mb[i]; }
       __syncthreads();
    }
-   if constexpr (VEC) wall_body<Real, DP, 2, FAST, NODES>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
-   else if (R.mode == 1) wall_body<Real, DP, 1, FAST, NODES>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
-   else wall_body<Real, DP, 0, FAST, NODES>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
+   if constexpr (VEC) wall_body<Real, DP, 2, FAST, NODES, MC>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
+   else if (R.mode == 1) wall_body<Real, DP, 1, FAST, NODES, MC>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
+   else wall_body<Real, DP, 0, FAST, NODES, MC>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
 }
 
 } // namespace pf
