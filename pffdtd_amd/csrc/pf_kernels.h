@@ -28,8 +28,9 @@ template <> struct VecOf<double> { typedef f64x2 type; static constexpr int V = 
 // ---- wave64 neighbour exchange along the unit-stride axis -------------------------------------------------
 // DPP wave shifts (gfx9 family): wave_shr:1 moves data to the next-higher lane (lane i reads lane i-1),
 // wave_shl:1 the other way.  Lanes with no source keep `old` (=0).
-__device__ __forceinline__ int dpp_from_lower(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ int dpp_from_upper(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
+// (bound_ctrl: a lane without a source gets 0 from the instruction itself, no register to preset)
+__device__ __forceinline__ int dpp_from_lower(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ int dpp_from_upper(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }
 
 template <bool DPP> __device__ __forceinline__ float lane_from_lower(float v) {
    if (DPP) return __int_as_float(dpp_from_lower(__float_as_int(v)));

@@ -277,6 +277,54 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
                      Real(&Out)[DP], bool own_m, const Real(&Fv)[12], const Real(&Fg)[12], Real(&Fvo)[12], Real(&Fgo)[12], Real Fsf, Real Fu2,
                      int32_t Fk, Real &nval, bool &st) __attribute__((always_inline)) {
       constexpr int STAGE = decltype(stage)::value;
+      if constexpr (FAST) {
+         // the block's structure is uniform and known (usx: node cells, usz: their adjacency, usw: the frequency-dependent one):
+         // one scalar bit test per cell decides between the air and the rigid update; the ABC loss can only apply next to the
+         // pencil's ghost cell: pencil cell 1 of a low-side region (tested in place), any cell of a high-side one (its ghost sits
+         // wherever the aligned pencil puts it: applied after the loop through selects -- one copy of the double-precision
+         // division instead of one per pencil cell)
+         st = false;
+         const uint32_t sx = NODES ? usx : 0u, sw5 = NODES ? (usw & 31u) : 0u, sk0 = usw >> 8;
+         Real pfd = Real(0);
+#pragma unroll
+         for (int k = 1; k < DP - 1; k++) {
+            const Real cc = Cur[k];
+            const Real lm = lane_from_lower<true>(cc), lp = lane_from_upper<true>(cc);
+            Real p;
+            if (NODES && ((sx >> k) & 1u)) {
+               const uint32_t jn = __popc(sx & ((1u << k) - 1u));
+               p = rigid((usz >> (6 * jn)) & 63u, cc, Old[k], Cur[k + 1], Cur[k - 1], Nxt[k], Prv[k], lp, lm);
+               if ((uint32_t)k == sk0) pfd = p;
+            } else {
+               p = air(cc, Old[k], Cur[k + 1], Cur[k - 1], Nxt[k], Prv[k], lp, lm);
+               if (k == 1) {
+                  const int nk = rnbase + k;
+                  if ((ng_lo && nk == 1) || (ng_hi && nk == NN - 2)) p = abc_loss<false>(p, Old[k], wp.l); // (cpu_engine.h:225-229)
+               }
+            }
+            Out[k] = p;
+         }
+         {
+            const int kh = NN - 2 - rnbase;
+            if (ng_hi && kh >= 2 && kh <= DP - 2 && !(NODES && ((sx >> kh) & 1u))) {
+               const Real t = abc_loss<false>(wall_sel<Real, DP>(Out, kh), wall_sel<Real, DP>(Old, kh), wp.l);
+#pragma unroll
+               for (int k = 2; k < DP - 1; k++) Out[k] = (k == kh) ? t : Out[k];
+            }
+         }
+         if (NODES && sw5 != 0u) { // (cpu_engine.h:290-301, 363-405) the pencils' frequency-dependent node: state in registers
+            const bool owner = own_m && own_lane && (int)sk0 >= rko0 && (int)sk0 < rko1;
+            if (eval_lane && (STAGE == 1 || owner)) {
+               pfd = fd_regs<Real, MC>(pfd, Fu2, Fsf, Fk, Fv, Fg, Fvo, Fgo, lds, wp.lo2);
+               st = owner;
+               nval = pfd;
+            }
+#pragma unroll
+            for (int k = 1; k < DP - 1; k++) Out[k] = ((uint32_t)k == sk0) ? pfd : Out[k];
+         }
+         mirror(Out);
+         return;
+      }
       const int qm = FAST ? 0 : (mx ? (((wp.first && m == 1) || (wp.last && m == wp.Nx - 2)) ? 1 : 0) : ((m == 1 || m == wp.Ny - 2) ? 1 : 0));
       st = false;
       // Do all the pencils of the wave look alike (same node cells, same adjacency, at most one frequency-dependent node, all
@@ -410,6 +458,9 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
       bool st1 = false, st2 = false;
       update(std::integral_constant<int, 1>(), m, Bm, Bc, Bn, Ac, Ec, Vn, own_m, F1v, F1g, F1v, F1g, F1sf, F1u2, F1k, nv1, st1);
       // stage 2: u^{n+2}(m-1) from u^{n+1}(m-2 .. m); a ghost plane of the march axis is the plane two further in
+      // (opaque again: otherwise every per-cell predicate of stage 1 is kept for stage 2 -- in vector-register lanes, two
+      // v_writelane per cell -- instead of being tested again with one scalar instruction)
+      asm volatile("" : "+s"(rkg), "+s"(rko0), "+s"(rko1), "+s"(rnbase), "+s"(usx), "+s"(usz), "+s"(usw));
       const bool do2 = m - 1 >= ms;
       if (do2) {
          if (!mx && !FAST) {
