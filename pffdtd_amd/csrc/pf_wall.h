@@ -518,7 +518,7 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
 // bound every branch m sat in a block of its own -- compare, jump, reload of the array pointers, wait -- 12 times per fetch, per
 // evaluation and per store.  Slots between the scene's count and MC are loaded and stored back unchanged.
 template <typename Real, int DP, bool VEC, bool FAST, bool NODES = true, int MC = 12>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FAST && DP * sizeof(Real) <= 64) ? 2 : 1))) void k_wall2(WallParams<Real> wp, Real a1, Real a2) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FAST && !VEC) ? 2 : 1))) void k_wall2(WallParams<Real> wp, Real a1, Real a2) {
    static_assert(FAST || NODES, "generic blocks have everything");
    const uint4 bd = wp.blk[blockIdx.x];
    const WallRegion R = wp.reg[bd.x & 7u];
