@@ -78,6 +78,8 @@ class Engine:
     """Step-wise oracle engine (used by the slab tests as the per-slab stepper and for grid comparisons)."""
 
     def __init__(self, sd, slab_first=True, slab_last=True, safeguarded=False, along_z=False):
+        if getattr(sd, "bn_mask", None) is None:
+            raise ValueError("the oracle steps by the boundary-node bit mask (cpu_engine.h:175-194): build the SimData with build_mask=True")
         self.L = lib()
         self.sd = sd
         self.sfx = _sfx(sd)

@@ -8,7 +8,7 @@ import pytest
 
 import cases
 import oracle
-from pffdtd_amd import engine
+from pffdtd_amd import engine, sim_data, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -120,6 +120,41 @@ def test_exchanged_axes_storage_gives_the_same_bits(name, variant, numerics):
         eng.close()
         assert np.array_equal(sd.u_out, ref_out), (prec, np.abs(sd.u_out - ref_out).max())
         assert np.array_equal(u1[1:-1, 1:-1, 1:-1], ref_u1[1:-1, 1:-1, 1:-1]), prec
+
+
+@pytest.mark.parametrize("fcc", [False, True], ids=["7pt", "13pt"])
+def test_room_boundary_pass_order_and_neighbour_fetch(fcc):
+    """The boundary pass of an exchanged-axes engine walks the node list in XCD-aware runs (windows of 512 workgroups of 128 nodes)
+    and skips the neighbours inside the wall.  A shoebox with more than 65536 boundary nodes (a full window plus a tail in plain
+    order) from seeded random fields: the oracle's bits, and the same bits with either switched off (debug 0x100000 / 0x200000)."""
+    n = (128, 144, 136) if fcc else (96, 112, 104)
+    sim = synth.shoebox(*n, Nt=6, fcc=fcc, Nm=2, Mb=[11, 3], wall=3)
+    if fcc:
+        sim = synth.fold_fcc(sim)
+    sd = sim_data.SimData.from_sim(sim, "single")  # (with bn_mask: the oracle steps by it)
+    sd.scale_input()
+    assert sd.Nb > 65536 + 128
+    rng = np.random.default_rng(29)
+    shape = (sd.Nx, sd.Ny, sd.Nz)
+    init = [(rng.standard_normal(shape) * 1e-2).astype(np.float32) for _ in range(2)]
+    e = oracle.Engine(sd)
+    for k in (0, 1):
+        e.grid(k)[...] = init[k]
+    for i in range(sd.Nt):
+        e.step(i)
+    ref_u1, ref_out = e.grid(1).copy(), sd.u_out.copy()
+    e.close()
+    for dbg in (0x1000, 0x1000 | 0x100000, 0x1000 | 0x200000):
+        sd.u_out[:] = 0
+        eng = engine.HipEngine(sd, debug=dbg)
+        assert eng.layout()[2]
+        for k in (0, 1):
+            eng.set_grid(k, init[k])
+        eng.run(0, sd.Nt)
+        u1 = eng.get_grid(1)
+        eng.close()
+        assert np.array_equal(sd.u_out, ref_out), hex(dbg)
+        assert np.array_equal(u1[1:-1, 1:-1, 1:-1], ref_u1[1:-1, 1:-1, 1:-1]), hex(dbg)
 
 
 def test_exchanged_axes_set_grid_round_trip_and_refusals():
