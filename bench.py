@@ -136,7 +136,8 @@ def roofline_block(args, sd, tm, K, real_bytes, interior_planes, interior_per_pl
             kernel = "k_tb2_fcc_x" if lw == 64 else "k_tb2_fcc"
             inst = f"pf::k_tb2_fcc_x<{T}, 2, 8>" if lw == 64 else f"pf::k_tb2_fcc<{T}, 2, 4, {lw}>"
         else:
-            kernel, inst = "k_tb2_reg", f"pf::k_tb2_reg<{T}, 3, 4, false, {lw}, false>"  # (..., true> = creation-time probes)
+            sgt = "true" if getattr(args, "numerics", 0) == 2 else "false"  # (<..., PROBE = true, ...> = creation-time probes)
+            kernel, inst = "k_tb2_reg", f"pf::k_tb2_reg<{T}, 3, 4, false, {lw}, false, {sgt}>"
         kernel_ms = tm["tb2_ms_total"] / tm["tb2_launches"]
         units = 2 * tm["tb2_cells"]
     else:
