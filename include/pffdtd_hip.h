@@ -104,7 +104,7 @@ typedef struct pf_opts {
                              0x10000000 blocked pairs keep the single-step shell (no wall regions); 0x8000000 wall regions: every block
                              generic; 0x4000000 all their launches on one stream; 0x2000000 wide column strips cut in two;
                              0x800000 replay the single-step loop from a hipGraph (six steps per graph; no faster on this stack);
-                             0x100000 boundary pass of a room in plain workgroup order; 0x200000 it fetches the neighbours inside
+                             0x100000 boundary pass in plain workgroup order; 0x200000 it fetches the neighbours inside
                              the wall too */
    int32_t energy;        /* 1 = keep what the energy diagnostic needs (explicit Laplacian grid, unfused kernel
                              sequence); then use pf_engine_energy_cfg + pf_engine_run_energy */

@@ -2064,13 +2064,14 @@ template <typename Real> struct Engine : EngineBase {
       const int64_t nfd = with_fd ? zs_nfd : 0;
       dim3 g((unsigned)cdiv(r.e - r.b + nfd, 128)), b(128);
 #define PF_BND(F, M) hipLaunchKernelGGL((pf::k_boundary<Real, F, M>), g, b, 0, s, u1, u0, d_bn, d_adj, d_lossy, a2, sl2, P, plane, ub[0], ub[2], d_ssaf, d_mat, d_Mb, d_mq, d_beta, vh1, gh1, bs_vout ? bs_vout : vh1, bs_gout ? bs_gout : gh1, lo2, (int64_t)mb_max, r.b, r.e, u0_src ? u0_src : (const Real *)u0, bnd_sel, swz ? 1 : 0, with_fd ? zs_fd : (const int32_t *)nullptr, nfd, d_bnl, bflags)
-      // Rooms (exchanged-axes storage; the list kernel visits every node): each XCD walks runs of 64 consecutive workgroups
+      // Each XCD walks runs of 64 consecutive workgroups
       // (8192 nodes, a few node rows) inside a window of 512, so most rows of u^n that consecutive node rows share are asked
       // for by ONE L2: fetched bytes 4.53 -> 3.7 GB on the Musikverein, 0.79-0.81 -> 0.75-0.76 ms (CTK 0.150 -> 0.141).
       // One run per XCD over the whole list fetches least (3.36 GB) and is slowest (0.90 ms: eight places in every stream);
-      // profiles/r04_rooms_hbm_traffic.md.  debug 0x100000: plain order; 0x200000: fetch the neighbours inside the wall too.
+      // profiles/r04_rooms_hbm_traffic.md.  (Box rooms in single steps: 1024^3 384 -> 388 Gvox/s; slabs: the same.)
+      // debug 0x100000: plain order; 0x200000: fetch the neighbours inside the wall too.
       const int bnd_g = 64;
-      const int bflags = ((swz && !(op.debug & 0x100000)) ? (1 | (bnd_g << 4)) : 0) | ((op.debug & 0x200000) ? 2 : 0);
+      const int bflags = ((!(op.debug & 0x100000)) ? (1 | (bnd_g << 4)) : 0) | ((op.debug & 0x200000) ? 2 : 0);
       if (fcc) { if (sg) PF_BND(true, true); else PF_BND(true, false); }
       else { if (sg) PF_BND(false, true); else PF_BND(false, false); }
 #undef PF_BND
