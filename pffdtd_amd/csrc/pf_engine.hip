@@ -188,8 +188,9 @@ template <typename Real> struct Engine : EngineBase {
    Range bn_lo, bn_mid, bn_hi, bnl_lo, bnl_mid, bnl_hi, bna_lo, bna_mid, bna_hi, in_lo, in_mid, in_hi;
    // the same lists cut for the split-phase pairs, whose edge stream owns two planes per side: planes 1-2 / 3..Nx-4 / Nx-3..Nx-2
    Range bn_lo2, bn_mid2, bn_hi2, bnl_lo2, bnl_mid2, bnl_hi2, in_lo2, in_mid2, in_hi2;
-   hipStream_t s_main = nullptr, s_edge = nullptr;
-   hipEvent_t ev_pre = nullptr, ev_edge = nullptr, ev_main = nullptr;
+   hipStream_t s_main = nullptr, s_edge = nullptr, s_wall = nullptr; // s_wall: a slab's wall regions (created on first use)
+   hipEvent_t ev_pre = nullptr, ev_edge = nullptr, ev_main = nullptr, ev_wall0 = nullptr, ev_wall = nullptr;
+   bool wall_pending = false;
    bool in_step = false;
    bool state_touched = false; // a caller wrote the field (pf_engine_set_grid): the placement search, which steps and then zeroes the offered grids, is refused
    int64_t steps_done = 0;
@@ -244,6 +245,7 @@ template <typename Real> struct Engine : EngineBase {
    const int32_t *bnd_sel = nullptr;                      // launch_boundary visits bnd_sel[range] when set
    // wall regions (pf_wall.h): the shell of a blocked pair -- wall layers, ABC cells, ghost mirrors -- stepped in pairs too
    bool wl_on = false;
+   Real *wsP[3] = {nullptr, nullptr, nullptr};            // slab pairs with wall regions: the node-value buffers u0b / u1b / u2b at the start of the pair
    // launch groups: 0 = regions normal to x / y (lanes along z, pencils of 8 cells); 1 / 2 / 3 = regions normal to z (lanes along
    // y) with vector pencils of 12 / 16 / 20 cells.  Each has a list of alike blocks and one of generic blocks.
    struct WlGroup { int nreg = 0; pf::WallRegion reg[pf::WALL_MAXREG]; uint32_t blk0[3] = {0, 0, 0}, nblk[3] = {0, 0, 0}; }; // lists: alike, generic, alike without nodes
@@ -284,9 +286,12 @@ template <typename Real> struct Engine : EngineBase {
       if (ev_main) hipEventDestroy(ev_main);
       if (gexec) hipGraphExecDestroy(gexec);
       if (d_ctr) hipFree(d_ctr);
+      if (s_wall) hipStreamDestroy(s_wall);
+      if (ev_wall0) hipEventDestroy(ev_wall0);
+      if (ev_wall) hipEventDestroy(ev_wall);
       if (s_main) hipStreamDestroy(s_main);
       if (s_edge) hipStreamDestroy(s_edge);
-      u0 = u1 = nullptr; s_main = s_edge = nullptr;
+      u0 = u1 = nullptr; s_main = s_edge = s_wall = nullptr; ev_wall0 = ev_wall = nullptr;
    }
 
    // file-layout linear index -> padded index
@@ -679,7 +684,7 @@ template <typename Real> struct Engine : EngineBase {
       }
       // Wall regions (init_walls): a column strip costs one 128-byte line per row whatever its width, but its pencils live in
       // registers -- a sliver cut off the box is shared between the two strips instead of all going to the right one.
-      if (!fcc && !sg && single && !(op.debug & 0x10000000)) {
+      if (!fcc && !sg && !(op.debug & 0x10000000)) { // (slab engines too: init_walls(true))
          const int z1full = (int)((Nz - mz1) / 4 * 4);
          if (tbz1 < z1full) {
             const int rem = z1full - tbz1;
@@ -921,19 +926,28 @@ template <typename Real> struct Engine : EngineBase {
       wl_on = false;
       for (auto &g : wl_grp) g = WlGroup{};
    }
-   int init_walls() {
+   // slab = true: a slab of a chain (pairs across two split-phase steps, step_begin): only the regions normal to y and z, over
+   // the box's planes -- the planes between the slab's faces and the box (two edge planes per side, which are exchanged between
+   // the two steps of a pair, and whatever x slab lies between them and the box) keep their single steps, and their boundary
+   // nodes stay with the list kernel (wl_rest = the nodes of the interior planes no region owns).
+   int init_walls(bool slab = false) {
       wl_on = false;
       const bool single = op.slab_first && op.slab_last;
-      if (!tb2 || fcc || sg || !single || tb_xr.empty() || swz || (op.debug & 0x10000000)) return PF_OK;
-      if (Nb > 0 && !fuse_boundary) return PF_OK;
-      if (Nbl >= ((int64_t)1 << 24) || Nb >= ((int64_t)1 << 31)) return PF_OK;
+      const bool vb = getenv("PFFDTD_VERBOSE") && atoi(getenv("PFFDTD_VERBOSE")) > 1;
+#define WL_NO(why) do { if (vb) fprintf(stderr, "pffdtd_hip: no wall regions (%s)\n", why); return PF_OK; } while (0)
+      if (slab ? (!tb2_slab || single) : (!tb2 || !single)) WL_NO("not a pair-stepping engine of this kind");
+      if (fcc || sg || tb_xr.empty() || swz || (op.debug & 0x10000000)) WL_NO("13-point / safeguarded / no box / exchanged axes / switched off");
+      if (Nb > 0 && !fuse_boundary) WL_NO("boundary pass not fused");
+      if (Nbl >= ((int64_t)1 << 24) || Nb >= ((int64_t)1 << 31)) WL_NO("too many nodes");
       constexpr int DPS = 8, V = pf::VecOf<Real>::V;
-      if (tbx0 + 2 > DPS || Nx - tbx1 + 2 > DPS || tby0 + 2 > DPS || Ny - tby1 + 2 > DPS) return PF_OK;
-      if (Nx < 2 * DPS || Ny < 2 * DPS) return PF_OK;
+      if (!slab && (tbx0 + 2 > DPS || Nx - tbx1 + 2 > DPS)) WL_NO("x margins");
+      if (tby0 + 2 > DPS || Ny - tby1 + 2 > DPS) WL_NO("y margins");
+      if ((!slab && Nx < 2 * DPS) || Ny < 2 * DPS) WL_NO("grid too small");
+      if (slab && (tbx0 < 3 || tbx1 > Nx - 3 || steps_done > 0)) WL_NO("slab: box reaches the edge planes, or stepping has begun"); // (the lossy arrays are re-ordered below: only before the first step)
       for (int64_t i = 0; i < Ns; i++) { // sources stay two cells inside the box
          int64_t ix, iy, iz;
          decode(sd.in_ixyz[i], ix, iy, iz);
-         if (ix < tbx0 + 1 || ix > tbx1 - 2 || iy < tby0 + 1 || iy > tby1 - 2 || iz < tbz0 + 1 || iz > tbz1 - 2) return PF_OK;
+         if (ix < tbx0 + 1 || ix > tbx1 - 2 || iy < tby0 + 1 || iy > tby1 - 2 || iz < tbz0 + 1 || iz > tbz1 - 2) WL_NO("a source outside the box");
       }
       std::vector<pf::WallRegion> reg;
       std::vector<int> dps, grp;
@@ -942,15 +956,22 @@ template <typename Real> struct Engine : EngineBase {
          R.mode = mode; R.nbase = nbase; R.kg = kg; R.ko0 = ko0; R.ko1 = ko1;
          R.kb0 = std::max(ko0 - 2, 0); R.kb1 = std::min(ko1 + 2, dp);
          R.l0 = l0; R.l1 = l1; R.m0 = m0; R.m1 = m1;
-         const int want = 16; // march steps per block: 8 and 16 equal, 24-32 1-2 % slower, 48-64 7 % (1024^3, measured)
+         // march steps per block.  Single domain (the regions run before the box kernel, the machine to themselves): 8 and 16
+         // equal, 24-32 1-2 % slower, 48-64 7 % (1024^3).  Slab of a chain (few hundred blocks, beside the box kernel on a stream
+         // of their own): a block is a chain of dependent steps, so short ones -- rank of 8: 0.473 (16) / 0.347 (8) / 0.334-0.354
+         // (4) / 0.349 (3) / 0.358 (2) ms per step against 0.334-0.373 without the regions; rank of 4: 0.69 / 0.60 / 0.56-0.59
+         // against 0.62-0.65; rank of 2: 1.06 (4-6) against 1.21; an end rank of 8: 0.338 against 0.388
+         const int want = slab ? 4 : 16;
          const int len = m1 - m0, nmc = (int)std::max<int64_t>(cdiv(len, want), 1);
          R.mchunk = (int)cdiv(len, nmc);
          R.nlt = (int)cdiv(l1 - l0, pf::WALL_LT);
          R.nlp = R.nlt * pf::WALL_LT + 4;
          reg.push_back(R); dps.push_back(dp); grp.push_back(group);
       };
-      mk(0, 0, 0, 0, 1, tbx0, DPS, 1, (int)Nz - 1, 1, (int)Ny - 1);
-      mk(0, 0, (int)Nx - DPS, DPS - 1, tbx1 - ((int)Nx - DPS), DPS - 1, DPS, 1, (int)Nz - 1, 1, (int)Ny - 1);
+      if (!slab) {
+         mk(0, 0, 0, 0, 1, tbx0, DPS, 1, (int)Nz - 1, 1, (int)Ny - 1);
+         mk(0, 0, (int)Nx - DPS, DPS - 1, tbx1 - ((int)Nx - DPS), DPS - 1, DPS, 1, (int)Nz - 1, 1, (int)Ny - 1);
+      }
       mk(0, 1, 0, 0, 1, tby0, DPS, 1, (int)Nz - 1, tbx0, tbx1);
       mk(0, 1, (int)Ny - DPS, DPS - 1, tby1 - ((int)Ny - DPS), DPS - 1, DPS, 1, (int)Nz - 1, tbx0, tbx1);
       // The column strips.  A strip of up to 10 columns is one region with pencils of 12 cells; a wider one (a sliver of the box went
@@ -985,7 +1006,8 @@ template <typename Real> struct Engine : EngineBase {
          } else if (opt == 3) { zb = z20; mk(3, 2, z20, (int)Nz - 1 - z20, tbz1 - z20, (int)Nz - 1 - z20, 20, tby0, tby1, tbx0, tbx1); }
          else zok = false;
       }
-      if (!zok) return PF_OK;
+      if (!zok) WL_NO("column strips too wide for the pencils");
+#undef WL_NO
       const int nregs = (int)reg.size();
       int64_t npen = 0;
       for (int i = 0; i < nregs; i++) { reg[i].pen_off = npen; npen += (int64_t)(reg[i].m1 - reg[i].m0 + 2) * reg[i].nlp; }
@@ -1019,7 +1041,7 @@ template <typename Real> struct Engine : EngineBase {
             if (kk >= reg[i].ko0 && kk < reg[i].ko1 && ll >= reg[i].l0 && ll < reg[i].l1 && mm >= reg[i].m0 && mm < reg[i].m1) { r = i; k = kk; lc = ll; m = mm; break; }
          }
          owner[nb] = (int8_t)r;
-         if (r == 8) rest.push_back((int32_t)nb);
+         if (r == 8 && (!slab || (nb >= bn_mid2.b && nb < bn_mid2.e))) rest.push_back((int32_t)nb); // (a slab's edge planes: range launches)
          if (hl[nb] >= 0) keys.push_back({r, m, lc, k, hl[nb]});
       }
       if ((int64_t)keys.size() != Nbl) return PF_OK; // (a lossy node that is no boundary node: fuse_boundary excludes it)
@@ -1222,6 +1244,7 @@ template <typename Real> struct Engine : EngineBase {
       if (!tb2_geom || (op.slab_first && op.slab_last)) return 1; // not an error: this engine keeps stepping singly
       bufC = (Real *)g2; bufD = (Real *)g3;
       tb2_slab = true;
+      if (!wl_on && !(op.debug & 0x10000000)) { int rcw = init_walls(true); if (rcw) return rcw; }
       return PF_OK;
    }
    // ---- which interior path?  Measured, not guessed: at creation the candidates run three times each on the real grids,
@@ -1616,6 +1639,7 @@ template <typename Real> struct Engine : EngineBase {
       u0 = pool[w[0]]; u1 = pool[w[1]]; bufC = pool[w[2]]; bufD = pool[w[3]];
       for (int i = 0; i < 4; i++) idx[i] = w[i];
       tb2_slab = true;
+      if (!wl_on && !(op.debug & 0x10000000)) { int rcw = init_walls(true); if (rcw) return rcw; }
       return PF_OK;
    }
    int autotune() {
@@ -1795,6 +1819,17 @@ template <typename Real> struct Engine : EngineBase {
          hipLaunchKernelGGL((pf::k_air_fcc<Real, 4, 4, 1, false, true, false, true, 64>), dim3((uint32_t)sh_ntiles), dim3(256), 0, s, u1, u0, mask, a1, a2,
                             ap, l, u0_src, sh_tiles);
       }
+   }
+   // planes [xlo, xhi) without the strips beside the box (slab pairs with wall regions): whole planes outside the box's x range
+   // and the box's own single-step tiles
+   void launch_shell_planes(hipStream_t s, int xlo, int xhi) {
+      int xa = xlo;
+      for (auto &r : tb_xr) {
+         if (r.first > xa) launch_air_lean(s, xa, r.first);
+         xa = std::max(xa, r.second);
+      }
+      if (xhi > xa) launch_air_lean(s, xa, xhi);
+      launch_dirty_tiles(s);
    }
    void launch_shell(hipStream_t s, int xlo, int xhi) { // planes [xlo, xhi) (the box lies inside)
       if (fcc) { launch_shell_fcc(s, xlo, xhi, !tb2_slab); return; } // (slab engines flip on the edge stream, after the exchange)
@@ -2058,7 +2093,7 @@ template <typename Real> struct Engine : EngineBase {
    void launch_boundary(hipStream_t s, Range r) {
       // (inside step_pair) the branch ODEs of the column strips' lossy nodes ride along in the same launch (k_fd_sel's work)
       // (a launch of its own, k_fd_sel, until round 3: same time within noise, one kernel fewer)
-      const bool with_fd = zs_mode == 2 && bnd_sel && zs_nfd > 0 && r.b == 0 && r.e == zs_nrest;
+      const bool with_fd = zs_mode == 2 && bnd_sel && bnd_sel == zs_rest && zs_nfd > 0 && r.b == 0 && r.e == zs_nrest;
       if (r.e <= r.b && !with_fd) return;
       launch_fold_row(s);
       const int64_t nfd = with_fd ? zs_nfd : 0;
@@ -2281,7 +2316,13 @@ template <typename Real> struct Engine : EngineBase {
       // main stream; phase 1 (step n+1): edge planes and shell n+1 -> n+2.  The exchanges in between are the usual ones.
       if (tb2_slab && (pair_phase == 1 || (n + 1 < Nt && ring_fill + 2 <= ring_depth && xh - xl >= 8))) {
          const bool first_half = pair_phase == 0;
-         if (first_half) { pA = u0; pB = u1; u0_src = pA; u1 = pB; u0 = bufC; }
+         // with wall regions (init_walls(true)): the first half also steps the row and column strips beside the box TWICE
+         // (k_wall2: branch state vh1 -> vh1b, node values P2, P1 -> P0, P1), so every other boundary launch of the pair follows
+         // the same buffers: first half state out of place into vh1b and node values into P0, second half both in place (P1)
+         if (first_half) {
+            pA = u0; pB = u1; u0_src = pA; u1 = pB; u0 = bufC;
+            if (wl_on) { wsP[0] = ub[0]; wsP[1] = ub[1]; wsP[2] = ub[2]; bs_vout = vh1b; bs_gout = gh1b; }
+         }
          fold_x0 = 0; fold_x1 = 0; // (virtual-ghost modes with a fold row do not block in pairs)
          if (fcc) {
             // 13-point: the ghost shell of u1 lives in memory; its flips touch the whole grid, ghost planes included, so
@@ -2305,13 +2346,29 @@ template <typename Real> struct Engine : EngineBase {
          auto get_ev = [&]() { std::pair<hipEvent_t, hipEvent_t> e{}; if (!ev_pool.empty()) { e = ev_pool.back(); ev_pool.pop_back(); } else { hipEventCreate(&e.first); hipEventCreate(&e.second); } return e; };
          if (op.timing) { eva = get_ev(); hipEventRecord(eva.first, s_main); }
          if (first_half) {
+            if (wl_on) { // beside the box kernel, on a stream of their own: a slab's regions are a few hundred waves, each a chain of dependent march steps
+               if (!s_wall) {
+                  int lo_prio = 0, hi_prio = 0;
+                  hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
+                  HIPCHK(hipStreamCreateWithPriority(&s_wall, hipStreamNonBlocking, hi_prio));
+                  HIPCHK(hipEventCreateWithFlags(&ev_wall0, hipEventDisableTiming));
+                  HIPCHK(hipEventCreateWithFlags(&ev_wall, hipEventDisableTiming));
+               }
+               HIPCHK(hipEventRecord(ev_wall0, s_main));
+               HIPCHK(hipStreamWaitEvent(s_wall, ev_wall0, 0));
+               launch_walls(s_wall, s_wall, pA, pB, bufC, bufD, wsP[0], wsP[1], wsP[2]);
+               HIPCHK(hipEventRecord(ev_wall, s_wall));
+               wall_pending = true;
+            }
             if (op.timing) { evt = get_ev(); hipEventRecord(evt.first, s_main); }
             launch_tb2(s_main, pA, pB, bufC, bufD);
             if (op.timing) { hipEventRecord(evt.second, s_main); tb2_ev.push_back(evt); }
          }
-         launch_shell(s_main, xl + 2, xh - 1);
+         if (wl_on) launch_shell_planes(s_main, xl + 2, xh - 1); // the strips beside the box are the wall regions'
+         else launch_shell(s_main, xl + 2, xh - 1);
          if (op.timing) { hipEventRecord(eva.second, s_main); air_ev.push_back(eva); }
-         launch_rigid(s_main, bn_mid2);
+         if (wl_on) { bnd_sel = wl_rest; launch_rigid(s_main, {0, wl_nrest}); bnd_sel = nullptr; }
+         else launch_rigid(s_main, bn_mid2);
          launch_fd(s_main, bnl_mid2);
          launch_io(s_main, n, true, in_mid2);
          HIPCHK(hipGetLastError());
@@ -2372,13 +2429,20 @@ template <typename Real> struct Engine : EngineBase {
       // The next step's interior (main stream) reads the edge planes but never the ghost planes, so it waits for
       // the edge *compute* only (ev_edge, recorded in step_begin before the exchange was issued) -- the exchange
       // itself stays off the main stream's critical path and only orders the edge stream.
+      if (wall_pending) { HIPCHK(hipStreamWaitEvent(s_main, ev_wall, 0)); wall_pending = false; }
       HIPCHK(hipEventRecord(ev_main, s_main));
       HIPCHK(hipStreamWaitEvent(s_edge, ev_main, 0));
       HIPCHK(hipStreamWaitEvent(s_main, ev_edge, 0));
       in_step = false;
       if (pair_now) {
          pair_now = false;
-         { Real *t = ub[2]; ub[2] = ub[1]; ub[1] = ub[0]; ub[0] = t; }
+         if (wl_on) {
+            if (pair_phase == 0) { // second half: node values and branch state in place
+               ub[0] = ub[2] = wsP[1];
+               std::swap(vh1, vh1b); std::swap(gh1, gh1b);
+               bs_vout = bs_gout = nullptr;
+            } else { ub[0] = wsP[2]; ub[1] = wsP[1]; ub[2] = wsP[0]; }
+         } else { Real *t = ub[2]; ub[2] = ub[1]; ub[1] = ub[0]; ub[0] = t; }
          if (pair_phase == 0) { // u^{n+1} is complete in bufC: second half reads u^n as the old state and writes bufD
             u0_src = pB; u1 = bufC; u0 = bufD;
             pair_phase = 1;

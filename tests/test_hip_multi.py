@@ -168,6 +168,35 @@ def test_chain_object_pairs_through_both_transports(transport):
     assert np.array_equal(sd2.u_out, want)
 
 
+@pytest.mark.parametrize("prec", ["single", "double"])
+def test_slab_pairs_step_their_row_and_column_strips_as_wall_regions(prec):
+    """Slabs that step in pairs hand the strips beside their box to k_wall2 (regions normal to y and z over the box's planes, on
+    a stream of their own beside the box kernel; edge planes and the x walls of the end slabs stay single steps, branch state
+    and node values of ALL boundary launches follow the regions' double buffers): lossy walls of two materials (11 and 3
+    branches), receivers in the wall layers and next to the cuts, 2 and 3 slabs -- the oracle's bits; and wall regions did run."""
+    kw = dict(Nx=112, Ny=70, Nz=276, Nt=41, wall=3, Nm=2, Mb=[11, 3], src=[47, 30, 100],
+              rcv=[[30, 25, 96], [66, 36, 110], [55, 4, 104], [56, 64, 101], [57, 30, 4], [54, 31, 270], [37, 4, 4], [74, 64, 270], [4, 30, 100], [106, 40, 120]])
+    sd = sim_data.SimData.from_sim(synth.shoebox(**kw), prec)
+    sd.scale_input()
+    oracle.run_sim(sd)
+    want = sd.u_out.copy()
+    assert np.abs(want).max() > 0 and np.abs(want[2:]).max() > 0
+    for devs in ([0, 0], [0, 0, 0]):
+        for dbg, expect in ((0, True), (0x10000000, False)):
+            sd2 = sim_data.SimData.from_sim(synth.shoebox(**kw), prec)
+            sd2.scale_input()
+            m = engine.HipMulti(sd2, devs, multi_flags=engine.PF_MULTI_FORCE_PAIRS, air_variant=40, verify_exchange=int(sd2.Nt), debug=dbg)
+            m.run(0, int(sd2.Nt))
+            info = m.info()
+            slabs = [m.slab(g) for g in range(len(devs))]
+            blocks = [sum(sl["engine"].timing()["wall_blocks"]) for sl in slabs]
+            m.close()
+            assert all(sl["paired"] for sl in slabs) and info["exchange_verified"] is True
+            # (a slab whose source lies outside its box -- next to a cut -- keeps the single-step shell)
+            assert (sum(b > 0 for b in blocks) >= len(devs) - 1) if expect else not any(blocks), (devs, hex(dbg), blocks)
+            assert np.array_equal(sd2.u_out, want), (devs, hex(dbg))
+
+
 def test_exchange_self_check_notices_a_missing_plane(tmp_path):
     """pf_opts.test_drop_exchange = 1 + n makes slab 1 skip the pull of its ghost planes in step n: the run must fail, naming the
     check -- also when the caller asked for no check at all (the fault injection switches it on)"""
