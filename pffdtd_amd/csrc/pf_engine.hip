@@ -947,7 +947,8 @@ template <typename Real> struct Engine : EngineBase {
       for (int64_t i = 0; i < Ns; i++) { // sources stay two cells inside the box
          int64_t ix, iy, iz;
          decode(sd.in_ixyz[i], ix, iy, iz);
-         if (ix < tbx0 + 1 || ix > tbx1 - 2 || iy < tby0 + 1 || iy > tby1 - 2 || iz < tbz0 + 1 || iz > tbz1 - 2) WL_NO("a source outside the box");
+         // (a slab's regions lie beside its box only: a source in the planes between a cut and the box is none of their business)
+         if ((!slab && (ix < tbx0 + 1 || ix > tbx1 - 2)) || iy < tby0 + 1 || iy > tby1 - 2 || iz < tbz0 + 1 || iz > tbz1 - 2) WL_NO("a source within a cell of the shell");
       }
       std::vector<pf::WallRegion> reg;
       std::vector<int> dps, grp;
