@@ -80,7 +80,8 @@ typedef enum pf_status {
                                     contraction: results are bit-identical to it (the parity target) */
 #define PF_NUM_GPU_SAFEGUARDED 2 /* the reference GPU engine's arithmetic for the air and rigid-node updates (fdtd_common.h:44-71,
                                     gpu_engine.h:220-274,288-348): pairwise neighbour sums -- in fp32 rounded TOWARDS ZERO, its
-                                    long-run stability safeguard -- then two round-to-nearest FMAs; single-step kernels only */
+                                    long-run stability safeguard -- then two round-to-nearest FMAs; single steps, 7-point blocked pairs and
+                                    their wall regions (13-point pairs exist in the CPU-exact arithmetic only) */
 
 typedef struct pf_opts {
    int32_t device;        /* HIP device ordinal */

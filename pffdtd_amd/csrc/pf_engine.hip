@@ -684,7 +684,7 @@ template <typename Real> struct Engine : EngineBase {
       }
       // Wall regions (init_walls): a column strip costs one 128-byte line per row whatever its width, but its pencils live in
       // registers -- a sliver cut off the box is shared between the two strips instead of all going to the right one.
-      if (!fcc && !sg && !(op.debug & 0x10000000)) { // (slab engines too: init_walls(true))
+      if (!fcc && !(op.debug & 0x10000000)) { // (slab engines too: init_walls(true))
          const int z1full = (int)((Nz - mz1) / 4 * 4);
          if (tbz1 < z1full) {
             const int rem = z1full - tbz1;
@@ -896,7 +896,7 @@ template <typename Real> struct Engine : EngineBase {
    // ---------------- wall regions: the shell of a blocked pair in pairs (pf_wall.h) ----------------
    // Six regions around the box: two whole-plane slabs normal to x, two row strips normal to y (the box's planes), two
    // column strips normal to z (the box's planes and rows) -- every interior cell outside the box belongs to exactly one.
-   // Conditions: 7-point, CPU-exact arithmetic, single domain, margins that fit the pencils (8 cells for the strided ones,
+   // Conditions: 7-point, margins that fit the pencils (8 cells for the strided ones,
    // 12 or 20 for the column strips), no source within one cell of the shell (a source is added BETWEEN the two steps,
    // which a region that keeps u^{n+1} in registers cannot see), fused boundary pass.  Otherwise the single-step shell of
    // round 2 runs (debug 0x10000000 forces that).
@@ -936,7 +936,7 @@ template <typename Real> struct Engine : EngineBase {
       const bool vb = getenv("PFFDTD_VERBOSE") && atoi(getenv("PFFDTD_VERBOSE")) > 1;
 #define WL_NO(why) do { if (vb) fprintf(stderr, "pffdtd_hip: no wall regions (%s)\n", why); return PF_OK; } while (0)
       if (slab ? (!tb2_slab || single) : (!tb2 || !single)) WL_NO("not a pair-stepping engine of this kind");
-      if (fcc || sg || tb_xr.empty() || swz || (op.debug & 0x10000000)) WL_NO("13-point / safeguarded / no box / exchanged axes / switched off");
+      if (fcc || tb_xr.empty() || swz || (op.debug & 0x10000000)) WL_NO("13-point / no box / exchanged axes / switched off");
       if (Nb > 0 && !fuse_boundary) WL_NO("boundary pass not fused");
       if (Nbl >= ((int64_t)1 << 24) || Nb >= ((int64_t)1 << 31)) WL_NO("too many nodes");
       constexpr int DPS = 8, V = pf::VecOf<Real>::V;
@@ -1159,8 +1159,8 @@ template <typename Real> struct Engine : EngineBase {
    }
    // both steps of the wall regions: A = u^{n-1}, B = u^n -> C = u^{n+1}, D = u^{n+2}; branch state vh1 / gh1 -> vh1b / gh1b;
    // node values: P2 = u^{n-1} and P1 = u^n are read, P0 <- u^{n+1}, P1 <- u^{n+2}
-   // (sg: the stream of the generic blocks -- edges, corners: few waves, each a long chain of dependent steps)
-   void launch_walls(hipStream_t s, hipStream_t sg, const Real *A, const Real *B, Real *C, Real *D, Real *P0, Real *P1, const Real *P2) {
+   // (s_gen: the stream of the generic blocks -- edges, corners: few waves, each a long chain of dependent steps)
+   void launch_walls(hipStream_t s, hipStream_t s_gen, const Real *A, const Real *B, Real *C, Real *D, Real *P0, Real *P1, const Real *P2) {
       pf::WallParams<Real> wp{};
       wp.A = A; wp.B = B; wp.C = C; wp.D = D;
       wp.plane = plane; wp.Nx = (int)Nx; wp.Ny = (int)Ny; wp.Nz = (int)Nz; wp.P = (int)P; wp.first = op.slab_first; wp.last = op.slab_last;
@@ -1177,19 +1177,21 @@ template <typename Real> struct Engine : EngineBase {
             if (!g.nblk[q]) continue;
             wp.blk = wl_blk + g.blk0[q];
             const dim3 gd(g.nblk[q]), b(64);
-            hipStream_t st = q == 1 ? sg : s;
-#define PF_WALL(DP, VEC) do { if (q == 2) { if constexpr (VEC) hipLaunchKernelGGL((pf::k_wall2<Real, DP, VEC, true, false>), gd, b, 0, st, wp, a1, a2); } \
+            hipStream_t st = q == 1 ? s_gen : s;
+#define PF_WALL_N(DP, VEC, S) do { if (q == 2) { if constexpr (VEC) hipLaunchKernelGGL((pf::k_wall2<Real, DP, VEC, true, false, 12, S>), gd, b, 0, st, wp, a1, a2); } \
                               else if (mb_max <= 4) { \
-                                 if (q == 0) hipLaunchKernelGGL((pf::k_wall2<Real, DP, VEC, true, true, 4>), gd, b, 0, st, wp, a1, a2); \
-                                 else hipLaunchKernelGGL((pf::k_wall2<Real, DP, VEC, false, true, 4>), gd, b, 0, st, wp, a1, a2); \
+                                 if (q == 0) hipLaunchKernelGGL((pf::k_wall2<Real, DP, VEC, true, true, 4, S>), gd, b, 0, st, wp, a1, a2); \
+                                 else hipLaunchKernelGGL((pf::k_wall2<Real, DP, VEC, false, true, 4, S>), gd, b, 0, st, wp, a1, a2); \
                               } else { \
-                                 if (q == 0) hipLaunchKernelGGL((pf::k_wall2<Real, DP, VEC, true, true, 12>), gd, b, 0, st, wp, a1, a2); \
-                                 else hipLaunchKernelGGL((pf::k_wall2<Real, DP, VEC, false, true, 12>), gd, b, 0, st, wp, a1, a2); } } while (0)
+                                 if (q == 0) hipLaunchKernelGGL((pf::k_wall2<Real, DP, VEC, true, true, 12, S>), gd, b, 0, st, wp, a1, a2); \
+                                 else hipLaunchKernelGGL((pf::k_wall2<Real, DP, VEC, false, true, 12, S>), gd, b, 0, st, wp, a1, a2); } } while (0)
+#define PF_WALL(DP, VEC) do { if (sg) PF_WALL_N(DP, VEC, true); else PF_WALL_N(DP, VEC, false); } while (0)
             if (gi == 0) PF_WALL(8, false);
             else if (gi == 1) PF_WALL(12, true);
             else if (gi == 2) PF_WALL(16, true);
             else if constexpr (sizeof(Real) == 4) PF_WALL(20, true);
 #undef PF_WALL
+#undef PF_WALL_N
          }
       }
    }

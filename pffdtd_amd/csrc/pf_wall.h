@@ -1,4 +1,4 @@
-// pf_wall.h -- the SHELL of a temporally blocked pair stepped in pairs too (7-point, CPU-exact arithmetic).
+// pf_wall.h -- the SHELL of a temporally blocked pair stepped in pairs too (7-point; CPU-exact or GPU-safeguarded arithmetic).
 //
 // k_tb2_reg (pf_tb2.h) advances the boundary-free box by two steps per pass; until round 3 everything around it -- the wall
 // layers with their frequency-dependent nodes, the ABC cells, the ghost mirrors -- was stepped twice by single-step kernels:
@@ -145,7 +145,7 @@ __device__ __forceinline__ Real fd_regs(Real p, Real u2, Real sf, int32_t k, con
 // axes: walls away from edges and corners, the bulk of the work.  The structure then arrives with the block (ds*) and the
 // per-lane node decoding, the node loop, the lane shuffles and the march-axis mirrors are compiled out.
 // NODES = false (FAST only): none of the block's pencils holds a boundary node (the plain-air part of a wide column strip).
-template <typename Real, int DP, int MODE, bool FAST, bool NODES, int MC>
+template <typename Real, int DP, int MODE, bool FAST, bool NODES, int MC, bool SG>
 __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const WallRegion &R, const int j, const int c, const Real a1, const Real a2,
                                           const WallLds<Real> *ldsp, const uint32_t dsx, const uint32_t dsz, const uint32_t dsw) {
    constexpr bool VEC = MODE == 2;
@@ -256,16 +256,16 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
    };
    // neighbours in file order (+x -x +y -y +z -z) from the pencil (np, nm), march (mp, mm) and lane (lp, lm) axes
    auto air = [&](Real cc, Real old, Real np_, Real nm, Real mp, Real mm, Real lp, Real lm) __attribute__((always_inline)) {
-      if (MODE == 2) return upd7<false>(a1, a2, cc, old, mp, mm, lp, lm, np_, nm);
-      if (MODE == 1) return upd7<false>(a1, a2, cc, old, mp, mm, np_, nm, lp, lm);
-      return upd7<false>(a1, a2, cc, old, np_, nm, mp, mm, lp, lm);
+      if (MODE == 2) return upd7<SG>(a1, a2, cc, old, mp, mm, lp, lm, np_, nm);
+      if (MODE == 1) return upd7<SG>(a1, a2, cc, old, mp, mm, np_, nm, lp, lm);
+      return upd7<SG>(a1, a2, cc, old, np_, nm, mp, mm, lp, lm);
    };
    auto rigid = [&](uint32_t adj, Real cc, Real old, Real np_, Real nm, Real mp, Real mm, Real lp, Real lm) __attribute__((always_inline)) {
       Real nb[6];
       if (MODE == 2) { nb[0] = mp; nb[1] = mm; nb[2] = lp; nb[3] = lm; nb[4] = np_; nb[5] = nm; }
       else if (MODE == 1) { nb[0] = mp; nb[1] = mm; nb[2] = np_; nb[3] = nm; nb[4] = lp; nb[5] = lm; }
       else { nb[0] = np_; nb[1] = nm; nb[2] = mp; nb[3] = mm; nb[4] = lp; nb[5] = lm; }
-      return upd_rigid<false, 6>(a2, wp.sl2, adj, cc, old, nb); // (cpu_engine.h:234-257)
+      return upd_rigid<SG, 6>(a2, wp.sl2, adj, cc, old, nb); // (cpu_engine.h:234-257)
    };
 
    // One update of the pencil cells 1 .. DP-2 at march coordinate m: Out = f(Cur; Prv, Nxt = the march planes before / after;
@@ -299,7 +299,7 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
                p = air(cc, Old[k], Cur[k + 1], Cur[k - 1], Nxt[k], Prv[k], lp, lm);
                if (k == 1) {
                   const int nk = rnbase + k;
-                  if ((ng_lo && nk == 1) || (ng_hi && nk == NN - 2)) p = abc_loss<false>(p, Old[k], wp.l); // (cpu_engine.h:225-229)
+                  if ((ng_lo && nk == 1) || (ng_hi && nk == NN - 2)) p = abc_loss<SG>(p, Old[k], wp.l); // (cpu_engine.h:225-229)
                }
             }
             Out[k] = p;
@@ -307,7 +307,7 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
          {
             const int kh = NN - 2 - rnbase;
             if (ng_hi && kh >= 2 && kh <= DP - 2 && !(NODES && ((sx >> kh) & 1u))) {
-               const Real t = abc_loss<false>(wall_sel<Real, DP>(Out, kh), wall_sel<Real, DP>(Old, kh), wp.l);
+               const Real t = abc_loss<SG>(wall_sel<Real, DP>(Out, kh), wall_sel<Real, DP>(Old, kh), wp.l);
 #pragma unroll
                for (int k = 2; k < DP - 1; k++) Out[k] = (k == kh) ? t : Out[k];
             }
@@ -349,7 +349,7 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
             const int qnm = (((ng_lo && nk == 1) || (ng_hi && nk == NN - 2)) ? 1 : 0) + qm;
             if (qnm > 0 || tile_ql) {
                const int Q = qnm + (FAST ? 0 : ql);
-               if (Q > 0) p = abc_loss<false>(p, Old[k], wp.l * (Real)Q); // (cpu_engine.h:225-229)
+               if (Q > 0) p = abc_loss<SG>(p, Old[k], wp.l * (Real)Q); // (cpu_engine.h:225-229)
             }
          }
          if (node_all) {
@@ -517,7 +517,8 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
 // (4 or 12; the state arrays hold 12 slots per node, pf_kernels.h: st_idx): with the count itself, a kernel argument, as the
 // bound every branch m sat in a block of its own -- compare, jump, reload of the array pointers, wait -- 12 times per fetch, per
 // evaluation and per store.  Slots between the scene's count and MC are loaded and stored back unchanged.
-template <typename Real, int DP, bool VEC, bool FAST, bool NODES = true, int MC = 12>
+// SG: the reference GPU engine's safeguarded arithmetic (pf_kernels.h: upd7 / upd_rigid / abc_loss<true>) instead of the C CPU engine's.
+template <typename Real, int DP, bool VEC, bool FAST, bool NODES = true, int MC = 12, bool SG = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FAST && !VEC) ? 2 : 1))) void k_wall2(WallParams<Real> wp, Real a1, Real a2) {
    static_assert(FAST || NODES, "generic blocks have everything");
    const uint4 bd = wp.blk[blockIdx.x];
@@ -529,9 +530,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FAST && !VE
       for (int i = threadIdx.x; i < wp.nmat; i += 64) { lds.beta[i] = wp.beta[i]; lds.M[i] = wp.Mb[i]; }
       __syncthreads();
    }
-   if constexpr (VEC) wall_body<Real, DP, 2, FAST, NODES, MC>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
-   else if (R.mode == 1) wall_body<Real, DP, 1, FAST, NODES, MC>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
-   else wall_body<Real, DP, 0, FAST, NODES, MC>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
+   if constexpr (VEC) wall_body<Real, DP, 2, FAST, NODES, MC, SG>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
+   else if (R.mode == 1) wall_body<Real, DP, 1, FAST, NODES, MC, SG>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
+   else wall_body<Real, DP, 0, FAST, NODES, MC, SG>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
 }
 
 } // namespace pf
