@@ -275,6 +275,41 @@ def test_wall_regions_from_random_fields(n, wall, expect, numerics):
             assert np.array_equal(a[1:-1, 1:-1, 1:-1], b[1:-1, 1:-1, 1:-1]), key
 
 
+@pytest.mark.parametrize("mb", [[4, 2], [1], [12, 5]], ids=["Mb4_2", "Mb1", "Mb12_5"])
+@pytest.mark.parametrize("prec", ["single", "double"])
+def test_wall_regions_with_few_and_many_branches(mb, prec):
+    """k_wall2 moves 4 or 12 branch-state slots per node (a compile-time bound of the scene's largest branch count): scenes whose
+    materials have up to 4, exactly 1 and the maximum of 12 branches, alike and generic blocks, both precisions -- the oracle's
+    receivers and the single-step engine's fields, every cell live from step 0."""
+    n = (37, 67, 280)
+    rcv = [[n[0] // 2 + 3, n[1] // 2, n[2] // 2 - 2], [6, 7, 8], [n[0] - 9, n[1] - 10, 200], [5, 30, 140], [18, 6, 270]]
+    sim = synth.shoebox(*n, Nt=12, Nm=len(mb), Mb=mb, src=[n[0] // 2, n[1] // 2 - 3, n[2] // 2 + 5], rcv=rcv, wall=3)
+    dt = np.float32 if prec == "single" else np.float64
+    rng = np.random.default_rng(23)
+    init = [(rng.standard_normal(n) * 1e-2).astype(dt) for _ in range(2)]
+    ref = sim_data.SimData.from_sim(sim, prec)
+    ref.scale_input()
+    e = oracle.Engine(ref)
+    for k in (0, 1):
+        e.grid(k)[...] = init[k]
+    for i in range(ref.Nt):
+        e.step(i)
+    ref_u1 = e.grid(1).copy()
+    e.close()
+    for dbg in (0, 0x8000000):
+        sd = sim_data.SimData.from_sim(sim, prec, build_mask=False)
+        sd.scale_input()
+        eng = engine.HipEngine(sd, air_variant=40, timing=True, debug=dbg)
+        for k in (0, 1):
+            eng.set_grid(k, init[k])
+        eng.run(0, sd.Nt)
+        tm, u1 = eng.timing(), eng.get_grid(1)
+        eng.close()
+        assert tm["tb2_launches"] > 0 and sum(tm["wall_blocks"]) > 0, (hex(dbg), tm["wall_blocks"])
+        assert np.array_equal(sd.u_out, ref.u_out), hex(dbg)
+        assert np.array_equal(u1[1:-1, 1:-1, 1:-1], ref_u1[1:-1, 1:-1, 1:-1]), hex(dbg)
+
+
 def test_wall_regions_step_aside_for_a_source_in_the_shell():
     """A source within a cell of the shell is added between the two steps, which a region that keeps u^{n+1} in registers cannot
     see: such scenes keep the single-step shell (and the oracle's bits)."""
