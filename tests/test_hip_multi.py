@@ -196,6 +196,35 @@ def test_slab_pairs_step_their_row_and_column_strips_as_wall_regions(prec):
             assert np.array_equal(sd2.u_out, want), (devs, hex(dbg))
 
 
+def test_chain_with_wall_regions_agrees_with_one_domain_over_many_steps():
+    """700 steps of a 288 x 200 x 280 room (reflections from step ~60), too long for the oracle: ONE domain in pairs with wall regions,
+    a chain of three slabs in pairs with wall regions (their own stream beside the box kernel), and the same chain with the
+    single-step shell -- receivers in the wall layers and next to the cuts must agree bit for bit, every exchange checked."""
+    n, ny, nz, G, K = 288, 200, 280, 3, 700
+    rcv = [[n // 3, ny // 2, nz // 2 + 3], [5, 6, 7], [n - 9, ny - 10, nz // 3], [n // 2, 4, nz // 2], [n // 2 + 1, ny // 2, nz - 7],
+           [n // G + 1, 9, 11], [n // G - 2, ny - 12, 13]]
+    sim = synth.shoebox(n, ny, nz, Nt=K, Nm=2, Mb=[11, 3], src=[n // 2 + 7, 41, 47], rcv=rcv)
+    outs = []
+    for kind, dbg in (("single", 0), ("chain", 0), ("chain", 0x10000000)):
+        sd = sim_data.SimData.from_sim(sim, "single", build_mask=False)
+        sd.scale_input()
+        if kind == "single":
+            e = engine.HipEngine(sd, timing=True, air_variant=40)
+            e.run(0, K)
+            blocks = [sum(e.timing()["wall_blocks"])]
+            e.close()
+        else:
+            m = engine.HipMulti(sd, [0] * G, multi_flags=engine.PF_MULTI_FORCE_PAIRS, air_variant=40, verify_exchange=K, debug=dbg)
+            m.run(0, K)
+            assert m.info()["exchange_verified"] is True
+            blocks = [sum(m.slab(g)["engine"].timing()["wall_blocks"]) for g in range(G)]
+            m.close()
+        assert all((b > 0) == (dbg == 0) for b in blocks), (kind, hex(dbg), blocks)
+        outs.append(sd.u_out.copy())
+    assert np.abs(outs[0]).max() > 0 and np.abs(outs[0][1:]).max() > 0
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
 def test_exchange_self_check_notices_a_missing_plane(tmp_path):
     """pf_opts.test_drop_exchange = 1 + n makes slab 1 skip the pull of its ghost planes in step n: the run must fail, naming the
     check -- also when the caller asked for no check at all (the fault injection switches it on)"""
