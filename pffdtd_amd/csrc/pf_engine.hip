@@ -188,8 +188,8 @@ template <typename Real> struct Engine : EngineBase {
    Range bn_lo, bn_mid, bn_hi, bnl_lo, bnl_mid, bnl_hi, bna_lo, bna_mid, bna_hi, in_lo, in_mid, in_hi;
    // the same lists cut for the split-phase pairs, whose edge stream owns two planes per side: planes 1-2 / 3..Nx-4 / Nx-3..Nx-2
    Range bn_lo2, bn_mid2, bn_hi2, bnl_lo2, bnl_mid2, bnl_hi2, in_lo2, in_mid2, in_hi2;
-   hipStream_t s_main = nullptr, s_edge = nullptr, s_wall = nullptr; // s_wall: a slab's wall regions (created on first use)
-   hipEvent_t ev_pre = nullptr, ev_edge = nullptr, ev_main = nullptr, ev_wall0 = nullptr, ev_wall = nullptr;
+   hipStream_t s_main = nullptr, s_edge = nullptr, s_wall = nullptr, s_wall2 = nullptr; // s_wall, s_wall2: a slab's wall regions, alike / generic blocks (created on first use)
+   hipEvent_t ev_pre = nullptr, ev_edge = nullptr, ev_main = nullptr, ev_wall0 = nullptr, ev_wall = nullptr, ev_wall2 = nullptr;
    bool wall_pending = false;
    bool in_step = false;
    bool state_touched = false; // a caller wrote the field (pf_engine_set_grid): the placement search, which steps and then zeroes the offered grids, is refused
@@ -287,11 +287,13 @@ template <typename Real> struct Engine : EngineBase {
       if (gexec) hipGraphExecDestroy(gexec);
       if (d_ctr) hipFree(d_ctr);
       if (s_wall) hipStreamDestroy(s_wall);
+      if (s_wall2) hipStreamDestroy(s_wall2);
       if (ev_wall0) hipEventDestroy(ev_wall0);
       if (ev_wall) hipEventDestroy(ev_wall);
+      if (ev_wall2) hipEventDestroy(ev_wall2);
       if (s_main) hipStreamDestroy(s_main);
       if (s_edge) hipStreamDestroy(s_edge);
-      u0 = u1 = nullptr; s_main = s_edge = s_wall = nullptr; ev_wall0 = ev_wall = nullptr;
+      u0 = u1 = nullptr; s_main = s_edge = s_wall = s_wall2 = nullptr; ev_wall0 = ev_wall = ev_wall2 = nullptr;
    }
 
    // file-layout linear index -> padded index
@@ -1825,14 +1827,14 @@ template <typename Real> struct Engine : EngineBase {
    }
    // planes [xlo, xhi) without the strips beside the box (slab pairs with wall regions): whole planes outside the box's x range
    // and the box's own single-step tiles
-   void launch_shell_planes(hipStream_t s, int xlo, int xhi) {
+   void launch_shell_planes(hipStream_t s, int xlo, int xhi, bool tiles = true) {
       int xa = xlo;
       for (auto &r : tb_xr) {
          if (r.first > xa) launch_air_lean(s, xa, r.first);
          xa = std::max(xa, r.second);
       }
       if (xhi > xa) launch_air_lean(s, xa, xhi);
-      launch_dirty_tiles(s);
+      if (tiles) launch_dirty_tiles(s);
    }
    void launch_shell(hipStream_t s, int xlo, int xhi) { // planes [xlo, xhi) (the box lies inside)
       if (fcc) { launch_shell_fcc(s, xlo, xhi, !tb2_slab); return; } // (slab engines flip on the edge stream, after the exchange)
@@ -2354,23 +2356,35 @@ template <typename Real> struct Engine : EngineBase {
                   int lo_prio = 0, hi_prio = 0;
                   hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
                   HIPCHK(hipStreamCreateWithPriority(&s_wall, hipStreamNonBlocking, hi_prio));
+                  HIPCHK(hipStreamCreateWithPriority(&s_wall2, hipStreamNonBlocking, hi_prio));
                   HIPCHK(hipEventCreateWithFlags(&ev_wall0, hipEventDisableTiming));
                   HIPCHK(hipEventCreateWithFlags(&ev_wall, hipEventDisableTiming));
+                  HIPCHK(hipEventCreateWithFlags(&ev_wall2, hipEventDisableTiming));
                }
+               // (the generic blocks -- a 0.3 ms chain of dependent steps at 1/8 of 1024^3 -- on a stream of their own: behind the
+               // alike blocks' launches in ONE stream the regions, 0.52 ms, outlasted the box kernel, 0.47)
                HIPCHK(hipEventRecord(ev_wall0, s_main));
                HIPCHK(hipStreamWaitEvent(s_wall, ev_wall0, 0));
-               launch_walls(s_wall, s_wall, pA, pB, bufC, bufD, wsP[0], wsP[1], wsP[2]);
+               HIPCHK(hipStreamWaitEvent(s_wall2, ev_wall0, 0));
+               launch_walls(s_wall, s_wall2, pA, pB, bufC, bufD, wsP[0], wsP[1], wsP[2]);
+               // the first step of the planes between the edge planes and the box (an end slab's x wall) and of the boundary nodes
+               // no region owns: behind the alike blocks, not behind the box kernel (they only read u^{n-1}, u^n)
+               launch_shell_planes(s_wall, xl + 2, xh - 1, false);
+               bnd_sel = wl_rest; launch_rigid(s_wall, {0, wl_nrest}); bnd_sel = nullptr;
                HIPCHK(hipEventRecord(ev_wall, s_wall));
+               HIPCHK(hipEventRecord(ev_wall2, s_wall2));
                wall_pending = true;
             }
             if (op.timing) { evt = get_ev(); hipEventRecord(evt.first, s_main); }
             launch_tb2(s_main, pA, pB, bufC, bufD);
             if (op.timing) { hipEventRecord(evt.second, s_main); tb2_ev.push_back(evt); }
          }
-         if (wl_on) launch_shell_planes(s_main, xl + 2, xh - 1); // the strips beside the box are the wall regions'
+         if (wl_on && first_half) launch_dirty_tiles(s_main); // (the strips beside the box are the wall regions'; the planes outside it: above)
+         else if (wl_on) launch_shell_planes(s_main, xl + 2, xh - 1);
          else launch_shell(s_main, xl + 2, xh - 1);
          if (op.timing) { hipEventRecord(eva.second, s_main); air_ev.push_back(eva); }
-         if (wl_on) { bnd_sel = wl_rest; launch_rigid(s_main, {0, wl_nrest}); bnd_sel = nullptr; }
+         if (wl_on && first_half) HIPCHK(hipStreamWaitEvent(s_main, ev_wall, 0)); // (a source in those planes is added after their update)
+         else if (wl_on) { bnd_sel = wl_rest; launch_rigid(s_main, {0, wl_nrest}); bnd_sel = nullptr; }
          else launch_rigid(s_main, bn_mid2);
          launch_fd(s_main, bnl_mid2);
          launch_io(s_main, n, true, in_mid2);
@@ -2432,7 +2446,7 @@ template <typename Real> struct Engine : EngineBase {
       // The next step's interior (main stream) reads the edge planes but never the ghost planes, so it waits for
       // the edge *compute* only (ev_edge, recorded in step_begin before the exchange was issued) -- the exchange
       // itself stays off the main stream's critical path and only orders the edge stream.
-      if (wall_pending) { HIPCHK(hipStreamWaitEvent(s_main, ev_wall, 0)); wall_pending = false; }
+      if (wall_pending) { HIPCHK(hipStreamWaitEvent(s_main, ev_wall, 0)); HIPCHK(hipStreamWaitEvent(s_main, ev_wall2, 0)); wall_pending = false; }
       HIPCHK(hipEventRecord(ev_main, s_main));
       HIPCHK(hipStreamWaitEvent(s_edge, ev_main, 0));
       HIPCHK(hipStreamWaitEvent(s_main, ev_edge, 0));
