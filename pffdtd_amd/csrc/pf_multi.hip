@@ -69,9 +69,9 @@ int fail(const char *fmt, const char *a = "") {
 }
 
 // owned plane ranges.  even: Nx/G planes each, +1 for the first Nx%G (gpu_engine.h:532-550).  balanced: equal estimated
-// cost (interior plane = 1; a full plane of lossy nodes with 11 branches = 12, of rigid nodes = 2.5: measured on MI355X -- round 4,
-// 1024^3 as 8 ranks: 134 interior planes 0.354 ms per step, 110 planes + an x wall 0.326; until the strips beside a slab's box became
-// wall regions the figures were 24 and 5)
+// cost (interior plane = 1; a full plane of lossy nodes with 11 branches = 23, of rigid nodes = 5: measured on MI355X -- round 4,
+// 1024^3 as 8 ranks with wall regions in the slabs: 132 interior planes 0.310 ms per step; 119 / 114 planes + an x wall, which stays
+// single steps, 0.337 / 0.329 -- an end rank is mostly fixed cost, 0.0014 ms per plane against 0.0024 inside)
 // along_z: the chain is cut along FILE Z instead (slab engines then store the grid with the x and z axes exchanged: Engine::swz)
 int partition(const pf_simdata *sd, int G, bool even, std::vector<int64_t> &cuts, bool along_z = false) {
    const int64_t Nx = along_z ? sd->Nz : sd->Nx; // planes along the cut axis
@@ -98,7 +98,7 @@ int partition(const pf_simdata *sd, int G, bool even, std::vector<int64_t> &cuts
    std::vector<double> cum(Nx + 1, 0.0);
    for (int64_t x = 0; x < Nx; x++) {
       double c = (x == 0 || x == Nx - 1) ? 0.0 : 1.0; // the global ghost planes are not updated
-      c += (12.0 * mb_scale * nl[x] + 2.5 * (nb[x] - nl[x])) / (double)NzNy;
+      c += (23.0 * mb_scale * nl[x] + 5.0 * (nb[x] - nl[x])) / (double)NzNy;
       cum[x + 1] = cum[x] + c;
    }
    for (int g = 1; g < G; g++) {

@@ -21,11 +21,11 @@ def partition(Nx, G):
     return [(int(x0[g]), int(x0[g + 1])) for g in range(G)]
 
 
-# measured on MI355X (1024^2 planes, round 4: slabs with wall regions; 24 / 5 before): one full plane of lossy (Mb=11) boundary nodes costs about as much as 12 planes
-# of interior update, a full plane of rigid boundary nodes about 2.5 (profiles/r04_slab_cost_model.txt; the same figures as
+# measured on MI355X (1024^2 planes, round 4: slabs with wall regions): one full plane of lossy (Mb=11) boundary nodes costs about as much as 23 planes
+# of interior update, a full plane of rigid boundary nodes about 5 (profiles/r04_slab_cost_model.txt; the same figures as
 # csrc/pf_multi.hip: partition)
-LOSSY_PLANE_EQ = 12.0
-RIGID_PLANE_EQ = 2.5
+LOSSY_PLANE_EQ = 23.0
+RIGID_PLANE_EQ = 5.0
 
 
 def partition_weighted(sd, G, along_z=False):
