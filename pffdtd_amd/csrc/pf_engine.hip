@@ -386,12 +386,11 @@ template <typename Real> struct Engine : EngineBase {
       const bool single = op.slab_first && op.slab_last, ext = op.ext_u0 && op.ext_u1;
       const int vb = op.air_variant & 255;
       if (op.debug & 0x1000) {
-         if (op.energy || vb == 40 || vb == 41)
-            return set_err(PF_ERR_ARG, "debug 0x1000 (axes exchanged in storage): single steps only, no energy diagnostic");
+         if (op.energy) return set_err(PF_ERR_ARG, "debug 0x1000 (axes exchanged in storage): no energy diagnostic");
          swz = true;
          return PF_OK;
       }
-      if ((op.debug & 0x2000) || !single || ext || op.energy || vb == 40 || vb == 41) return PF_OK;
+      if ((op.debug & 0x2000) || !single || ext || op.energy || vb == 41) return PF_OK;
       int64_t counts[2];
       swz = pf__axis_exchange_pays(&sd, counts) != 0;
       if (counts[0] + counts[1] > 0 && getenv("PFFDTD_VERBOSE") && atoi(getenv("PFFDTD_VERBOSE")) > 0)
@@ -635,12 +634,14 @@ template <typename Real> struct Engine : EngineBase {
    int init_tb2() {
       tb2 = tb2_geom = tb2_slab = false;
       const bool single = op.slab_first && op.slab_last;
-      if (op.energy || (op.debug & 0x4000) || swz) return PF_OK; // 0x4000: single steps only; exchanged axes: single-step kernels only
+      if (op.energy || (op.debug & 0x4000)) return PF_OK; // 0x4000: single steps only
+      // exchanged axes (rooms): the pair kernels work in storage coordinates and take their neighbours in the FILE's order (template
+      // flag SWZ: 64-lane row segments, single-domain engines); 7-point: k_tb2_reg / k_tb1_tile / k_air_zstrip<..., SWZ>
+      if (swz && !single) return PF_OK;
       // 7-point: the fused single-step kernels carry the shell; 13-point: folded grids with the flips in memory and the ABC
       // loss in the interior kernel (the automatic 13-point arrangement)
       if (fcc ? !(fold && abck) : !(lean || vg)) return PF_OK;
       if (!(vbase == 0 || vbase == 40 || vbase == 41) || !use_dpp) return PF_OK;
-      if (sg && fcc) return PF_OK; // (GPU-safeguarded arithmetic: the 7-point pair kernels have it, round 4; the 13-point ones do not)
       if (Nb > 0 && !boundary_fused()) return PF_OK;
       // Margins of the box: three cells off every grid face (the ABC cells sit at index 1 and the box must stay two cells
       // away from anything that is not a plain air update), deeper where a wall layer hugs the face -- a face whose plane at
@@ -649,7 +650,8 @@ template <typename Real> struct Engine : EngineBase {
       const int64_t NzNy = Nz * Ny;
       int64_t hist[6][16] = {};
       for (int64_t i = 0; i < Nb; i++) {
-         const int64_t ii = sd.bn_ixyz[i], ix = ii / NzNy, iy = (ii / Nz) % Ny, iz = ii % Nz;
+         int64_t ix, iy, iz; // storage coordinates
+         decode(sd.bn_ixyz[i], ix, iy, iz);
          const int64_t d[6] = {ix, Nx - 1 - ix, iy, Ny - 1 - iy, iz, Nz - 1 - iz};
          for (int f = 0; f < 6; f++) if (d[f] < 16) hist[f][d[f]]++;
       }
@@ -674,6 +676,7 @@ template <typename Real> struct Engine : EngineBase {
          int64_t best = -1;
          for (int lw : {64, 32, 16}) {
             if (op.debug & 0x300) { if (lw != ((op.debug & 0x100) ? 32 : 16)) continue; } // tuning override (as pick_lw)
+            else if ((op.debug & 0x400) && lw != 64) continue;
             const int TC = (lw - 2) * V;
             int z1 = (int)((Nz - mz1) / 4 * 4);
             const int nz = z1 - tbz0, rem = nz % TC;
@@ -683,6 +686,7 @@ template <typename Real> struct Engine : EngineBase {
             if (best < 0 || lanes < best) { best = lanes; tb_lw = lw; tbz1 = z1; }
          }
          if (best < 0) return PF_OK; // no room for a single row segment
+         if (swz && tb_lw != 64) return PF_OK; // (the SWZ instantiations exist for 64-lane segments only: rooms stored along their longest axis have long rows)
       }
       // Wall regions (init_walls): a column strip costs one 128-byte line per row whatever its width, but its pencils live in
       // registers -- a sliver cut off the box is shared between the two strips instead of all going to the right one.
@@ -719,7 +723,9 @@ template <typename Real> struct Engine : EngineBase {
          if (ntile >= ((int64_t)1 << 31)) return PF_OK;
          std::vector<uint8_t> dirty((size_t)ntile, 0);
          auto mark = [&](int64_t ii) { // every tile whose core, grown by one cell, holds this cell
-            const int ix = (int)(ii / NzNy), iy = (int)((ii / Nz) % Ny), iz = (int)(ii % Nz);
+            int64_t ix64, iy64, iz64;
+            decode(ii, ix64, iy64, iz64);
+            const int ix = (int)ix64, iy = (int)iy64, iz = (int)iz64;
             auto span = [](int c, int org, int size, int n, int end, int &lo, int &hi) {
                if (c < org - 1 || c > end) return false;
                lo = (c - 1 - org) >= 0 ? (c - 1 - org) / size : 0;
@@ -1205,8 +1211,10 @@ template <typename Real> struct Engine : EngineBase {
       Real *A = u0, *B = u1, *C = bufC, *D = bufD;
       Real *P0 = ub[0], *P1 = ub[1], *P2 = ub[2];
       auto get_ev = [&]() { std::pair<hipEvent_t, hipEvent_t> e{}; if (!ev_pool.empty()) { e = ev_pool.back(); ev_pool.pop_back(); } else { hipEventCreate(&e.first); hipEventCreate(&e.second); } return e; };
-      std::pair<hipEvent_t, hipEvent_t> ev{}, ev2{}, evt{};
-      if (op.timing) { ev = get_ev(); ev2 = get_ev(); evt = get_ev(); hipEventRecord(ev.first, s); }
+      std::pair<hipEvent_t, hipEvent_t> ev{}, ev2{}, evt{}, eva{};
+      // "air" of a pair with wall regions (pf_timing.air_ms_total, the CLI's "Air update" line): the alike blocks' launches and the
+      // box kernel on the main stream -- the regions' boundary nodes are inside those launches and cannot be told apart
+      if (op.timing) { ev = get_ev(); ev2 = get_ev(); evt = get_ev(); eva = get_ev(); hipEventRecord(ev.first, s); hipEventRecord(eva.first, s); }
       // The wall regions read u^{n-1}, u^n and the old branch state only and write cells the box kernel does not: any order will do.
       // The generic blocks (edges, corners: a few hundred waves, each a long chain of dependent steps) go to the second stream
       // and run beside the alike blocks' launches, which are issue-bound; beside the bandwidth-bound box kernel they crawl
@@ -1221,7 +1229,7 @@ template <typename Real> struct Engine : EngineBase {
       launch_walls(s, sw, A, B, C, D, P0, P1, P2); // (every wall launch beside the box kernel instead of before it: 492 vs 511-516 Gvox/s)
       if (op.timing) hipEventRecord(evt.first, s);
       launch_tb2(s, A, B, C, D);
-      if (op.timing) { hipEventRecord(evt.second, s); tb2_ev.push_back(evt); }
+      if (op.timing) { hipEventRecord(evt.second, s); tb2_ev.push_back(evt); hipEventRecord(eva.second, s); air_ev.push_back(eva); }
       if (beside) { HIPCHK(hipEventRecord(ev_edge, s_edge)); HIPCHK(hipStreamWaitEvent(s_main, ev_edge, 0)); }
       launch_io(s, n, true, {0, Ns}); // (receivers read u^n; the source goes into u^{n+1}, which only the second step below reads)
       if (ring_fill == 0) ring_n0 = n;
@@ -1762,8 +1770,18 @@ template <typename Real> struct Engine : EngineBase {
       if (sample) tp.tiles = tb_sample;
       const dim3 g((uint32_t)(sample ? tb_nsample : tb_nclean)), b(256);
       if (fcc) {
-         if (tb_lw == 64) hipLaunchKernelGGL((pf::k_tb2_fcc_x<Real, 2, 8>), g, dim3(512), 0, s, tp, a1, a2); // 12-row tiles
-         else pf::launch_tb2_fcc<Real>(s, tp, a1, a2, tb_lw, (uint32_t)tb_nclean);
+         if (tb_lw == 64) { // 12-row tiles; k_tb2_fcc_w: half the vector arithmetic of k_tb2_fcc_x (debug 0x40000: that one, CPU-exact file order only)
+            if ((op.debug & 0x40000) && !sg && !swz) hipLaunchKernelGGL((pf::k_tb2_fcc_x<Real, 2, 8>), g, dim3(512), 0, s, tp, a1, a2);
+            else if (sg) { if (swz) hipLaunchKernelGGL((pf::k_tb2_fcc_w<Real, 2, 8, true, true>), g, dim3(512), 0, s, tp, a1, a2);
+                           else hipLaunchKernelGGL((pf::k_tb2_fcc_w<Real, 2, 8, true, false>), g, dim3(512), 0, s, tp, a1, a2); }
+            else { if (swz) hipLaunchKernelGGL((pf::k_tb2_fcc_w<Real, 2, 8, false, true>), g, dim3(512), 0, s, tp, a1, a2);
+                   else hipLaunchKernelGGL((pf::k_tb2_fcc_w<Real, 2, 8, false, false>), g, dim3(512), 0, s, tp, a1, a2); }
+         } else pf::launch_tb2_fcc<Real>(s, tp, a1, a2, tb_lw, (uint32_t)(sample ? tb_nsample : tb_nclean), sg, swz);
+         return;
+      }
+      if (swz) { // axes exchanged in storage (64-lane segments only, init_tb2)
+         if (sg) hipLaunchKernelGGL((pf::k_tb2_reg<Real, 3, 4, false, 64, false, true, true>), g, b, 0, s, tp, a1, a2);
+         else hipLaunchKernelGGL((pf::k_tb2_reg<Real, 3, 4, false, 64, false, false, true>), g, b, 0, s, tp, a1, a2);
          return;
       }
       if (sg) { // the reference GPU engine's arithmetic (towards-zero pairwise sums, two FMAs)
@@ -1786,6 +1804,11 @@ template <typename Real> struct Engine : EngineBase {
       tp.tiles = tb_dirty; tp.mask = mask;
       tp.xsub = tb_ndirty <= 256 ? std::min(4, std::max(tb_chunk / 4, 1)) : 1; // few tiles: shorter marches, more workgroups
       const dim3 g((uint32_t)tb_ndirty * (uint32_t)tp.xsub), b(256);
+      if (swz) {
+         if (sg) hipLaunchKernelGGL((pf::k_tb1_tile<Real, 3, 4, 64, true, true>), g, b, 0, s, tp, a1, a2);
+         else hipLaunchKernelGGL((pf::k_tb1_tile<Real, 3, 4, 64, false, true>), g, b, 0, s, tp, a1, a2);
+         return;
+      }
       if (sg) {
          if (tb_lw == 32) hipLaunchKernelGGL((pf::k_tb1_tile<Real, 3, 4, 32, true>), g, b, 0, s, tp, a1, a2);
          else if (tb_lw == 16) hipLaunchKernelGGL((pf::k_tb1_tile<Real, 3, 4, 16, true>), g, b, 0, s, tp, a1, a2);
@@ -1812,16 +1835,23 @@ template <typename Real> struct Engine : EngineBase {
          zp.x_begin = tbx0; zp.x_end = tbx1; zp.zl = tbz0; zp.zr = tbz1; zp.first = op.slab_first; zp.last = op.slab_last;
          const int64_t nthreads = (int64_t)(zp.zl / V + (P - zp.zr) / V) * (Ny - 2);
          const int xchunk = 16;
-         hipLaunchKernelGGL(pf::k_zstrip_fcc<Real>, dim3((unsigned)cdiv(nthreads, 256), (unsigned)cdiv(tbx1 - tbx0, xchunk)), dim3(256), 0, s, zp,
-                            a1, a2, l, xchunk, fold ? 1 : 0);
+         const dim3 gz((unsigned)cdiv(nthreads, 256), (unsigned)cdiv(tbx1 - tbx0, xchunk));
+         if (nthreads > 0) {
+            if (sg) { if (swz) hipLaunchKernelGGL((pf::k_zstrip_fcc<Real, true, true>), gz, dim3(256), 0, s, zp, a1, a2, l, xchunk, fold ? 1 : 0);
+                      else hipLaunchKernelGGL((pf::k_zstrip_fcc<Real, true, false>), gz, dim3(256), 0, s, zp, a1, a2, l, xchunk, fold ? 1 : 0); }
+            else { if (swz) hipLaunchKernelGGL((pf::k_zstrip_fcc<Real, false, true>), gz, dim3(256), 0, s, zp, a1, a2, l, xchunk, fold ? 1 : 0);
+                   else hipLaunchKernelGGL((pf::k_zstrip_fcc<Real, false, false>), gz, dim3(256), 0, s, zp, a1, a2, l, xchunk, fold ? 1 : 0); }
+         }
       }
       if (sh_ntiles > 0) {
          pf::AirParams ap;
          ap.Ny = Ny; ap.P = P; ap.plane = plane;
          ap.x_begin = tbx0; ap.x_end = tbx1; ap.chunk = tb_chunk; ap.nxc = tb_nxc; ap.nzt = sh_nzt; ap.nyt = sh_nyt;
-         ap.swizzle = 0; ap.swz = 0;
+         ap.swizzle = 0; ap.swz = swz ? 1 : 0;
          ap.Nx = (int)Nx; ap.Nz = (int)Nz; ap.first = op.slab_first; ap.last = op.slab_last; ap.fold = fold ? 1 : 0;
-         hipLaunchKernelGGL((pf::k_air_fcc<Real, 4, 4, 1, false, true, false, true, 64>), dim3((uint32_t)sh_ntiles), dim3(256), 0, s, u1, u0, mask, a1, a2,
+         if (sg) hipLaunchKernelGGL((pf::k_air_fcc<Real, 4, 4, 1, true, true, false, true, 64>), dim3((uint32_t)sh_ntiles), dim3(256), 0, s, u1, u0, mask, a1, a2,
+                                    ap, l, u0_src, sh_tiles);
+         else hipLaunchKernelGGL((pf::k_air_fcc<Real, 4, 4, 1, false, true, false, true, 64>), dim3((uint32_t)sh_ntiles), dim3(256), 0, s, u1, u0, mask, a1, a2,
                             ap, l, u0_src, sh_tiles);
       }
    }
@@ -1872,7 +1902,9 @@ template <typename Real> struct Engine : EngineBase {
          const int64_t nthreads = (int64_t)(zp.zl / V + (P - zp.zr) / V) * (Ny - 2);
          const int xchunk = 16;
          const dim3 gz((unsigned)cdiv(nthreads, 256), (unsigned)cdiv(xe - xb, xchunk));
-         if (sg) hipLaunchKernelGGL((pf::k_air_zstrip<Real, true>), gz, dim3(256), 0, s, zp, a1, a2, l, xchunk);
+         if (swz) { if (sg) hipLaunchKernelGGL((pf::k_air_zstrip<Real, true, true>), gz, dim3(256), 0, s, zp, a1, a2, l, xchunk);
+                    else hipLaunchKernelGGL((pf::k_air_zstrip<Real, false, true>), gz, dim3(256), 0, s, zp, a1, a2, l, xchunk); }
+         else if (sg) hipLaunchKernelGGL((pf::k_air_zstrip<Real, true>), gz, dim3(256), 0, s, zp, a1, a2, l, xchunk);
          else hipLaunchKernelGGL((pf::k_air_zstrip<Real, false>), gz, dim3(256), 0, s, zp, a1, a2, l, xchunk);
       }
       launch_dirty_tiles(s); // ... and the tiles of the box that hold geometry or a source
@@ -2015,8 +2047,9 @@ template <typename Real> struct Engine : EngineBase {
          hipLaunchKernelGGL((pf::k_air_cart<Real, R, WY, WZ, false, true, true, false, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l, v1_dst);
          return;
       }
-      if (fcc && abck && !sg && u0_src) { // out of place (shell of a temporally blocked pair, creation-time measurement)
-         hipLaunchKernelGGL((pf::k_air_fcc<Real, R, WY, WZ, false, true, false, true, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l, u0_src, (const int32_t *)nullptr);
+      if (fcc && abck && u0_src) { // out of place (shell of a temporally blocked pair, creation-time measurement)
+         if (sg) hipLaunchKernelGGL((pf::k_air_fcc<Real, R, WY, WZ, true, true, false, true, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l, u0_src, (const int32_t *)nullptr);
+         else hipLaunchKernelGGL((pf::k_air_fcc<Real, R, WY, WZ, false, true, false, true, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l, u0_src, (const int32_t *)nullptr);
          return;
       }
 #define PF_LAUNCH(K, SG) do { if (vg) hipLaunchKernelGGL((K<Real, R, WY, WZ, SG, true, true, false, LW>), g, b, 0, s, u1, u0, mask, a1, a2, ap, l); \

@@ -34,7 +34,9 @@ struct Tb2Params {
 // PROBE: the same code under another name, for the creation-time measurements (grid placement search, path choice): per-kernel
 // profiler statistics of k_tb2_reg<..., false> then hold the launches of the time loop only.
 // SG: the reference GPU engine's arithmetic (pf_kernels.h: upd7<true>) instead of the C CPU engine's.
-template <typename Real, int R, int WY, bool NTA = true, int LW = 64, bool PROBE = false, bool SG = false>
+// SWZ: the grid is stored with the file's x and z axes exchanged (Engine::swz): the neighbours enter the sum in the FILE's order
+// +x, -x, +y, -y, +z, -z = storage +z, -z, +y, -y, +x, -x.
+template <typename Real, int R, int WY, bool NTA = true, int LW = 64, bool PROBE = false, bool SG = false, bool SWZ = false>
 __global__ __launch_bounds__(64 * WY) void k_tb2_reg(Tb2Params tp, Real a1, Real a2) {
    typedef typename VecOf<Real>::type vec;
    // LW lanes span a row segment of LW*V columns whose first and last lane are z halo (their u^{n+1} values feed their
@@ -93,7 +95,8 @@ __global__ __launch_bounds__(64 * WY) void k_tb2_reg(Tb2Params tp, Real a1, Real
       for (int i = 0; i < V; i++) {
          const Real zp = (i == V - 1) ? rt : c[i < V - 1 ? i + 1 : V - 1];
          const Real zm = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
-         o[i] = upd7<SG>(a1, a2, c[i], old[i], xp[i], xm[i], yp[i], ym[i], zp, zm);
+         if constexpr (SWZ) o[i] = upd7<SG>(a1, a2, c[i], old[i], zp, zm, yp[i], ym[i], xp[i], xm[i]);
+         else o[i] = upd7<SG>(a1, a2, c[i], old[i], xp[i], xm[i], yp[i], ym[i], zp, zm);
       }
       return o;
    };
@@ -142,6 +145,13 @@ __global__ __launch_bounds__(64 * WY) void k_tb2_reg(Tb2Params tp, Real a1, Real
    }
 }
 
+// S = the twelve neighbours in storage terms, in the order a file-order grid accumulates them:
+//   0 (+x+y) 1 (-x-y) 2 (+y+z) 3 (-y-z) 4 (+x+z) 5 (-x-z) 6 (+x-y) 7 (-x+y) 8 (+y-z) 9 (-y+z) 10 (+x-z) 11 (-x+z);
+// with the axes exchanged the file's k-th neighbour is S[perm[k]] (entries 0<->2, 1<->3, 6<->9, 7<->8, 10<->11 change places)
+template <bool SWZ> struct FccOrder;
+template <> struct FccOrder<false> { static constexpr int p[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11}; };
+template <> struct FccOrder<true> { static constexpr int p[12] = {2, 3, 0, 1, 4, 5, 9, 8, 7, 6, 11, 10}; };
+
 // ---------------------------------------------------------------------------------------------------------------
 // k_tb2_fcc -- the two-steps-per-pass scheme for the 13-point FCC stencil on the folded grid (cpu_engine.h:195-223;
 // neighbour / accumulation order (+x+y)(-x-y)(+y+z)(-y-z)(+x+z)(-x-z)(+x-y)(-x+y)(+y-z)(-y+z)(+x-z)(-x+z) as k_air_fcc).
@@ -150,7 +160,7 @@ __global__ __launch_bounds__(64 * WY) void k_tb2_reg(Tb2Params tp, Real a1, Real
 // The z +-1 neighbours of a row are the row itself shifted by one column: in-lane for three of four columns, one DPP
 // wave shift for the fourth.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename Real, int R, int WY, int LW = 64>
+template <typename Real, int R, int WY, int LW = 64, bool SG = false, bool SWZ = false>
 __global__ __launch_bounds__(64 * WY) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tb2_fcc(Tb2Params tp, Real a1, Real a2_) {
    typedef typename VecOf<Real>::type vec;
    static_assert(LW == 64 || LW == 32 || LW == 16, "row segments are 64, 32 or 16 lanes wide");
@@ -199,20 +209,21 @@ __global__ __launch_bounds__(64 * WY) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
       for (int i = 0; i < V; i++) {
          const int im = i > 0 ? i - 1 : 0, ip = i < V - 1 ? i + 1 : V - 1;
-         Real p = a1 * c[i] - old[i];
-         p = p + a2 * nU[i];                               // +x+y
-         p = p + a2 * pD[i];                               // -x-y
-         p = p + a2 * ((i == V - 1) ? cUp : cU[ip]);       // +y+z
-         p = p + a2 * ((i == 0) ? cDm : cD[im]);           // -y-z
-         p = p + a2 * ((i == V - 1) ? nCp : nC[ip]);       // +x+z
-         p = p + a2 * ((i == 0) ? pCm : pC[im]);           // -x-z
-         p = p + a2 * nD[i];                               // +x-y
-         p = p + a2 * pU[i];                               // -x+y
-         p = p + a2 * ((i == 0) ? cUm : cU[im]);           // +y-z
-         p = p + a2 * ((i == V - 1) ? cDp : cD[ip]);       // -y+z
-         p = p + a2 * ((i == 0) ? nCm : nC[im]);           // +x-z
-         p = p + a2 * ((i == V - 1) ? pCp : pC[ip]);       // -x+z
-         o[i] = p;
+         // storage order (+x+y)(-x-y)(+y+z)(-y-z)(+x+z)(-x-z)(+x-y)(-x+y)(+y-z)(-y+z)(+x-z)(-x+z); accumulated in the FILE's order (FccOrder)
+         const Real S[12] = {nU[i], pD[i], (i == V - 1) ? cUp : cU[ip], (i == 0) ? cDm : cD[im],
+                             (i == V - 1) ? nCp : nC[ip], (i == 0) ? pCm : pC[im], nD[i], pU[i],
+                             (i == 0) ? cUm : cU[im], (i == V - 1) ? cDp : cD[ip], (i == 0) ? nCm : nC[im], (i == V - 1) ? pCp : pC[ip]};
+         if constexpr (SG) {
+            Real nb[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) nb[k] = S[FccOrder<SWZ>::p[k]];
+            o[i] = upd13<true>(a1, a2, c[i], old[i], nb);
+         } else {
+            Real p = a1 * c[i] - old[i];
+#pragma unroll
+            for (int k = 0; k < 12; k++) p = p + a2 * S[FccOrder<SWZ>::p[k]];
+            o[i] = p;
+         }
       }
       return o;
    };
@@ -401,8 +412,159 @@ __global__ __launch_bounds__(64 * WT) void k_tb2_fcc_x(Tb2Params tp, Real a1, Re
    }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_tb2_fcc_w -- k_tb2_fcc_x's scheme (waves stacked in y, u^{n+1} halo rows exchanged through LDS, first / last wave pure
+// halo providers) with HALF the vector arithmetic, in both numerics, and for either storage order (round 5).
+//   CPU-exact (SG = false): the reference accumulates  p += a2 * u1[neighbour]  twelve times per cell (cpu_engine.h:200-218), and
+//     every cell is the neighbour of twelve others: the product a2 * u is rounded ONCE per cell here -- each u^n row becomes
+//     N = a2 * u when it first serves as a neighbour row, each new u^{n+1} row likewise before it is published -- and a cell
+//     update is a1 * c - old followed by twelve plain adds of N values in the reference's order: 14 vector operations instead
+//     of 26, the same bits (the products are the same roundings, -ffp-contract=off).  Only the centre rows are also kept raw
+//     (for a1 * c and as stage 2's old value).  k_tb2_fcc_x prevented exactly this sharing (the compiler tried it across all
+//     rows at once and spilled); done by hand it costs 10 more vectors of state per lane than k_tb2_fcc_x.
+//   GPU-safeguarded (SG = true): the rows stay raw; a cell update is upd13<true>: the towards-zero pairwise tree of
+//     gpu_engine.h:257-267 and two FMAs, 13 operations.
+//   SWZ: the grid is stored with the file's x and z axes exchanged (Engine::swz); the kernel works in storage coordinates, only
+//     the ORDER in which the neighbours enter the sum (or the tree) follows the file's axes.
+// 64-lane row segments only; R rows per wave, WT waves (WT - 2 of them own rows).
+// ---------------------------------------------------------------------------------------------------------------
+template <typename Real, int R, int WT, bool SG, bool SWZ = false>
+__global__ __launch_bounds__(64 * WT) void k_tb2_fcc_w(Tb2Params tp, Real a1, Real a2) {
+   typedef typename VecOf<Real>::type vec;
+   constexpr int V = VecOf<Real>::V, W = 64 * V;
+   __shared__ __attribute__((aligned(16))) Real sV[2][WT * R][W];
+   const uint32_t t = tp.tiles ? (uint32_t)tp.tiles[blockIdx.x] : blockIdx.x;
+   const int zt = t % tp.nzt, yt = (t / tp.nzt) % tp.nyt, xc = t / (tp.nzt * tp.nyt);
+   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+   const bool inner = w >= 1 && w <= WT - 2;
+   const int ze0 = tp.z_begin - V + zt * (W - 2 * V);
+   const int yo = tp.y_begin + (yt * (WT - 2) + (w - 1)) * R;   // first own row of this wave (wave 0: the R rows above the tile)
+   const int xs = tp.x_begin + xc * tp.chunk, xe = min(xs + tp.chunk, tp.x_end);
+   const int P = tp.P;
+   const int64_t plane = tp.plane;
+   const int zc = min(max(ze0 + lane * V, 0), P - V);
+   uint32_t offB[R + 2];                                      // rows yo-1 .. yo+R
+#pragma unroll
+   for (int i = 0; i < R + 2; i++) offB[i] = (uint32_t)min(max(yo - 1 + i, 0), tp.Ny - 1) * (uint32_t)P + (uint32_t)zc;
+   const int z_end = tp.z_end ? tp.z_end : tp.Nz - tp.z_begin, y_end = tp.y_end ? tp.y_end : tp.Ny - tp.y_begin;
+   const bool core_col = inner && (lane >= 1 && lane <= 62) && (ze0 + lane * V + V - 1 < z_end);
+   bool core_row[R];
+#pragma unroll
+   for (int r = 0; r < R; r++) core_row[r] = (yo + r < y_end);
+
+   auto loadB = [&](int x, vec *d) {
+      const Real *pl = (const Real *)tp.B + (int64_t)x * plane;
+#pragma unroll
+      for (int i = 0; i < R + 2; i++) d[i] = *(const vec *)(pl + offB[i]);
+   };
+   auto loadA = [&](int x, vec *d) { // rows yo .. yo+R-1
+      const Real *pl = (const Real *)tp.A + (int64_t)x * plane;
+#pragma unroll
+      for (int j = 0; j < R; j++) d[j] = __builtin_nontemporal_load((const vec *)(pl + offB[j + 1]));
+   };
+   // c, old: the cell's own row and its value two steps back, RAW; the eight neighbour rows in N form (a2 * u, SG: raw):
+   // cU / cD: rows y+1 / y-1 of plane x; n*: plane x+1, p*: plane x-1 (U, C, D = rows y+1, y, y-1)
+   auto stencil = [&](const vec &c, const vec &old, const vec &cU, const vec &cD, const vec &nU, const vec &nC, const vec &nD,
+                      const vec &pU, const vec &pC, const vec &pD) {
+      const Real cUm = lane_from_lower<true>(cU[V - 1]), cUp = lane_from_upper<true>(cU[0]);
+      const Real cDm = lane_from_lower<true>(cD[V - 1]), cDp = lane_from_upper<true>(cD[0]);
+      const Real nCm = lane_from_lower<true>(nC[V - 1]), nCp = lane_from_upper<true>(nC[0]);
+      const Real pCm = lane_from_lower<true>(pC[V - 1]), pCp = lane_from_upper<true>(pC[0]);
+      vec o;
+#pragma unroll
+      for (int i = 0; i < V; i++) {
+         const int im = i > 0 ? i - 1 : 0, ip = i < V - 1 ? i + 1 : V - 1;
+         const Real S[12] = {nU[i], pD[i], (i == V - 1) ? cUp : cU[ip], (i == 0) ? cDm : cD[im],
+                             (i == V - 1) ? nCp : nC[ip], (i == 0) ? pCm : pC[im], nD[i], pU[i],
+                             (i == 0) ? cUm : cU[im], (i == V - 1) ? cDp : cD[ip], (i == 0) ? nCm : nC[im], (i == V - 1) ? pCp : pC[ip]};
+         if constexpr (SG) {
+            Real nb[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) nb[k] = S[FccOrder<SWZ>::p[k]];
+            o[i] = upd13<true>(a1, a2, c[i], old[i], nb);
+         } else {
+            Real p = a1 * c[i] - old[i]; // cpu_engine.h:200-218 with the products a2 * u1[...] taken from the N rows
+#pragma unroll
+            for (int k = 0; k < 12; k++) p = p + S[FccOrder<SWZ>::p[k]];
+            o[i] = p;
+         }
+      }
+      return o;
+   };
+   auto to_n = [&](const vec &v) -> vec { // N form of a raw row
+      if constexpr (SG) return v;
+      else return v * a2;
+   };
+   // Four u^n plane buffers whose roles rotate with the turn (x1-1, x1, x1+1 in N form, x1+2 in flight: planes are requested two
+   // turns ahead, as in k_tb2_fcc_x), each with the raw copy of its R centre rows; two u^{n-1} buffers.  The x loop is unrolled by
+   // four so that these roles are renamings; the three u^{n+1} planes rotate by moves.
+   vec b0[R + 2], b1[R + 2], b2[R + 2], b3[R + 2], c0[R], c1[R], c2[R], c3[R], A0[R], A1[R];
+   vec Vm[R + 2], Vc[R + 2], Vn[R + 2], rVc[R], rVn[R];
+   loadB(xs - 2, b0);
+   loadB(xs - 1, b1);
+   loadB(xs, b2);
+   loadB(min(xs + 1, xe + 1), b3);
+   loadA(xs - 1, A0);
+   loadA(xs, A1);
+#pragma unroll
+   for (int r = 0; r < R; r++) { c0[r] = b0[r + 1]; c1[r] = b1[r + 1]; rVc[r] = vec{}; }
+#pragma unroll
+   for (int j = 0; j < R + 2; j++) { b0[j] = to_n(b0[j]); b1[j] = to_n(b1[j]); Vm[j] = vec{}; Vc[j] = vec{}; Vn[j] = vec{}; }
+   // one turn: x1 = plane of the u^{n+1} values computed; Pm / Pc / Pn = u^n planes x1-1 / x1 / x1+1 (Pn arrives raw), Cm / Cc /
+   // Cn their raw centre rows; Vm / Vc = u^{n+1} planes x1-2 / x1-1 in N form, Vn receives plane x1
+   auto turn = [&](int x1, vec(&Pm)[R + 2], vec(&Pc)[R + 2], vec(&Pn)[R + 2], vec(&Cm)[R], vec(&Cc)[R], vec(&Cn)[R], vec(&Ac)[R]) {
+      const int buf = (x1 - xs + 1) & 1;
+#pragma unroll
+      for (int r = 0; r < R; r++) Cn[r] = Pn[r + 1];
+#pragma unroll
+      for (int j = 0; j < R + 2; j++) Pn[j] = to_n(Pn[j]);
+      // stage 1: u^{n+1}(x1) on the wave's own rows yo .. yo+R-1, published to the workgroup in N form
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+         rVn[j] = stencil(Cc[j], Ac[j], Pc[j + 2], Pc[j], Pn[j + 2], Pn[j + 1], Pn[j], Pm[j + 2], Pm[j + 1], Pm[j]);
+         Vn[j + 1] = to_n(rVn[j]);
+         *(vec *)&sV[buf][w * R + j][lane * V] = Vn[j + 1];
+      }
+      if (x1 + 3 <= xe + 1) loadB(x1 + 3, Pm);
+      if (x1 + 2 <= xe) loadA(x1 + 2, Ac);
+      __syncthreads();
+      if (inner) {
+         Vn[0] = *(const vec *)&sV[buf][w * R - 1][lane * V];
+         Vn[R + 1] = *(const vec *)&sV[buf][w * R + R][lane * V];
+      }
+      if (x1 >= xs && x1 < xe) {
+         Real *pc = (Real *)tp.C + (int64_t)x1 * plane;
+#pragma unroll
+         for (int r = 0; r < R; r++)
+            if (core_col && core_row[r]) __builtin_nontemporal_store(rVn[r], (vec *)(pc + offB[r + 1]));
+      }
+      // stage 2 (inner waves): u^{n+2}(x1-1) from u^{n+1} planes x1-2, x1-1, x1; its old value is u^n(x1-1)
+      if (inner && x1 - 1 >= xs) {
+         Real *pd = (Real *)tp.D + (int64_t)(x1 - 1) * plane;
+#pragma unroll
+         for (int r = 0; r < R; r++) {
+            const vec o = stencil(rVc[r], Cm[r], Vc[r + 2], Vc[r], Vn[r + 2], Vn[r + 1], Vn[r], Vm[r + 2], Vm[r + 1], Vm[r]);
+            if (core_col && core_row[r]) __builtin_nontemporal_store(o, (vec *)(pd + offB[r + 1]));
+         }
+      }
+#pragma unroll
+      for (int j = 0; j < R + 2; j++) { Vm[j] = Vc[j]; Vc[j] = Vn[j]; }
+#pragma unroll
+      for (int r = 0; r < R; r++) rVc[r] = rVn[r];
+   };
+   for (int x1 = xs - 1; x1 <= xe; x1 += 4) {
+      turn(x1, b0, b1, b2, c0, c1, c2, A0);
+      if (x1 + 1 > xe) break;
+      turn(x1 + 1, b1, b2, b3, c1, c2, c3, A1);
+      if (x1 + 2 > xe) break;
+      turn(x1 + 2, b2, b3, b0, c2, c3, c0, A0);
+      if (x1 + 3 > xe) break;
+      turn(x1 + 3, b3, b0, b1, c3, c0, c1, A1);
+   }
+}
+
 // host-side launcher, defined (and the kernel instantiated) in pf_tb2_fcc.hip, which is built with its own flags
-template <typename Real> void launch_tb2_fcc(hipStream_t s, const Tb2Params &tp, Real a1, Real a2, int lw, uint32_t nblocks);
+template <typename Real> void launch_tb2_fcc(hipStream_t s, const Tb2Params &tp, Real a1, Real a2, int lw, uint32_t nblocks, bool sg = false, bool swz = false);
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_tb1_tile -- ONE 7-point air update of the tiles k_tb2_reg must leave alone (a boundary node, a source or the ABC
@@ -410,7 +572,7 @@ template <typename Real> void launch_tb2_fcc(hipStream_t s, const Tb2Params &tp,
 // Cells whose skip-mask bit is set (boundary nodes) are not written: the boundary pass writes them afterwards.
 // Inside the box of tiles there are no ghost cells and no ABC cells, so none of that is handled here.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename Real, int R, int WY, int LW = 64, bool SG = false>
+template <typename Real, int R, int WY, int LW = 64, bool SG = false, bool SWZ = false>
 __global__ __launch_bounds__(64 * WY) void k_tb1_tile(Tb2Params tp, Real a1, Real a2) {
    typedef typename VecOf<Real>::type vec;
    static_assert(LW == 64 || LW == 32 || LW == 16, "row segments are 64, 32 or 16 lanes wide");
@@ -469,7 +631,8 @@ __global__ __launch_bounds__(64 * WY) void k_tb1_tile(Tb2Params tp, Real a1, Rea
          for (int i = 0; i < V; i++) {
             const Real zp = (i == V - 1) ? rt : c[i < V - 1 ? i + 1 : V - 1];
             const Real zm = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
-            o[i] = upd7<SG>(a1, a2, c[i], old[i], Bn[r + 1][i], Bp[r][i], Bc[r + 2][i], Bc[r][i], zp, zm);
+            if constexpr (SWZ) o[i] = upd7<SG>(a1, a2, c[i], old[i], zp, zm, Bc[r + 2][i], Bc[r][i], Bn[r + 1][i], Bp[r][i]);
+            else o[i] = upd7<SG>(a1, a2, c[i], old[i], Bn[r + 1][i], Bp[r][i], Bc[r + 2][i], Bc[r][i], zp, zm);
          }
          if (core_col && core_row[r]) {
             if ((bits & ((1u << V) - 1u)) == 0u) __builtin_nontemporal_store(o, (vec *)(pc + off[r + 1]));
@@ -514,7 +677,7 @@ template <typename Real> struct ZStripParams {
    Real sl2;
 };
 
-template <typename Real, bool SG = false>
+template <typename Real, bool SG = false, bool SWZ = false>
 __global__ __launch_bounds__(256) void k_air_zstrip(ZStripParams<Real> zp, Real a1, Real a2, Real l, int xchunk) {
    // thread = one 16-byte vector of one row; it marches xchunk planes with the x neighbours in registers, so every
    // 128-byte line of u1 / u0s next to the strip is fetched once (a thread-per-cell version re-fetched the x neighbours
@@ -570,7 +733,8 @@ __global__ __launch_bounds__(256) void k_air_zstrip(ZStripParams<Real> zp, Real 
       for (int i = 0; i < V; i++) {
          const Real zpv = (i == V - 1) ? rt : c[i < V - 1 ? i + 1 : V - 1];
          const Real zmv = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
-         Real p = upd7<SG>(a1, a2, c[i], old[i], cp[i], cm[i], yp[i], ym[i], zpv, zmv);
+         Real p = SWZ ? upd7<SG>(a1, a2, c[i], old[i], zpv, zmv, yp[i], ym[i], cp[i], cm[i]) // (file order of the neighbours: axes exchanged in storage)
+                      : upd7<SG>(a1, a2, c[i], old[i], cp[i], cm[i], yp[i], ym[i], zpv, zmv);
          const int Q = qxy + ((z0 + i == 1 || z0 + i == Nz - 2) ? 1 : 0);
          if (Q > 0) p = abc_loss<SG>(p, old[i], l * (Real)Q); // (cpu_engine.h:225-229 incl. the double literal of :228; SG: gpu_engine.h:351-365)
          if ((bits >> i) & 1u) {
@@ -578,7 +742,7 @@ __global__ __launch_bounds__(256) void k_air_zstrip(ZStripParams<Real> zp, Real 
             const int32_t nb = ((zrec >> i) & 1u) ? (int32_t)((zrec >> 4) + __popc(zrec & ((1u << i) - 1u))) : -1;
             if (nb >= 0) { // boundary node (its number in strip order): rigid update from the registers (k_boundary's expression), then the FD branches
                const uint32_t adj = zp.adjv[nb];
-               const Real nbk[6] = {cp[i], cm[i], yp[i], ym[i], zpv, zmv};
+               const Real nbk[6] = {SWZ ? zpv : cp[i], SWZ ? zmv : cm[i], yp[i], ym[i], SWZ ? cp[i] : zpv, SWZ ? cm[i] : zmv}; // adjacency-bit (file) order
                p = upd_rigid<SG, 6>(a2, zp.sl2, adj, c[i], old[i], nbk);
                const int32_t li = zp.lossy[nb];
                if (li >= 0) zp.u0b[li] = p;
@@ -598,7 +762,7 @@ __global__ __launch_bounds__(256) void k_air_zstrip(ZStripParams<Real> zp, Real 
 // columns next to a vector are simply loaded.  Boundary nodes keep their old value (the list kernel writes them).
 // Same accumulation order as k_air_fcc (bit-identical).
 // ---------------------------------------------------------------------------------------------------------------
-template <typename Real>
+template <typename Real, bool SG = false, bool SWZ = false>
 __global__ __launch_bounds__(256) void k_zstrip_fcc(ZStripParams<Real> zp, Real a1, Real a2, Real l, int xchunk, int fold) {
    typedef typename VecOf<Real>::type vec;
    constexpr int V = VecOf<Real>::V;
@@ -637,25 +801,15 @@ __global__ __launch_bounds__(256) void k_zstrip_fcc(ZStripParams<Real> zp, Real 
       vec o;
 #pragma unroll
       for (int i = 0; i < V; i++) {
-         Real p = a1 * pc[1].c[i] - old[i];
-         p = p + a2 * pn[2].c[i];      // +x+y
-         p = p + a2 * pm[0].c[i];      // -x-y
-         p = p + a2 * hi(pc[2], i);    // +y+z
-         p = p + a2 * lo(pc[0], i);    // -y-z
-         p = p + a2 * hi(pn[1], i);    // +x+z
-         p = p + a2 * lo(pm[1], i);    // -x-z
-         p = p + a2 * pn[0].c[i];      // +x-y
-         p = p + a2 * pm[2].c[i];      // -x+y
-         p = p + a2 * lo(pc[2], i);    // +y-z
-         p = p + a2 * hi(pc[0], i);    // -y+z
-         p = p + a2 * lo(pn[1], i);    // +x-z
-         p = p + a2 * hi(pm[1], i);    // -x+z
+         // storage order of the twelve neighbours; they enter the sum in the FILE's order (FccOrder: axes exchanged in storage)
+         const Real S[12] = {pn[2].c[i], pm[0].c[i], hi(pc[2], i), lo(pc[0], i), hi(pn[1], i), lo(pm[1], i),
+                             pn[0].c[i], pm[2].c[i], lo(pc[2], i), hi(pc[0], i), lo(pn[1], i), hi(pm[1], i)};
+         Real nb[12];
+#pragma unroll
+         for (int k = 0; k < 12; k++) nb[k] = S[FccOrder<SWZ>::p[k]];
+         Real p = upd13<SG>(a1, a2, pc[1].c[i], old[i], nb);
          const int Q = qxy + ((z0 + i == 1 || z0 + i == Nz - 2) ? 1 : 0);
-         if (Q > 0) { // ABC loss (cpu_engine.h:225-229), double literal of :228
-            const Real lQ = l * (Real)Q;
-            const Real num = p + lQ * old[i];
-            p = (Real)((double)num / (1.0 + (double)lQ));
-         }
+         if (Q > 0) p = abc_loss<SG>(p, old[i], l * (Real)Q); // ABC loss (cpu_engine.h:225-229 incl. the double literal of :228; SG: gpu_engine.h:351-365)
          if ((bits >> i) & 1u) p = old[i]; // ghost / pad column or a boundary node
          o[i] = p;
       }

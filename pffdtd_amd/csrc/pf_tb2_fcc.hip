@@ -10,12 +10,15 @@ namespace pf {
 
 // (32- and 16-lane row segments only; the 64-lane LDS-exchange variant k_tb2_fcc_x is launched from pf_engine.hip: it has
 // registers to spare and gains 16 % from the packed fp32 operations this translation unit switches off)
-template <typename Real> void launch_tb2_fcc(hipStream_t s, const Tb2Params &tp, Real a1, Real a2, int lw, uint32_t nblocks) {
+template <typename Real> void launch_tb2_fcc(hipStream_t s, const Tb2Params &tp, Real a1, Real a2, int lw, uint32_t nblocks, bool sg, bool swz) {
    const dim3 g(nblocks), b(256);
-   if (lw == 32) hipLaunchKernelGGL((k_tb2_fcc<Real, 2, 4, 32>), g, b, 0, s, tp, a1, a2);
-   else hipLaunchKernelGGL((k_tb2_fcc<Real, 2, 4, 16>), g, b, 0, s, tp, a1, a2);
+#define PF_FCC_LW(SG, SWZ) do { if (lw == 32) hipLaunchKernelGGL((k_tb2_fcc<Real, 2, 4, 32, SG, SWZ>), g, b, 0, s, tp, a1, a2); \
+                                else hipLaunchKernelGGL((k_tb2_fcc<Real, 2, 4, 16, SG, SWZ>), g, b, 0, s, tp, a1, a2); } while (0)
+   if (sg) { if (swz) PF_FCC_LW(true, true); else PF_FCC_LW(true, false); }
+   else { if (swz) PF_FCC_LW(false, true); else PF_FCC_LW(false, false); }
+#undef PF_FCC_LW
 }
-template void launch_tb2_fcc<float>(hipStream_t, const Tb2Params &, float, float, int, uint32_t);
-template void launch_tb2_fcc<double>(hipStream_t, const Tb2Params &, double, double, int, uint32_t);
+template void launch_tb2_fcc<float>(hipStream_t, const Tb2Params &, float, float, int, uint32_t, bool, bool);
+template void launch_tb2_fcc<double>(hipStream_t, const Tb2Params &, double, double, int, uint32_t, bool, bool);
 
 } // namespace pf

@@ -349,3 +349,84 @@ def test_blocked_pairs_in_the_gpu_safeguarded_arithmetic(prec, src, kw):
     peak = np.abs(exact.u_out).max()
     d = np.abs(ref_out - exact.u_out).max()
     assert 0 < d <= (3e-5 if prec == "single" else 1e-12) * peak
+
+
+# ---- round 5: 13-point pairs in the safeguarded arithmetic, pairs on grids stored with exchanged axes -----------------------
+@pytest.mark.parametrize("prec", ["single", "double"])
+@pytest.mark.parametrize("dbg", [0x400, 0x100, 0x200], ids=["lw64", "lw32", "lw16"])
+def test_fcc_blocked_pairs_in_the_gpu_safeguarded_arithmetic(prec, dbg):
+    """PF_NUM_GPU_SAFEGUARDED in the 13-point pair kernels (k_tb2_fcc_w<..., SG> with 64-lane segments, k_tb2_fcc<..., SG> with
+    32 / 16) and their single-step shell (k_zstrip_fcc, k_air_fcc tiles): the towards-zero tree of gpu_engine.h:257-267 and the two
+    FMAs of :268 -- forced pairs give the bits of the oracle's restatement of that arithmetic, receivers and whole field."""
+    sim = fcc_scene(blocks=((12, 17, 20, 40, 60, 130),), src=[19, 45, 138])
+    sd = sim_data.SimData.from_sim(sim, prec)
+    sd.scale_input()
+    e = oracle.Engine(sd, safeguarded=True)
+    for n in range(sd.Nt):
+        e.step(n)
+    ref_out, ref_u1 = sd.u_out.copy(), e.grid(1).copy()
+    e.close()
+    assert np.abs(ref_out).max() > 0
+    exact = sim_data.SimData.from_sim(sim, prec)
+    exact.scale_input()
+    oracle.run_sim(exact)
+    assert not np.array_equal(ref_out, exact.u_out)  # (the two arithmetics do differ in the last bits)
+    for variant, d in ((0, 0x4000), (40, dbg)):
+        out, g, tm = run(sim, variant, prec=prec, numerics=engine.PF_NUM_GPU_SAFEGUARDED, debug=d)
+        assert (tm["tb2_launches"] > 0) == (variant == 40), (variant, tm)
+        if variant == 40:
+            assert tm["tb2_lw"] == {0x400: 64, 0x100: 32, 0x200: 16}[dbg]
+        assert np.array_equal(out, ref_out), variant
+        assert np.array_equal(g[1][1:-1, 1:-1, 1:-1], ref_u1[1:-1, 1:-1, 1:-1]), variant
+
+
+@pytest.mark.parametrize("prec", ["single", "double"])
+def test_fcc_pair_kernels_old_and_new_give_the_same_bits(prec):
+    """k_tb2_fcc_w (every product a2 * u rounded once per cell and shared by the twelve sums it enters) against k_tb2_fcc_x
+    (debug 0x40000: the products inside every sum) and the oracle."""
+    sim = fcc_scene(Nt=21)
+    ref = sim_data.SimData.from_sim(sim, prec)
+    ref.scale_input()
+    oracle.run_sim(ref)
+    fields = []
+    for dbg in (0x400, 0x400 | 0x40000):
+        out, g, tm = run(sim, 40, prec=prec, debug=dbg)
+        assert tm["tb2_launches"] > 0 and tm["tb2_lw"] == 64
+        assert np.array_equal(out, ref.u_out), hex(dbg)
+        fields.append(g)
+    for a, b in zip(*fields):
+        assert np.array_equal(a[1:-1, 1:-1, 1:-1], b[1:-1, 1:-1, 1:-1])
+
+
+@pytest.mark.parametrize("prec", ["single", "double"])
+@pytest.mark.parametrize("numerics", [engine.PF_NUM_CPU_EXACT, engine.PF_NUM_GPU_SAFEGUARDED], ids=["exact", "safeguarded"])
+@pytest.mark.parametrize("fcc", [False, True], ids=["cart", "fcc"])
+def test_blocked_pairs_on_a_grid_stored_with_exchanged_axes(fcc, numerics, prec):
+    """Rooms are stored with the file's x and z axes exchanged (unit stride along the longest axis, debug 0x1000 forces it): the
+    pair kernels then work in storage coordinates but take their neighbours in the FILE's order (k_tb2_reg / k_tb1_tile /
+    k_air_zstrip / k_tb2_fcc_w / k_zstrip_fcc<..., SWZ>) -- forced pairs with a block standing in the room give the oracle's bits."""
+    blocks = ((60, 130, 20, 40, 12, 17), (150, 260, 8, 12, 22, 24))
+    if fcc:
+        n = (280, 70, 36)
+        src = [138, 45, 19]
+        src = [src[0], src[1], src[2] + (sum(src) % 2)]
+        rcv = [[src[0] + dx, src[1] + dy, src[2] + dz + ((dx + dy + dz) % 2)] for dx, dy, dz in ((-4, 3, 2), (6, 2, -5), (9, -6, 3), (-8, -3, -2))]
+        sim = synth.shoebox(n[0], 2 * (n[1] - 1), n[2], Nt=33, fcc=True, Nm=2, Mb=[11, 3], src=src, rcv=rcv, blocks=blocks)
+        synth.fold_fcc(sim)
+        synth.sort_sim(sim)
+    else:
+        n = (280, 64, 36)
+        sim = synth.shoebox(*n, Nt=33, Nm=2, Mb=[11, 3], src=[138, 45, 19], rcv=[[140, 50, 20], [133, 41, 15], [141, 49, 24], [131, 40, 19]], blocks=blocks)
+    sd = sim_data.SimData.from_sim(sim, prec)
+    sd.scale_input()
+    e = oracle.Engine(sd, safeguarded=numerics == engine.PF_NUM_GPU_SAFEGUARDED)
+    for k in range(sd.Nt):
+        e.step(k)
+    ref_out, ref_u1 = sd.u_out.copy(), e.grid(1).copy()
+    e.close()
+    assert (np.abs(ref_out).max(axis=1) > 0).all()
+    for variant, dbg in ((0, 0x1000 | 0x4000), (40, 0x1000)):
+        out, g, tm = run(sim, variant, prec=prec, numerics=numerics, debug=dbg, readout_chunk=7)
+        assert (tm["tb2_launches"] > 0) == (variant == 40), (variant, tm)
+        assert np.array_equal(out, ref_out), variant
+        assert np.array_equal(g[1][1:-1, 1:-1, 1:-1], ref_u1[1:-1, 1:-1, 1:-1]), variant
