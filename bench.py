@@ -133,8 +133,11 @@ def roofline_block(args, sd, tm, K, real_bytes, interior_planes, interior_per_pl
         # bytes are therefore 2 x 12.125 B per cell and launch (SURVEY 8d's per-update figure x the updates it performs)
         lw = int(tm["tb2_lw"])
         if args.fcc:
-            kernel = "k_tb2_fcc_x" if lw == 64 else "k_tb2_fcc"
-            inst = f"pf::k_tb2_fcc_x<{T}, 2, 8>" if lw == 64 else f"pf::k_tb2_fcc<{T}, 2, 4, {lw}>"
+            sgt = "true" if getattr(args, "numerics", 0) == 2 else "false"
+            old_kernel = bool(getattr(args, "debug", 0) & 0x40000) and sgt == "false"
+            kernel = ("k_tb2_fcc_x" if old_kernel else "k_tb2_fcc_w") if lw == 64 else "k_tb2_fcc"
+            inst = ((f"pf::k_tb2_fcc_x<{T}, 2, 8>" if old_kernel else f"pf::k_tb2_fcc_w<{T}, 2, 8, {sgt}, false>") if lw == 64
+                    else f"pf::k_tb2_fcc<{T}, 2, 4, {lw}, {sgt}, false>")
         else:
             sgt = "true" if getattr(args, "numerics", 0) == 2 else "false"  # (<..., PROBE = true, ...> = creation-time probes)
             kernel, inst = "k_tb2_reg", f"pf::k_tb2_reg<{T}, 3, 4, false, {lw}, false, {sgt}>"
@@ -248,11 +251,12 @@ def run_chain(args, only=None):
     lossy = not args.rigid
     real_bytes = 4 if args.precision == "single" else 8
     sd = build_scene(args.size, (R + 1) * K + W, args.precision, args.fcc, lossy, args.mb, args.nx, args.ny)
-    transport = {"auto": engine.PF_TRANSPORT_AUTO, "peer": engine.PF_TRANSPORT_PEER, "rccl": engine.PF_TRANSPORT_RCCL}[args.transport]
+    transport = {"auto": engine.PF_TRANSPORT_AUTO, "peer": engine.PF_TRANSPORT_PEER, "rccl": engine.PF_TRANSPORT_RCCL,
+                 "host": engine.PF_TRANSPORT_HOST}[args.transport]
     if only:
         transport = engine.PF_TRANSPORT_RCCL if args.emulate_transport == "rccl" else engine.PF_TRANSPORT_PEER
     m = engine.HipMulti(sd, devices, numerics=args.numerics, air_variant=args.variant, air_chunk=args.chunk, debug=args.debug,
-                        transport=transport, verify_exchange=0 if only else min(W, 4), only_slab=(only[0] + 1) if only else 0)
+                        transport=transport, verify_exchange=0 if only else 2, only_slab=(only[0] + 1) if only else 0)  # (first contact: the first two exchanges of every chain are checksummed -- inside the warm-up unless W < 2)
     live = [only[0]] if only else list(range(N))
     slabs = [m.slab(g) for g in live]
     for g, sl in zip(live, slabs):
@@ -300,6 +304,9 @@ def run_chain(args, only=None):
     rl["slab"] = g0
     res["roofline"] = rl
     res["exchange_verified"] = None if only else info["exchange_verified"]
+    res["transport"] = info["transport_name"]  # "peer copies" | "rccl" | "host-staged" (the last resort: neither peer access nor a working RCCL)
+    if info.get("transport_note"):
+        res["transport_note"] = info["transport_note"]
     res["exchange"] = {"backend": info["transport_name"], "ranks": N, "checked_steps": info["exchanges_checked"],
                        "nonzero_planes": info["exchange_nonzero"], "plane_bytes": info["plane_bytes"],
                        "what": "position-weighted bit-pattern checksums of the received ghost planes == the senders' planes, every slab"}
@@ -331,7 +338,7 @@ def main():
     ap.add_argument("--numerics", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug", type=lambda v: int(v, 0), default=0, help="pf_opts.debug (tuning switches)")
-    ap.add_argument("--transport", default="auto", choices=["auto", "peer", "rccl"],
+    ap.add_argument("--transport", default="auto", choices=["auto", "peer", "rccl", "host"],
                     help="N>1 from one process: how ghost planes travel (pf_opts.transport)")
     ap.add_argument("--split-phase", action="store_true", help="N=1: drive the split-phase step like N>1 does")
     ap.add_argument("--emulate-slab", default="", help="debug: 'r/N' = run only slab r of an N-way split on this GPU, the exchange\n                    replaced by device copies of the same planes (per-rank cost model; physics is wrong)")

@@ -80,8 +80,8 @@ typedef enum pf_status {
                                     contraction: results are bit-identical to it (the parity target) */
 #define PF_NUM_GPU_SAFEGUARDED 2 /* the reference GPU engine's arithmetic for the air and rigid-node updates (fdtd_common.h:44-71,
                                     gpu_engine.h:220-274,288-348): pairwise neighbour sums -- in fp32 rounded TOWARDS ZERO, its
-                                    long-run stability safeguard -- then two round-to-nearest FMAs; single steps, 7-point blocked pairs and
-                                    their wall regions (13-point pairs exist in the CPU-exact arithmetic only) */
+                                    long-run stability safeguard -- then two round-to-nearest FMAs; every kernel family has it: single steps,
+                                    7-point blocked pairs with their wall regions, 13-point blocked pairs (round 5) */
 
 typedef struct pf_opts {
    int32_t device;        /* HIP device ordinal */
@@ -106,7 +106,7 @@ typedef struct pf_opts {
                              generic; 0x4000000 all their launches on one stream; 0x2000000 wide column strips cut in two;
                              0x800000 replay the single-step loop from a hipGraph (six steps per graph; no faster on this stack);
                              0x100000 boundary pass in plain workgroup order; 0x200000 it fetches the neighbours inside
-                             the wall too */
+                             the wall too; 0x40000 13-point pairs by the round-4 kernel k_tb2_fcc_x (A/B measurements) */
    int32_t energy;        /* 1 = keep what the energy diagnostic needs (explicit Laplacian grid, unfused kernel
                              sequence); then use pf_engine_energy_cfg + pf_engine_run_energy */
    int32_t multi_flags;   /* pf_run_sim_devices / pf_multi_create only: PF_MULTI_* */
@@ -117,14 +117,22 @@ typedef struct pf_opts {
                              physics is wrong, the work and the launches are a rank's); 0 = the whole chain */
    int32_t test_drop_exchange; /* tests only, pf_multi_create: 1 + n = slab 1 misses the ghost planes of step n (the exchange self-check, which
                              then always covers that step, must notice) */
+   int32_t test_faults;   /* tests only, pf_multi_create: fault injection for the first-contact paths of a multi-device box.  1: no peer
+                             access between any two devices; 2: RCCL unusable; 4: the host thread of slab 1 stalls before the barrier
+                             of its fourth step (the watchdog of the others must turn the hang into an error) */
 } pf_opts;
 
-#define PF_TRANSPORT_AUTO 0 /* peer copies where hipDeviceCanAccessPeer says yes for every neighbouring pair, else RCCL */
+#define PF_TRANSPORT_AUTO 0 /* peer copies where hipDeviceCanAccessPeer says yes for every neighbouring pair, else RCCL, else -- librccl
+                               missing, its communicators failing or not returning within PFFDTD_RCCL_INIT_TIMEOUT_S (60) seconds --
+                               host-staged copies (pf_multi_info.transport / transport_note say which and why) */
 #define PF_TRANSPORT_PEER 1 /* each slab pulls its ghost planes with hipMemcpyPeerAsync on its edge stream (gpu_engine.h:1086-1126
-                               uses cudaMemcpyPeerAsync after a full sync); an error, not a host-staged copy, without peer access */
+                               uses cudaMemcpyPeerAsync after a full sync); an error without peer access when asked for explicitly */
 #define PF_TRANSPORT_RCCL 2 /* ncclSend / ncclRecv of both planes, grouped per slab on its edge stream, one single-process
                                communicator clique over the chain (librccl is loaded at run time); environment PFFDTD_TRANSPORT=
-                               peer|rccl|auto overrides pf_opts.transport */
+                               peer|rccl|host|auto overrides pf_opts.transport */
+#define PF_TRANSPORT_HOST 3 /* the last resort: every slab copies its two edge planes into a pinned bounce buffer on its edge stream and its
+                               neighbours copy them out on theirs; the two sides meet on the host (hipEventSynchronize).  Needs nothing
+                               from the driver beyond device <-> pinned-host copies.  No counterpart in the reference */
 
 #define PF_MULTI_EVEN_SPLIT  1 /* the reference's Nx/G planes per slab (gpu_engine.h:532-550) instead of the cost-balanced cut */
 #define PF_MULTI_ONE_THREAD  2 /* one host thread drives every slab (the reference's arrangement) instead of one thread per slab */
@@ -194,6 +202,7 @@ typedef struct pf_multi_info {
    int64_t plane_bytes;        /* bytes of one exchanged plane */
    double  last_run_seconds;   /* wall time of the last pf_multi_run */
    char    transport_name[64];
+   char    transport_note[256]; /* why this transport: the fallbacks PF_TRANSPORT_AUTO took ("" = its first choice) */
 } pf_multi_info;
 int  pf_multi_create(pf_simdata *sd, int32_t nslabs, const int32_t *devices, const pf_opts *base, pf_multi **out);
 /* steps n0 .. n0+nsteps-1 on every slab; returns when all streams have drained and the receiver rows are in sd->u_out */

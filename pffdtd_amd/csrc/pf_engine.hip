@@ -676,7 +676,7 @@ template <typename Real> struct Engine : EngineBase {
          int64_t best = -1;
          for (int lw : {64, 32, 16}) {
             if (op.debug & 0x300) { if (lw != ((op.debug & 0x100) ? 32 : 16)) continue; } // tuning override (as pick_lw)
-            else if ((op.debug & 0x400) && lw != 64) continue;
+            else if (((op.debug & 0x400) || swz) && lw != 64) continue; // (exchanged axes: the SWZ instantiations exist for 64-lane segments only; such rooms have long rows)
             const int TC = (lw - 2) * V;
             int z1 = (int)((Nz - mz1) / 4 * 4);
             const int nz = z1 - tbz0, rem = nz % TC;
@@ -686,7 +686,6 @@ template <typename Real> struct Engine : EngineBase {
             if (best < 0 || lanes < best) { best = lanes; tb_lw = lw; tbz1 = z1; }
          }
          if (best < 0) return PF_OK; // no room for a single row segment
-         if (swz && tb_lw != 64) return PF_OK; // (the SWZ instantiations exist for 64-lane segments only: rooms stored along their longest axis have long rows)
       }
       // Wall regions (init_walls): a column strip costs one 128-byte line per row whatever its width, but its pencils live in
       // registers -- a sliver cut off the box is shared between the two strips instead of all going to the right one.
@@ -815,7 +814,8 @@ template <typename Real> struct Engine : EngineBase {
                      const int za = std::max(zt * 64 * V, tbz0), zb = std::min((zt + 1) * 64 * V, tbz1);
                      if (za >= zb) continue; // only column-strip cells: k_zstrip_fcc
                      bool need = ya < tby0 || yb > tby1;
-                     if (!need) {
+                     // (64-lane segments: the box's dirty tiles are stepped tile for tile by k_tb1_fcc_tile, launch_dirty_tiles)
+                     if (!need && (tb_lw != 64 || (op.debug & 0x80000))) { // (debug 0x80000: the round-4 arrangement, A/B measurements)
                         const int t0y = (ya - tby0) / TR, t1y = (yb - 1 - tby0) / TR, t0z = (za - tbz0) / TC, t1z = (zb - 1 - tbz0) / TC;
                         for (int a = t0y; a <= t1y && !need; a++)
                            for (int c = t0z; c <= t1z && !need; c++) need = dirty[((size_t)xc * tb_nyt + a) * tb_nzt + c] != 0;
@@ -1804,6 +1804,15 @@ template <typename Real> struct Engine : EngineBase {
       tp.tiles = tb_dirty; tp.mask = mask;
       tp.xsub = tb_ndirty <= 256 ? std::min(4, std::max(tb_chunk / 4, 1)) : 1; // few tiles: shorter marches, more workgroups
       const dim3 g((uint32_t)tb_ndirty * (uint32_t)tp.xsub), b(256);
+      if (fcc) { // (64-lane segments only, init_tb2; the narrower ones keep k_air_fcc over its own tiles)
+         if (tb_lw != 64 || (op.debug & 0x80000)) return;
+         const dim3 bf(64 * (fcc_wt - 2));
+         if (sg) { if (swz) hipLaunchKernelGGL((pf::k_tb1_fcc_tile<Real, 2, fcc_wt - 2, true, true>), g, bf, 0, s, tp, a1, a2);
+                   else hipLaunchKernelGGL((pf::k_tb1_fcc_tile<Real, 2, fcc_wt - 2, true, false>), g, bf, 0, s, tp, a1, a2); }
+         else { if (swz) hipLaunchKernelGGL((pf::k_tb1_fcc_tile<Real, 2, fcc_wt - 2, false, true>), g, bf, 0, s, tp, a1, a2);
+                else hipLaunchKernelGGL((pf::k_tb1_fcc_tile<Real, 2, fcc_wt - 2, false, false>), g, bf, 0, s, tp, a1, a2); }
+         return;
+      }
       if (swz) {
          if (sg) hipLaunchKernelGGL((pf::k_tb1_tile<Real, 3, 4, 64, true, true>), g, b, 0, s, tp, a1, a2);
          else hipLaunchKernelGGL((pf::k_tb1_tile<Real, 3, 4, 64, false, true>), g, b, 0, s, tp, a1, a2);
@@ -1854,6 +1863,7 @@ template <typename Real> struct Engine : EngineBase {
          else hipLaunchKernelGGL((pf::k_air_fcc<Real, 4, 4, 1, false, true, false, true, 64>), dim3((uint32_t)sh_ntiles), dim3(256), 0, s, u1, u0, mask, a1, a2,
                             ap, l, u0_src, sh_tiles);
       }
+      launch_dirty_tiles(s);
    }
    // planes [xlo, xhi) without the strips beside the box (slab pairs with wall regions): whole planes outside the box's x range
    // and the box's own single-step tiles
@@ -1919,17 +1929,24 @@ template <typename Real> struct Engine : EngineBase {
       auto get_ev = [&]() { std::pair<hipEvent_t, hipEvent_t> e{}; if (!ev_pool.empty()) { e = ev_pool.back(); ev_pool.pop_back(); } else { hipEventCreate(&e.first); hipEventCreate(&e.second); } return e; };
       if (op.timing) { ev = get_ev(); eva = get_ev(); hipEventRecord(ev.first, s); hipEventRecord(eva.first, s); } // step events: one per step
       std::pair<hipEvent_t, hipEvent_t> evt{};
-      if (op.timing) { evt = get_ev(); hipEventRecord(evt.first, s); }
-      launch_tb2(s, A, B, C, D);
-      if (op.timing) { hipEventRecord(evt.second, s); tb2_ev.push_back(evt); }
+      // The FIRST step of the shell reads u^{n-1}, u^n only and writes cells the pair kernel does not: it runs BESIDE the pair
+      // kernel, on the edge stream (its launches are small and latency-bound -- strided strips, list gathers -- and fill the gaps
+      // the bandwidth-bound pair kernel leaves); the second step needs the box's u^{n+1} and follows.  debug 0x4000000: one stream.
+      const bool beside = !(op.debug & 0x4000000);
+      hipStream_t sh = beside ? s_edge : s;
+      if (beside) { HIPCHK(hipEventRecord(ev_pre, s)); HIPCHK(hipStreamWaitEvent(s_edge, ev_pre, 0)); }
       u0_src = A; u1 = B; u0 = C;
       const Range bnd = zs_map ? Range{0, zs_nrest} : Range{0, Nb};
       bnd_sel = zs_map ? zs_rest : nullptr;
-      launch_shell(s);
-      if (op.timing) { hipEventRecord(eva.second, s); air_ev.push_back(eva); eva = get_ev(); }
-      launch_rigid(s, bnd);
-      launch_fd(s, {0, Nbl});
-      launch_io(s, n, true, {0, Ns});
+      launch_shell(sh);
+      launch_rigid(sh, bnd);
+      launch_fd(sh, {0, Nbl});
+      launch_io(sh, n, true, {0, Ns});
+      if (op.timing) { evt = get_ev(); hipEventRecord(evt.first, s); }
+      launch_tb2(s, A, B, C, D);
+      if (op.timing) { hipEventRecord(evt.second, s); tb2_ev.push_back(evt); }
+      if (beside) { HIPCHK(hipEventRecord(ev_edge, s_edge)); HIPCHK(hipStreamWaitEvent(s, ev_edge, 0)); }
+      if (op.timing) { hipEventRecord(eva.second, s); air_ev.push_back(eva); eva = get_ev(); } // ("air" of the first step: the pair kernel and the shell beside it)
       { Real *t = ub[2]; ub[2] = ub[1]; ub[1] = ub[0]; ub[0] = t; }
       if (ring_fill == 0) ring_n0 = n;
       ring_fill++; steps_done++;

@@ -280,27 +280,48 @@ std::mutex g_rccl_mu;
 
 // sense-reversing spin barrier (a step takes 0.3-3 ms; the threads meet within microseconds).  The last thread to arrive
 // samples the error flag and publishes it with the release, so that all threads take the same decision to stop.
+// WATCHDOG: a thread that has waited longer than timeout_s gives up -- a neighbour's thread is stuck inside a driver or RCCL call
+// (a hung device, a collective that never completes) -- raises `timed_out` and returns "stop"; every other waiting thread does
+// the same within its own timeout, so a hang becomes an error (pf_last_error) instead of a process that never returns.  The
+// barrier is unusable afterwards (the chain is in its error state and only waits to be destroyed).
 struct SpinBarrier {
    std::atomic<int> count{0};
    std::atomic<int> sense{0};
    std::atomic<int> stop{0};
+   std::atomic<int> timed_out{0};
    int n = 1;
-   bool wait(int &local, const std::atomic<int> &err) {
+   bool wait(int &local, const std::atomic<int> &err, double timeout_s = 0.0) {
+      if (timed_out.load(std::memory_order_relaxed)) return true;
       local ^= 1;
       if (count.fetch_add(1, std::memory_order_acq_rel) == n - 1) {
          count.store(0, std::memory_order_relaxed);
          stop.store(err.load() != 0 ? 1 : 0, std::memory_order_relaxed);
          sense.store(local, std::memory_order_release);
       } else {
-         int spins = 0;
-         while (sense.load(std::memory_order_acquire) != local)
-            if (++spins > 2000) std::this_thread::yield();
+         int64_t spins = 0;
+         bool timing = false;
+         std::chrono::steady_clock::time_point t0;
+         while (sense.load(std::memory_order_acquire) != local) {
+            if (++spins <= 2000) continue;
+            std::this_thread::yield();
+            if (timeout_s > 0 && (spins & 255) == 0) {
+               if (timed_out.load(std::memory_order_relaxed)) return true;
+               const auto now = std::chrono::steady_clock::now();
+               if (!timing) { timing = true; t0 = now; }
+               else if (std::chrono::duration<double>(now - t0).count() > timeout_s) { timed_out.store(1); return true; }
+            }
+         }
       }
-      return stop.load(std::memory_order_relaxed) != 0;
+      return stop.load(std::memory_order_relaxed) != 0 || timed_out.load(std::memory_order_relaxed) != 0;
    }
 };
+// seconds a slab thread waits for the others before it declares the chain hung (PFFDTD_BARRIER_TIMEOUT_S; creation: ten times that)
+double barrier_timeout() {
+   if (const char *ev = getenv("PFFDTD_BARRIER_TIMEOUT_S")) { const double v = atof(ev); if (v > 0) return v; }
+   return 120.0;
+}
 
-enum { TR_PEER = PF_TRANSPORT_PEER, TR_RCCL = PF_TRANSPORT_RCCL };
+enum { TR_PEER = PF_TRANSPORT_PEER, TR_RCCL = PF_TRANSPORT_RCCL, TR_HOST = PF_TRANSPORT_HOST };
 
 struct Shared {
    int G = 1;
@@ -329,6 +350,14 @@ struct Shared {
                                                                  // planes sent to itself (the RCCL code path on a 1-GPU box)
    std::vector<ncclComm_t> comm;                                 // [g]
    std::vector<int> rank;                                        // [g] peer rank of slab g in the clique
+   // host-staged transport (the last resort: neither peer access nor a working RCCL): slab g copies its two edge planes into a
+   // pinned bounce buffer of its own on its edge stream, its neighbours copy them out on theirs; the two sides meet on the HOST
+   // (hipEventSynchronize), nothing device-to-device is asked of the driver
+   std::vector<void *> hstage[2];                                // [n&1][g]: lo plane, hi plane (2 * plane_bytes, pinned, portable)
+   std::vector<hipEvent_t> ev_d2h[2], ev_h2d[2];                 // [n&1][g]: my planes are in my buffer / my ghost planes have left the neighbours' buffers
+   std::string transport_note;                                   // why this transport (fallbacks taken)
+   double bar_timeout = 120.0;
+   int faults = 0;                                               // pf_opts.test_faults
    // exchange self-check: the first `verify_n` exchanges after creation
    int64_t verify_n = 0;
    int64_t drop_step = -1; // test hook (pf_opts.test_drop_exchange): slab 1 misses the planes of that step; the self-check then always covers it
@@ -446,21 +475,79 @@ void create_slab(Shared &S, int g) {
             }
             (void)hipGetLastError();
          }
+   if (S.transport == TR_HOST)
+      for (int k = 0; k < 2; k++) {
+         MCHK(g, hipHostMalloc(&S.hstage[k][g], 2 * S.plane_bytes, hipHostMallocPortable));
+         MCHK(g, hipEventCreateWithFlags(&S.ev_d2h[k][g], hipEventDisableTiming));
+         MCHK(g, hipEventCreateWithFlags(&S.ev_h2d[k][g], hipEventDisableTiming));
+      }
    if (S.verify_n > 0) S.hbuf[g].resize(4 * S.plane_bytes);
 }
 
-// Which transport carries the ghost planes?  requested: PF_TRANSPORT_AUTO / _PEER / _RCCL (pf_opts.transport), overridden by
-// PFFDTD_TRANSPORT=peer|rccl.  AUTO = peer copies when every neighbouring pair of devices can access each other's memory
-// (hipDeviceCanAccessPeer), else RCCL.  Peer copies without peer access would silently stage through host memory: refused.
+// Which transport carries the ghost planes?  requested: PF_TRANSPORT_AUTO / _PEER / _RCCL / _HOST (pf_opts.transport), overridden by
+// PFFDTD_TRANSPORT=peer|rccl|host|auto.  AUTO = peer copies when every neighbouring pair of devices can access each other's
+// memory (hipDeviceCanAccessPeer), else RCCL, else -- librccl missing, its communicators failing or not coming back within
+// PFFDTD_RCCL_INIT_TIMEOUT_S (60) seconds -- host-staged copies through pinned bounce buffers: slower, but it needs nothing from
+// the driver beyond device <-> pinned-host copies, so a first contact with a new multi-GPU box cannot end without a run.  An
+// EXPLICITLY requested transport that is not available is an error, never silently replaced.
+int init_rccl(Shared &S, bool all_same, std::string &why) {
+   std::lock_guard<std::mutex> lk(g_rccl_mu);
+   if (S.faults & 2) { why = "RCCL switched off by pf_opts.test_faults"; return PF_ERR_ARG; }
+   if (!g_rccl.load(why)) return PF_ERR_ARG;
+   S.comm.assign(S.G, nullptr);
+   S.rank.assign(S.G, 0);
+   S.rccl_self = all_same && S.G > 1;
+   // RCCL greets with a version banner on STDOUT when NCCL_DEBUG asks for one; a host that prints machine-readable results
+   // there (bench.py: one JSON line) must not find it in between: stdout points at stderr while the communicators are made
+   // (process-wide and not thread-safe: another thread of the host writing to stdout in this window lands on stderr; chains
+   // are created from one thread, before the time loop)
+   fflush(stdout);
+   const int saved_out = dup(1);
+   if (saved_out >= 0) dup2(2, 1);
+   // the communicators are made on a helper thread: a rendezvous that never completes (seen on mis-configured boxes) must not
+   // hang the caller.  After the timeout the helper is abandoned (it holds only heap state of its own).
+   struct Job { std::mutex mu; std::condition_variable cv; bool done = false; ncclResult_t r = ncclSuccess; std::vector<ncclComm_t> comm; std::vector<int> dev; bool self = false; int only = -1; };
+   auto job = std::make_shared<Job>();
+   job->comm.assign(S.G, nullptr); job->dev = S.dev; job->self = S.rccl_self; job->only = S.only;
+   std::thread([job] {
+      ncclResult_t r = ncclSuccess;
+      const int G = (int)job->dev.size();
+      if (job->self) {
+         // virtual slabs: slab g's communicator has ONE rank (the device); its exchange sends the neighbour's plane -- same
+         // device, directly addressable -- to itself.  Group semantics, stream ordering and error paths as on a real chain.
+         for (int g = 0; g < G && r == ncclSuccess; g++) { if (job->only >= 0 && g != job->only) continue; const int d = job->dev[g]; r = g_rccl.CommInitAll(&job->comm[g], 1, &d); }
+      } else r = g_rccl.CommInitAll(job->comm.data(), G, job->dev.data()); // one clique over the chain's devices, rank g = slab g
+      { std::lock_guard<std::mutex> l2(job->mu); job->r = r; job->done = true; }
+      job->cv.notify_all();
+   }).detach();
+   double tmo = 60.0;
+   if (const char *ev = getenv("PFFDTD_RCCL_INIT_TIMEOUT_S")) { const double v = atof(ev); if (v > 0) tmo = v; }
+   bool finished;
+   { std::unique_lock<std::mutex> l2(job->mu); finished = job->cv.wait_for(l2, std::chrono::duration<double>(tmo), [&] { return job->done; }); }
+   if (saved_out >= 0) { fflush(stdout); dup2(saved_out, 1); close(saved_out); }
+   if (!finished) { char b[160]; snprintf(b, sizeof b, "ncclCommInitAll over %d device(s) did not return within %.0f s", S.rccl_self ? 1 : S.G, tmo); why = b; S.comm.clear(); return PF_ERR_HIP; }
+   if (job->r != ncclSuccess) {
+      char b[384];
+      snprintf(b, sizeof b, "ncclCommInitAll over %d device(s) failed: %s", S.rccl_self ? 1 : S.G, g_rccl.GetErrorString(job->r));
+      why = b;
+      for (auto &c : job->comm) if (c) { g_rccl.CommDestroy(c); c = nullptr; }
+      S.comm.clear();
+      return PF_ERR_HIP;
+   }
+   S.comm = job->comm;
+   if (!S.rccl_self) for (int g = 0; g < S.G; g++) S.rank[g] = g;
+   return PF_OK;
+}
 int choose_transport(Shared &S, int requested) {
    if (const char *ev = getenv("PFFDTD_TRANSPORT")) {
       if (!strcmp(ev, "peer")) requested = PF_TRANSPORT_PEER;
       else if (!strcmp(ev, "rccl")) requested = PF_TRANSPORT_RCCL;
+      else if (!strcmp(ev, "host")) requested = PF_TRANSPORT_HOST;
       else if (!strcmp(ev, "auto") || !*ev) requested = PF_TRANSPORT_AUTO;
-      else return fail("PFFDTD_TRANSPORT must be peer, rccl or auto (got '%s')", ev);
+      else return fail("PFFDTD_TRANSPORT must be peer, rccl, host or auto (got '%s')", ev);
    }
-   if (requested != PF_TRANSPORT_AUTO && requested != PF_TRANSPORT_PEER && requested != PF_TRANSPORT_RCCL)
-      return fail("pf_opts.transport must be PF_TRANSPORT_AUTO, _PEER or _RCCL");
+   if (requested != PF_TRANSPORT_AUTO && requested != PF_TRANSPORT_PEER && requested != PF_TRANSPORT_RCCL && requested != PF_TRANSPORT_HOST)
+      return fail("pf_opts.transport must be PF_TRANSPORT_AUTO, _PEER, _RCCL or _HOST");
    bool all_same = true, all_distinct = true, peer_ok = true;
    int bad_a = -1, bad_b = -1;
    for (int g = 0; g < S.G; g++) {
@@ -474,47 +561,29 @@ int choose_transport(Shared &S, int requested) {
          if (!(ab && ba) && peer_ok) { peer_ok = false; bad_a = S.dev[g]; bad_b = S.dev[g + 1]; }
       }
    }
+   if ((S.faults & 1) && peer_ok) { peer_ok = false; bad_a = S.dev[0]; bad_b = S.dev[S.G > 1 ? 1 : 0]; } // (test hook: pretend there is no peer access)
+   char nopeer[200] = "";
+   if (!peer_ok) snprintf(nopeer, sizeof nopeer, "devices %d and %d cannot access each other's memory (hipDeviceCanAccessPeer)", bad_a, bad_b);
    if (requested == PF_TRANSPORT_PEER && !peer_ok) {
-      char b[256];
-      snprintf(b, sizeof b, "devices %d and %d cannot access each other's memory (hipDeviceCanAccessPeer): the peer-copy transport "
-                            "would stage through the host; use the RCCL transport (pf_opts.transport / PFFDTD_TRANSPORT=rccl)", bad_a, bad_b);
+      char b[400];
+      snprintf(b, sizeof b, "%s: the peer-copy transport would stage through the host; use the RCCL or the host-staged transport "
+                            "(pf_opts.transport / PFFDTD_TRANSPORT=rccl|host) or leave the choice to the library (auto)", nopeer);
       pf__set_error(b);
       return PF_ERR_ARG;
    }
-   S.transport = (requested == PF_TRANSPORT_RCCL || (requested == PF_TRANSPORT_AUTO && !peer_ok)) ? TR_RCCL : TR_PEER;
-   if (S.transport != TR_RCCL) return PF_OK;
-   if (!(all_distinct || all_same))
-      return fail("the RCCL transport needs every slab on its own device (or all slabs on ONE device: self-communicators, tests)");
-   std::lock_guard<std::mutex> lk(g_rccl_mu);
-   std::string err;
-   if (!g_rccl.load(err)) { pf__set_error(err.c_str()); return PF_ERR_ARG; }
-   S.comm.assign(S.G, nullptr);
-   S.rank.assign(S.G, 0);
-   S.rccl_self = all_same && S.G > 1;
-   ncclResult_t r = ncclSuccess;
-   // RCCL greets with a version banner on STDOUT when NCCL_DEBUG asks for one; a host that prints machine-readable results
-   // there (bench.py: one JSON line) must not find it in between: stdout points at stderr while the communicators are made
-   // (process-wide and not thread-safe: another thread of the host writing to stdout in this window lands on stderr; chains
-   // are created from one thread, before the time loop)
-   fflush(stdout);
-   const int saved_out = dup(1);
-   if (saved_out >= 0) dup2(2, 1);
-   if (S.rccl_self) {
-      // virtual slabs: slab g's communicator has ONE rank (the device); its exchange sends the neighbour's plane -- same
-      // device, directly addressable -- to itself.  Group semantics, stream ordering and error paths as on a real chain.
-      for (int g = 0; g < S.G && r == ncclSuccess; g++) { if (S.only >= 0 && g != S.only) continue; const int d = S.dev[g]; r = g_rccl.CommInitAll(&S.comm[g], 1, &d); }
-   } else {
-      for (int g = 0; g < S.G; g++) S.rank[g] = g;
-      r = g_rccl.CommInitAll(S.comm.data(), S.G, S.dev.data()); // one clique over the chain's devices, rank g = slab g
-   }
-   if (saved_out >= 0) { fflush(stdout); dup2(saved_out, 1); close(saved_out); }
-   if (r != ncclSuccess) {
-      char b[384];
-      snprintf(b, sizeof b, "ncclCommInitAll over %d device(s) failed: %s", S.rccl_self ? 1 : S.G, g_rccl.GetErrorString(r));
-      pf__set_error(b);
-      for (auto &c : S.comm) if (c) { g_rccl.CommDestroy(c); c = nullptr; }
-      return PF_ERR_HIP;
-   }
+   if (requested == PF_TRANSPORT_HOST) { S.transport = TR_HOST; S.transport_note = "requested"; return PF_OK; }
+   if (requested == PF_TRANSPORT_PEER || (requested == PF_TRANSPORT_AUTO && peer_ok)) { S.transport = TR_PEER; return PF_OK; }
+   // RCCL: asked for, or AUTO without peer access
+   std::string why;
+   int rc = PF_OK;
+   if (!(all_distinct || all_same)) { why = "the RCCL transport needs every slab on its own device (or all slabs on ONE device: self-communicators, tests)"; rc = PF_ERR_ARG; }
+   else rc = init_rccl(S, all_same, why);
+   if (rc == PF_OK) { S.transport = TR_RCCL; if (requested == PF_TRANSPORT_AUTO) S.transport_note = nopeer; return PF_OK; }
+   if (requested == PF_TRANSPORT_RCCL) { pf__set_error(why.c_str()); return rc; }
+   S.transport = TR_HOST; // the last resort
+   S.rccl_self = false;
+   S.transport_note = std::string(nopeer) + "; RCCL: " + why;
+   fprintf(stderr, "pffdtd_hip: ghost planes travel HOST-STAGED (pinned bounce buffers): %s\n", S.transport_note.c_str());
    return PF_OK;
 }
 
@@ -577,6 +646,37 @@ void phase_rccl(Shared &S, int g, int64_t n, bool grouped) {
    }
    if (!grouped) NCHK(g, g_rccl.GroupEnd());
 }
+// host-staged, part 1 (sender, right after its edge event): my two edge planes -> my pinned buffer, on my edge stream.  The
+// buffer of this parity was last read two steps ago: its readers' copies must be complete (host wait, normally long over).
+void phase_stage(Shared &S, int g, int64_t n) {
+   if (S.err.load()) return;
+   const int k = (int)(n & 1);
+   if (S.steps_done[g] >= 2)
+      for (int nb : {g - 1, g + 1}) {
+         if (S.only >= 0) nb = g;
+         if (nb >= 0 && nb < S.G) MCHK(g, hipEventSynchronize(S.ev_h2d[k][nb]));
+      }
+   uint8_t *hb = (uint8_t *)S.hstage[k][g];
+   MCHK(g, hipMemcpyAsync(hb, S.send_lo[k][g], S.plane_bytes, hipMemcpyDeviceToHost, S.edge[g]));
+   MCHK(g, hipMemcpyAsync(hb + S.plane_bytes, S.send_hi[k][g], S.plane_bytes, hipMemcpyDeviceToHost, S.edge[g]));
+   MCHK(g, hipEventRecord(S.ev_d2h[k][g], S.edge[g]));
+}
+// part 2 (receiver, after the barrier): wait ON THE HOST until the neighbour's planes are in its buffer, then copy them into my
+// ghost planes on my edge stream (ordered after my own edge kernels, the last readers of those ghost planes)
+void phase_unstage(Shared &S, int g, int64_t n) {
+   const int k = (int)(n & 1);
+   if (S.drop_step >= 0 && g == 1 && n == S.drop_step) { MCHK(g, hipEventRecord(S.ev_h2d[k][g], S.edge[g])); return; } // (test hook: the self-check must notice)
+   const int ql = S.only >= 0 ? g : g - 1, qh = S.only >= 0 ? g : g + 1; // (cost model of one rank: its own planes)
+   if (g > 0) {
+      MCHK(g, hipEventSynchronize(S.ev_d2h[k][ql]));
+      MCHK(g, hipMemcpyAsync(S.recv_lo[k][g], (const uint8_t *)S.hstage[k][ql] + S.plane_bytes, S.plane_bytes, hipMemcpyHostToDevice, S.edge[g])); // left neighbour's LAST owned plane
+   }
+   if (g < S.G - 1) {
+      MCHK(g, hipEventSynchronize(S.ev_d2h[k][qh]));
+      MCHK(g, hipMemcpyAsync(S.recv_hi[k][g], (const uint8_t *)S.hstage[k][qh], S.plane_bytes, hipMemcpyHostToDevice, S.edge[g]));                 // right neighbour's FIRST owned plane
+   }
+   MCHK(g, hipEventRecord(S.ev_h2d[k][g], S.edge[g]));
+}
 // B': exchange self-check, part 1: bit-pattern checksums of the two planes I sent and the two I received (after the edge
 // stream has drained: the exchange of this step is complete on my side)
 void phase_checksum(Shared &S, int g, int64_t n) {
@@ -624,6 +724,11 @@ void destroy_slab(Shared &S, int g) {
    if (S.eng[g]) { pf_engine_sync(S.eng[g]); pf_engine_destroy(S.eng[g]); S.eng[g] = nullptr; }
    for (int k = 0; k < 2; k++) if (S.ev[k][g]) { hipEventDestroy(S.ev[k][g]); S.ev[k][g] = nullptr; }
    for (int k = 0; k < 4; k++) if (S.grids[k][g]) { hipFree(S.grids[k][g]); S.grids[k][g] = nullptr; }
+   for (int k = 0; k < 2; k++) {
+      if (!S.hstage[k].empty() && S.hstage[k][g]) { hipHostFree(S.hstage[k][g]); S.hstage[k][g] = nullptr; }
+      if (!S.ev_d2h[k].empty() && S.ev_d2h[k][g]) { hipEventDestroy(S.ev_d2h[k][g]); S.ev_d2h[k][g] = nullptr; }
+      if (!S.ev_h2d[k].empty() && S.ev_h2d[k][g]) { hipEventDestroy(S.ev_h2d[k][g]); S.ev_h2d[k][g] = nullptr; }
+   }
 }
 
 // steps [n0, n0+ns) of slab g (its own host thread); returns when its streams have drained and its receivers are flushed
@@ -633,16 +738,28 @@ void run_slab(Shared &S, int g, int &local, int64_t n0, int64_t ns) {
       hipSetDevice(S.dev[g]);
       const bool verify = S.steps_done[g] < S.verify_n; // the same decision in every thread: all slabs have done the same steps
       phase_begin(S, g, n);
-      stop = S.bar.wait(local, S.err); // every slab's edge event of step n is recorded, its plane pointers published
+      if (S.transport == TR_HOST) phase_stage(S, g, n);
+      if ((S.faults & 4) && g == 1 && S.steps_done[g] == 3) // (test hook: this slab's thread hangs; the watchdog of the others must turn that into an error)
+         std::this_thread::sleep_for(std::chrono::duration<double>(3.0 * S.bar_timeout + 1.0));
+      stop = S.bar.wait(local, S.err, S.bar_timeout); // every slab's edge event of step n is recorded, its plane pointers published
       if (stop) break;
-      if (S.transport == TR_RCCL) phase_rccl(S, g, n, false); else phase_pull(S, g, n);
+      if (S.transport == TR_RCCL) phase_rccl(S, g, n, false);
+      else if (S.transport == TR_HOST) phase_unstage(S, g, n);
+      else phase_pull(S, g, n);
       if (verify) {
          if (!S.err.load()) phase_checksum(S, g, n);
-         stop = S.bar.wait(local, S.err);
+         stop = S.bar.wait(local, S.err, S.bar_timeout);
          if (stop) break;
          phase_compare(S, g);
       }
       phase_end(S, g, n);
+   }
+   if (S.bar.timed_out.load()) { // (the watchdog fired: report once, do not touch the devices any more -- a stuck stream would block the flush too)
+      char b[200];
+      snprintf(b, sizeof b, "slab chain hung: a slab's host thread did not reach the step barrier within %.0f s (a device or a collective is stuck; "
+                            "PFFDTD_BARRIER_TIMEOUT_S sets the limit)", S.bar_timeout);
+      S.set_error(PF_ERR_HIP, b);
+      return;
    }
    finish_slab(S, g);
 }
@@ -662,6 +779,7 @@ struct pf_multi {
    bool created = false;
    double last_seconds = 0;
    bool one_thread = false;
+   bool broken = false;              // the watchdog fired and a slab thread never came back: threads are abandoned, the object leaks
 };
 
 namespace {
@@ -670,7 +788,7 @@ void worker(pf_multi *m, int g) {
    Shared &S = m->S;
    int local = 0;
    create_slab(S, g);
-   S.bar.wait(local, S.err); // all engines exist (or an error is up)
+   S.bar.wait(local, S.err, 10.0 * S.bar_timeout); // all engines exist (or an error is up)
    { std::lock_guard<std::mutex> lk(m->mu); m->done++; }
    m->cv_done.notify_all();
    int64_t seen = 0;
@@ -684,7 +802,7 @@ void worker(pf_multi *m, int g) {
       }
       if (kind == 2) break;
       run_slab(S, g, local, n0, ns);
-      S.bar.wait(local, S.err);
+      S.bar.wait(local, S.err, S.bar_timeout);
       { std::lock_guard<std::mutex> lk(m->mu); m->done++; }
       m->cv_done.notify_all();
    }
@@ -699,7 +817,16 @@ void post(pf_multi *m, int kind, int64_t n0, int64_t ns) {
 }
 void wait_done(pf_multi *m) {
    std::unique_lock<std::mutex> lk(m->mu);
-   m->cv_done.wait(lk, [&] { return m->done == (m->S.only >= 0 ? 1 : m->S.G); });
+   const int want = m->S.only >= 0 ? 1 : m->S.G;
+   for (;;) {
+      if (m->cv_done.wait_for(lk, std::chrono::milliseconds(200), [&] { return m->done == want; })) return;
+      // the watchdog fired in the slab threads: give the healthy ones a moment to report, then stop waiting for the stuck one
+      if (m->S.bar.timed_out.load()) {
+         if (m->cv_done.wait_for(lk, std::chrono::duration<double>(std::min(5.0, m->S.bar_timeout)), [&] { return m->done == want; })) return;
+         m->broken = true;
+         return;
+      }
+   }
 }
 
 void scatter_outputs(pf_multi *m) { // receivers: every slab filled its own rows (gpu_engine.h:1066-1075)
@@ -714,7 +841,9 @@ void scatter_outputs(pf_multi *m) { // receivers: every slab filled its own rows
 }
 
 const char *transport_name(const Shared &S) {
-   return S.G == 1 ? "none (one slab)" : (S.transport == TR_RCCL ? (S.rccl_self ? "rccl (self-communicators, one device)" : "rccl") : "peer copies");
+   if (S.G == 1) return "none (one slab)";
+   if (S.transport == TR_HOST) return "host-staged";
+   return S.transport == TR_RCCL ? (S.rccl_self ? "rccl (self-communicators, one device)" : "rccl") : "peer copies";
 }
 
 } // namespace
@@ -754,6 +883,9 @@ int pf_multi_create(pf_simdata *sd, int32_t nslabs, const int32_t *devices, cons
       S.recv_lo[k].assign(G, nullptr); S.recv_hi[k].assign(G, nullptr);
    }
    for (int k = 0; k < 4; k++) S.grids[k].assign(G, nullptr);
+   for (int k = 0; k < 2; k++) { S.hstage[k].assign(G, nullptr); S.ev_d2h[k].assign(G, nullptr); S.ev_h2d[k].assign(G, nullptr); }
+   S.bar_timeout = barrier_timeout();
+   S.faults = S.base.test_faults;
    if (G == 1) { // plain single-domain engine
       pf_opts o = S.base;
       o.device = devices[0]; o.slab_first = o.slab_last = 1;
@@ -804,6 +936,7 @@ int pf_multi_create(pf_simdata *sd, int32_t nslabs, const int32_t *devices, cons
    } else {
       for (int g = 0; g < G; g++) if (S.only < 0 || g == S.only) m->th.emplace_back(worker, m, g);
       wait_done(m);
+      if (m->broken && !S.err.load()) S.set_error(PF_ERR_HIP, "slab chain hung while its engines were created");
    }
    m->created = true;
    if (S.err.load()) { const std::string keep = S.err_msg; const int code = S.err.load(); pf_multi_destroy(m); pf__set_error(keep.c_str()); return code; }
@@ -832,12 +965,14 @@ int pf_multi_run(pf_multi *m, int64_t n0, int64_t nsteps) {
       const int G = S.G;
       for (int64_t n = n0; n < n0 + nsteps && !S.err.load(); n++) {
          const bool verify = S.steps_done[0] < S.verify_n;
-         for (int g = 0; g < G; g++) { hipSetDevice(S.dev[g]); phase_begin(S, g, n); }
+         for (int g = 0; g < G; g++) { hipSetDevice(S.dev[g]); phase_begin(S, g, n); if (S.transport == TR_HOST) phase_stage(S, g, n); }
          if (S.err.load()) break;
          if (S.transport == TR_RCCL) {
             bool open = g_rccl.GroupStart() == ncclSuccess;
             for (int g = 0; g < G && !S.err.load(); g++) { hipSetDevice(S.dev[g]); phase_rccl(S, g, n, true); }
             if (!open || g_rccl.GroupEnd() != ncclSuccess) S.set_error(PF_ERR_HIP, "RCCL group call failed");
+         } else if (S.transport == TR_HOST) {
+            for (int g = 0; g < G && !S.err.load(); g++) { hipSetDevice(S.dev[g]); phase_unstage(S, g, n); }
          } else {
             for (int g = 0; g < G && !S.err.load(); g++) { hipSetDevice(S.dev[g]); phase_pull(S, g, n); }
          }
@@ -851,6 +986,7 @@ int pf_multi_run(pf_multi *m, int64_t n0, int64_t nsteps) {
    } else {
       post(m, 1, n0, nsteps);
       wait_done(m);
+      if (m->broken && !S.err.load()) S.set_error(PF_ERR_HIP, "slab chain hung: a slab's host thread never came back");
    }
    m->last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
    if (S.err.load()) { pf__set_error(S.err_msg.c_str()); return S.err.load(); }
@@ -872,6 +1008,7 @@ int pf_multi_get_info(pf_multi *m, pf_multi_info *info) {
    info->last_run_seconds = m->last_seconds;
    info->plane_bytes = (int64_t)S.plane_bytes;
    snprintf(info->transport_name, sizeof info->transport_name, "%s", transport_name(S));
+   snprintf(info->transport_note, sizeof info->transport_note, "%s", S.transport_note.c_str());
    return PF_OK;
 }
 
@@ -889,6 +1026,10 @@ int pf_multi_get_slab(pf_multi *m, int32_t g, int64_t *x0, int64_t *x1, int32_t 
 void pf_multi_destroy(pf_multi *m) {
    if (!m) return;
    Shared &S = m->S;
+   if (m->broken) { // a slab thread is stuck inside a driver / RCCL call: it cannot be joined and may still use the object -- abandon both
+      for (auto &t : m->th) t.detach();
+      return;
+   }
    if (!m->th.empty()) {
       post(m, 2, 0, 0);
       for (auto &t : m->th) t.join();

@@ -25,7 +25,8 @@ class PfOpts(ctypes.Structure):
                 ("air_chunk", ctypes.c_int32), ("timing", ctypes.c_int32), ("ext_u0", ctypes.c_void_p),
                 ("ext_u1", ctypes.c_void_p), ("x_global0", ctypes.c_int32), ("debug", ctypes.c_int32),
                 ("energy", ctypes.c_int32), ("multi_flags", ctypes.c_int32), ("transport", ctypes.c_int32),
-                ("verify_exchange", ctypes.c_int32), ("only_slab", ctypes.c_int32), ("test_drop_exchange", ctypes.c_int32)]
+                ("verify_exchange", ctypes.c_int32), ("only_slab", ctypes.c_int32), ("test_drop_exchange", ctypes.c_int32),
+                ("test_faults", ctypes.c_int32)]
 
 
 class PfTiming(ctypes.Structure):
@@ -41,7 +42,8 @@ class PfMultiInfo(ctypes.Structure):
     _fields_ = [("nslabs", ctypes.c_int32), ("transport", ctypes.c_int32), ("rccl_self", ctypes.c_int32),
                 ("exchange_verified", ctypes.c_int32), ("exchanges_checked", ctypes.c_int64),
                 ("exchange_nonzero", ctypes.c_int32), ("cut_along_z", ctypes.c_int32), ("plane_bytes", ctypes.c_int64),
-                ("last_run_seconds", ctypes.c_double), ("transport_name", ctypes.c_char * 64)]
+                ("last_run_seconds", ctypes.c_double), ("transport_name", ctypes.c_char * 64),
+                ("transport_note", ctypes.c_char * 256)]
 
 
 class PfError(RuntimeError):
@@ -57,7 +59,7 @@ EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_grid_bytes", "p
 
 
 PF_MULTI_EVEN_SPLIT, PF_MULTI_ONE_THREAD, PF_MULTI_NO_PAIRS, PF_MULTI_FORCE_PAIRS, PF_MULTI_CUT_Z, PF_MULTI_CUT_X = 1, 2, 4, 8, 16, 32
-PF_TRANSPORT_AUTO, PF_TRANSPORT_PEER, PF_TRANSPORT_RCCL = 0, 1, 2
+PF_TRANSPORT_AUTO, PF_TRANSPORT_PEER, PF_TRANSPORT_RCCL, PF_TRANSPORT_HOST = 0, 1, 2, 3
 
 
 def _preload_torch_hip():
@@ -211,7 +213,7 @@ class HipMulti:
                 "rccl_self": bool(i.rccl_self), "exchanges_checked": i.exchanges_checked,
                 "exchange_verified": None if i.exchange_verified < 0 else bool(i.exchange_verified),
                 "exchange_nonzero": bool(i.exchange_nonzero), "cut_along_z": bool(i.cut_along_z), "plane_bytes": i.plane_bytes,
-                "last_run_seconds": i.last_run_seconds}
+                "last_run_seconds": i.last_run_seconds, "transport_note": i.transport_note.decode()}
 
     def slab(self, g):
         """-> dict(x0, x1, device, paired, engine): engine = a non-owning HipEngine view of slab g's engine (state_grids, timing)"""

@@ -303,3 +303,74 @@ def test_run_sim_runs_a_room_as_two_slabs_on_one_device(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         assert (expect in r.stderr) if expect else ("slabs" not in r.stderr), r.stderr[-1500:]
         assert np.array_equal(np.load(tmp_path / "u.npy"), want)
+
+
+# ---- round 5: first contact with a multi-device box cannot end without a run ---------------------------------------------
+@pytest.mark.parametrize("flags", [0, engine.PF_MULTI_ONE_THREAD])
+@pytest.mark.parametrize("name,prec", [("cart_outside", "single"), ("fcc2_mb11", "double")])
+def test_host_staged_transport_gives_the_oracles_bits(name, prec, flags):
+    """PF_TRANSPORT_HOST, the last resort: edge planes -> pinned bounce buffer on the sender's edge stream, -> ghost planes on the
+    receiver's, the two sides meeting on the host; three virtual slabs, every exchange checksummed on both sides."""
+    want = _ref(name, prec)
+    sd = cases.make_sd(name, prec)
+    m = engine.HipMulti(sd, [0, 0, 0], multi_flags=flags, transport=engine.PF_TRANSPORT_HOST, verify_exchange=int(sd.Nt))
+    m.run(0, 5)
+    m.run(5, int(sd.Nt) - 5)
+    info = m.info()
+    m.close()
+    assert info["transport"] == engine.PF_TRANSPORT_HOST and info["transport_name"] == "host-staged"
+    assert info["exchange_verified"] is True and info["exchanges_checked"] == sd.Nt and info["exchange_nonzero"]
+    assert np.array_equal(sd.u_out, want)
+
+
+def test_host_staged_transport_carries_slab_pairs():
+    kw = dict(Nx=100, Ny=70, Nz=276, Nt=45, wall=3, Nm=1, Mb=3, src=[47, 30, 100], rcv=[[30, 25, 96], [66, 36, 110], [48, 35, 104], [47, 4, 101]])
+    sd = sim_data.SimData.from_sim(synth.shoebox(**kw), "single")
+    sd.scale_input()
+    oracle.run_sim(sd)
+    want = sd.u_out.copy()
+    sd2 = sim_data.SimData.from_sim(synth.shoebox(**kw), "single")
+    sd2.scale_input()
+    m = engine.HipMulti(sd2, [0, 0, 0], multi_flags=engine.PF_MULTI_FORCE_PAIRS, air_variant=40, transport=engine.PF_TRANSPORT_HOST, verify_exchange=45)
+    m.run(0, 45)
+    info, paired = m.info(), [m.slab(g)["paired"] for g in range(3)]
+    m.close()
+    assert all(paired) and info["exchange_verified"] is True
+    assert np.array_equal(sd2.u_out, want)
+
+
+@pytest.mark.parametrize("faults,expect", [(1, engine.PF_TRANSPORT_RCCL), (3, engine.PF_TRANSPORT_HOST)], ids=["no_peer_access", "no_peer_access_no_rccl"])
+def test_automatic_transport_falls_back_edge_by_edge(faults, expect):
+    """pf_opts.test_faults forces every fallback edge of PF_TRANSPORT_AUTO on one device: without peer access the chain takes RCCL,
+    without RCCL as well the host-staged copies -- and says why (pf_multi_info.transport_note); the bits stay the oracle's.  An
+    explicitly requested transport that is unavailable remains an error."""
+    want = _ref("cart_outside", "single")
+    sd = cases.make_sd("cart_outside", "single")
+    m = engine.HipMulti(sd, [0, 0, 0], transport=engine.PF_TRANSPORT_AUTO, verify_exchange=int(sd.Nt), test_faults=faults)
+    m.run(0, int(sd.Nt))
+    info = m.info()
+    m.close()
+    assert info["transport"] == expect, info
+    assert "cannot access each other" in info["transport_note"]
+    if expect == engine.PF_TRANSPORT_HOST:
+        assert "RCCL" in info["transport_note"]
+    assert info["exchange_verified"] is True and np.array_equal(sd.u_out, want)
+    sd = cases.make_sd("cart_outside", "single")
+    with pytest.raises(engine.PfError, match="cannot access each other"):
+        engine.HipMulti(sd, [0, 0], transport=engine.PF_TRANSPORT_PEER, test_faults=1)
+    with pytest.raises(engine.PfError, match="RCCL"):
+        engine.HipMulti(sd, [0, 0], transport=engine.PF_TRANSPORT_RCCL, test_faults=2)
+
+
+def test_a_hung_slab_thread_becomes_an_error_not_a_hang(tmp_path):
+    """pf_opts.test_faults = 4: the host thread of slab 1 stalls before the barrier of its fourth step.  The watchdog of the other
+    slabs' barrier waits (PFFDTD_BARRIER_TIMEOUT_S) turns that into pf_last_error instead of a process that never returns.  In a
+    process of its own: the chain object is abandoned with its stuck thread."""
+    code = ("import sys, time; sys.path[:0] = [%r, %r]; import cases; from pffdtd_amd import engine; "
+            "sd = cases.make_sd('cart_outside', 'single'); m = engine.HipMulti(sd, [0, 0, 0], test_faults=4); t0 = time.time()\n"
+            "try:\n    m.run(0, int(sd.Nt)); print('NO ERROR', flush=True)\n"
+            "except engine.PfError as e:\n    print('ERROR after %%.1f s: %%s' %% (time.time() - t0, e), flush=True)\n"
+            "import os; os._exit(0)\n" % (str(ROOT), str(ROOT / "tests")))
+    r = subprocess.run([os.sys.executable, "-c", code], env={**os.environ, "PFFDTD_BARRIER_TIMEOUT_S": "2"}, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "ERROR after" in r.stdout and "hung" in r.stdout, (r.stdout, r.stderr[-1500:])

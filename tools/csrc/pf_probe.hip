@@ -6,6 +6,7 @@
 
 #include "pf_probe.h"
 #include "pf_probe_kernels.h"
+#include "pf_tb3_probe.h"
 
 namespace {
 std::string g_perr;
@@ -143,5 +144,42 @@ double pf_tb2_probe(const void *A, const void *B, void *C, void *D, int64_t Nx, 
    return reps > 0 ? ms / reps : 0.0;
 }
 
+
+// three fused steps (pf_tb3_probe.h): A = u^{n-1}, B = u^n -> D = u^{n+2}, E = u^{n+3} on the box [m, N-m)^3.  variant = 100*R + WT
+// (+10000: banded tile order).  Returns the average milliseconds per launch (<0 on error).
+double pf_tb3_probe(const void *A, const void *B, void *D, void *E, int64_t Nx, int64_t Ny, int64_t Nz, double a1, double a2,
+                    int32_t margin, int32_t variant, int32_t chunk, int32_t reps) {
+   pf::Tb2Params tp{};
+   const int64_t P = grid_pitch(Nz, 4);
+   tp.A = (const float *)A; tp.B = (const float *)B; tp.C = nullptr; tp.D = (float *)D;
+   tp.plane = Ny * P; tp.Nx = (int)Nx; tp.Ny = (int)Ny; tp.Nz = (int)Nz; tp.P = (int)P;
+   if (margin < 4 || (margin % 4) != 0 || ((Nz - 2 * margin) % 4) != 0) { probe_err("tb3 probe: margin must be a multiple of 4 >= 4"); return -1.0; }
+   tp.x_begin = margin; tp.x_end = (int)Nx - margin;
+   tp.y_begin = margin; tp.z_begin = margin;
+   tp.chunk = chunk > 0 ? chunk : 32;
+   tp.nxc = (int)cdiv(tp.x_end - tp.x_begin, tp.chunk);
+   tp.nzt = (int)cdiv(Nz - 2 * margin, 248);
+   tp.band = variant >= 10000 ? 1 : 0;
+   variant %= 10000;
+   auto nblk = [&]() { const uint32_t T = (uint32_t)tp.nzt * tp.nyt; return tp.band ? 8 * ((T + 7) / 8) * (uint32_t)tp.nxc : T * (uint32_t)tp.nxc; };
+   auto launch = [&]() {
+#define PF_TB3(r, wt) if (variant == 100 * r + wt) { tp.nyt = (int)cdiv(Ny - 2 * margin, wt * r - 4); hipLaunchKernelGGL((pf::k_tb3_lds<r, wt>), dim3(nblk()), dim3(64 * wt), 0, 0, tp, E, (float)a1, (float)a2); return true; }
+      PF_TB3(3, 8) PF_TB3(2, 8) PF_TB3(3, 4) PF_TB3(4, 4) PF_TB3(2, 12) PF_TB3(3, 6)
+#undef PF_TB3
+      return false;
+   };
+   hipEvent_t e0, e1;
+   hipEventCreate(&e0); hipEventCreate(&e1);
+   if (!launch()) { probe_err("tb3 probe: variant = 100*R + WT, one of 308 208 304 404 212 306"); return -1.0; }
+   if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { probe_err("tb3 probe launch failed"); return -1.0; }
+   hipEventRecord(e0, 0);
+   for (int i = 0; i < reps; i++) launch();
+   hipEventRecord(e1, 0);
+   hipEventSynchronize(e1);
+   float ms = 0;
+   hipEventElapsedTime(&ms, e0, e1);
+   hipEventDestroy(e0); hipEventDestroy(e1);
+   return reps > 0 ? ms / reps : 0.0;
+}
 
 } // extern "C"

@@ -1,0 +1,142 @@
+// pf_tb3_probe.h -- research probe (round 5, tools/tb3_probe.py): THREE leap-frog steps of the pure 7-point air update per pass
+// over a boundary-free box.  Reads A = u^{n-1}, B = u^n; writes D = u^{n+2}, E = u^{n+3}; u^{n+1} never leaves the chip:
+// 16 bytes of compulsory traffic per cell and THREE steps (k_tb2_reg: per two).  Not part of libpffdtd_hip.so.
+//
+// Tiling: a workgroup = WT waves stacked in y, each owning R rows x 256 columns (64 lanes x 16 B; lanes 0 / 63 are z halo, as in
+// k_tb2_reg: 248 core columns), marching x.  Stage 1 gives u^{n+1} on all WT*R rows of the tile, stage 2 u^{n+2} on WT*R - 2,
+// stage 3 u^{n+3} on WT*R - 4: tiles overlap by 4 rows.  The rows a wave needs from its neighbours (one above, one below, of the
+// u^n plane that becomes the centre plane next turn and of the u^{n+1} / u^{n+2} planes just computed) travel through LDS: every
+// wave publishes its first and last row of the three planes, ONE barrier per plane, double-buffered (96 KB at WT = 8).  The two
+// outermost u^n halo rows of a tile have no owner in the workgroup and are loaded by the edge waves, one turn ahead.
+// Turn x1: stage 1 -> u^{n+1}(x1) from u^n(x1-1, x1, x1+1), u^{n-1}(x1); stage 2 -> u^{n+2}(x1-1) from u^{n+1}(x1-2, x1-1, x1),
+// u^n(x1-1); stage 3 -> u^{n+3}(x1-2) from u^{n+2}(x1-3, x1-2, x1-1), u^{n+1}(x1-2).  A chunk [xs, xe) takes turns xs-2 .. xe+1.
+#pragma once
+#include "pf_tb2.h"
+
+namespace pf {
+
+template <int R, int WT>
+__global__ __launch_bounds__(64 * WT) void k_tb3_lds(Tb2Params tp, void *Ev, float a1, float a2) {
+   typedef f32x4 vec;
+   constexpr int V = 4, W = 256, TRO = WT * R - 4;
+   __shared__ __attribute__((aligned(16))) float sH[2][3][WT][2][W];
+   uint32_t b = blockIdx.x;
+   int zt, yt, xc;
+   if (tp.band) {
+      const uint32_t T = (uint32_t)tp.nzt * tp.nyt, Tp = (T + 7) / 8;
+      xc = b / (8 * Tp);
+      const uint32_t r = b % (8 * Tp), j = (r % 8) * Tp + r / 8;
+      if (j >= T || xc >= tp.nxc) return;
+      zt = j % tp.nzt; yt = j / tp.nzt;
+   } else { zt = b % tp.nzt; yt = (b / tp.nzt) % tp.nyt; xc = b / (tp.nzt * tp.nyt); }
+   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+   const int ze0 = tp.z_begin - V + zt * (W - 2 * V);
+   const int y0 = tp.y_begin - 2 + yt * TRO, yo = y0 + w * R;
+   const int xs = tp.x_begin + xc * tp.chunk, xe = min(xs + tp.chunk, tp.x_end);
+   const int P = tp.P;
+   const int64_t plane = tp.plane;
+   const int zc = min(max(ze0 + lane * V, 0), P - V);
+   uint32_t off[R];
+#pragma unroll
+   for (int r = 0; r < R; r++) off[r] = (uint32_t)min(max(yo + r, 0), tp.Ny - 1) * (uint32_t)P + (uint32_t)zc;
+   const bool edge_lo = w == 0, edge_hi = w == WT - 1;
+   const uint32_t offh = (uint32_t)min(max(edge_lo ? yo - 1 : yo + R, 0), tp.Ny - 1) * (uint32_t)P + (uint32_t)zc; // the tile's outer u^n halo row (edge waves)
+   const int z_end = tp.z_end ? tp.z_end : tp.Nz - tp.z_begin, y_end = tp.y_end ? tp.y_end : tp.Ny - tp.y_begin;
+   const bool core_col = (lane >= 1 && lane <= 62) && (ze0 + lane * V + V - 1 < z_end);
+   bool ok[R];
+#pragma unroll
+   for (int r = 0; r < R; r++) ok[r] = core_col && (w * R + r >= 2) && (w * R + r <= WT * R - 3) && (yo + r < y_end);
+   const float *A = (const float *)tp.A, *B = (const float *)tp.B;
+   float *D = (float *)tp.D, *E = (float *)Ev;
+   auto stencil = [&](const vec &c, const vec &xp, const vec &xm, const vec &yp, const vec &ym, const vec &old) {
+      const float lf = lane_from_lower<true>(c[V - 1]);
+      const float rt = lane_from_upper<true>(c[0]);
+      vec o;
+#pragma unroll
+      for (int i = 0; i < V; i++) {
+         const float zp = (i == V - 1) ? rt : c[i < V - 1 ? i + 1 : V - 1];
+         const float zm = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
+         o[i] = upd7<false>(a1, a2, c[i], old[i], xp[i], xm[i], yp[i], ym[i], zp, zm);
+      }
+      return o;
+   };
+   auto loadrows = [&](const float *g, int x, vec *d) {
+      const float *pl = g + (int64_t)x * plane;
+#pragma unroll
+      for (int r = 0; r < R; r++) d[r] = *(const vec *)(pl + off[r]);
+   };
+   vec Bm[R], Bc[R + 2], Bn[R], Bf[R], Ac[R], Af[R];
+   vec V1m[R], V1c[R + 2], V1n[R], V2m[R], V2c[R + 2], V2n[R];
+   vec BhN = vec{}, BhF = vec{}; // edge waves: the outer halo row of the planes in Bn / Bf
+   {
+      vec t[R];
+      loadrows(B, xs - 3, Bm);
+      loadrows(B, xs - 2, t);
+#pragma unroll
+      for (int r = 0; r < R; r++) Bc[r + 1] = t[r];
+      // (prologue only: every wave fetches its two halo rows of the first centre plane itself)
+      Bc[0] = *(const vec *)(B + (int64_t)(xs - 2) * plane + (uint32_t)min(max(yo - 1, 0), tp.Ny - 1) * (uint32_t)P + (uint32_t)zc);
+      Bc[R + 1] = *(const vec *)(B + (int64_t)(xs - 2) * plane + (uint32_t)min(max(yo + R, 0), tp.Ny - 1) * (uint32_t)P + (uint32_t)zc);
+      loadrows(B, xs - 1, Bn);
+      loadrows(B, xs, Bf);
+      loadrows(A, xs - 2, Ac);
+      loadrows(A, xs - 1, Af);
+      if (edge_lo || edge_hi) { BhN = *(const vec *)(B + (int64_t)(xs - 1) * plane + offh); BhF = *(const vec *)(B + (int64_t)xs * plane + offh); }
+   }
+#pragma unroll
+   for (int r = 0; r < R; r++) { V1m[r] = vec{}; V2m[r] = vec{}; }
+#pragma unroll
+   for (int j = 0; j < R + 2; j++) { V1c[j] = vec{}; V2c[j] = vec{}; }
+   for (int x1 = xs - 2; x1 <= xe + 1; x1++) {
+      const int buf = (x1 - xs) & 1;
+      // stage 1: u^{n+1}(x1)
+#pragma unroll
+      for (int r = 0; r < R; r++) V1n[r] = stencil(Bc[r + 1], Bn[r], Bm[r], Bc[r + 2], Bc[r], Ac[r]);
+      // stage 2: u^{n+2}(x1-1); its old value is u^n(x1-1)
+#pragma unroll
+      for (int r = 0; r < R; r++) V2n[r] = stencil(V1c[r + 1], V1n[r], V1m[r], V1c[r + 2], V1c[r], Bm[r]);
+      // the planes x1+3 of u^n and x1+2 of u^{n-1}, two turns ahead
+      vec Bnew[R], Anew[R], Bhnew = vec{};
+      const int xb = min(x1 + 3, xe + 2), xa = min(x1 + 2, xe + 1);
+      loadrows(B, xb, Bnew);
+      loadrows(A, xa, Anew);
+      if (edge_lo || edge_hi) Bhnew = *(const vec *)(B + (int64_t)xb * plane + offh);
+      // stage 3: u^{n+3}(x1-2); its old value is u^{n+1}(x1-2)
+      if (x1 - 2 >= xs && x1 - 2 < xe) {
+         float *pe = E + (int64_t)(x1 - 2) * plane;
+#pragma unroll
+         for (int r = 0; r < R; r++) {
+            const vec o = stencil(V2c[r + 1], V2n[r], V2m[r], V2c[r + 2], V2c[r], V1m[r]);
+            if (ok[r]) __builtin_nontemporal_store(o, (vec *)(pe + off[r]));
+         }
+      }
+      if (x1 - 1 >= xs && x1 - 1 < xe) {
+         float *pd = D + (int64_t)(x1 - 1) * plane;
+#pragma unroll
+         for (int r = 0; r < R; r++)
+            if (ok[r]) __builtin_nontemporal_store(V2n[r], (vec *)(pd + off[r]));
+      }
+      // publish the rows the neighbouring waves need next turn
+      *(vec *)&sH[buf][0][w][0][lane * V] = Bn[0];  *(vec *)&sH[buf][0][w][1][lane * V] = Bn[R - 1];
+      *(vec *)&sH[buf][1][w][0][lane * V] = V1n[0]; *(vec *)&sH[buf][1][w][1][lane * V] = V1n[R - 1];
+      *(vec *)&sH[buf][2][w][0][lane * V] = V2n[0]; *(vec *)&sH[buf][2][w][1][lane * V] = V2n[R - 1];
+      __syncthreads();
+      vec hB0, hB1, hV10 = vec{}, hV11 = vec{}, hV20 = vec{}, hV21 = vec{};
+      if (!edge_lo) { hB0 = *(const vec *)&sH[buf][0][w - 1][1][lane * V]; hV10 = *(const vec *)&sH[buf][1][w - 1][1][lane * V]; hV20 = *(const vec *)&sH[buf][2][w - 1][1][lane * V]; }
+      else hB0 = BhN;
+      if (!edge_hi) { hB1 = *(const vec *)&sH[buf][0][w + 1][0][lane * V]; hV11 = *(const vec *)&sH[buf][1][w + 1][0][lane * V]; hV21 = *(const vec *)&sH[buf][2][w + 1][0][lane * V]; }
+      else hB1 = BhN;
+      // rotate
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+         Bm[r] = Bc[r + 1]; Bc[r + 1] = Bn[r]; Bn[r] = Bf[r]; Bf[r] = Bnew[r];
+         Ac[r] = Af[r]; Af[r] = Anew[r];
+         V1m[r] = V1c[r + 1]; V1c[r + 1] = V1n[r];
+         V2m[r] = V2c[r + 1]; V2c[r + 1] = V2n[r];
+      }
+      Bc[0] = hB0; Bc[R + 1] = hB1; V1c[0] = hV10; V1c[R + 1] = hV11; V2c[0] = hV20; V2c[R + 1] = hV21;
+      BhN = BhF; BhF = Bhnew;
+   }
+}
+
+} // namespace pf
