@@ -132,7 +132,11 @@ def roofline_block(args, sd, tm, K, real_bytes, interior_planes, interior_per_pl
         # temporal blocking: the dominant kernel advances `tb2_cells` cells by TWO steps per launch; its algorithmic
         # bytes are therefore 2 x 12.125 B per cell and launch (SURVEY 8d's per-update figure x the updates it performs)
         lw = int(tm["tb2_lw"])
-        if args.fcc:
+        spp = int(tm.get("tb_steps_per_pass") or 2)  # steps a launch advances its cells by: 2 (pairs) or 3 (k_tb3)
+        if spp == 3:
+            sgt = "true" if getattr(args, "numerics", 0) == 2 else "false"  # (<..., PROBE = true> = creation-time probes)
+            kernel, inst = "k_tb3", f"pf::k_tb3<{T}, 3, 8, {sgt}, false>"
+        elif args.fcc:
             sgt = "true" if getattr(args, "numerics", 0) == 2 else "false"
             old_kernel = bool(getattr(args, "debug", 0) & 0x40000) and sgt == "false"
             kernel = ("k_tb2_fcc_x" if old_kernel else "k_tb2_fcc_w") if lw == 64 else "k_tb2_fcc"
@@ -142,7 +146,7 @@ def roofline_block(args, sd, tm, K, real_bytes, interior_planes, interior_per_pl
             sgt = "true" if getattr(args, "numerics", 0) == 2 else "false"  # (<..., PROBE = true, ...> = creation-time probes)
             kernel, inst = "k_tb2_reg", f"pf::k_tb2_reg<{T}, 3, 4, false, {lw}, false, {sgt}>"
         kernel_ms = tm["tb2_ms_total"] / tm["tb2_launches"]
-        units = 2 * tm["tb2_cells"]
+        units = spp * tm["tb2_cells"]
     else:
         kernel = "k_air_fcc" if args.fcc else ("k_air_cart" if tm.get("air_path") == 1 else "k_air_cart_lean")
         inst = f"pf::{kernel}<{T},"
@@ -159,28 +163,83 @@ def roofline_block(args, sd, tm, K, real_bytes, interior_planes, interior_per_pl
           "grid_placement": {"candidates": tm.get("place_candidates", 0),
                              "kernel_ms_as_allocated_chosen_slowest": [round(v, 4) for v in tm.get("place_ms", [0, 0, 0])]}}
     if tm.get("tb2_launches", 0) > 0 and kernel_ms > 0:
-        # what a two-steps-per-pass kernel MUST move: u^{n-1}, u^n read once, u^{n+1}, u^{n+2} written once = 4 values per cell
-        # and launch -- a fraction of a hardware limit (<= 1 by construction), unlike `frac` above
+        # what a two- (three-) steps-per-pass kernel MUST move: u^{n-1}, u^n read once, two time levels written once = 4 values per
+        # cell and launch -- a fraction of a hardware limit (<= 1 by construction), unlike `frac` above
+        rl["steps_per_launch"] = int(tm.get("tb_steps_per_pass") or 2)
         comp = tm["tb2_cells"] * 4 * real_bytes
         rl["blocked_compulsory_GB_per_launch"] = round(comp / 1e9, 3)
         rl["frac_of_blocked_compulsory"] = round(comp / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         wb = tm.get("wall_blocks", [0, 0])
-        rl["shell"] = ("wall regions in pairs (k_wall2): %d blocks of alike pencils, %d generic" % (wb[0], wb[1])) if sum(wb) else "single steps"
+        rl["shell"] = ("wall regions in pairs (k_wall2): %d blocks of alike pencils, %d generic" % (wb[0], wb[1])
+                       + ("; third step of a triple: one single step" if rl["steps_per_launch"] == 3 else "")) if sum(wb) else "single steps"
     return rl, bpv, kernel_ms, units
 
 
-def add_traffic(rl, res, sd, kernel_ms, units, bpv):
+def measure_traffic_live(args, inst):
+    """HBM bytes per launch of the dominant kernel, measured NOW on this box: two child passes of this same command under
+    rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in separate runs, kernel trace only, as guides/MI355X_MICROARCH.md prescribes;
+    gfx950: FETCH_SIZE x 2 for wide coalesced reads), a few steps each, no creation-time measurement (debug 0x8000: under counter
+    collection it can reject the path the timed run uses).  None when rocprofv3 is not on the box or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if Path("/opt/rocm/bin/rocprofv3").exists() else None)
+    if not rp:
+        return None
+    child = [sys.executable, str(ROOT / "bench.py"), "--steps", "6", "--warmup", "2", "--repeats", "1", "--no-rigid-run", "--no-cpu-baseline",
+             "--no-selfcheck", "--no-pmc", "--size", str(args.size), "--precision", args.precision, "--mb", str(args.mb),
+             "--variant", str(args.variant), "--chunk", str(args.chunk), "--numerics", str(args.numerics), "--debug", hex(args.debug | 0x8000)]
+    child += (["--fcc"] if args.fcc else []) + (["--rigid"] if args.rigid else []) + (["--nx", str(args.nx)] if args.nx else []) + (["--ny", str(args.ny)] if args.ny else [])
+    out = {}
+    t0 = time.perf_counter()
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = Path(td) / counter
+            try:
+                r = subprocess.run([rp, "--pmc", counter, "--kernel-trace", "-d", str(d), "-o", "p", "--output-format", "csv", "--"] + child,
+                                   cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, capture_output=True, text=True, timeout=600)
+            except (OSError, subprocess.TimeoutExpired):
+                return None
+            vals = []
+            for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if inst in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                        vals.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or not vals:
+                return None
+            out[counter] = sorted(vals)[len(vals) // 2]
+    rd, wr = out["FETCH_SIZE"] * 1024 * 2, out["WRITE_SIZE"] * 1024  # KiB -> bytes; x2: gfx950 tallies 128-B read requests as 64 B
+    return {"read_bytes": rd, "write_bytes": wr, "total_bytes": rd + wr, "seconds": round(time.perf_counter() - t0, 1)}
+
+
+def add_traffic(rl, res, sd, kernel_ms, units, bpv, live=None):
     """HBM bytes per launch of the dominant kernel: from the committed PMC passes of this same command (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 x2 read correction applied; tools/collect_n1_profile.sh) -- counters
     cannot be read from inside the process.  Only quoted when the committed profile is of the very kernel instantiation this
     run launched, advancing the same number of voxel updates per launch on the same scene; otherwise null."""
-    for tag in ("r04", "r03", "r02"):
+    inst = rl["kernel_instantiation"]
+    note = (f"a launch advances its cells by {rl.get('steps_per_launch', 2)} steps: achieved = steps x 12.125 B per cell / launch time (SURVEY 8d's per-update "
+            "figure x the updates of a launch), which temporal blocking is allowed to beat (frac may exceed 1); measured_traffic_GBs = the "
+            "HBM bytes the launch really moves / launch time, measured_traffic_frac = that over the 8 TB/s peak")
+    if live:
+        rl["traffic"] = round(live["total_bytes"] / 1e9, 3)
+        rl["traffic_source"] = ("measured in this run: two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE; gfx950 x2 read correction) of this "
+                                f"same workload on this box, {live['seconds']} s")
+        rl["traffic_unit"] = f"GB per launch of {inst} (PMC: {live['read_bytes'] / 1e9:.3f} read + {live['write_bytes'] / 1e9:.3f} written)"
+        rl["algorithmic_GB_per_launch"] = round(units * bpv / 1e9, 3)
+        rl["measured_traffic_GBs"] = round(live["total_bytes"] / 1e9 / (kernel_ms * 1e-3), 1)
+        rl["measured_traffic_frac"] = round(rl["measured_traffic_GBs"] / HBM_PEAK_GBS, 4)  # the fraction of a hardware limit
+        if "k_tb" in inst:
+            rl["note"] = note
+        return
+    for tag in ("r05", "r04", "r03", "r02"):
         tfile, pfile = ROOT / "profiles" / f"{tag}_bench_n1_hbm_traffic.json", ROOT / "profiles" / f"{tag}_bench_n1.json"
         if tfile.exists():
             break
     else:
         return
-    inst = rl["kernel_instantiation"]
     try:
         ks = json.load(open(tfile))["kernels"]
         # (pfile absent = the profile collection itself: the passes just taken are of this build)
@@ -190,13 +249,12 @@ def add_traffic(rl, res, sd, kernel_ms, units, bpv):
                                 and prof["config"]["Nb"] == sd.Nb and prof["dtype"] == res["dtype"])
         if hit and same:
             rl["traffic"] = round(hit[0]["total_bytes"] / 1e9, 3)
+            rl["traffic_source"] = f"committed: profiles/{tfile.name} (PMC passes of this same command on another run; rocprofv3 not usable in this one)"
             rl["traffic_unit"] = f"GB per launch of {inst} (PMC, profiles/{tfile.name})"
             rl["algorithmic_GB_per_launch"] = round(units * bpv / 1e9, 3)
             rl["measured_traffic_GBs"] = round(hit[0]["total_bytes"] / 1e9 / (kernel_ms * 1e-3), 1)
             rl["measured_traffic_frac"] = round(rl["measured_traffic_GBs"] / HBM_PEAK_GBS, 4)  # the fraction of a hardware limit
-            rl["note"] = ("a launch advances its cells by TWO steps: achieved = 2 x 12.125 B per cell / launch time (SURVEY 8d's per-update "
-                          "figure x the updates of a launch), which temporal blocking is allowed to beat (frac may exceed 1); measured_traffic_GBs = the "
-                          "HBM bytes the launch really moves / launch time, measured_traffic_frac = that over the 8 TB/s peak")
+            rl["note"] = note
         else:
             rl["traffic_note"] = "committed profile is of another kernel instantiation / workload: not quoted"
     except (OSError, KeyError, ValueError):
@@ -337,6 +395,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--numerics", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc child passes (then: the committed profile's figure)")
     ap.add_argument("--debug", type=lambda v: int(v, 0), default=0, help="pf_opts.debug (tuning switches)")
     ap.add_argument("--transport", default="auto", choices=["auto", "peer", "rccl", "host"],
                     help="N>1 from one process: how ghost planes travel (pf_opts.transport)")
@@ -492,8 +551,6 @@ def main():
         res = base_result(args, sd, world, K, W, R, regions, el, real_bytes, lossy, parallelism)
         rl, bpv, kernel_ms, units = roofline_block(args, sd, tm, K, real_bytes, interior_planes)
         res["roofline"] = rl
-        if world == 1:
-            add_traffic(rl, res, sd, kernel_ms, units, bpv)
         if world > 1:
             res["exchange_verified"] = runner.exchange_verified
             res["exchange"] = {"backend": backend, "ranks": world, "checked_steps": min(W, 4),
@@ -551,6 +608,11 @@ def main():
                                   "blocked_pairs": tm_r.get("air_path") == 2,
                                   "autotune_ms_per_step": {k: round(v, 4) for k, v in zip(("lean", "barrier_free", "blocked_pair"), tm_r.get("tune_ms", [0, 0, 0]))}}
             rr.st.close()
+        if world == 1 and emu is None:
+            # HBM traffic of the dominant kernel: measured now (every engine of this process is closed, the device is free), on
+            # this box, by counter passes of this same command; the committed passes only when rocprofv3 cannot run here
+            live = None if args.no_pmc else measure_traffic_live(args, rl["kernel_instantiation"])
+            add_traffic(rl, res, sd, kernel_ms, units, bpv, live)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.precision, args.fcc, args.mb, lossy)
         print(json.dumps(res), flush=True)

@@ -106,7 +106,8 @@ typedef struct pf_opts {
                              generic; 0x4000000 all their launches on one stream; 0x2000000 wide column strips cut in two;
                              0x800000 replay the single-step loop from a hipGraph (six steps per graph; no faster on this stack);
                              0x100000 boundary pass in plain workgroup order; 0x200000 it fetches the neighbours inside
-                             the wall too; 0x40000 13-point pairs by the round-4 kernel k_tb2_fcc_x (A/B measurements) */
+                             the wall too; 0x40000 13-point pairs by the round-4 kernel k_tb2_fcc_x (A/B measurements); 0x20000 never three
+                             steps per pass (pairs as in round 4) */
    int32_t energy;        /* 1 = keep what the energy diagnostic needs (explicit Laplacian grid, unfused kernel
                              sequence); then use pf_engine_energy_cfg + pf_engine_run_energy */
    int32_t multi_flags;   /* pf_run_sim_devices / pf_multi_create only: PF_MULTI_* */
@@ -160,6 +161,7 @@ typedef struct pf_timing {
    double  place_ms[3];     /*   ms per launch on the first (as allocated), the chosen (fastest) and the slowest of them */
    int64_t wall_blocks[2];  /* blocked pairs with the shell in pairs too (wall regions, pf_wall.h): blocks of the launches whose pencils
                                are all alike / generic blocks (edges, corners); 0, 0: the shell takes single steps */
+   int64_t tb_steps_per_pass; /* steps one launch behind tb2_ms_total advances its cells by: 2 (pairs), 3 (k_tb3, pf_tb3.h), 0: none */
 } pf_timing;
 
 typedef struct pf_engine pf_engine;
@@ -256,7 +258,11 @@ int  pf_engine_layout(pf_engine *e, int64_t *dims, int64_t *pitch, int32_t *exch
 void *pf_engine_stream(pf_engine *e, int32_t which); /* 0 main, 1 edge: hipStream_t */
 int  pf_engine_sync(pf_engine *e);
 int  pf_engine_flush_outputs(pf_engine *e);          /* ring -> sd->u_out */
-/* copy a state grid to/from a host array in FILE layout [Nx*Ny*Nz] Real; which: 0 = u0, 1 = u1 */
+/* copy a state grid to/from a host array in FILE layout [Nx*Ny*Nz] Real; which: 0 = u0, 1 = u1.
+ * pf_engine_set_grid: the field must be FINITE everywhere, the cells inside the walls included.  In the CPU-exact arithmetic the
+ * boundary pass does not fetch a neighbour whose adjacency bit is clear (a cell inside the wall): the reference adds (a2 * 0) * u1
+ * there, which is +-0 for a finite u1 and leaves the sum as it is (the sums of the time loop never hold -0), but NaN for an Inf
+ * or NaN -- pf_opts.debug 0x200000 fetches every neighbour, the exact reference behaviour for such fields too. */
 int  pf_engine_get_grid(pf_engine *e, int32_t which, void *host);
 int  pf_engine_set_grid(pf_engine *e, int32_t which, const void *host);
 int  pf_engine_timing(pf_engine *e, pf_timing *t, int32_t reset);

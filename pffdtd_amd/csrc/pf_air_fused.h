@@ -53,6 +53,8 @@ struct LeanParams {
    int32_t yt_split, yt_hi0; // two row strips in one launch: tiles [yt0, yt0+yt_split) and [yt_hi0, ...) (yt_split < 0: off)
    int32_t x2_begin, x2_nlo; // k_air_cart_lean, two x slabs in one launch (x2_nlo > 0): chunks [0, x2_nlo) march [x_begin, x_lo_end),
    int32_t x_lo_end;         //   the others [x2_begin, x_end)
+   int32_t skip_y0, skip_y1; // rows [skip_y0, skip_y1) are computed but NOT stored (row-strip launches beside a box whose u^{n-1} is not
+                             // in memory: the third step of a triple, pf_tb3.h); 0, 0: every row is stored
 };
 
 template <typename Real, int R, int WY, bool SG, bool NT = false>
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(64 * WY) void k_air_cart_lean(LeanParams fp, Real a
    for (int r = 0; r < R; r++) {
       ro[r] = (uint32_t)rowsrc(y0 + r) * (uint32_t)P + (uint32_t)zl;
       so[r] = (uint32_t)min(y0 + r, Ny - 1) * (uint32_t)P + (uint32_t)zl;
-      valid[r] = active && (y0 + r <= Ny - 2);
+      valid[r] = active && (y0 + r <= Ny - 2) && !(y0 + r >= fp.skip_y0 && y0 + r < fp.skip_y1);
    }
    const uint32_t ro_halo = (uint32_t)rowsrc(top_wave ? y0 - 1 : y0 + R) * (uint32_t)P + (uint32_t)zl;
    const bool halo_wave = top_wave || bot_wave;

@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <numeric>
 #include <string>
@@ -20,6 +21,7 @@
 #include "pf_air_fused.h"
 #include "pf_energy.h"
 #include "pf_tb2.h"
+#include "pf_tb3.h"
 #include "pf_wall.h"
 
 namespace {
@@ -114,6 +116,11 @@ int check_dpp(hipStream_t s) {
 
 struct Range { int64_t b, e; };
 
+// The creation-time measurements (kernel choice, grid placement) of engines that share a device run one at a time: one engine's
+// temporary candidate grids (up to 85 % of the device, pool_extra) must not starve another's mandatory allocations, and
+// measurements taken side by side would time each other's kernels.
+std::mutex g_tune_mu[64];
+
 struct EngineBase {
    virtual ~EngineBase() {}
    virtual int run(int64_t n0, int64_t nsteps) = 0;
@@ -207,6 +214,13 @@ template <typename Real> struct Engine : EngineBase {
    bool pair_now = false;                                 // the step in flight is half of a pair
    Real *pA = nullptr, *pB = nullptr;                     // u^{n-1}, u^n of the pair in flight
    Real *bufC = nullptr, *bufD = nullptr;                 // the two extra state grids of the out-of-place pair
+   // three steps per pass (pf_tb3.h, Engine::step_triple): single-domain 7-point engines whose shell steps as wall regions.  Five
+   // grids: the state (u^{n-1}, u^n) -> bufD = u^{n+2}, bufE = u^{n+3}; bufC holds u^{n+1} where somebody needs it in memory (the
+   // shell, the single-step tiles and their neighbours)
+   bool tb3 = false;
+   Real *bufE = nullptr;
+   Real *home[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // the placed role cycle: state (0, 1) <-> targets (2, 3), 4 = the u^{n+1} grid
+   static constexpr int tb3_wt = 8, tb3_r = 3, tb3_rows = tb3_wt * tb3_r - 4; // k_tb3<Real, 3, 8>: 20 core rows per tile
    int tbx0 = 0, tbx1 = 0, tby0 = 0, tby1 = 0, tbz0 = 0, tbz1 = 0; // box of cells k_tb2_reg produces
    int szl = 0, szr = 0;                                  // 7-point column strips: columns [0, szl) and [szr, P)
    // planes per x chunk of k_tb2_reg: 12-20 are equally fast, 24 is 1 % and 48 is 6 % slower although longer chunks
@@ -597,6 +611,7 @@ template <typename Real> struct Engine : EngineBase {
          if ((rc = dzalloc(&ring, Nr * ring_depth))) return rc;
          HIPCHK(hipHostMalloc((void **)&h_ring, std::max<int64_t>(Nr * ring_depth, 1) * sizeof(Real), hipHostMallocDefault));
       }
+      std::lock_guard<std::mutex> tune_lock(g_tune_mu[op.device & 63]);
       { int rc = init_tb2(); if (rc) return rc; }
       tb2_probe = true;
       // pairs or single steps?  A first measurement on the grids as allocated drops pairs that are hopeless (rooms whose clean
@@ -609,6 +624,7 @@ template <typename Real> struct Engine : EngineBase {
       if (tb2) { int rc = autotune(); if (rc) { tb2_probe = false; return rc; } }
       else if (fcc) { int rc = autotune_fcc_lw(); if (rc) { tb2_probe = false; return rc; } } // (pairs dropped or never offered)
       tb2_probe = false;
+      if (tb3) tb3_remember_home();
       if (!tb2 && op.slab_first && op.slab_last) { int rc = sample_placement_single(); if (rc) return rc; }
       // hipGraph replay of the step loop (six steps per graph): measured on MI355X / ROCm 7.2 it does not beat plain
       // launches even on launch-bound grids (234x154x85: 0.0503 vs 0.0473 ms/step, 256^3: 0.0951 vs 0.0921) -- the gaps
@@ -618,7 +634,7 @@ template <typename Real> struct Engine : EngineBase {
       if (getenv("PFFDTD_VERBOSE") && atoi(getenv("PFFDTD_VERBOSE")) > 0)
          fprintf(stderr, "pffdtd_hip: engine on device %d, %ldx%ldx%ld %s %s, interior path: %s%s, numerics: %s, %d-lane row segments\n", op.device, (long)Nx, (long)Ny, (long)Nz,
                  fcc ? "13-point" : "7-point", sizeof(Real) == 4 ? "fp32" : "fp64",
-                 tb2 ? "temporally blocked pairs" : (lean ? "lean fused kernel" : (vg ? "barrier-free kernel, virtual ghosts" : (abck ? "barrier-free kernel, in-kernel ABC" : "unfused reference sequence"))),
+                 tb3 ? "three steps per pass (k_tb3), shell as wall regions + one single step" : tb2 ? "temporally blocked pairs" : (lean ? "lean fused kernel" : (vg ? "barrier-free kernel, virtual ghosts" : (abck ? "barrier-free kernel, in-kernel ABC" : "unfused reference sequence"))),
                  tb2_geom && !tb2 ? " (pairs when the caller hands over four grids)" : (swz ? " (stored with the file's x and z axes exchanged)" : ""), sg ? "GPU-safeguarded" : "CPU-exact", tb2 ? tb_lw : (lean ? 64 : pick_lw()));
       HIPCHK(hipDeviceSynchronize());
       return PF_OK;
@@ -631,7 +647,31 @@ template <typename Real> struct Engine : EngineBase {
    // The shell around the box (x slabs, row strips, column strips; all boundary / ABC / source cells live there) is
    // stepped twice by the single-step kernels, out of place.  Rooms with interior geometry have no such box: tb2 stays
    // off and nothing changes.  air_variant 0 (auto) and 40 enable it, 41 = same driver with the box disabled (tests).
+   // undo a temporal-blocking arrangement (its grids, tile lists, strip tables, wall regions): the engine steps singly
+   void drop_blocking() {
+      tb2 = tb3 = false;
+      free_walls();
+      for (Real **g : {&bufC, &bufD, &bufE})
+         if (*g) { own_list.erase(std::remove(own_list.begin(), own_list.end(), *g), own_list.end()); hipFree(*g); *g = nullptr; }
+      auto F = [](auto *&p) { if (p) hipFree((void *)p); p = nullptr; };
+      F(zs_map); F(zs_adj); F(zs_li); F(zs_rest); F(zs_fd);
+      zs_mode = 0;
+   }
+   // Three steps per pass where they can be had: single-domain 7-point engines in file-order storage, 64-lane row segments, the
+   // shell as wall regions (init_walls).  The box then keeps THREE cells from anything that is not a plain air update (k_tb3
+   // computes u^{n+1} two cells beyond it).  Anything else: pairs as before.  debug 0x20000: never triples.
    int init_tb2() {
+      tb3 = false;
+      const bool single = op.slab_first && op.slab_last;
+      if (single && !fcc && !swz && !(op.debug & (0x20000 | 0x300 | 0x10000000)) && vbase != 41) {
+         int rc = init_tb2_impl(true);
+         if (rc) return rc;
+         if (tb2 && wl_on) { tb3 = true; return PF_OK; }
+         drop_blocking();
+      }
+      return init_tb2_impl(false);
+   }
+   int init_tb2_impl(bool triple) {
       tb2 = tb2_geom = tb2_slab = false;
       const bool single = op.slab_first && op.slab_last;
       if (op.energy || (op.debug & 0x4000)) return PF_OK; // 0x4000: single steps only
@@ -655,12 +695,14 @@ template <typename Real> struct Engine : EngineBase {
          const int64_t d[6] = {ix, Nx - 1 - ix, iy, Ny - 1 - iy, iz, Nz - 1 - iz};
          for (int f = 0; f < 6; f++) if (d[f] < 16) hist[f][d[f]]++;
       }
+      const int reach = triple ? 3 : 2; // how far the blocked kernel's own u^{n+1} (u^{n+2}) reach beyond the box, plus one
       auto margin = [&](int f, int64_t area) {
-         int m = 3;
-         for (int d = 0; d <= 12; d++) if (hist[f][d] * 2 >= area) m = std::max(m, d + 2);
+         int m = reach + 1;
+         for (int d = 0; d <= 12; d++) if (hist[f][d] * 2 >= area) m = std::max(m, d + reach);
          return m;
       };
       constexpr int V = pf::VecOf<Real>::V;
+      const int hl = (triple && V < 4) ? 2 : 1; // halo lanes per side of a row segment (k_tb3 in fp64: two, pf_tb3.h)
       // towards a neighbouring slab the box stops three planes short of the ghost plane: planes 1-2 / Nx-3..Nx-2 are the
       // edge planes of a split-phase pair (plane 1 needs the neighbour's data between the two steps; with plane 2 on the
       // edge stream as well the box kernel never reads a ghost plane, so the main stream never waits for an exchange)
@@ -676,8 +718,8 @@ template <typename Real> struct Engine : EngineBase {
          int64_t best = -1;
          for (int lw : {64, 32, 16}) {
             if (op.debug & 0x300) { if (lw != ((op.debug & 0x100) ? 32 : 16)) continue; } // tuning override (as pick_lw)
-            else if (((op.debug & 0x400) || swz) && lw != 64) continue; // (exchanged axes: the SWZ instantiations exist for 64-lane segments only; such rooms have long rows)
-            const int TC = (lw - 2) * V;
+            else if (((op.debug & 0x400) || swz || triple) && lw != 64) continue; // (exchanged axes: the SWZ instantiations exist for 64-lane segments only; such rooms have long rows; k_tb3: 64 lanes)
+            const int TC = (lw - 2 * hl) * V;
             int z1 = (int)((Nz - mz1) / 4 * 4);
             const int nz = z1 - tbz0, rem = nz % TC;
             if (nz > TC && rem > 0 && rem * (int)sizeof(Real) <= 256) z1 -= rem;
@@ -709,26 +751,29 @@ template <typename Real> struct Engine : EngineBase {
       if (vbase == 41) tbx1 = tbx0; // driver test: everything goes through the out-of-place single-step path
       tb_xr.clear();
       // rows of a workgroup: 4 waves x R = 3 (7-point); 13-point: 6 inner waves x R = 2 with 64-lane segments (k_tb2_fcc_x), else 4 x 2
-      const int TC = (tb_lw - 2) * V, TR = fcc ? ((tb_lw == 64 && fcc_wt) ? 2 * (fcc_wt - 2) : 8 * (64 / tb_lw)) : 12 * (64 / tb_lw);
+      const int TC = (tb_lw - 2 * hl) * V, TR = triple ? tb3_rows : (fcc ? ((tb_lw == 64 && fcc_wt) ? 2 * (fcc_wt - 2) : 8 * (64 / tb_lw)) : 12 * (64 / tb_lw));
       int64_t vol = 0;
       if (tbx1 - tbx0 >= 16 && tby1 - tby0 >= 24 && tbz1 - tbz0 >= TC / 2) {
          tb_xr.push_back({tbx0, tbx1});
          const int np = tbx1 - tbx0;
          // ~16-plane chunks, even split (tools/tb2_probe.py); 13-point: ~24 (3.93 vs 4.07 ms per launch at 1024^3, 32-48 the same)
-         const int want_chunk = fcc ? 24 : tb2_chunk;
+         // (k_tb3: 64 -- 3.28 ms per launch at 1024^3 against 3.57 with 32 and 3.63 with 16 in the plain tile order, tools/tb3_probe.py)
+         const int want_chunk = triple ? 64 : (fcc ? 24 : tb2_chunk);
          tb_chunk = (int)cdiv(np, std::max<int64_t>(cdiv(np, want_chunk), 1));
          tb_nxc = (int)cdiv(np, tb_chunk); tb_nyt = (int)cdiv(tby1 - tby0, TR); tb_nzt = (int)cdiv(tbz1 - tbz0, TC);
          const int64_t ntile = (int64_t)tb_nxc * tb_nyt * tb_nzt;
          if (ntile >= ((int64_t)1 << 31)) return PF_OK;
          std::vector<uint8_t> dirty((size_t)ntile, 0);
-         auto mark = [&](int64_t ii) { // every tile whose core, grown by one cell, holds this cell
+         // every tile whose core, grown by `grow` cells, holds this cell (pairs: one cell -- the kernel's own u^{n+1} reach one cell
+         // beyond the core; triples: two)
+         auto mark = [&](int64_t ii, int grow) {
             int64_t ix64, iy64, iz64;
             decode(ii, ix64, iy64, iz64);
             const int ix = (int)ix64, iy = (int)iy64, iz = (int)iz64;
-            auto span = [](int c, int org, int size, int n, int end, int &lo, int &hi) {
-               if (c < org - 1 || c > end) return false;
-               lo = (c - 1 - org) >= 0 ? (c - 1 - org) / size : 0;
-               hi = std::min((c + 1 - org) / size, n - 1);
+            auto span = [grow](int c, int org, int size, int n, int end, int &lo, int &hi) {
+               if (c < org - grow || c > end - 1 + grow) return false;
+               lo = (c - grow - org) >= 0 ? (c - grow - org) / size : 0;
+               hi = std::min(std::max(c + grow - org, 0) / size, n - 1);
                return lo <= hi;
             };
             int x0, x1, y0, y1, z0, z1;
@@ -737,8 +782,11 @@ template <typename Real> struct Engine : EngineBase {
             for (int a = x0; a <= x1; a++) for (int b = y0; b <= y1; b++) for (int c = z0; c <= z1; c++)
                dirty[((size_t)a * tb_nyt + b) * tb_nzt + c] = 1;
          };
-         for (int64_t i = 0; i < Nb; i++) mark(sd.bn_ixyz[i]);
-         for (int64_t i = 0; i < Ns; i++) mark(sd.in_ixyz[i]); // (the source is added between the two steps)
+         const int grow = triple ? 2 : 1;
+         for (int64_t i = 0; i < Nb; i++) mark(sd.bn_ixyz[i], grow);
+         for (int64_t i = 0; i < Ns; i++) mark(sd.in_ixyz[i], grow); // (the source is added between the steps)
+         if (triple) // a receiver reads u^{n+1} from memory, which a clean tile of k_tb3 never stores: its tile steps singly
+            for (int64_t i = 0; i < Nr; i++) mark(sd.out_ixyz[i], 0);
          std::vector<int32_t> cl, di;
          for (int64_t t = 0; t < ntile; t++) {
             if (dirty[t]) { di.push_back((int32_t)t); continue; }
@@ -776,7 +824,22 @@ template <typename Real> struct Engine : EngineBase {
          int rc;
          if (tb_clean) { hipFree(tb_clean); tb_clean = nullptr; }
          if (tb_dirty) { hipFree(tb_dirty); tb_dirty = nullptr; }
-         if ((rc = upload(&tb_clean, cl.data(), tb_nclean))) return rc;
+         {
+            // k_tb3 keeps u^{n+1} on the chip: the clean neighbours of a tile that steps singly (26-neighbourhood) are flagged to
+            // store theirs, which that tile's second step reads
+            std::vector<int32_t> clf(cl);
+            if (triple && tb_ndirty > 0)
+               for (auto &t : clf) {
+                  const int zt = (int)(t % tb_nzt), yt = (int)((t / tb_nzt) % tb_nyt), xc = (int)(t / ((int64_t)tb_nzt * tb_nyt));
+                  bool rim = false;
+                  for (int a = std::max(xc - 1, 0); a <= std::min(xc + 1, tb_nxc - 1) && !rim; a++)
+                     for (int b = std::max(yt - 1, 0); b <= std::min(yt + 1, tb_nyt - 1) && !rim; b++)
+                        for (int c = std::max(zt - 1, 0); c <= std::min(zt + 1, tb_nzt - 1) && !rim; c++)
+                           rim = dirty[((size_t)a * tb_nyt + b) * tb_nzt + c] != 0;
+                  if (rim) t = (int32_t)((uint32_t)t | pf::TB3_RIM);
+               }
+            if ((rc = upload(&tb_clean, clf.data(), tb_nclean))) return rc;
+         }
          if ((rc = upload(&tb_dirty, di.data(), tb_ndirty))) return rc;
          { // The placement search times the pair kernel on a SAMPLE of the clean tiles: every k-th x chunk, whole chunks in the
            // launch's own order (the effect it looks for is a property of how the four grids' pages lie relative to each
@@ -814,8 +877,10 @@ template <typename Real> struct Engine : EngineBase {
                      const int za = std::max(zt * 64 * V, tbz0), zb = std::min((zt + 1) * 64 * V, tbz1);
                      if (za >= zb) continue; // only column-strip cells: k_zstrip_fcc
                      bool need = ya < tby0 || yb > tby1;
-                     // (64-lane segments: the box's dirty tiles are stepped tile for tile by k_tb1_fcc_tile, launch_dirty_tiles)
-                     if (!need && (tb_lw != 64 || (op.debug & 0x80000))) { // (debug 0x80000: the round-4 arrangement, A/B measurements)
+                     // (Stepping the box's dirty tiles tile for tile, with the pair kernel's 12-row geometry, was measured in round 5 and
+                     // LOSES: Musikverein, 28 % of the cells dirty, 4.11 ms per step against 3.80 with these 16-row tiles -- two rows per
+                     // wave fetch twice the lines per cell.)
+                     if (!need) {
                         const int t0y = (ya - tby0) / TR, t1y = (yb - 1 - tby0) / TR, t0z = (za - tbz0) / TC, t1z = (zb - 1 - tbz0) / TC;
                         for (int a = t0y; a <= t1y && !need; a++)
                            for (int c = t0z; c <= t1z && !need; c++) need = dirty[((size_t)xc * tb_nyt + a) * tb_nzt + c] != 0;
@@ -827,6 +892,7 @@ template <typename Real> struct Engine : EngineBase {
             if ((rc = upload(&sh_tiles, sh.data(), sh_ntiles))) return rc;
          }
       }
+      if (triple && vol == 0) return PF_OK; // (every 20-row tile holds a receiver, a source or geometry: init_tb2 tries the pairs' smaller tiles)
       if (vbase == 40 && vol == 0) return set_err(PF_ERR_ARG, "air_variant 40 (temporal blocking) requested but the scene has no boundary-free tiles");
       // auto: the shell costs grow with the perimeter of the y-z cross-section, the gain with its area -- measured on
       // MI355X: 512^2 planes -4.5 %, 768^2 +9 %, 1024^2 +13 % for a box room; and two extra grids must be worth it.
@@ -846,8 +912,14 @@ template <typename Real> struct Engine : EngineBase {
          return PF_OK;
       }
       own_list.push_back(bufC); own_list.push_back(bufD);
+      if (triple) {
+         bufE = try_dzalloc<Real>(npad);
+         if (!bufE) return PF_OK; // (no room for a fifth grid: init_tb2 falls back to pairs)
+         own_list.push_back(bufE);
+      }
       tb2 = true;
       { int rcw = init_walls(); if (rcw) return rcw; }
+      if (triple) return PF_OK; // (with wall regions: triples; without: init_tb2 starts over with the pairs' geometry)
       if (wl_on) { zs_mode = 0; return PF_OK; } // (no single-step shell: nothing for the column-strip kernel to share)
       // Boundary nodes inside the column strips are updated by k_air_zstrip, which streams their lines anyway and holds
       // their six neighbours in registers (in k_boundary the floor / ceiling nodes of a box room -- stride-P neighbours,
@@ -1018,6 +1090,15 @@ template <typename Real> struct Engine : EngineBase {
       if (!zok) WL_NO("column strips too wide for the pencils");
 #undef WL_NO
       const int nregs = (int)reg.size();
+      // every feasibility check comes BEFORE a device array is touched (the lossy arrays are re-ordered in place below)
+      std::vector<uint32_t> rloc((size_t)nregs); // a region's place in its launch group
+      {
+         int cnt[4] = {0, 0, 0, 0};
+         for (int i = 0; i < nregs; i++) {
+            if (cnt[grp[i]] >= pf::WALL_MAXREG) return PF_OK;
+            rloc[i] = (uint32_t)cnt[grp[i]]++;
+         }
+      }
       int64_t npen = 0;
       for (int i = 0; i < nregs; i++) { reg[i].pen_off = npen; npen += (int64_t)(reg[i].m1 - reg[i].m0 + 2) * reg[i].nlp; }
       if (npen >= ((int64_t)1 << 31)) return PF_OK;
@@ -1097,10 +1178,11 @@ template <typename Real> struct Engine : EngineBase {
          }
       });
       int rc;
-      if ((rc = upload(&wl_pen, pen.data(), npen))) return rc;
-      if ((rc = upload(&wl_rec, rec.data(), nrec))) return rc;
+      free_walls(); // (a second call -- set_spares after place_grids -- must not leak the first one's tables)
+      if ((rc = upload(&wl_pen, pen.data(), npen))) { free_walls(); return rc; }
+      if ((rc = upload(&wl_rec, rec.data(), nrec))) { free_walls(); return rc; }
       wl_nrest = (int64_t)rest.size();
-      if ((rc = upload(&wl_rest, rest.data(), wl_nrest))) return rc;
+      if ((rc = upload(&wl_rest, rest.data(), wl_nrest))) { free_walls(); return rc; }
       // the lossy arrays in the new order (state and node-value arrays are all zeros at creation)
       if (Nbl) {
          std::vector<int64_t> bl(Nbl), bl2(Nbl);
@@ -1116,13 +1198,11 @@ template <typename Real> struct Engine : EngineBase {
          for (int64_t nb = 0; nb < Nb; nb++) if (hl[nb] >= 0) hl[nb] = newli[hl[nb]];
          HIPCHK(hipMemcpy(d_lossy, hl.data(), Nb * sizeof(int32_t), hipMemcpyHostToDevice));
       }
-      if ((rc = dzalloc(&vh1b, round_up(Nbl, 64) * PF_MMB))) return rc;
-      if ((rc = dzalloc(&gh1b, round_up(Nbl, 64) * PF_MMB))) return rc;
-      std::vector<uint32_t> rloc((size_t)nregs); // a region's place in its launch group
+      if ((rc = dzalloc(&vh1b, round_up(Nbl, 64) * PF_MMB))) { free_walls(); return rc; }
+      if ((rc = dzalloc(&gh1b, round_up(Nbl, 64) * PF_MMB))) { free_walls(); return rc; }
+      for (auto &g : wl_grp) g = WlGroup{};
       for (int i = 0; i < nregs; i++) {
          WlGroup &g = wl_grp[grp[i]];
-         if (g.nreg >= pf::WALL_MAXREG) return PF_OK;
-         rloc[i] = (uint32_t)g.nreg;
          g.reg[g.nreg++] = reg[i];
       }
       // Block lists.  A block (lane tile x march chunk of a region) whose pencils all have the same structure and that touches no
@@ -1157,7 +1237,7 @@ template <typename Real> struct Engine : EngineBase {
       {
          std::vector<uint4> all;
          for (int q = 0; q < 12; q++) { wl_grp[q / 3].blk0[q % 3] = (uint32_t)all.size(); wl_grp[q / 3].nblk[q % 3] = (uint32_t)lists[q].size(); all.insert(all.end(), lists[q].begin(), lists[q].end()); }
-         if ((rc = upload(&wl_blk, all.data(), (int64_t)all.size()))) return rc;
+         if ((rc = upload(&wl_blk, all.data(), (int64_t)all.size()))) { free_walls(); return rc; }
       }
       wl_on = true;
       if (getenv("PFFDTD_VERBOSE") && atoi(getenv("PFFDTD_VERBOSE")) > 0)
@@ -1246,7 +1326,86 @@ template <typename Real> struct Engine : EngineBase {
       launch_io(s, n + 1, true, {0, Ns});
       ring_fill++; steps_done++;
       u0_src = nullptr; u0 = C; u1 = D; bufC = A; bufD = B;
+      if (tb3) tb3_pick();
       if (op.timing) { hipEventRecord(ev2.second, s); step_ev.push_back(ev2); }
+      HIPCHK(hipGetLastError());
+      if (ring_fill == ring_depth) return flush();
+      return PF_OK;
+   }
+   // tb3: which grids does the next blocked step write?  Where the five grids lie relative to each other decides the speed of k_tb3
+   // (grid placement): the assignment measured at creation -- state home[0], home[1] -> home[2], home[3] and back, home[4]
+   // the u^{n+1} grid -- is kept wherever the state allows; after a pair or an odd number of single steps (the end of a run) the
+   // next triple is one step off that cycle and returns to it.
+   void tb3_remember_home() { home[0] = u0; home[1] = u1; home[2] = bufD; home[3] = bufE; home[4] = bufC; }
+   void tb3_pick() {
+      if (!home[0]) return;
+      if (u0 == home[0] && u1 == home[1]) { bufD = home[2]; bufE = home[3]; bufC = home[4]; return; }
+      if (u0 == home[2] && u1 == home[3]) { bufD = home[0]; bufE = home[1]; bufC = home[4]; return; }
+      Real *fr[3];
+      int nf = 0;
+      for (Real *g : home) if (g != u0 && g != u1 && nf < 3) fr[nf++] = g;
+      if (nf != 3) return; // (cannot happen: the state is two of the five)
+      auto is_free = [&](Real *g) { return g == fr[0] || g == fr[1] || g == fr[2]; };
+      if (is_free(home[0]) && is_free(home[1])) { bufD = home[0]; bufE = home[1]; }
+      else if (is_free(home[2]) && is_free(home[3])) { bufD = home[2]; bufE = home[3]; }
+      else { bufD = fr[0]; bufE = fr[1]; }
+      for (Real *g : fr) if (g != bufD && g != bufE) bufC = g;
+   }
+   // steps n, n+1 and n+2 in one go (tb3): the box by k_tb3 (u^{n+1} stays on the chip), the shell's first two steps as wall regions
+   // (k_wall2, exactly as in step_pair_walls), its third as a single step out of memory (the lean kernel on the x slabs and row
+   // strips, k_air_zstrip on the column strips, k_boundary over every node); the tiles that step singly (sources, receivers,
+   // geometry inside the box) and the box's own boundary nodes take three single steps, the second of which reads the u^{n+1}
+   // their flagged neighbours left in bufC.  State (u0, u1) -> (bufD, bufE); the old state grids become the next triple's targets.
+   int step_triple(int64_t n) {
+      if (n < 0 || n + 2 >= Nt) return set_err(PF_ERR_ARG, "step triple %ld outside [0,Nt=%ld)", (long)n, (long)Nt);
+      hipStream_t s = s_main;
+      Real *A = u0, *B = u1, *C = bufC, *D = bufD, *E = bufE;
+      Real *P0 = ub[0], *P1 = ub[1], *P2 = ub[2]; // node values: P2 = u^{n-1}, P1 = u^n, P0 free
+      auto get_ev = [&]() { std::pair<hipEvent_t, hipEvent_t> e{}; if (!ev_pool.empty()) { e = ev_pool.back(); ev_pool.pop_back(); } else { hipEventCreate(&e.first); hipEventCreate(&e.second); } return e; };
+      std::pair<hipEvent_t, hipEvent_t> ev{}, evt{}, eva{};
+      if (op.timing) { ev = get_ev(); evt = get_ev(); eva = get_ev(); hipEventRecord(ev.first, s); hipEventRecord(eva.first, s); }
+      const bool beside = !(op.debug & 0x4000000);
+      hipStream_t sw = beside ? s_edge : s_main; // the generic wall blocks and the first step of the single-step tiles: beside the alike blocks
+      if (beside) { HIPCHK(hipEventRecord(ev_pre, s_main)); HIPCHK(hipStreamWaitEvent(s_edge, ev_pre, 0)); }
+      // ---- step n: single-step tiles and the box's own nodes A, B -> C; wall regions A, B -> C, D; box A, B -> D, E
+      u0_src = A; u1 = B; u0 = C;
+      launch_dirty_tiles(sw);
+      bnd_sel = wl_rest; bs_vout = vh1b; bs_gout = gh1b;
+      launch_rigid(sw, {0, wl_nrest});
+      launch_walls(s, sw, A, B, C, D, P0, P1, P2);
+      if (op.timing) hipEventRecord(evt.first, s);
+      launch_tb3(s, A, B, C, D, E);
+      if (op.timing) { hipEventRecord(evt.second, s); tb2_ev.push_back(evt); hipEventRecord(eva.second, s); air_ev.push_back(eva); }
+      if (beside) { HIPCHK(hipEventRecord(ev_edge, s_edge)); HIPCHK(hipStreamWaitEvent(s_main, ev_edge, 0)); }
+      launch_io(s, n, true, {0, Ns}); // receivers read u^n (B); the source goes into u^{n+1} (C), which only the single-step tiles read
+      if (ring_fill == 0) ring_n0 = n;
+      ring_fill++; steps_done++;
+      if (op.timing) { hipEventRecord(ev.second, s); step_ev.push_back(ev); ev = get_ev(); hipEventRecord(ev.first, s); }
+      std::swap(vh1, vh1b); std::swap(gh1, gh1b); // the state after two steps (the nodes inside the box: after their first)
+      // ---- step n+1: single-step tiles and their nodes B, C -> D (the regions and the box have theirs)
+      u0_src = B; u1 = C; u0 = D;
+      launch_dirty_tiles(s);
+      bs_vout = bs_gout = nullptr;
+      ub[0] = P1; ub[2] = P1; // u2b = u^n of the node, overwritten by its u^{n+2} (where the regions put theirs)
+      launch_rigid(s, {0, wl_nrest});
+      bnd_sel = nullptr;
+      launch_io(s, n + 1, true, {0, Ns}); // receivers read u^{n+1} (C: shell and single-step tiles hold it); source into u^{n+2} (D)
+      ring_fill++; steps_done++;
+      if (op.timing) { hipEventRecord(ev.second, s); step_ev.push_back(ev); ev = get_ev(); hipEventRecord(ev.first, s); eva = get_ev(); hipEventRecord(eva.first, s); }
+      // ---- step n+2: the whole shell and the single-step tiles C, D -> E as ONE single step, every boundary node by the list kernel
+      // (node values: u^{n+1} in P0, u^{n+2} in P1 -> u^{n+3} into P2; branch state in place)
+      u0_src = C; u1 = D; u0 = E;
+      ub[0] = P2; ub[1] = P1; ub[2] = P0;
+      launch_shell(s);
+      if (op.timing) { hipEventRecord(eva.second, s); air_ev.push_back(eva); }
+      launch_rigid(s, {0, Nb});
+      launch_fd(s, {0, Nbl});
+      launch_io(s, n + 2, true, {0, Ns});
+      ring_fill++; steps_done++;
+      ub[0] = P0; ub[1] = P2; ub[2] = P1; // (newest in ub[1], the one before in ub[2], ub[0] free: the single steps' convention)
+      u0_src = nullptr; u0 = D; u1 = E; bufD = A; bufE = B; // bufC stays the u^{n+1} grid ...
+      tb3_pick();                                           // ... on the placed cycle; off it: back towards it
+      if (op.timing) { hipEventRecord(ev.second, s); step_ev.push_back(ev); }
       HIPCHK(hipGetLastError());
       if (ring_fill == ring_depth) return flush();
       return PF_OK;
@@ -1378,8 +1537,8 @@ template <typename Real> struct Engine : EngineBase {
       const float scale = sampled ? (float)(1.0 / tb_sample_frac) : 1.f; // sampled times are reported as whole-launch equivalents
       auto time_fwd = [&](Real *A, Real *B, Real *C, Real *D) -> float {
          hipEventRecord(e0, s_main);
-         launch_tb2(s_main, A, B, C, D, true);
-         launch_tb2(s_main, A, B, C, D, true);
+         launch_probe(s_main, A, B, C, D, true);
+         launch_probe(s_main, A, B, C, D, true);
          hipEventRecord(e1, s_main);
          hipEventSynchronize(e1);
          float ms = 0;
@@ -1387,7 +1546,7 @@ template <typename Real> struct Engine : EngineBase {
          return ms / 2 * scale;
       };
       auto grid = [&](int i, Real *fallback) { return i >= 0 ? pool[i] : fallback; };
-      for (int i = 0; i < 4; i++) launch_tb2(s_main, grid(first[0], u0), grid(first[1], u1), pool[first[2]], pool[first[3]]); // clocks up
+      for (int i = 0; i < 4; i++) launch_probe(s_main, grid(first[0], u0), grid(first[1], u1), pool[first[2]], pool[first[3]]); // clocks up
       struct Cand { int r[4]; float ms; };
       std::vector<Cand> cands;
       auto eval = [&](const int r[4]) {
@@ -1448,7 +1607,7 @@ template <typename Real> struct Engine : EngineBase {
             Real *A = grid(c.r[0], u0), *B = grid(c.r[1], u1), *C = pool[c.r[2]], *D = pool[c.r[3]];
             auto full = [&](Real *a, Real *b, Real *cc, Real *d) {
                hipEventRecord(e0, s_main);
-               launch_tb2(s_main, a, b, cc, d); launch_tb2(s_main, a, b, cc, d);
+               launch_probe(s_main, a, b, cc, d); launch_probe(s_main, a, b, cc, d);
                hipEventRecord(e1, s_main); hipEventSynchronize(e1);
                float ms = 0; hipEventElapsedTime(&ms, e0, e1);
                return ms / 2;
@@ -1561,12 +1720,15 @@ template <typename Real> struct Engine : EngineBase {
    }
    int sample_placement() {
       if (!tb2 || tb2_slab || !bufC || !bufD || (op.debug & 0x8000) || vbase == 41) return PF_OK;
-      int extra = 4;
-      extra = pool_extra(extra, 4);
+      int extra = tb3 ? 3 : 4;
+      extra = pool_extra(extra, tb3 ? 5 : 4);
       if (extra == 0 && !own_grids) return PF_OK;
       std::vector<Real *> pool;
       if (own_grids) { pool.push_back(u0); pool.push_back(u1); }
-      pool.push_back(bufC); pool.push_back(bufD);
+      if (tb3) { // (roles 2, 3 = the grids k_tb3 writes; the fifth grid is one more candidate)
+         if (!own_grids || !bufE) return PF_OK;
+         pool.push_back(bufD); pool.push_back(bufE); pool.push_back(bufC);
+      } else { pool.push_back(bufC); pool.push_back(bufD); }
       for (int i = 0; i < extra; i++) {
          Real *p = try_dzalloc<Real>(npad);
          if (!p) break; // no room for another candidate
@@ -1580,7 +1742,7 @@ template <typename Real> struct Engine : EngineBase {
       // rule).  For the 7-point kernel the fast level is known -- the compulsory bytes of a pair, 4 grids x cells, at
       // 5.5 TB/s -- so a search that ends well above it gets four more grids to choose from, twice at most.
       const float as_allocated = place_ms.empty() ? 0.f : place_ms[0];
-      for (int round = 0; round < 2 && !fcc && own_grids; round++) {
+      for (int round = 0; round < 2 && !fcc && !tb3 && own_grids; round++) {
          const float best = *std::min_element(place_ms.begin(), place_ms.end());
          const float target = (float)((double)tb_clean_cells * 4.0 * sizeof(Real) / 5.5e12 * 1e3);
          if (best <= 1.05f * target) break;
@@ -1597,8 +1759,17 @@ template <typename Real> struct Engine : EngineBase {
       }
       std::vector<Real *> keep;
       if (own_grids) { u0 = pool[w[0]]; u1 = pool[w[1]]; keep.push_back(u0); keep.push_back(u1); }
+      if (tb3) { // the four streams of k_tb3 are u0, u1 -> bufD, bufE; bufC (u^{n+1} of the shell and of a few tiles) is any other member
+         bufD = pool[w[2]]; bufE = pool[w[3]];
+         bufC = nullptr;
+         for (Real *g : pool)
+            if (g != u0 && g != u1 && g != bufD && g != bufE) { bufC = g; break; }
+         if (!bufC) return set_err(PF_ERR_STATE, "placement search: no fifth grid left"); // (the pool holds the engine's five)
+         keep.push_back(bufC); keep.push_back(bufD); keep.push_back(bufE);
+      } else {
       bufC = pool[w[2]]; bufD = pool[w[3]];
       keep.push_back(bufC); keep.push_back(bufD);
+      }
       for (Real *g : pool) {
          own_list.erase(std::remove(own_list.begin(), own_list.end(), g), own_list.end());
          if (std::find(keep.begin(), keep.end(), g) == keep.end()) hipFree(g);
@@ -1706,7 +1877,24 @@ template <typename Real> struct Engine : EngineBase {
       if (hipGetLastError() != hipSuccess) { lean = lean0; vg = vg0; }
       else if (tune_ms[1] < 0.97f * tune_ms[0]) { lean = false; vg = true; }
       else if (tune_ms[0] < 0.97f * tune_ms[1]) { lean = true; vg = false; }
-      if (tb2 && wl_on) {
+      if (tb3) {
+         // three steps per pass, the boundary pass included: the single steps get theirs added (fields and branch state are all zeros
+         // at creation and stay so)
+         u0_src = U0; u0 = scr;
+         const float tb = timed([&] { launch_rigid(s_main, {0, Nb}); });
+         u0_src = nullptr; u0 = U0;
+         tune_ms[0] += tb; tune_ms[1] += tb;
+         tune_ms[2] = (1.f / 3.f) * timed([&] {
+            bnd_sel = wl_rest;
+            u0_src = U0; u1 = U1; u0 = bufC; launch_dirty_tiles(s_main); launch_rigid(s_main, {0, wl_nrest});
+            launch_walls(s_main, s_main, U0, U1, bufC, bufD, ub[0], ub[1], ub[2]);
+            launch_tb3(s_main, U0, U1, bufC, bufD, bufE);
+            u0_src = U1; u1 = bufC; u0 = bufD; launch_dirty_tiles(s_main); launch_rigid(s_main, {0, wl_nrest});
+            bnd_sel = nullptr;
+            u0_src = bufC; u1 = bufD; u0 = bufE; launch_shell(s_main); launch_rigid(s_main, {0, Nb});
+            u0_src = nullptr; u0 = U0; u1 = U1;
+         });
+      } else if (tb2 && wl_on) {
          // wall regions: the pair then includes the boundary pass, so the single steps get theirs added (fields and branch state
          // are all zeros at creation and stay so)
          u0_src = U0; u0 = scr;
@@ -1731,21 +1919,13 @@ template <typename Real> struct Engine : EngineBase {
          });
       }
       if (tb2) {
-         if (!(tune_ms[2] < pair_margin * std::min(tune_ms[0], tune_ms[1]))) { // not worth it: drop the pair path and its two grids
-            tb2 = false;
-            free_walls();
-            for (Real *g : {bufC, bufD}) { own_list.erase(std::remove(own_list.begin(), own_list.end(), g), own_list.end()); hipFree(g); }
+         if (!(tune_ms[2] < pair_margin * std::min(tune_ms[0], tune_ms[1]))) { // not worth it: drop the blocked path and its extra grids
             if (scr == bufC) scr = nullptr;
-            bufC = bufD = nullptr;
-            if (zs_map) { hipFree(zs_map); zs_map = nullptr; }
-            if (zs_adj) { hipFree(zs_adj); zs_adj = nullptr; }
-            if (zs_li) { hipFree(zs_li); zs_li = nullptr; }
-            if (zs_rest) { hipFree(zs_rest); zs_rest = nullptr; }
-            if (zs_fd) { hipFree(zs_fd); zs_fd = nullptr; }
-            zs_mode = 0;
+            drop_blocking();
          } else {
             HIPCHK(hipMemsetAsync(bufC, 0, npad * sizeof(Real), s_main));
             HIPCHK(hipMemsetAsync(bufD, 0, npad * sizeof(Real), s_main));
+            if (bufE) HIPCHK(hipMemsetAsync(bufE, 0, npad * sizeof(Real), s_main));
          }
       }
       HIPCHK(hipDeviceSynchronize());
@@ -1761,7 +1941,38 @@ template <typename Real> struct Engine : EngineBase {
       return tp;
    }
    // two steps of the clean tiles
+   // three steps of the clean tiles: A = u^{n-1}, B = u^n -> D = u^{n+2}, E = u^{n+3}; C: where flagged tiles leave their u^{n+1} (null: nowhere)
+   void launch_tb3(hipStream_t s, const Real *A, const Real *B, Real *C, Real *D, Real *E, bool sample = false) {
+      if (tb_xr.empty() || tb_nclean <= 0) return;
+      pf::Tb2Params tp = tile_params();
+      tp.A = A; tp.B = B; tp.C = C; tp.D = D; tp.E = E;
+      sample = sample && tb_sample && tb_nsample > 0;
+      tp.tiles = sample ? tb_sample : tb_clean;
+      const dim3 g((uint32_t)(sample ? tb_nsample : tb_nclean)), b(64 * tb3_wt);
+      if (sg) {
+         if (tb2_probe) hipLaunchKernelGGL((pf::k_tb3<Real, tb3_r, tb3_wt, true, true>), g, b, 0, s, tp, a1, a2);
+         else hipLaunchKernelGGL((pf::k_tb3<Real, tb3_r, tb3_wt, true, false>), g, b, 0, s, tp, a1, a2);
+      } else {
+         if (tb2_probe) hipLaunchKernelGGL((pf::k_tb3<Real, tb3_r, tb3_wt, false, true>), g, b, 0, s, tp, a1, a2);
+         else hipLaunchKernelGGL((pf::k_tb3<Real, tb3_r, tb3_wt, false, false>), g, b, 0, s, tp, a1, a2);
+      }
+   }
+   // the blocked kernel as the creation-time measurements see it: its four streams (k_tb3: two grids read, two written)
+   void launch_probe(hipStream_t s, const Real *A, const Real *B, Real *C, Real *D, bool sample = false) {
+      if (tb3) launch_tb3(s, A, B, nullptr, C, D, sample);
+      else launch_tb2(s, A, B, C, D, sample);
+   }
    void launch_tb2(hipStream_t s, const Real *A, const Real *B, Real *C, Real *D, bool sample = false) {
+      if (tb3) { // a pair on the triples' tiles: k_tb3's two-step form (the last two steps of a run, Engine::run)
+         if (tb_xr.empty() || tb_nclean <= 0) return;
+         pf::Tb2Params tp = tile_params();
+         tp.A = A; tp.B = B; tp.C = C; tp.D = D; tp.E = nullptr;
+         tp.tiles = tb_clean;
+         const dim3 g((uint32_t)tb_nclean), b(64 * tb3_wt);
+         if (sg) hipLaunchKernelGGL((pf::k_tb3<Real, tb3_r, tb3_wt, true, false, 2>), g, b, 0, s, tp, a1, a2);
+         else hipLaunchKernelGGL((pf::k_tb3<Real, tb3_r, tb3_wt, false, false, 2>), g, b, 0, s, tp, a1, a2);
+         return;
+      }
       if (tb_xr.empty() || tb_nclean <= 0) return;
       pf::Tb2Params tp = tile_params();
       tp.A = A; tp.B = B; tp.C = C; tp.D = D;
@@ -1804,13 +2015,12 @@ template <typename Real> struct Engine : EngineBase {
       tp.tiles = tb_dirty; tp.mask = mask;
       tp.xsub = tb_ndirty <= 256 ? std::min(4, std::max(tb_chunk / 4, 1)) : 1; // few tiles: shorter marches, more workgroups
       const dim3 g((uint32_t)tb_ndirty * (uint32_t)tp.xsub), b(256);
-      if (fcc) { // (64-lane segments only, init_tb2; the narrower ones keep k_air_fcc over its own tiles)
-         if (tb_lw != 64 || (op.debug & 0x80000)) return;
-         const dim3 bf(64 * (fcc_wt - 2));
-         if (sg) { if (swz) hipLaunchKernelGGL((pf::k_tb1_fcc_tile<Real, 2, fcc_wt - 2, true, true>), g, bf, 0, s, tp, a1, a2);
-                   else hipLaunchKernelGGL((pf::k_tb1_fcc_tile<Real, 2, fcc_wt - 2, true, false>), g, bf, 0, s, tp, a1, a2); }
-         else { if (swz) hipLaunchKernelGGL((pf::k_tb1_fcc_tile<Real, 2, fcc_wt - 2, false, true>), g, bf, 0, s, tp, a1, a2);
-                else hipLaunchKernelGGL((pf::k_tb1_fcc_tile<Real, 2, fcc_wt - 2, false, false>), g, bf, 0, s, tp, a1, a2); }
+      if (fcc) return; // (13-point: k_air_fcc over its own tiling of the box's planes, sh_tiles)
+      if (tb3) { // k_tb3's tiles: 20 rows
+         static_assert(tb3_rows == 20, "k_tb1_tile<Real, 5, 4>: 20-row tiles");
+         constexpr int HL = pf::VecOf<Real>::V >= 3 ? 1 : 2; // (the tiles' column ranges are k_tb3's)
+         if (sg) hipLaunchKernelGGL((pf::k_tb1_tile<Real, 5, 4, 64, true, false, HL>), g, b, 0, s, tp, a1, a2);
+         else hipLaunchKernelGGL((pf::k_tb1_tile<Real, 5, 4, 64, false, false, HL>), g, b, 0, s, tp, a1, a2);
          return;
       }
       if (swz) {
@@ -2087,6 +2297,9 @@ template <typename Real> struct Engine : EngineBase {
       fp.nzt = lean_nzt;
       fp.nyt = (int)cdiv(Ny - 2, (int64_t)WY * R);
       fp.u0_src = u0_src; fp.yt0 = 0; fp.yt_split = -1; fp.yt_hi0 = 0;
+      // (row strips of a triple's third step: the strips' tiles reach into the box, whose u^{n+1} -- the step's old value -- is not in
+      // memory: those rows are left to k_tb3's own result)
+      if (lean_nyt >= 0 && tb3) { fp.skip_y0 = tby0; fp.skip_y1 = tby1; }
       if (lean_nyt >= 0) { // row strips: tiles [0, lean_nyt) and [lean_yt0, all) in units of this configuration's tile height
          const int all = fp.nyt, lo = std::min(lean_nyt, all), hi0 = std::max(std::min(lean_yt0, all), lo);
          fp.yt_split = lo; fp.yt_hi0 = hi0;
@@ -2339,7 +2552,14 @@ template <typename Real> struct Engine : EngineBase {
       for (int64_t n = n0; n < n0 + nsteps;) {
          int rc;
          // temporally blocked pairs come in twos, so that the state is back in the caller's two grids afterwards
-         if (tb2 && n + 4 <= n0 + nsteps && ring_fill + 4 <= ring_depth) {
+         if (tb3) tb3_pick(); // (single steps swap the state grids: the targets follow)
+         if (tb3 && n + 3 <= n0 + nsteps && ring_fill + 3 <= ring_depth) {
+            if ((rc = step_triple(n))) return rc;
+            n += 3;
+         } else if (tb3 && n + 2 <= n0 + nsteps && ring_fill + 2 <= ring_depth) {
+            if ((rc = step_pair(n))) return rc; // the last two steps of a run: a pair on the triples' tiles (k_tb3's two-step form)
+            n += 2;
+         } else if (tb2 && !tb3 && n + 4 <= n0 + nsteps && ring_fill + 4 <= ring_depth) {
             if ((rc = step_pair(n))) return rc;
             if ((rc = step_pair(n + 2))) return rc;
             n += 4;
@@ -2569,6 +2789,7 @@ template <typename Real> struct Engine : EngineBase {
       }
       tb2_ev.clear();
       tm.tb2_cells = tb_clean_cells;
+      tm.tb_steps_per_pass = tb3 ? 3 : ((tb2 || tb2_slab) ? 2 : 0);
       for (auto &p : step_ev) {
          float ms = 0;
          HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));

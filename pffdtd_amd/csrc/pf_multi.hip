@@ -75,7 +75,8 @@ int fail(const char *fmt, const char *a = "") {
 // along_z: the chain is cut along FILE Z instead (slab engines then store the grid with the x and z axes exchanged: Engine::swz)
 int partition(const pf_simdata *sd, int G, bool even, std::vector<int64_t> &cuts, bool along_z = false) {
    const int64_t Nx = along_z ? sd->Nz : sd->Nx; // planes along the cut axis
-   if (G < 1 || G >= Nx) return fail("need 1 <= number of slabs < Nx (gpu_engine.h:682)");
+   if (G < 1 || G >= Nx) return fail(along_z ? "need 1 <= number of slabs < Nz: this scene's chain is cut along file z (the reference: ngpus < Nx, gpu_engine.h:682)"
+                                             : "need 1 <= number of slabs < Nx (gpu_engine.h:682)");
    cuts.assign(G + 1, 0);
    cuts[G] = Nx;
    if (G == 1) return PF_OK;

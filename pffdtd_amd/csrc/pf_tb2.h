@@ -22,6 +22,7 @@ struct Tb2Params {
                                   // geometry: the clean tiles for k_tb2_reg, the others for k_tb1_tile)
    const uint8_t *mask;           // k_tb1_tile: the engine's skip-mask
    int32_t xsub;                  // k_tb1_tile: > 1: that many workgroups share a tile, each marching a piece of its x chunk
+   void *E;                       // k_tb3 (pf_tb3.h): u^{n+3}; C = scratch for the u^{n+1} of flagged tiles, D = u^{n+2}
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -572,7 +573,8 @@ template <typename Real> void launch_tb2_fcc(hipStream_t s, const Tb2Params &tp,
 // Cells whose skip-mask bit is set (boundary nodes) are not written: the boundary pass writes them afterwards.
 // Inside the box of tiles there are no ghost cells and no ABC cells, so none of that is handled here.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename Real, int R, int WY, int LW = 64, bool SG = false, bool SWZ = false>
+// HL: halo lanes per side of a row segment (1; 2 for the fp64 tiles of k_tb3, whose three stages need three halo cells)
+template <typename Real, int R, int WY, int LW = 64, bool SG = false, bool SWZ = false, int HL = 1>
 __global__ __launch_bounds__(64 * WY) void k_tb1_tile(Tb2Params tp, Real a1, Real a2) {
    typedef typename VecOf<Real>::type vec;
    static_assert(LW == 64 || LW == 32 || LW == 16, "row segments are 64, 32 or 16 lanes wide");
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(64 * WY) void k_tb1_tile(Tb2Params tp, Real a1, Rea
    const int zt = t % tp.nzt, yt = (t / tp.nzt) % tp.nyt, xc = t / (tp.nzt * tp.nyt);
    const int wlane = threadIdx.x & 63, w = threadIdx.x >> 6;
    const int lane = wlane % LW, sub = wlane / LW;
-   const int ze0 = tp.z_begin - V + zt * (W - 2 * V);
+   const int ze0 = tp.z_begin - HL * V + zt * (W - 2 * HL * V);
    const int yo = tp.y_begin + ((yt * WY + w) * NSUB + sub) * R;
    const int xs0 = tp.x_begin + xc * tp.chunk, xe0 = min(xs0 + tp.chunk, tp.x_end);
    const int plen = (xe0 - xs0 + (int)nsplit - 1) / (int)nsplit;
@@ -597,7 +599,7 @@ __global__ __launch_bounds__(64 * WY) void k_tb1_tile(Tb2Params tp, Real a1, Rea
 #pragma unroll
    for (int i = 0; i < R + 2; i++) off[i] = (int64_t)min(max(yo - 1 + i, 0), tp.Ny - 1) * P + zc;
    const int z_end = tp.z_end ? tp.z_end : tp.Nz - tp.z_begin, y_end = tp.y_end ? tp.y_end : tp.Ny - tp.y_begin;
-   const bool core_col = (lane >= 1 && lane <= LW - 2) && (ze0 + lane * V + V - 1 < z_end);
+   const bool core_col = (lane >= HL && lane <= LW - 1 - HL) && (ze0 + lane * V + V - 1 < z_end);
    bool core_row[R];
 #pragma unroll
    for (int r = 0; r < R; r++) core_row[r] = (yo + r < y_end);
@@ -647,88 +649,6 @@ __global__ __launch_bounds__(64 * WY) void k_tb1_tile(Tb2Params tp, Real a1, Rea
       for (int r = 0; r < R; r++) Bp[r] = Bc[r + 1];
 #pragma unroll
       for (int i = 0; i < R + 2; i++) Bc[i] = Bn[i];
-   }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// k_tb1_fcc_tile -- ONE 13-point air update of the tiles the 13-point pair kernels must leave alone (a boundary node or a source
-// within one cell of their core), with the pair kernels' tile geometry (64-lane segments, WY waves x R rows = the rows of a
-// k_tb2_fcc_w tile), out of place: A = u^{n-1}, B = u^n -> C = u^{n+1}.  Cells whose skip-mask bit is set (boundary nodes) are
-// not written.  Inside the box of tiles there are no ghost cells and no ABC cells.  (Until round 4 these tiles were stepped by
-// k_air_fcc over ITS tiling of the planes, 16 rows x 256 columns: every such tile that touched a dirty tile was stepped whole,
-// 40-45 % of a room's cells for the 28 % that needed it.)
-// ---------------------------------------------------------------------------------------------------------------
-template <typename Real, int R, int WY, bool SG = false, bool SWZ = false>
-__global__ __launch_bounds__(64 * WY) void k_tb1_fcc_tile(Tb2Params tp, Real a1, Real a2) {
-   typedef typename VecOf<Real>::type vec;
-   constexpr int V = VecOf<Real>::V, W = 64 * V;
-   const uint32_t nsplit = tp.xsub > 1 ? (uint32_t)tp.xsub : 1u, tb = blockIdx.x / nsplit, piece = blockIdx.x % nsplit;
-   const uint32_t t = tp.tiles ? (uint32_t)tp.tiles[tb] : tb;
-   const int zt = t % tp.nzt, yt = (t / tp.nzt) % tp.nyt, xc = t / (tp.nzt * tp.nyt);
-   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-   const int ze0 = tp.z_begin - V + zt * (W - 2 * V);
-   const int yo = tp.y_begin + (yt * WY + w) * R;
-   const int xs0 = tp.x_begin + xc * tp.chunk, xe0 = min(xs0 + tp.chunk, tp.x_end);
-   const int plen = (xe0 - xs0 + (int)nsplit - 1) / (int)nsplit;
-   const int xs = xs0 + (int)piece * plen, xe = min(xs + plen, xe0);
-   if (xs >= xe) return;
-   const int P = tp.P;
-   const int64_t plane = tp.plane;
-   const int zc = min(max(ze0 + lane * V, 0), P - V);
-   uint32_t off[R + 2];                                       // rows yo-1 .. yo+R
-#pragma unroll
-   for (int i = 0; i < R + 2; i++) off[i] = (uint32_t)min(max(yo - 1 + i, 0), tp.Ny - 1) * (uint32_t)P + (uint32_t)zc;
-   const int z_end = tp.z_end ? tp.z_end : tp.Nz - tp.z_begin, y_end = tp.y_end ? tp.y_end : tp.Ny - tp.y_begin;
-   const bool core_col = (lane >= 1 && lane <= 62) && (ze0 + lane * V + V - 1 < z_end);
-   bool core_row[R];
-#pragma unroll
-   for (int r = 0; r < R; r++) core_row[r] = (yo + r < y_end);
-   auto loadB = [&](int x, vec *d) {
-      const Real *pl = (const Real *)tp.B + (int64_t)x * plane;
-#pragma unroll
-      for (int i = 0; i < R + 2; i++) d[i] = *(const vec *)(pl + off[i]);
-   };
-   vec Bp[R + 2], Bc[R + 2], Bn[R + 2];
-   loadB(xs - 1, Bp);
-   loadB(xs, Bc);
-   for (int x = xs; x < xe; x++) {
-      loadB(x + 1, Bn);
-      const Real *pa = (const Real *)tp.A + (int64_t)x * plane;
-      Real *pc = (Real *)tp.C + (int64_t)x * plane;
-      const uint8_t *pm = tp.mask + (((int64_t)x * plane) >> 3);
-#pragma unroll
-      for (int r = 0; r < R; r++) {
-         const int j = r + 1;
-         const vec old = __builtin_nontemporal_load((const vec *)(pa + off[j]));
-         const uint32_t bits = (uint32_t)pm[off[j] >> 3] >> (uint32_t)(off[j] & 7);
-         const vec &c = Bc[j], &cU = Bc[j + 1], &cD = Bc[j - 1], &nU = Bn[j + 1], &nC = Bn[j], &nD = Bn[j - 1], &pU = Bp[j + 1], &pC = Bp[j], &pD = Bp[j - 1];
-         const Real cUm = lane_from_lower<true>(cU[V - 1]), cUp = lane_from_upper<true>(cU[0]);
-         const Real cDm = lane_from_lower<true>(cD[V - 1]), cDp = lane_from_upper<true>(cD[0]);
-         const Real nCm = lane_from_lower<true>(nC[V - 1]), nCp = lane_from_upper<true>(nC[0]);
-         const Real pCm = lane_from_lower<true>(pC[V - 1]), pCp = lane_from_upper<true>(pC[0]);
-         vec o;
-#pragma unroll
-         for (int i = 0; i < V; i++) {
-            const int im = i > 0 ? i - 1 : 0, ip = i < V - 1 ? i + 1 : V - 1;
-            const Real S[12] = {nU[i], pD[i], (i == V - 1) ? cUp : cU[ip], (i == 0) ? cDm : cD[im],
-                                (i == V - 1) ? nCp : nC[ip], (i == 0) ? pCm : pC[im], nD[i], pU[i],
-                                (i == 0) ? cUm : cU[im], (i == V - 1) ? cDp : cD[ip], (i == 0) ? nCm : nC[im], (i == V - 1) ? pCp : pC[ip]};
-            Real nb[12];
-#pragma unroll
-            for (int k = 0; k < 12; k++) nb[k] = S[FccOrder<SWZ>::p[k]];
-            o[i] = upd13<SG>(a1, a2, c[i], old[i], nb);
-         }
-         if (core_col && core_row[r]) {
-            if ((bits & ((1u << V) - 1u)) == 0u) __builtin_nontemporal_store(o, (vec *)(pc + off[j]));
-            else {
-#pragma unroll
-               for (int i = 0; i < V; i++)
-                  if (!((bits >> i) & 1u)) pc[off[j] + i] = o[i];
-            }
-         }
-      }
-#pragma unroll
-      for (int i = 0; i < R + 2; i++) { Bp[i] = Bc[i]; Bc[i] = Bn[i]; }
    }
 }
 

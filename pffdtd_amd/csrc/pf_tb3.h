@@ -1,28 +1,48 @@
-// pf_tb3_probe.h -- research probe (round 5, tools/tb3_probe.py): THREE leap-frog steps of the pure 7-point air update per pass
-// over a boundary-free box.  Reads A = u^{n-1}, B = u^n; writes D = u^{n+2}, E = u^{n+3}; u^{n+1} never leaves the chip:
-// 16 bytes of compulsory traffic per cell and THREE steps (k_tb2_reg: per two).  Not part of libpffdtd_hip.so.
+// pf_tb3.h -- temporal blocking, three steps per pass (round 5): k_tb3 produces u^{n+2} and u^{n+3} of the boundary-free box of a
+// 7-point room from u^{n-1} and u^n in ONE pass; u^{n+1} never leaves the chip.  16 bytes of compulsory traffic per cell and
+// THREE steps (k_tb2_reg: per two steps; a single-step kernel: 12 per step).  On the product path: Engine::step_triple.
 //
-// Tiling: a workgroup = WT waves stacked in y, each owning R rows x 256 columns (64 lanes x 16 B; lanes 0 / 63 are z halo, as in
-// k_tb2_reg: 248 core columns), marching x.  Stage 1 gives u^{n+1} on all WT*R rows of the tile, stage 2 u^{n+2} on WT*R - 2,
-// stage 3 u^{n+3} on WT*R - 4: tiles overlap by 4 rows.  The rows a wave needs from its neighbours (one above, one below, of the
-// u^n plane that becomes the centre plane next turn and of the u^{n+1} / u^{n+2} planes just computed) travel through LDS: every
-// wave publishes its first and last row of the three planes, ONE barrier per plane, double-buffered (96 KB at WT = 8).  The two
-// outermost u^n halo rows of a tile have no owner in the workgroup and are loaded by the edge waves, one turn ahead.
+// Tiling: a workgroup = WT waves stacked in y, each owning R rows x 64 lanes x 16 B (the outermost lanes are z halo -- one 4-cell
+// lane per side in fp32, two 2-cell lanes in fp64: 248 / 120 core columns), marching x.  Stage 1 gives u^{n+1} on all WT*R rows of the tile, stage 2 u^{n+2} on
+// WT*R - 2, stage 3 u^{n+3} on WT*R - 4: tiles overlap by 4 rows (R = 3, WT = 8: 20 core rows of 24).  The rows a wave needs from its
+// neighbours (one above, one below, of the u^n plane that becomes the centre plane next turn and of the u^{n+1} / u^{n+2} planes
+// just computed) travel through LDS: every wave publishes its first and last row of the three planes, ONE barrier per plane,
+// double-buffered (96 KB at WT = 8: one workgroup per CU, two waves per SIMD).  The two outermost u^n halo rows of a tile have
+// no owner in the workgroup and are loaded by the edge waves, a plane ahead.
 // Turn x1: stage 1 -> u^{n+1}(x1) from u^n(x1-1, x1, x1+1), u^{n-1}(x1); stage 2 -> u^{n+2}(x1-1) from u^{n+1}(x1-2, x1-1, x1),
 // u^n(x1-1); stage 3 -> u^{n+3}(x1-2) from u^{n+2}(x1-3, x1-2, x1-1), u^{n+1}(x1-2).  A chunk [xs, xe) takes turns xs-2 .. xe+1.
+// The kernel computes u^{n+1} two cells and u^{n+2} one cell beyond the box: everything within THREE cells of the box must be a
+// plain air update (Engine::init_tb2 keeps the box three cells away from boundary nodes, the ABC shell and sources).
+// Tiles flagged in the tile list (bit 31: a neighbour of a tile that steps singly) also store their u^{n+1} -- into C, a scratch
+// grid --, which the single-step tiles' second step reads.
+// Measured on MI355X, 1024^3 fp32 (tools/tb3_probe.py): 3.28-3.30 ms per launch = 1.10 ms per step against 1.53 (k_tb2_reg on
+// placed grids) -- 5.0 TB/s of compulsory traffic.
 #pragma once
 #include "pf_tb2.h"
 
 namespace pf {
 
-template <int R, int WT>
-__global__ __launch_bounds__(64 * WT) void k_tb3_lds(Tb2Params tp, void *Ev, float a1, float a2) {
-   typedef f32x4 vec;
-   constexpr int V = 4, W = 256, TRO = WT * R - 4;
-   __shared__ __attribute__((aligned(16))) float sH[2][3][WT][2][W];
+constexpr uint32_t TB3_RIM = 0x80000000u; // tile-list flag: store u^{n+1} too
+
+// PROBE: the same code under another name, for the creation-time measurements (as k_tb2_reg's)
+// NS = 2: the same tiles, TWO steps -- stages 1 and 2 only, u^{n+1} stored into C by every tile, u^{n+2} into D: what steps the
+// last two steps of a run whose length is no multiple of three (Engine::run), with the triples' tile lists and wall regions.
+template <typename Real, int R, int WT, bool SG = false, bool PROBE = false, int NS = 3>
+__global__ __launch_bounds__(64 * WT) void k_tb3(Tb2Params tp, Real a1, Real a2) {
+   typedef typename VecOf<Real>::type vec;
+   // z halo: a stage loses one cell at each end of a row segment, so three stages need THREE halo cells per side: one 4-cell lane
+   // in fp32, two 2-cell lanes in fp64 (k_tb2_reg: two stages, one lane either way)
+   constexpr int V = VecOf<Real>::V, W = 64 * V, TRO = WT * R - 4, HL = V >= 3 ? 1 : 2;
+   __shared__ __attribute__((aligned(16))) Real sH[2][3][WT][2][W];
    uint32_t b = blockIdx.x;
    int zt, yt, xc;
-   if (tp.band) {
+   bool rim = false;
+   if (tp.tiles) {
+      const uint32_t t = (uint32_t)tp.tiles[b];
+      rim = (t & TB3_RIM) != 0u && tp.C != nullptr;
+      b = t & ~TB3_RIM;
+      zt = b % tp.nzt; yt = (b / tp.nzt) % tp.nyt; xc = b / (tp.nzt * tp.nyt);
+   } else if (tp.band) {
       const uint32_t T = (uint32_t)tp.nzt * tp.nyt, Tp = (T + 7) / 8;
       xc = b / (8 * Tp);
       const uint32_t r = b % (8 * Tp), j = (r % 8) * Tp + r / 8;
@@ -30,7 +50,7 @@ __global__ __launch_bounds__(64 * WT) void k_tb3_lds(Tb2Params tp, void *Ev, flo
       zt = j % tp.nzt; yt = j / tp.nzt;
    } else { zt = b % tp.nzt; yt = (b / tp.nzt) % tp.nyt; xc = b / (tp.nzt * tp.nyt); }
    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-   const int ze0 = tp.z_begin - V + zt * (W - 2 * V);
+   const int ze0 = tp.z_begin - HL * V + zt * (W - 2 * HL * V);
    const int y0 = tp.y_begin - 2 + yt * TRO, yo = y0 + w * R;
    const int xs = tp.x_begin + xc * tp.chunk, xe = min(xs + tp.chunk, tp.x_end);
    const int P = tp.P;
@@ -42,26 +62,26 @@ __global__ __launch_bounds__(64 * WT) void k_tb3_lds(Tb2Params tp, void *Ev, flo
    const bool edge_lo = w == 0, edge_hi = w == WT - 1;
    const uint32_t offh = (uint32_t)min(max(edge_lo ? yo - 1 : yo + R, 0), tp.Ny - 1) * (uint32_t)P + (uint32_t)zc; // the tile's outer u^n halo row (edge waves)
    const int z_end = tp.z_end ? tp.z_end : tp.Nz - tp.z_begin, y_end = tp.y_end ? tp.y_end : tp.Ny - tp.y_begin;
-   const bool core_col = (lane >= 1 && lane <= 62) && (ze0 + lane * V + V - 1 < z_end);
+   const bool core_col = (lane >= HL && lane <= 63 - HL) && (ze0 + lane * V + V - 1 < z_end);
    bool ok[R];
 #pragma unroll
    for (int r = 0; r < R; r++) ok[r] = core_col && (w * R + r >= 2) && (w * R + r <= WT * R - 3) && (yo + r < y_end);
-   const float *A = (const float *)tp.A, *B = (const float *)tp.B;
-   float *D = (float *)tp.D, *E = (float *)Ev;
+   const Real *A = (const Real *)tp.A, *B = (const Real *)tp.B;
+   Real *C = (Real *)tp.C, *D = (Real *)tp.D, *E = (Real *)tp.E;
    auto stencil = [&](const vec &c, const vec &xp, const vec &xm, const vec &yp, const vec &ym, const vec &old) {
-      const float lf = lane_from_lower<true>(c[V - 1]);
-      const float rt = lane_from_upper<true>(c[0]);
+      const Real lf = lane_from_lower<true>(c[V - 1]);
+      const Real rt = lane_from_upper<true>(c[0]);
       vec o;
 #pragma unroll
       for (int i = 0; i < V; i++) {
-         const float zp = (i == V - 1) ? rt : c[i < V - 1 ? i + 1 : V - 1];
-         const float zm = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
-         o[i] = upd7<false>(a1, a2, c[i], old[i], xp[i], xm[i], yp[i], ym[i], zp, zm);
+         const Real zp = (i == V - 1) ? rt : c[i < V - 1 ? i + 1 : V - 1];
+         const Real zm = (i == 0) ? lf : c[i > 0 ? i - 1 : 0];
+         o[i] = upd7<SG>(a1, a2, c[i], old[i], xp[i], xm[i], yp[i], ym[i], zp, zm);
       }
       return o;
    };
-   auto loadrows = [&](const float *g, int x, vec *d) {
-      const float *pl = g + (int64_t)x * plane;
+   auto loadrows = [&](const Real *g, int x, vec *d) {
+      const Real *pl = g + (int64_t)x * plane;
 #pragma unroll
       for (int r = 0; r < R; r++) d[r] = *(const vec *)(pl + off[r]);
    };
@@ -92,6 +112,12 @@ __global__ __launch_bounds__(64 * WT) void k_tb3_lds(Tb2Params tp, void *Ev, flo
       // stage 1: u^{n+1}(x1)
 #pragma unroll
       for (int r = 0; r < R; r++) V1n[r] = stencil(Bc[r + 1], Bn[r], Bm[r], Bc[r + 2], Bc[r], Ac[r]);
+      if ((NS == 2 || rim) && x1 >= xs && x1 < xe) { // a neighbour of a single-step tile (or the two-step form): its u^{n+1} is needed in memory
+         Real *pc = C + (int64_t)x1 * plane;
+#pragma unroll
+         for (int r = 0; r < R; r++)
+            if (ok[r]) __builtin_nontemporal_store(V1n[r], (vec *)(pc + off[r]));
+      }
       // stage 2: u^{n+2}(x1-1); its old value is u^n(x1-1)
 #pragma unroll
       for (int r = 0; r < R; r++) V2n[r] = stencil(V1c[r + 1], V1n[r], V1m[r], V1c[r + 2], V1c[r], Bm[r]);
@@ -102,8 +128,8 @@ __global__ __launch_bounds__(64 * WT) void k_tb3_lds(Tb2Params tp, void *Ev, flo
       loadrows(A, xa, Anew);
       if (edge_lo || edge_hi) Bhnew = *(const vec *)(B + (int64_t)xb * plane + offh);
       // stage 3: u^{n+3}(x1-2); its old value is u^{n+1}(x1-2)
-      if (x1 - 2 >= xs && x1 - 2 < xe) {
-         float *pe = E + (int64_t)(x1 - 2) * plane;
+      if (NS == 3 && x1 - 2 >= xs && x1 - 2 < xe) {
+         Real *pe = E + (int64_t)(x1 - 2) * plane;
 #pragma unroll
          for (int r = 0; r < R; r++) {
             const vec o = stencil(V2c[r + 1], V2n[r], V2m[r], V2c[r + 2], V2c[r], V1m[r]);
@@ -111,7 +137,7 @@ __global__ __launch_bounds__(64 * WT) void k_tb3_lds(Tb2Params tp, void *Ev, flo
          }
       }
       if (x1 - 1 >= xs && x1 - 1 < xe) {
-         float *pd = D + (int64_t)(x1 - 1) * plane;
+         Real *pd = D + (int64_t)(x1 - 1) * plane;
 #pragma unroll
          for (int r = 0; r < R; r++)
             if (ok[r]) __builtin_nontemporal_store(V2n[r], (vec *)(pd + off[r]));
@@ -119,12 +145,12 @@ __global__ __launch_bounds__(64 * WT) void k_tb3_lds(Tb2Params tp, void *Ev, flo
       // publish the rows the neighbouring waves need next turn
       *(vec *)&sH[buf][0][w][0][lane * V] = Bn[0];  *(vec *)&sH[buf][0][w][1][lane * V] = Bn[R - 1];
       *(vec *)&sH[buf][1][w][0][lane * V] = V1n[0]; *(vec *)&sH[buf][1][w][1][lane * V] = V1n[R - 1];
-      *(vec *)&sH[buf][2][w][0][lane * V] = V2n[0]; *(vec *)&sH[buf][2][w][1][lane * V] = V2n[R - 1];
+      if (NS == 3) { *(vec *)&sH[buf][2][w][0][lane * V] = V2n[0]; *(vec *)&sH[buf][2][w][1][lane * V] = V2n[R - 1]; }
       __syncthreads();
       vec hB0, hB1, hV10 = vec{}, hV11 = vec{}, hV20 = vec{}, hV21 = vec{};
-      if (!edge_lo) { hB0 = *(const vec *)&sH[buf][0][w - 1][1][lane * V]; hV10 = *(const vec *)&sH[buf][1][w - 1][1][lane * V]; hV20 = *(const vec *)&sH[buf][2][w - 1][1][lane * V]; }
+      if (!edge_lo) { hB0 = *(const vec *)&sH[buf][0][w - 1][1][lane * V]; hV10 = *(const vec *)&sH[buf][1][w - 1][1][lane * V]; if (NS == 3) hV20 = *(const vec *)&sH[buf][2][w - 1][1][lane * V]; }
       else hB0 = BhN;
-      if (!edge_hi) { hB1 = *(const vec *)&sH[buf][0][w + 1][0][lane * V]; hV11 = *(const vec *)&sH[buf][1][w + 1][0][lane * V]; hV21 = *(const vec *)&sH[buf][2][w + 1][0][lane * V]; }
+      if (!edge_hi) { hB1 = *(const vec *)&sH[buf][0][w + 1][0][lane * V]; hV11 = *(const vec *)&sH[buf][1][w + 1][0][lane * V]; if (NS == 3) hV21 = *(const vec *)&sH[buf][2][w + 1][0][lane * V]; }
       else hB1 = BhN;
       // rotate
 #pragma unroll

@@ -111,10 +111,11 @@ def run_devices(a, devices):
     """`--gpus N` / `--devices`: the C library's chain object in this process (what pf_run_sim_devices does inside)"""
     print(f"--Date and time: {time.ctime()}")
     sd = sim_data.SimData.from_folder(Path(a.data_dir), a.precision, build_mask=False)
-    if len(devices) >= sd.Nx:
-        raise SystemExit(f"need ngpus < Nx (got {len(devices)}, Nx={sd.Nx})")  # gpu_engine.h:682
     sd.scale_input()
-    m = engine.HipMulti(sd, devices, timing=1, verify_exchange=2)
+    try:  # (the library checks the slab count against the axis it actually cuts -- file x, or file z for rooms; gpu_engine.h:682)
+        m = engine.HipMulti(sd, devices, timing=1, verify_exchange=2)
+    except engine.PfError as e:
+        raise SystemExit(f"cannot run on {len(devices)} slabs: {e}")
     info = m.info()
     spans = [(m.slab(g)["x0"], m.slab(g)["x1"]) for g in range(m.nslabs)]
     print(f"--{len(devices)} slabs on devices {devices}, cut along file {'z' if info['cut_along_z'] else 'x'}: planes {spans}, ghost planes by {info['transport_name']}")

@@ -430,3 +430,78 @@ def test_blocked_pairs_on_a_grid_stored_with_exchanged_axes(fcc, numerics, prec)
         assert (tm["tb2_launches"] > 0) == (variant == 40), (variant, tm)
         assert np.array_equal(out, ref_out), variant
         assert np.array_equal(g[1][1:-1, 1:-1, 1:-1], ref_u1[1:-1, 1:-1, 1:-1]), variant
+
+
+def test_pairs_with_wall_regions_report_their_air_time():
+    """pf_timing.air_ms_total (the CLI's 'Air update' line and the --progress fields) with wall regions on: the alike blocks' launches
+    and the box kernel are recorded -- not 0, not more than the steps took."""
+    sim = scene(None, Nt=41, n=(38, 66, 280))
+    out, _, tm = run(sim, 40)
+    assert tm["tb2_launches"] > 0 and sum(tm["wall_blocks"]) > 0
+    assert tm["steps"] == 41 and tm["air_launches"] > 0
+    assert 0.2 * tm["step_ms_total"] < tm["air_ms_total"] <= tm["step_ms_total"], tm
+
+
+# ---- round 5: three steps per pass (k_tb3, Engine::step_triple) ---------------------------------------------------------------
+def triple_scene(Nt=40, n=(48, 100, 280), wall=3, **kw):
+    """a box room whose 20-row tiles stay partly clean: the source dirties the middle tile, one receiver the last one, the other
+    receivers sit in the wall layers (the shell) and next to the source (receivers are the 8 corner nodes of a cell: p .. p+1)"""
+    src = [n[0] // 2, n[1] // 2, n[2] // 2]
+    lo, hi = wall + 1, [d - wall - 3 for d in n]
+    rcv = [[src[0] + 2, src[1] - 1, src[2] + 3], [lo, src[1] - 3, src[2] + 2], [hi[0], src[1] + 2, src[2] - 5], [src[0], hi[1], src[2] + 4],
+           [src[0] + 3, n[1] - 12, src[2] - 3], [lo + 1, lo, src[2] + 1], [src[0] - 2, src[1] + 1, hi[2]]]
+    return synth.shoebox(*n, Nt=Nt, Nm=2, Mb=[11, 3], src=src, rcv=rcv, wall=wall, **kw)
+
+
+@pytest.mark.parametrize("prec", ["single", "double"])
+@pytest.mark.parametrize("numerics", [engine.PF_NUM_CPU_EXACT, engine.PF_NUM_GPU_SAFEGUARDED], ids=["exact", "safeguarded"])
+def test_three_steps_per_pass_give_the_oracles_bits(prec, numerics):
+    """k_tb3 advances the box by three steps per pass (u^{n+1} never stored); the shell takes two steps as wall regions and one single
+    step, the source's and a receiver's tiles three single steps, reading the u^{n+1} their flagged neighbours left behind.  Receivers
+    in the box, in the shell and in the wall layers equal the oracle's; whole fields the single-step engine's.  Step counts that mix
+    triples, single steps and ring flushes."""
+    sim = triple_scene(Nt=100)
+    sd = sim_data.SimData.from_sim(sim, prec)
+    sd.scale_input()
+    e = oracle.Engine(sd, safeguarded=numerics == engine.PF_NUM_GPU_SAFEGUARDED)
+    for k in range(sd.Nt):
+        e.step(k)
+    ref_out, ref_u1 = sd.u_out.copy(), e.grid(1).copy()
+    e.close()
+    assert (np.abs(ref_out[:-8]).max(axis=1) > 0).all()  # (all but the receiver in the far z wall layer: the random-field test covers that)
+    base_out, base_g, _ = run(sim, 25, prec=prec, numerics=numerics)
+    assert np.array_equal(base_out, ref_out)
+    for variant, chunk, dbg in ((40, 0, 0), (40, 7, 0), (40, 8, 0x4000000)):
+        out, g, tm = run(sim, variant, prec=prec, numerics=numerics, readout_chunk=chunk, debug=dbg)
+        assert tm["tb_steps_per_pass"] == 3 and tm["tb2_launches"] > 0 and sum(tm["wall_blocks"]) > 0, (variant, chunk, tm)
+        assert tm["tb2_dirty_tiles"] >= 2 and tm["steps"] == 100
+        assert np.array_equal(out, ref_out), (variant, chunk, hex(dbg))
+        assert np.array_equal(g[1][1:-1, 1:-1, 1:-1], ref_u1[1:-1, 1:-1, 1:-1]), (variant, chunk)
+        for a, b in zip(g, base_g):
+            assert np.array_equal(a[1:-1, 1:-1, 1:-1], b[1:-1, 1:-1, 1:-1]), (variant, chunk)
+    out, _, tm = run(sim, 40, prec=prec, numerics=numerics, debug=0x20000)  # never triples: the round-4 pairs
+    assert tm["tb_steps_per_pass"] == 2 and np.array_equal(out, ref_out)
+
+
+@pytest.mark.parametrize("n,wall", [((47, 101, 283), 3), ((50, 96, 280), 4), ((44, 90, 528), 3)], ids=["odd", "deep_walls", "two_tiles"])
+def test_three_steps_per_pass_from_random_fields(n, wall):
+    """every cell live from step 0 (seeded random u^{n-1}, u^n): ghost mirrors, ABC faces / edges / corners, both wall layers on
+    every face, odd sizes, a second column tile -- triples against the single-step engine, all cells, 11 steps (3 triples + 2)"""
+    sim = triple_scene(Nt=11, n=n, wall=wall)
+    rng = np.random.default_rng(29)
+    init = [(rng.standard_normal(n) * 1e-2).astype(np.float32) for _ in range(2)]
+    fields = {}
+    for variant in (25, 40):
+        sd = sim_data.SimData.from_sim(sim, "single", build_mask=False)
+        sd.scale_input()
+        eng = engine.HipEngine(sd, air_variant=variant, timing=True)
+        for k in (0, 1):
+            eng.set_grid(k, init[k])
+        eng.run(0, sd.Nt)
+        tm = eng.timing()
+        fields[variant] = (sd.u_out.copy(), eng.get_grid(0).copy(), eng.get_grid(1).copy())
+        eng.close()
+        if variant == 40:
+            assert tm["tb_steps_per_pass"] == 3 and tm["tb2_launches"] == 3, tm
+    for a, b in zip(fields[40], fields[25]):
+        assert np.array_equal(a if a.ndim == 2 else a[1:-1, 1:-1, 1:-1], b if b.ndim == 2 else b[1:-1, 1:-1, 1:-1])

@@ -19,7 +19,7 @@ double pf_membench(void *u0, void *u1, int64_t Nx, int64_t Ny, int64_t Nz, int32
 double pf_tb2_probe(const void *A, const void *B, void *C, void *D, int64_t Nx, int64_t Ny, int64_t Nz, double a1, double a2,
                     int32_t margin, int32_t tye, int32_t chunk, int32_t reps);
 
-/* ---- research probe (tools/tb3_probe.py): THREE fused steps, A=u^{n-1}, B=u^n -> D=u^{n+2}, E=u^{n+3} (pf_tb3_probe.h).
+/* ---- research probe (tools/tb3_probe.py): THREE fused steps, A=u^{n-1}, B=u^n -> D=u^{n+2}, E=u^{n+3} (k_tb3, pf_tb3.h).
  * variant = 100*R + WT (+10000: banded tile order).  Returns the average milliseconds per launch (<0 on error). */
 double pf_tb3_probe(const void *A, const void *B, void *D, void *E, int64_t Nx, int64_t Ny, int64_t Nz, double a1, double a2,
                     int32_t margin, int32_t variant, int32_t chunk, int32_t reps);

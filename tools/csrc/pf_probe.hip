@@ -6,7 +6,7 @@
 
 #include "pf_probe.h"
 #include "pf_probe_kernels.h"
-#include "pf_tb3_probe.h"
+#include "pf_tb3.h"
 
 namespace {
 std::string g_perr;
@@ -145,13 +145,13 @@ double pf_tb2_probe(const void *A, const void *B, void *C, void *D, int64_t Nx, 
 }
 
 
-// three fused steps (pf_tb3_probe.h): A = u^{n-1}, B = u^n -> D = u^{n+2}, E = u^{n+3} on the box [m, N-m)^3.  variant = 100*R + WT
+// three fused steps (the product kernel k_tb3, pf_tb3.h): A = u^{n-1}, B = u^n -> D = u^{n+2}, E = u^{n+3} on the box [m, N-m)^3.  variant = 100*R + WT
 // (+10000: banded tile order).  Returns the average milliseconds per launch (<0 on error).
 double pf_tb3_probe(const void *A, const void *B, void *D, void *E, int64_t Nx, int64_t Ny, int64_t Nz, double a1, double a2,
                     int32_t margin, int32_t variant, int32_t chunk, int32_t reps) {
    pf::Tb2Params tp{};
    const int64_t P = grid_pitch(Nz, 4);
-   tp.A = (const float *)A; tp.B = (const float *)B; tp.C = nullptr; tp.D = (float *)D;
+   tp.A = (const float *)A; tp.B = (const float *)B; tp.C = nullptr; tp.D = (float *)D; tp.E = E;
    tp.plane = Ny * P; tp.Nx = (int)Nx; tp.Ny = (int)Ny; tp.Nz = (int)Nz; tp.P = (int)P;
    if (margin < 4 || (margin % 4) != 0 || ((Nz - 2 * margin) % 4) != 0) { probe_err("tb3 probe: margin must be a multiple of 4 >= 4"); return -1.0; }
    tp.x_begin = margin; tp.x_end = (int)Nx - margin;
@@ -163,7 +163,7 @@ double pf_tb3_probe(const void *A, const void *B, void *D, void *E, int64_t Nx, 
    variant %= 10000;
    auto nblk = [&]() { const uint32_t T = (uint32_t)tp.nzt * tp.nyt; return tp.band ? 8 * ((T + 7) / 8) * (uint32_t)tp.nxc : T * (uint32_t)tp.nxc; };
    auto launch = [&]() {
-#define PF_TB3(r, wt) if (variant == 100 * r + wt) { tp.nyt = (int)cdiv(Ny - 2 * margin, wt * r - 4); hipLaunchKernelGGL((pf::k_tb3_lds<r, wt>), dim3(nblk()), dim3(64 * wt), 0, 0, tp, E, (float)a1, (float)a2); return true; }
+#define PF_TB3(r, wt) if (variant == 100 * r + wt) { tp.nyt = (int)cdiv(Ny - 2 * margin, wt * r - 4); hipLaunchKernelGGL((pf::k_tb3<float, r, wt>), dim3(nblk()), dim3(64 * wt), 0, 0, tp, (float)a1, (float)a2); return true; }
       PF_TB3(3, 8) PF_TB3(2, 8) PF_TB3(3, 4) PF_TB3(4, 4) PF_TB3(2, 12) PF_TB3(3, 6)
 #undef PF_TB3
       return false;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Research probe (round 5): THREE fused time steps per pass of the pure 7-point air update (tools/csrc/pf_tb3_probe.h) against
+"""Research probe (round 5): THREE fused time steps per pass of the pure 7-point air update (the product kernel k_tb3, pffdtd_amd/csrc/pf_tb3.h) against
 three passes of the production single-step kernel and against the production two-steps-per-pass kernel, on a free-field grid.
 Validates bit-equality on the box [m, N-m)^3 and times it.   usage: tb3_probe.py [n] [variants] [chunks]"""
 import functools
