@@ -331,7 +331,15 @@ template <typename Real> struct Engine : EngineBase {
    template <typename T> int dzalloc(T **dst, int64_t n) {
       *dst = nullptr;
       size_t bytes = std::max<int64_t>(n, 1) * sizeof(T);
-      HIPCHK(hipMalloc((void **)dst, bytes));
+      { // (a full device is the one failure a caller can act on: say how much was asked for and how much there was)
+         const hipError_t e = hipMalloc((void **)dst, bytes);
+         if (e != hipSuccess) {
+            size_t fr = 0, tot = 0;
+            (void)hipGetLastError();
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess) { fr = tot = 0; (void)hipGetLastError(); }
+            return set_err(PF_ERR_HIP, "HIP error %s allocating %zu bytes of engine state (%zu of %zu bytes free on device %d): %s", hipGetErrorName(e), bytes, fr, tot, op.device, hipGetErrorString(e));
+         }
+      }
       HIPCHK(hipMemset(*dst, 0, bytes));
       return PF_OK;
    }
@@ -1179,10 +1187,16 @@ template <typename Real> struct Engine : EngineBase {
       });
       int rc;
       free_walls(); // (a second call -- set_spares after place_grids -- must not leak the first one's tables)
-      if ((rc = upload(&wl_pen, pen.data(), npen))) { free_walls(); return rc; }
-      if ((rc = upload(&wl_rec, rec.data(), nrec))) { free_walls(); return rc; }
+      // Wall regions are an optimisation: when the device has no room for their tables and the second copy of the branch state, the
+      // engine keeps the single-step shell instead of failing (everything is allocated BEFORE the lossy arrays are re-ordered).
+      auto no_room = [&]() { free_walls(); (void)hipGetLastError(); g_err.clear(); if (vb) fprintf(stderr, "pffdtd_hip: no wall regions (no device memory for their tables)\n"); return PF_OK; };
+      vh1b = try_dzalloc<Real>(round_up(Nbl, 64) * PF_MMB);
+      gh1b = vh1b ? try_dzalloc<Real>(round_up(Nbl, 64) * PF_MMB) : nullptr;
+      if (!gh1b) return no_room();
+      if ((rc = upload(&wl_pen, pen.data(), npen))) return no_room();
+      if ((rc = upload(&wl_rec, rec.data(), nrec))) return no_room();
       wl_nrest = (int64_t)rest.size();
-      if ((rc = upload(&wl_rest, rest.data(), wl_nrest))) { free_walls(); return rc; }
+      if ((rc = upload(&wl_rest, rest.data(), wl_nrest))) return no_room();
       // the lossy arrays in the new order (state and node-value arrays are all zeros at creation)
       if (Nbl) {
          std::vector<int64_t> bl(Nbl), bl2(Nbl);
@@ -1198,8 +1212,6 @@ template <typename Real> struct Engine : EngineBase {
          for (int64_t nb = 0; nb < Nb; nb++) if (hl[nb] >= 0) hl[nb] = newli[hl[nb]];
          HIPCHK(hipMemcpy(d_lossy, hl.data(), Nb * sizeof(int32_t), hipMemcpyHostToDevice));
       }
-      if ((rc = dzalloc(&vh1b, round_up(Nbl, 64) * PF_MMB))) { free_walls(); return rc; }
-      if ((rc = dzalloc(&gh1b, round_up(Nbl, 64) * PF_MMB))) { free_walls(); return rc; }
       for (auto &g : wl_grp) g = WlGroup{};
       for (int i = 0; i < nregs; i++) {
          WlGroup &g = wl_grp[grp[i]];
@@ -1237,7 +1249,7 @@ template <typename Real> struct Engine : EngineBase {
       {
          std::vector<uint4> all;
          for (int q = 0; q < 12; q++) { wl_grp[q / 3].blk0[q % 3] = (uint32_t)all.size(); wl_grp[q / 3].nblk[q % 3] = (uint32_t)lists[q].size(); all.insert(all.end(), lists[q].begin(), lists[q].end()); }
-         if ((rc = upload(&wl_blk, all.data(), (int64_t)all.size()))) { free_walls(); return rc; }
+         if ((rc = upload(&wl_blk, all.data(), (int64_t)all.size()))) return no_room(); // (the lossy arrays are re-ordered by now: consistently, which any path accepts)
       }
       wl_on = true;
       if (getenv("PFFDTD_VERBOSE") && atoi(getenv("PFFDTD_VERBOSE")) > 0)
@@ -1372,7 +1384,8 @@ template <typename Real> struct Engine : EngineBase {
       launch_dirty_tiles(sw);
       bnd_sel = wl_rest; bs_vout = vh1b; bs_gout = gh1b;
       launch_rigid(sw, {0, wl_nrest});
-      launch_walls(s, sw, A, B, C, D, P0, P1, P2);
+      // (debug 0x10000, an experiment: the alike blocks too beside k_tb3 instead of before it)
+      launch_walls((beside && (op.debug & 0x10000)) ? s_edge : s, sw, A, B, C, D, P0, P1, P2);
       if (op.timing) hipEventRecord(evt.first, s);
       launch_tb3(s, A, B, C, D, E);
       if (op.timing) { hipEventRecord(evt.second, s); tb2_ev.push_back(evt); hipEventRecord(eva.second, s); air_ev.push_back(eva); }
@@ -1726,7 +1739,7 @@ template <typename Real> struct Engine : EngineBase {
       std::vector<Real *> pool;
       if (own_grids) { pool.push_back(u0); pool.push_back(u1); }
       if (tb3) { // (roles 2, 3 = the grids k_tb3 writes; the fifth grid is one more candidate)
-         if (!own_grids || !bufE) return PF_OK;
+         if (!bufE) return PF_OK;
          pool.push_back(bufD); pool.push_back(bufE); pool.push_back(bufC);
       } else { pool.push_back(bufC); pool.push_back(bufD); }
       for (int i = 0; i < extra; i++) {

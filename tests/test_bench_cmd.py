@@ -29,7 +29,7 @@ def test_plain_command_line_with_two_gpus(transport):
     res = _bench("--gpus", "2", "--steps", "6", "--warmup", "3", *extra)
     assert res["n_gpus"] == 2 and res["steps"] == 6 and res["warmup"] == 3
     assert res["value"] > 0 and res["metric"] == "Gvoxel-updates/s" and res["config"]["grid"] == [1024, 1024, 1024]
-    assert res["exchange_verified"] is True and res["exchange"]["checked_steps"] == 3 and res["exchange"]["nonzero_planes"]
+    assert res["exchange_verified"] is True and res["exchange"]["checked_steps"] == 2 and res["exchange"]["nonzero_planes"]
     assert ("rccl" in res["exchange"]["backend"]) == (transport == "rccl")
     assert len(res["slabs"]) == 2 and res["slabs"][0]["planes"][1] == res["slabs"][1]["planes"][0]
     assert res["roofline"]["kernel_ms_per_launch"] > 0
@@ -49,7 +49,7 @@ def test_plain_command_line_with_eight_virtual_gpus():
     """The driver's N = 8 command on this 1-GPU box: eight virtual slabs through the C chain, exchange checksummed."""
     res = _bench("--gpus", "8", "--steps", "6", "--warmup", "3", "--repeats", "2")
     assert res["n_gpus"] == 8 and len(res["slabs"]) == 8 and res["virtual_slabs"] is True
-    assert res["exchange_verified"] is True and res["exchange"]["checked_steps"] == 3 and res["exchange"]["nonzero_planes"]
+    assert res["exchange_verified"] is True and res["exchange"]["checked_steps"] == 2 and res["exchange"]["nonzero_planes"]
     assert [s["planes"][1] for s in res["slabs"][:-1]] == [s["planes"][0] for s in res["slabs"][1:]]
     assert res["slabs"][0]["planes"][0] == 0 and res["slabs"][-1]["planes"][1] == 1024 and res["value"] > 0
 

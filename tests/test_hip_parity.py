@@ -169,7 +169,11 @@ def test_exchanged_axes_set_grid_round_trip_and_refusals():
     assert eng.layout()[2] is False
     eng.close()
     with pytest.raises(engine.PfError, match="0x1000"):
-        engine.HipEngine(sd, debug=0x1000, air_variant=40)
+        engine.HipEngine(sd, debug=0x1000, energy=True)  # (the energy diagnostic's kernels know the file's storage order only)
+    eng = engine.HipEngine(sd, debug=0x1000, air_variant=40, timing=True)  # (pairs exist for exchanged axes since round 5; this grid has no room for a row segment: single steps)
+    eng.run(0, 4)
+    assert eng.layout()[2] is True and eng.timing()["tb2_launches"] == 0
+    eng.close()
 
 
 def test_rooms_with_large_surfaces_normal_to_file_z_are_stored_exchanged():

@@ -127,7 +127,7 @@ def test_blocked_steps_long_run():
     ref.scale_input()
     oracle.run_sim(ref)
     out, _, tm = run(sim, 40, readout_chunk=64)
-    assert tm["tb2_launches"] >= 140 and tm["steps"] == 301  # (one launch per pair: the source only dirties its own tiles)
+    assert tm["tb2_launches"] >= 95 and tm["steps"] == 301  # (one launch per pair or triple: the source only dirties its own tiles)
     assert np.array_equal(out, ref.u_out)
 
 
@@ -460,7 +460,7 @@ def test_three_steps_per_pass_give_the_oracles_bits(prec, numerics):
     step, the source's and a receiver's tiles three single steps, reading the u^{n+1} their flagged neighbours left behind.  Receivers
     in the box, in the shell and in the wall layers equal the oracle's; whole fields the single-step engine's.  Step counts that mix
     triples, single steps and ring flushes."""
-    sim = triple_scene(Nt=100)
+    sim = triple_scene(Nt=100, n=(48, 100, 280 if prec == "single" else 264))  # (column counts whose strips fit the wall regions' pencils)
     sd = sim_data.SimData.from_sim(sim, prec)
     sd.scale_input()
     e = oracle.Engine(sd, safeguarded=numerics == engine.PF_NUM_GPU_SAFEGUARDED)
@@ -483,10 +483,13 @@ def test_three_steps_per_pass_give_the_oracles_bits(prec, numerics):
     assert tm["tb_steps_per_pass"] == 2 and np.array_equal(out, ref_out)
 
 
-@pytest.mark.parametrize("n,wall", [((47, 101, 283), 3), ((50, 96, 280), 4), ((44, 90, 528), 3)], ids=["odd", "deep_walls", "two_tiles"])
-def test_three_steps_per_pass_from_random_fields(n, wall):
+@pytest.mark.parametrize("n,wall,triples", [((47, 101, 280), 3, True), ((50, 96, 280), 4, False), ((44, 90, 528), 3, True), ((47, 101, 283), 3, False)],
+                         ids=["odd", "deep_walls", "two_tiles", "strips_too_wide"])
+def test_three_steps_per_pass_from_random_fields(n, wall, triples):
     """every cell live from step 0 (seeded random u^{n-1}, u^n): ghost mirrors, ABC faces / edges / corners, both wall layers on
-    every face, odd sizes, a second column tile -- triples against the single-step engine, all cells, 11 steps (3 triples + 2)"""
+    every face, odd sizes, a second column tile -- triples against the single-step engine, all cells, 11 steps (3 triples + a pair
+    on the triples' tiles).  Walls four cells deep or strips too wide for the pencils: no wall regions for the triples' box, the
+    engine falls back to pairs (same bits)."""
     sim = triple_scene(Nt=11, n=n, wall=wall)
     rng = np.random.default_rng(29)
     init = [(rng.standard_normal(n) * 1e-2).astype(np.float32) for _ in range(2)]
@@ -502,6 +505,27 @@ def test_three_steps_per_pass_from_random_fields(n, wall):
         fields[variant] = (sd.u_out.copy(), eng.get_grid(0).copy(), eng.get_grid(1).copy())
         eng.close()
         if variant == 40:
-            assert tm["tb_steps_per_pass"] == 3 and tm["tb2_launches"] == 3, tm
+            assert tm["tb_steps_per_pass"] == (3 if triples else 2) and tm["tb2_launches"] == 4, tm  # (3 triples + a pair; pairs come in twos: 2 x 2 + 3 single steps)
     for a, b in zip(fields[40], fields[25]):
         assert np.array_equal(a if a.ndim == 2 else a[1:-1, 1:-1, 1:-1], b if b.ndim == 2 else b[1:-1, 1:-1, 1:-1])
+
+
+@pytest.mark.parametrize("prec", ["single", "double"])
+def test_three_steps_per_pass_with_geometry_inside_the_box(prec):
+    """a block standing in the room: its surface nodes live INSIDE the box of k_tb3 -- their tiles (grown by two cells) take three
+    single steps, the nodes three passes of the list kernel (first step beside the wall regions, branch state double-buffered
+    with theirs), the neighbouring tiles leave their u^{n+1} behind.  Receivers equal the oracle's, whole fields the single-step
+    engine's."""
+    n = (48, 100, 280 if prec == "single" else 264)
+    sim = triple_scene(Nt=61, n=n, blocks=((14, 18, 30, 40, 60, 130),))
+    ref = sim_data.SimData.from_sim(sim, prec)
+    ref.scale_input()
+    oracle.run_sim(ref)
+    assert np.abs(ref.u_out).max() > 0
+    _, base_g, _ = run(sim, 25, prec=prec)
+    for chunk in (0, 5):
+        out, g, tm = run(sim, 40, prec=prec, readout_chunk=chunk)
+        assert tm["tb_steps_per_pass"] == 3 and tm["tb2_launches"] > 0 and tm["tb2_dirty_tiles"] >= 3, tm
+        assert np.array_equal(out, ref.u_out), chunk
+        for a, b in zip(g, base_g):
+            assert np.array_equal(a[1:-1, 1:-1, 1:-1], b[1:-1, 1:-1, 1:-1]), chunk
