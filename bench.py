@@ -135,7 +135,7 @@ def roofline_block(args, sd, tm, K, real_bytes, interior_planes, interior_per_pl
         spp = int(tm.get("tb_steps_per_pass") or 2)  # steps a launch advances its cells by: 2 (pairs) or 3 (k_tb3)
         if spp == 3:
             sgt = "true" if getattr(args, "numerics", 0) == 2 else "false"  # (<..., PROBE = true> = creation-time probes)
-            kernel, inst = "k_tb3", f"pf::k_tb3<{T}, 3, 8, {sgt}, false>"
+            kernel, inst = "k_tb3", f"pf::k_tb3<{T}, 3, 8, {sgt}, false, 3>"
         elif args.fcc:
             sgt = "true" if getattr(args, "numerics", 0) == 2 else "false"
             old_kernel = bool(getattr(args, "debug", 0) & 0x40000) and sgt == "false"

@@ -143,6 +143,8 @@ typedef struct pf_opts {
                                   exchanged (pf_engine_layout), what rooms whose large surfaces are normal to z gain 11-15 % from;
                                   chosen automatically for such rooms */
 #define PF_MULTI_CUT_X      32 /* never (the reference's arrangement, gpu_engine.h:516-662) */
+#define PF_MULTI_NO_TRIPLES 64 /* slabs step in pairs at most (round 5: by default a slab whose wall regions fit steps THREE steps per
+                                  pass across three split-phase steps, pf_engine_place_grids5) */
 
 typedef struct pf_timing {
    double  air_ms_total;    /* sum of HIP-event durations of the air kernel launches */
@@ -210,7 +212,7 @@ int  pf_multi_create(pf_simdata *sd, int32_t nslabs, const int32_t *devices, con
 /* steps n0 .. n0+nsteps-1 on every slab; returns when all streams have drained and the receiver rows are in sd->u_out */
 int  pf_multi_run(pf_multi *m, int64_t n0, int64_t nsteps);
 int  pf_multi_get_info(pf_multi *m, pf_multi_info *info);
-/* slab g: owned global planes [x0, x1), device, whether it steps in temporally blocked pairs, and its engine (for
+/* slab g: owned global planes [x0, x1), device, whether it steps in temporally blocked pairs (1) or triples (3), and its engine (for
  * pf_engine_state_grids / pf_engine_timing between runs; do not step it directly) */
 int  pf_multi_get_slab(pf_multi *m, int32_t g, int64_t *x0, int64_t *x1, int32_t *device, int32_t *paired, pf_engine **engine);
 void pf_multi_destroy(pf_multi *m);
@@ -245,6 +247,11 @@ int  pf_engine_set_spares(pf_engine *e, void *grid2, void *grid3);
  * (pf_engine_set_grid, device writes) only afterwards; after pf_engine_set_grid the call is refused with PF_ERR_STATE.
  * No counterpart in the reference. */
 int  pf_engine_place_grids(pf_engine *e, void *const *pool, int32_t n, int32_t idx[4]);
+/* The same with room for TRIPLES (round 5): a slab engine offered n >= 5 grids whose wall regions fit steps three steps per pass
+ * across three split-phase steps (k_tb3, pf_tb3.h): idx[0], idx[1] = the state grids, idx[2], idx[3] = the two grids its blocked
+ * kernel writes, idx[4] = the grid that holds u^{n+1} where somebody needs it in memory.  idx[4] = -1: pairs (idx[2], idx[3] the
+ * spares) or single steps (idx[2] = idx[3] = -1), exactly as pf_engine_place_grids reports them.  No counterpart in the reference. */
+int  pf_engine_place_grids5(pf_engine *e, void *const *pool, int32_t n, int32_t idx[5]);
 /* Device pointers of the two state grids as they stand between runs (u_prev = u^{n-1}, overwritten by the next step;
  * u_cur = u^n), each pf_grid_bytes() long: the engine's own allocations unless pf_opts.ext_u0 / ext_u1 were given.
  * Lets a host that left the allocation to the engine (which then also chooses WHERE the grids live, see DESIGN.md

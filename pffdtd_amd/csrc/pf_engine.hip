@@ -133,6 +133,7 @@ struct EngineBase {
    virtual int flush() = 0;
    virtual int set_spares(void *g2, void *g3) = 0;
    virtual int place_grids(void *const *grids, int n, int32_t *idx) = 0;
+   virtual int place_grids5(void *const *grids, int n, int32_t *idx) = 0;
    virtual int get_grid(int which, void *host) = 0;
    virtual int set_grid(int which, const void *host) = 0;
    virtual int timing(pf_timing *t, int reset) = 0;
@@ -195,6 +196,8 @@ template <typename Real> struct Engine : EngineBase {
    Range bn_lo, bn_mid, bn_hi, bnl_lo, bnl_mid, bnl_hi, bna_lo, bna_mid, bna_hi, in_lo, in_mid, in_hi;
    // the same lists cut for the split-phase pairs, whose edge stream owns two planes per side: planes 1-2 / 3..Nx-4 / Nx-3..Nx-2
    Range bn_lo2, bn_mid2, bn_hi2, bnl_lo2, bnl_mid2, bnl_hi2, in_lo2, in_mid2, in_hi2;
+   // ... and for the split-phase triples, three planes per side: planes 1-3 / 4..Nx-5 / Nx-4..Nx-2
+   Range bn_lo3, bn_mid3, bn_hi3, bnl_lo3, bnl_mid3, bnl_hi3, in_lo3, in_mid3, in_hi3;
    hipStream_t s_main = nullptr, s_edge = nullptr, s_wall = nullptr, s_wall2 = nullptr; // s_wall, s_wall2: a slab's wall regions, alike / generic blocks (created on first use)
    hipEvent_t ev_pre = nullptr, ev_edge = nullptr, ev_main = nullptr, ev_wall0 = nullptr, ev_wall = nullptr, ev_wall2 = nullptr;
    bool wall_pending = false;
@@ -212,12 +215,15 @@ template <typename Real> struct Engine : EngineBase {
    bool tb2_geom = false, tb2_slab = false;               // slab engines: pairs across two split-phase steps (set_spares)
    int pair_phase = 0;                                    // 1: between the two steps of a split-phase pair
    bool pair_now = false;                                 // the step in flight is half of a pair
+   bool triple_now = false;                               // ... a third of a triple (tb3_slab; pair_phase then counts 0, 1, 2)
    Real *pA = nullptr, *pB = nullptr;                     // u^{n-1}, u^n of the pair in flight
    Real *bufC = nullptr, *bufD = nullptr;                 // the two extra state grids of the out-of-place pair
    // three steps per pass (pf_tb3.h, Engine::step_triple): single-domain 7-point engines whose shell steps as wall regions.  Five
    // grids: the state (u^{n-1}, u^n) -> bufD = u^{n+2}, bufE = u^{n+3}; bufC holds u^{n+1} where somebody needs it in memory (the
    // shell, the single-step tiles and their neighbours)
    bool tb3 = false;
+   bool tb3_geom = false, tb3_slab = false;               // slab engines: the box and its tiles are k_tb3's / triples across three split-phase steps (place_grids5)
+   bool triples() const { return tb3 || tb3_slab; }
    Real *bufE = nullptr;
    Real *home[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // the placed role cycle: state (0, 1) <-> targets (2, 3), 4 = the u^{n+1} grid
    static constexpr int tb3_wt = 8, tb3_r = 3, tb3_rows = tb3_wt * tb3_r - 4; // k_tb3<Real, 3, 8>: 20 core rows per tile
@@ -356,7 +362,7 @@ template <typename Real> struct Engine : EngineBase {
    void plane_ranges(const std::vector<int64_t> &idx, Range &lo, Range &mid, Range &hi, int w = 1) const {
       const int64_t n = (int64_t)idx.size();
       auto first_ge = [&](int64_t px) { return (int64_t)(std::lower_bound(idx.begin(), idx.end(), px * plane) - idx.begin()); };
-      if (w == 2 && Nx < 8) { lo = mid = hi = {0, 0}; return; } // (pairs need far thicker slabs anyway)
+      if (w >= 2 && Nx < 4 * w) { lo = mid = hi = {0, 0}; return; } // (pairs / triples need far thicker slabs anyway)
       const int64_t b1 = first_ge(1), b2 = first_ge(1 + w), b3 = first_ge(Nx - 1 - w), b4 = first_ge(Nx - 1);
       lo = {b1, std::min(b2, b4)};
       if (Nx - 2 > 1) { mid = {b2, std::max(b2, b3)}; hi = {std::max(b2, b3), b4}; }
@@ -509,6 +515,7 @@ template <typename Real> struct Engine : EngineBase {
          if ((rc = upload(&d_adj, adj.data(), Nb))) return rc;
          plane_ranges(idx, bn_lo, bn_mid, bn_hi);
          plane_ranges(idx, bn_lo2, bn_mid2, bn_hi2, 2);
+         plane_ranges(idx, bn_lo3, bn_mid3, bn_hi3, 3);
          // which interior path?  0 = automatic; 3 = the reference's kernel sequence (memory flips, marching kernel, ABC list
          // kernels); 4 = barrier-free marching kernel with virtual ghost shell + in-kernel ABC; 7 = the same with the flips in
          // memory (the 13-point default); 25 = lean fused kernel (7-point); 40 / 41 = temporally blocked pairs forced / driver only
@@ -564,6 +571,7 @@ template <typename Real> struct Engine : EngineBase {
          if ((rc = upload(&d_mat, mat.data(), Nbl))) return rc;
          plane_ranges(idx, bnl_lo, bnl_mid, bnl_hi);
          plane_ranges(idx, bnl_lo2, bnl_mid2, bnl_hi2, 2);
+         plane_ranges(idx, bnl_lo3, bnl_mid3, bnl_hi3, 3);
          for (int i = 0; i < 3; i++) if ((rc = dzalloc(&ub[i], Nbl))) return rc;
          if ((rc = dzalloc(&vh1, round_up(Nbl, 64) * PF_MMB))) return rc; // [node / 64][branch][node % 64], pf::st_idx
          if ((rc = dzalloc(&gh1, round_up(Nbl, 64) * PF_MMB))) return rc;
@@ -608,6 +616,7 @@ template <typename Real> struct Engine : EngineBase {
          if ((rc = upload(&d_insig, sig.data(), Ns * Nt))) return rc;
          plane_ranges(idx, in_lo, in_mid, in_hi);
          plane_ranges(idx, in_lo2, in_mid2, in_hi2, 2);
+         plane_ranges(idx, in_lo3, in_mid3, in_hi3, 3);
       }
       { // receivers
          auto perm = sorted_perm(sd.out_ixyz, Nr, idx);
@@ -669,12 +678,15 @@ template <typename Real> struct Engine : EngineBase {
    // shell as wall regions (init_walls).  The box then keeps THREE cells from anything that is not a plain air update (k_tb3
    // computes u^{n+1} two cells beyond it).  Anything else: pairs as before.  debug 0x20000: never triples.
    int init_tb2() {
-      tb3 = false;
+      tb3 = tb3_geom = tb3_slab = false;
       const bool single = op.slab_first && op.slab_last;
-      if (single && !fcc && !swz && !(op.debug & (0x20000 | 0x300 | 0x10000000)) && vbase != 41) {
+      if (!fcc && !swz && !(op.debug & (0x20000 | 0x300 | 0x10000000)) && vbase != 41) {
          int rc = init_tb2_impl(true);
          if (rc) return rc;
-         if (tb2 && wl_on) { tb3 = true; return PF_OK; }
+         if (single && tb2 && wl_on) { tb3 = true; return PF_OK; }
+         // slab engines: the triples' box and tiles stand; whether they are used is decided when the caller hands over its grids
+         // (pf_engine_place_grids5: five grids and wall regions that fit; else the pairs' geometry is rebuilt there)
+         if (!single && tb2_geom) { tb3_geom = true; return PF_OK; }
          drop_blocking();
       }
       return init_tb2_impl(false);
@@ -714,7 +726,8 @@ template <typename Real> struct Engine : EngineBase {
       // towards a neighbouring slab the box stops three planes short of the ghost plane: planes 1-2 / Nx-3..Nx-2 are the
       // edge planes of a split-phase pair (plane 1 needs the neighbour's data between the two steps; with plane 2 on the
       // edge stream as well the box kernel never reads a ghost plane, so the main stream never waits for an exchange)
-      tbx0 = op.slab_first ? margin(0, NzNy) : 3; tbx1 = (int)Nx - (op.slab_last ? margin(1, NzNy) : 3);
+      // (triples: the edge stream owns three planes per side, the box stops four short of the ghost plane)
+      tbx0 = op.slab_first ? margin(0, NzNy) : reach + 1; tbx1 = (int)Nx - (op.slab_last ? margin(1, NzNy) : reach + 1);
       tby0 = margin(2, Nx * Nz); tby1 = (int)Ny - margin(3, Nx * Nz);
       const int mz0 = (margin(4, Nx * Ny) + 3) / 4 * 4, mz1 = (margin(5, Nx * Ny) + 3) / 4 * 4;
       tbz0 = mz0;
@@ -1139,7 +1152,8 @@ template <typename Real> struct Engine : EngineBase {
             if (kk >= reg[i].ko0 && kk < reg[i].ko1 && ll >= reg[i].l0 && ll < reg[i].l1 && mm >= reg[i].m0 && mm < reg[i].m1) { r = i; k = kk; lc = ll; m = mm; break; }
          }
          owner[nb] = (int8_t)r;
-         if (r == 8 && (!slab || (nb >= bn_mid2.b && nb < bn_mid2.e))) rest.push_back((int32_t)nb); // (a slab's edge planes: range launches)
+         const Range &midr = tb3_geom ? bn_mid3 : bn_mid2;
+         if (r == 8 && (!slab || (nb >= midr.b && nb < midr.e))) rest.push_back((int32_t)nb); // (a slab's edge planes: range launches)
          if (hl[nb] >= 0) keys.push_back({r, m, lc, k, hl[nb]});
       }
       if ((int64_t)keys.size() != Nbl) return PF_OK; // (a lossy node that is no boundary node: fuse_boundary excludes it)
@@ -1423,9 +1437,18 @@ template <typename Real> struct Engine : EngineBase {
       if (ring_fill == ring_depth) return flush();
       return PF_OK;
    }
+   // slab engines are created with the triples' box and tiles where those exist (init_tb2); a caller that hands over four grids
+   // only, or whose wall regions do not fit that box, gets the pairs' geometry instead (before the first step)
+   int pairs_geometry() {
+      if (!tb3_geom) return PF_OK;
+      free_walls();
+      tb3_geom = tb3_slab = false;
+      return init_tb2_impl(false);
+   }
    int set_spares(void *g2, void *g3) override {
       if (in_step || pair_phase) return set_err(PF_ERR_STATE, "pf_engine_set_spares inside a step");
       if (!g2 || !g3) return set_err(PF_ERR_ARG, "pf_engine_set_spares: null grid");
+      if (steps_done == 0) { int rcg = pairs_geometry(); if (rcg) return rcg; }
       if (!tb2_geom || (op.slab_first && op.slab_last)) return 1; // not an error: this engine keeps stepping singly
       bufC = (Real *)g2; bufD = (Real *)g3;
       tb2_slab = true;
@@ -1797,7 +1820,11 @@ template <typename Real> struct Engine : EngineBase {
    // Slab engines (caller-owned grids): the caller offers a pool of n >= 4 zero-filled grids before the first step; the
    // engine adopts the fastest assignment of four of them -- idx[0], idx[1]: the state grids (they replace ext_u0 / ext_u1),
    // idx[2], idx[3]: the spares of pf_engine_set_spares, or idx = 0, 1, -1, -1 when this engine steps singly.
-   int place_grids(void *const *grids, int n, int32_t *idx) override {
+   int place_grids(void *const *grids, int n, int32_t *idx) override { return place_grids_impl(grids, n, idx, false); }
+   int place_grids5(void *const *grids, int n, int32_t *idx) override { return place_grids_impl(grids, n, idx, true); }
+   // five: idx has five entries and the engine may step in TRIPLES across three split-phase steps (idx[2], idx[3] = the grids k_tb3
+   // writes, idx[4] = the u^{n+1} grid; idx[4] = -1: pairs or single steps as pf_engine_place_grids reports them)
+   int place_grids_impl(void *const *grids, int n, int32_t *idx, bool five) {
       if (in_step || pair_phase || steps_done > 0) return set_err(PF_ERR_STATE, "pf_engine_place_grids after the first step");
       if (state_touched) return set_err(PF_ERR_STATE, "pf_engine_place_grids after pf_engine_set_grid: the placement search runs step kernels on the offered grids and zeroes them");
       if (own_grids) return set_err(PF_ERR_STATE, "pf_engine_place_grids: this engine allocated its own grids");
@@ -1809,6 +1836,36 @@ template <typename Real> struct Engine : EngineBase {
       HIPCHK(hipSetDevice(op.device));
       u0 = (Real *)grids[0]; u1 = (Real *)grids[1];
       idx[0] = 0; idx[1] = 1; idx[2] = idx[3] = -1;
+      if (five) idx[4] = -1;
+      if (five && n >= 5 && tb3_geom && tb2_geom && !(op.slab_first && op.slab_last)) {
+         // triples: the wall regions must fit the triples' box (init_walls re-orders the lossy arrays: before the first step only)
+         tb2_slab = true;
+         if (!(op.debug & 0x10000000)) { int rcw = init_walls(true); if (rcw) return rcw; }
+         if (wl_on) {
+            std::vector<Real *> pool;
+            for (int i = 0; i < n; i++) pool.push_back((Real *)grids[i]);
+            int w[4] = {0, 1, 2, 3};
+            if (n > 5 && !(op.debug & 0x8000)) {
+               const int first[4] = {0, 1, 2, 3};
+               tb2_probe = true;
+               int rc = search_placement(pool, false, true, place_evals(), first, w);
+               tb2_probe = false;
+               if (rc) return rc;
+               for (int i = 0; i < n; i++) HIPCHK(hipMemsetAsync(pool[i], 0, npad * sizeof(Real), s_main));
+               HIPCHK(hipStreamSynchronize(s_main));
+            }
+            int c = -1;
+            for (int i = 0; i < n && c < 0; i++) if (i != w[0] && i != w[1] && i != w[2] && i != w[3]) c = i;
+            u0 = pool[w[0]]; u1 = pool[w[1]]; bufD = pool[w[2]]; bufE = pool[w[3]]; bufC = pool[c];
+            for (int i = 0; i < 4; i++) idx[i] = w[i];
+            idx[4] = c;
+            tb3_slab = true;
+            tb3_remember_home();
+            return PF_OK;
+         }
+         tb2_slab = false; // (the regions do not fit the triples' box: pairs)
+      }
+      if (steps_done == 0) { int rcg = pairs_geometry(); if (rcg) return rcg; }
       if (n < 4 || !tb2_geom || (op.slab_first && op.slab_last)) { // keeps stepping singly: on the fastest pair of the pool
          if (n > 2 && place_single_ok()) {
             std::vector<Real *> pool;
@@ -1959,6 +2016,7 @@ template <typename Real> struct Engine : EngineBase {
       if (tb_xr.empty() || tb_nclean <= 0) return;
       pf::Tb2Params tp = tile_params();
       tp.A = A; tp.B = B; tp.C = C; tp.D = D; tp.E = E;
+      if (!(op.slab_first && op.slab_last)) tp.band |= 2; // a slab: the planes beside the box read the u^{n+1} of its first and last plane
       sample = sample && tb_sample && tb_nsample > 0;
       tp.tiles = sample ? tb_sample : tb_clean;
       const dim3 g((uint32_t)(sample ? tb_nsample : tb_nclean)), b(64 * tb3_wt);
@@ -1972,11 +2030,11 @@ template <typename Real> struct Engine : EngineBase {
    }
    // the blocked kernel as the creation-time measurements see it: its four streams (k_tb3: two grids read, two written)
    void launch_probe(hipStream_t s, const Real *A, const Real *B, Real *C, Real *D, bool sample = false) {
-      if (tb3) launch_tb3(s, A, B, nullptr, C, D, sample);
+      if (triples() || tb3_geom) launch_tb3(s, A, B, nullptr, C, D, sample);
       else launch_tb2(s, A, B, C, D, sample);
    }
    void launch_tb2(hipStream_t s, const Real *A, const Real *B, Real *C, Real *D, bool sample = false) {
-      if (tb3) { // a pair on the triples' tiles: k_tb3's two-step form (the last two steps of a run, Engine::run)
+      if (triples()) { // a pair on the triples' tiles: k_tb3's two-step form (the last two steps of a run, Engine::run)
          if (tb_xr.empty() || tb_nclean <= 0) return;
          pf::Tb2Params tp = tile_params();
          tp.A = A; tp.B = B; tp.C = C; tp.D = D; tp.E = nullptr;
@@ -2026,10 +2084,10 @@ template <typename Real> struct Engine : EngineBase {
       pf::Tb2Params tp = tile_params();
       tp.A = u0_src ? u0_src : u0; tp.B = u1; tp.C = u0; tp.D = nullptr;
       tp.tiles = tb_dirty; tp.mask = mask;
-      tp.xsub = tb_ndirty <= 256 ? std::min(4, std::max(tb_chunk / 4, 1)) : 1; // few tiles: shorter marches, more workgroups
+      tp.xsub = tb_ndirty <= 256 ? std::min(16, std::max(tb_chunk / 4, 1)) : 1; // few tiles: shorter marches (4 planes), more workgroups
       const dim3 g((uint32_t)tb_ndirty * (uint32_t)tp.xsub), b(256);
       if (fcc) return; // (13-point: k_air_fcc over its own tiling of the box's planes, sh_tiles)
-      if (tb3) { // k_tb3's tiles: 20 rows
+      if (triples() || tb3_geom) { // k_tb3's tiles: 20 rows
          static_assert(tb3_rows == 20, "k_tb1_tile<Real, 5, 4>: 20-row tiles");
          constexpr int HL = pf::VecOf<Real>::V >= 3 ? 1 : 2; // (the tiles' column ranges are k_tb3's)
          if (sg) hipLaunchKernelGGL((pf::k_tb1_tile<Real, 5, 4, 64, true, false, HL>), g, b, 0, s, tp, a1, a2);
@@ -2165,10 +2223,12 @@ template <typename Real> struct Engine : EngineBase {
       launch_rigid(sh, bnd);
       launch_fd(sh, {0, Nbl});
       launch_io(sh, n, true, {0, Ns});
+      // (with per-launch events on, the pair kernel waits for the shell: its recorded duration is the kernel's own, not the overlap's)
+      if (op.timing && beside) { HIPCHK(hipEventRecord(ev_edge, s_edge)); HIPCHK(hipStreamWaitEvent(s, ev_edge, 0)); }
       if (op.timing) { evt = get_ev(); hipEventRecord(evt.first, s); }
       launch_tb2(s, A, B, C, D);
       if (op.timing) { hipEventRecord(evt.second, s); tb2_ev.push_back(evt); }
-      if (beside) { HIPCHK(hipEventRecord(ev_edge, s_edge)); HIPCHK(hipStreamWaitEvent(s, ev_edge, 0)); }
+      if (beside && !op.timing) { HIPCHK(hipEventRecord(ev_edge, s_edge)); HIPCHK(hipStreamWaitEvent(s, ev_edge, 0)); }
       if (op.timing) { hipEventRecord(eva.second, s); air_ev.push_back(eva); eva = get_ev(); } // ("air" of the first step: the pair kernel and the shell beside it)
       { Real *t = ub[2]; ub[2] = ub[1]; ub[1] = ub[0]; ub[0] = t; }
       if (ring_fill == 0) ring_n0 = n;
@@ -2312,7 +2372,7 @@ template <typename Real> struct Engine : EngineBase {
       fp.u0_src = u0_src; fp.yt0 = 0; fp.yt_split = -1; fp.yt_hi0 = 0;
       // (row strips of a triple's third step: the strips' tiles reach into the box, whose u^{n+1} -- the step's old value -- is not in
       // memory: those rows are left to k_tb3's own result)
-      if (lean_nyt >= 0 && tb3) { fp.skip_y0 = tby0; fp.skip_y1 = tby1; }
+      if (lean_nyt >= 0 && triples()) { fp.skip_y0 = tby0; fp.skip_y1 = tby1; }
       if (lean_nyt >= 0) { // row strips: tiles [0, lean_nyt) and [lean_yt0, all) in units of this configuration's tile height
          const int all = fp.nyt, lo = std::min(lean_nyt, all), hi0 = std::max(std::min(lean_yt0, all), lo);
          fp.yt_split = lo; fp.yt_hi0 = hi0;
@@ -2592,6 +2652,17 @@ template <typename Real> struct Engine : EngineBase {
       return harvest();
    }
 
+   int wall_streams() { // a slab's wall regions run on two streams of their own (created on first use)
+      if (s_wall) return PF_OK;
+      int lo_prio = 0, hi_prio = 0;
+      hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
+      HIPCHK(hipStreamCreateWithPriority(&s_wall, hipStreamNonBlocking, hi_prio));
+      HIPCHK(hipStreamCreateWithPriority(&s_wall2, hipStreamNonBlocking, hi_prio));
+      HIPCHK(hipEventCreateWithFlags(&ev_wall0, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&ev_wall, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&ev_wall2, hipEventDisableTiming));
+      return PF_OK;
+   }
    // split-phase step for slab chains: edge planes and every boundary list entry that lives in them first
    // (high-priority stream), interior concurrently on the main stream.
    int step_begin(int64_t n) override {
@@ -2602,7 +2673,60 @@ template <typename Real> struct Engine : EngineBase {
       // Slab engines with all four grids at hand step in temporally blocked pairs that span two split-phase steps:
       // phase 0 (step n): edge planes n -> n+1 on the edge stream; box n -> n+1, n+2 plus the shell n -> n+1 on the
       // main stream; phase 1 (step n+1): edge planes and shell n+1 -> n+2.  The exchanges in between are the usual ones.
-      if (tb2_slab && (pair_phase == 1 || (n + 1 < Nt && ring_fill + 2 <= ring_depth && xh - xl >= 8))) {
+      // Slab engines with FIVE grids and wall regions that fit step in TRIPLES across three split-phase steps (tb3_slab): the edge
+      // stream owns three planes per side (single steps, exchanged after every step as always); phase 0 (step n): box n -> n+2, n+3
+      // by k_tb3 -- its first and last plane leave their u^{n+1} too --, wall regions n -> n+1, n+2, the planes between edge planes and
+      // box, the single-step tiles and the box's own nodes n -> n+1; phase 1: those n+1 -> n+2; phase 2: they and the whole strips
+      // beside the box n+2 -> n+3 as one single step, every node of the interior planes by the list kernel.
+      if (tb3_slab && (pair_phase > 0 || (n + 2 < Nt && ring_fill + 3 <= ring_depth && xh - xl >= 12))) {
+         const int ph = pair_phase;
+         if (ph == 0) {
+            tb3_pick();
+            pA = u0; pB = u1; u0_src = pA; u1 = pB; u0 = bufC;
+            wsP[0] = ub[0]; wsP[1] = ub[1]; wsP[2] = ub[2]; bs_vout = vh1b; bs_gout = gh1b;
+         }
+         fold_x0 = 0; fold_x1 = 0;
+         launch_air_lean(s_edge, xl, xl + 3);
+         launch_air_lean(s_edge, xh - 2, xh + 1);
+         launch_rigid(s_edge, bn_lo3); launch_rigid(s_edge, bn_hi3);
+         launch_fd(s_edge, bnl_lo3); launch_fd(s_edge, bnl_hi3);
+         launch_io(s_edge, n, false, in_lo3); launch_io(s_edge, n, false, in_hi3);
+         HIPCHK(hipEventRecord(ev_edge, s_edge));
+         std::pair<hipEvent_t, hipEvent_t> eva{}, evt{};
+         auto get_ev = [&]() { std::pair<hipEvent_t, hipEvent_t> e{}; if (!ev_pool.empty()) { e = ev_pool.back(); ev_pool.pop_back(); } else { hipEventCreate(&e.first); hipEventCreate(&e.second); } return e; };
+         if (op.timing) { eva = get_ev(); hipEventRecord(eva.first, s_main); }
+         if (ph == 0) {
+            { int rcs = wall_streams(); if (rcs) return rcs; }
+            HIPCHK(hipEventRecord(ev_wall0, s_main));
+            HIPCHK(hipStreamWaitEvent(s_wall, ev_wall0, 0));
+            HIPCHK(hipStreamWaitEvent(s_wall2, ev_wall0, 0));
+            launch_walls(s_wall, s_wall2, pA, pB, bufC, bufD, wsP[0], wsP[1], wsP[2]);
+            launch_shell_planes(s_wall, xl + 3, xh - 2, false);
+            bnd_sel = wl_rest; launch_rigid(s_wall, {0, wl_nrest}); bnd_sel = nullptr;
+            HIPCHK(hipEventRecord(ev_wall, s_wall));
+            HIPCHK(hipEventRecord(ev_wall2, s_wall2));
+            wall_pending = true;
+            if (op.timing) { evt = get_ev(); hipEventRecord(evt.first, s_main); }
+            launch_tb3(s_main, pA, pB, bufC, bufD, bufE);
+            if (op.timing) { hipEventRecord(evt.second, s_main); tb2_ev.push_back(evt); }
+            launch_dirty_tiles(s_main);
+            HIPCHK(hipStreamWaitEvent(s_main, ev_wall, 0)); // (a source in those planes is added after their update)
+         } else if (ph == 1) {
+            launch_shell_planes(s_main, xl + 3, xh - 2);
+            bnd_sel = wl_rest; launch_rigid(s_main, {0, wl_nrest}); bnd_sel = nullptr;
+         } else {
+            launch_shell(s_main, xl + 3, xh - 2);
+            launch_rigid(s_main, bn_mid3);
+         }
+         if (op.timing) { hipEventRecord(eva.second, s_main); air_ev.push_back(eva); }
+         launch_fd(s_main, bnl_mid3);
+         launch_io(s_main, n, true, in_mid3);
+         HIPCHK(hipGetLastError());
+         in_step = true;
+         pair_now = true; triple_now = true;
+         return PF_OK;
+      }
+      if (tb2_slab && !tb3_slab && (pair_phase == 1 || (n + 1 < Nt && ring_fill + 2 <= ring_depth && xh - xl >= 8))) {
          const bool first_half = pair_phase == 0;
          // with wall regions (init_walls(true)): the first half also steps the row and column strips beside the box TWICE
          // (k_wall2: branch state vh1 -> vh1b, node values P2, P1 -> P0, P1), so every other boundary launch of the pair follows
@@ -2635,15 +2759,7 @@ template <typename Real> struct Engine : EngineBase {
          if (op.timing) { eva = get_ev(); hipEventRecord(eva.first, s_main); }
          if (first_half) {
             if (wl_on) { // beside the box kernel, on a stream of their own: a slab's regions are a few hundred waves, each a chain of dependent march steps
-               if (!s_wall) {
-                  int lo_prio = 0, hi_prio = 0;
-                  hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
-                  HIPCHK(hipStreamCreateWithPriority(&s_wall, hipStreamNonBlocking, hi_prio));
-                  HIPCHK(hipStreamCreateWithPriority(&s_wall2, hipStreamNonBlocking, hi_prio));
-                  HIPCHK(hipEventCreateWithFlags(&ev_wall0, hipEventDisableTiming));
-                  HIPCHK(hipEventCreateWithFlags(&ev_wall, hipEventDisableTiming));
-                  HIPCHK(hipEventCreateWithFlags(&ev_wall2, hipEventDisableTiming));
-               }
+               { int rcs = wall_streams(); if (rcs) return rcs; }
                // (the generic blocks -- a 0.3 ms chain of dependent steps at 1/8 of 1024^3 -- on a stream of their own: behind the
                // alike blocks' launches in ONE stream the regions, 0.52 ms, outlasted the box kernel, 0.47)
                HIPCHK(hipEventRecord(ev_wall0, s_main));
@@ -2734,6 +2850,26 @@ template <typename Real> struct Engine : EngineBase {
       HIPCHK(hipStreamWaitEvent(s_edge, ev_main, 0));
       HIPCHK(hipStreamWaitEvent(s_main, ev_edge, 0));
       in_step = false;
+      if (pair_now && triple_now) {
+         pair_now = triple_now = false;
+         if (pair_phase == 0) {        // u^{n+1} complete in bufC; node values and branch state in place from here on
+            ub[0] = ub[2] = wsP[1];
+            std::swap(vh1, vh1b); std::swap(gh1, gh1b);
+            bs_vout = bs_gout = nullptr;
+            u0_src = pB; u1 = bufC; u0 = bufD;
+            pair_phase = 1;
+         } else if (pair_phase == 1) { // u^{n+2} complete in bufD; node values: u^{n+1} in P0, u^{n+2} in P1 -> u^{n+3} into P2
+            ub[0] = wsP[2]; ub[1] = wsP[1]; ub[2] = wsP[0];
+            u0_src = bufC; u1 = bufD; u0 = bufE;
+            pair_phase = 2;
+         } else {                      // triple done: state = (bufD, bufE), the former state grids become the next targets
+            ub[0] = wsP[0]; ub[1] = wsP[2]; ub[2] = wsP[1];
+            Real *D = bufD, *E = bufE;
+            u0_src = nullptr; u0 = D; u1 = E; bufD = pA; bufE = pB;
+            pair_phase = 0;
+         }
+         return after_step(n);
+      }
       if (pair_now) {
          pair_now = false;
          if (wl_on) {
@@ -2802,7 +2938,7 @@ template <typename Real> struct Engine : EngineBase {
       }
       tb2_ev.clear();
       tm.tb2_cells = tb_clean_cells;
-      tm.tb_steps_per_pass = tb3 ? 3 : ((tb2 || tb2_slab) ? 2 : 0);
+      tm.tb_steps_per_pass = triples() ? 3 : ((tb2 || tb2_slab) ? 2 : 0);
       for (auto &p : step_ev) {
          float ms = 0;
          HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));
@@ -2844,7 +2980,7 @@ template <typename Real> struct Engine : EngineBase {
       HIPCHK(hipSetDevice(op.device));
       int rc = sync();
       if (rc) return rc;
-      const Real *src = which == 0 ? (pair_phase == 1 ? pB : u0) : u1; // mid-pair u0 already names the grid being written
+      const Real *src = which == 0 ? (pair_phase > 0 ? (const Real *)u0_src : (const Real *)u0) : u1; // mid-pair u0 already names the grid being written
       if ((lean || vg) && which == 1) { // write the virtual ghost shell out, exactly as the reference's flips would have
          launch_flips(s_main);
          HIPCHK(hipStreamSynchronize(s_main));
@@ -2959,6 +3095,7 @@ int pf_engine_state_grids(pf_engine *e, void **u_prev, void **u_cur) { PF_NEED(e
 int pf_engine_layout(pf_engine *e, int64_t *dims, int64_t *pitch, int32_t *exchanged) { PF_NEED(e); return e->impl->layout(dims, pitch, exchanged); }
 int pf_engine_set_spares(pf_engine *e, void *g2, void *g3) { PF_NEED(e); return e->impl->set_spares(g2, g3); }
 int pf_engine_place_grids(pf_engine *e, void *const *grids, int32_t n, int32_t *idx) { PF_NEED(e); return e->impl->place_grids(grids, n, idx); }
+int pf_engine_place_grids5(pf_engine *e, void *const *grids, int32_t n, int32_t *idx) { PF_NEED(e); return e->impl->place_grids5(grids, n, idx); }
 void *pf_engine_stream(pf_engine *e, int32_t which) { return (e && e->impl) ? e->impl->stream(which) : nullptr; }
 int pf_engine_sync(pf_engine *e) { PF_NEED(e); return e->impl->sync(); }
 int pf_engine_flush_outputs(pf_engine *e) { PF_NEED(e); return e->impl->flush(); }

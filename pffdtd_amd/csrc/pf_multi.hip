@@ -334,7 +334,7 @@ struct Shared {
    std::vector<hipStream_t> edge;
    std::vector<hipEvent_t> ev[2];                                // edge planes of step n computed: [n&1][g]
    std::vector<void *> send_lo[2], send_hi[2], recv_lo[2], recv_hi[2];
-   std::vector<void *> grids[4];                                 // caller-owned state grids per slab (pairs need four)
+   std::vector<void *> grids[5];                                 // caller-owned state grids per slab (pairs need four, triples five)
    std::vector<int> paired;
    size_t plane_bytes = 0;
    SpinBarrier bar;
@@ -452,14 +452,16 @@ void create_slab(Shared &S, int g) {
          pool.push_back(p);
       }
       MCHK(g, hipDeviceSynchronize());
-      int32_t idx[4] = {0, 1, -1, -1};
+      int32_t idx[5] = {0, 1, -1, -1, -1};
       int rc = 0;
-      if (pool.size() >= 4) rc = pf_engine_place_grids(S.eng[g], pool.data(), (int32_t)pool.size(), idx);
+      // (five or more grids on offer: the engine may step in triples, pf_engine_place_grids5; PF_MULTI_NO_TRIPLES: pairs at most)
+      if (pool.size() >= 5 && !(flags & PF_MULTI_NO_TRIPLES)) rc = pf_engine_place_grids5(S.eng[g], pool.data(), (int32_t)pool.size(), idx);
+      else if (pool.size() >= 4) rc = pf_engine_place_grids(S.eng[g], pool.data(), (int32_t)pool.size(), idx);
       if (rc != 0) { for (size_t k = 2; k < pool.size(); k++) hipFree(pool[k]); S.set_error(rc, pf_last_error()); return; }
-      for (int k = 0; k < 4; k++) S.grids[k][g] = idx[k] >= 0 ? pool[idx[k]] : nullptr;
+      for (int k = 0; k < 5; k++) S.grids[k][g] = idx[k] >= 0 ? pool[idx[k]] : nullptr;
       for (size_t k = 0; k < pool.size(); k++)
-         if ((int)k != idx[0] && (int)k != idx[1] && (int)k != idx[2] && (int)k != idx[3]) hipFree(pool[k]);
-      S.paired[g] = idx[2] >= 0;
+         if ((int)k != idx[0] && (int)k != idx[1] && (int)k != idx[2] && (int)k != idx[3] && (int)k != idx[4]) hipFree(pool[k]);
+      S.paired[g] = idx[4] >= 0 ? 3 : (idx[2] >= 0 ? 1 : 0); // (steps per pass: 3 triples, 1 = pairs, 0 single steps)
    }
    S.edge[g] = (hipStream_t)pf_engine_stream(S.eng[g], 1);
    for (int k = 0; k < 2; k++) MCHK(g, hipEventCreateWithFlags(&S.ev[k][g], hipEventDisableTiming));
@@ -724,7 +726,7 @@ void destroy_slab(Shared &S, int g) {
    hipSetDevice(S.dev[g]);
    if (S.eng[g]) { pf_engine_sync(S.eng[g]); pf_engine_destroy(S.eng[g]); S.eng[g] = nullptr; }
    for (int k = 0; k < 2; k++) if (S.ev[k][g]) { hipEventDestroy(S.ev[k][g]); S.ev[k][g] = nullptr; }
-   for (int k = 0; k < 4; k++) if (S.grids[k][g]) { hipFree(S.grids[k][g]); S.grids[k][g] = nullptr; }
+   for (int k = 0; k < 5; k++) if (S.grids[k][g]) { hipFree(S.grids[k][g]); S.grids[k][g] = nullptr; }
    for (int k = 0; k < 2; k++) {
       if (!S.hstage[k].empty() && S.hstage[k][g]) { hipHostFree(S.hstage[k][g]); S.hstage[k][g] = nullptr; }
       if (!S.ev_d2h[k].empty() && S.ev_d2h[k][g]) { hipEventDestroy(S.ev_d2h[k][g]); S.ev_d2h[k][g] = nullptr; }
@@ -883,7 +885,7 @@ int pf_multi_create(pf_simdata *sd, int32_t nslabs, const int32_t *devices, cons
       S.send_lo[k].assign(G, nullptr); S.send_hi[k].assign(G, nullptr);
       S.recv_lo[k].assign(G, nullptr); S.recv_hi[k].assign(G, nullptr);
    }
-   for (int k = 0; k < 4; k++) S.grids[k].assign(G, nullptr);
+   for (int k = 0; k < 5; k++) S.grids[k].assign(G, nullptr);
    for (int k = 0; k < 2; k++) { S.hstage[k].assign(G, nullptr); S.ev_d2h[k].assign(G, nullptr); S.ev_h2d[k].assign(G, nullptr); }
    S.bar_timeout = barrier_timeout();
    S.faults = S.base.test_faults;
@@ -943,7 +945,7 @@ int pf_multi_create(pf_simdata *sd, int32_t nslabs, const int32_t *devices, cons
    if (S.err.load()) { const std::string keep = S.err_msg; const int code = S.err.load(); pf_multi_destroy(m); pf__set_error(keep.c_str()); return code; }
    if (getenv("PFFDTD_VERBOSE")) {
       fprintf(stderr, "pffdtd_hip: %d slabs%s, ghost planes by %s%s%s:", G, S.along_z ? " cut along file z (engines store the x and z axes exchanged)" : "", transport_name(S), S.transport == TR_RCCL ? ", " : "", S.transport == TR_RCCL ? g_rccl.where.c_str() : "");
-      for (int g = 0; g < G; g++) fprintf(stderr, " [dev %d: planes %ld-%ld%s]", S.dev[g], (long)S.cuts[g], (long)S.cuts[g + 1] - 1, S.paired[g] ? ", pairs" : "");
+      for (int g = 0; g < G; g++) fprintf(stderr, " [dev %d: planes %ld-%ld%s]", S.dev[g], (long)S.cuts[g], (long)S.cuts[g + 1] - 1, S.paired[g] == 3 ? ", triples" : (S.paired[g] ? ", pairs" : ""));
       fprintf(stderr, "\n");
    }
    *out = m;

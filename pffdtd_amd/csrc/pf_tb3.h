@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64 * WT) void k_tb3(Tb2Params tp, Real a1, Real a2)
       rim = (t & TB3_RIM) != 0u && tp.C != nullptr;
       b = t & ~TB3_RIM;
       zt = b % tp.nzt; yt = (b / tp.nzt) % tp.nyt; xc = b / (tp.nzt * tp.nyt);
-   } else if (tp.band) {
+   } else if (tp.band & 1) {
       const uint32_t T = (uint32_t)tp.nzt * tp.nyt, Tp = (T + 7) / 8;
       xc = b / (8 * Tp);
       const uint32_t r = b % (8 * Tp), j = (r % 8) * Tp + r / 8;
@@ -112,7 +112,9 @@ __global__ __launch_bounds__(64 * WT) void k_tb3(Tb2Params tp, Real a1, Real a2)
       // stage 1: u^{n+1}(x1)
 #pragma unroll
       for (int r = 0; r < R; r++) V1n[r] = stencil(Bc[r + 1], Bn[r], Bm[r], Bc[r + 2], Bc[r], Ac[r]);
-      if ((NS == 2 || rim) && x1 >= xs && x1 < xe) { // a neighbour of a single-step tile (or the two-step form): its u^{n+1} is needed in memory
+      // (tp.band & 2: slabs of a chain -- the planes beside the box step singly, the box's first and last plane leave their u^{n+1} too)
+      const bool xedge = (tp.band & 2) && C != nullptr && (x1 == tp.x_begin || x1 == tp.x_end - 1);
+      if ((NS == 2 || rim || xedge) && x1 >= xs && x1 < xe) { // a neighbour of a single-step tile (or the two-step form): its u^{n+1} is needed in memory
          Real *pc = C + (int64_t)x1 * plane;
 #pragma unroll
          for (int r = 0; r < R; r++)

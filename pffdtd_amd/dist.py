@@ -73,7 +73,10 @@ class HipSlabStepper:
                     torch.cuda.synchronize()
             except torch.OutOfMemoryError:  # no room for more: what fits
                 torch.cuda.empty_cache()
-            if len(pool) >= 4:
+            if len(pool) >= 5:  # (five or more: the engine may step in triples, pf_engine_place_grids5)
+                self.paired, idx = self.eng.place_grids5([g.data_ptr() for g in pool])
+                self.grids = [pool[i] for i in idx if i >= 0]
+            elif len(pool) >= 4:
                 self.paired, idx = self.eng.place_grids([g.data_ptr() for g in pool])
                 self.grids = [pool[i] for i in idx if i >= 0]
             del pool

@@ -52,13 +52,14 @@ class PfError(RuntimeError):
 
 EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_grid_bytes", "pf_grid_pitch", "pf_opts_default",
            "pf_run_sim", "pf_engine_create", "pf_engine_destroy", "pf_engine_run", "pf_engine_step_begin",
-           "pf_engine_halo_ptrs", "pf_engine_step_end", "pf_engine_state_grids", "pf_engine_layout", "pf_engine_place_grids", "pf_engine_set_spares", "pf_engine_stream", "pf_engine_sync",
+           "pf_engine_halo_ptrs", "pf_engine_step_end", "pf_engine_state_grids", "pf_engine_layout", "pf_engine_place_grids", "pf_engine_place_grids5", "pf_engine_set_spares", "pf_engine_stream", "pf_engine_sync",
            "pf_engine_flush_outputs", "pf_engine_get_grid", "pf_engine_set_grid", "pf_engine_timing", "pf_engine_set_timing",
            "pf_engine_energy_cfg", "pf_engine_run_energy", "pf_run_sim_devices", "pf_slab_partition",
            "pf_multi_create", "pf_multi_run", "pf_multi_get_info", "pf_multi_get_slab", "pf_multi_destroy"]
 
 
 PF_MULTI_EVEN_SPLIT, PF_MULTI_ONE_THREAD, PF_MULTI_NO_PAIRS, PF_MULTI_FORCE_PAIRS, PF_MULTI_CUT_Z, PF_MULTI_CUT_X = 1, 2, 4, 8, 16, 32
+PF_MULTI_NO_TRIPLES = 64
 PF_TRANSPORT_AUTO, PF_TRANSPORT_PEER, PF_TRANSPORT_RCCL, PF_TRANSPORT_HOST = 0, 1, 2, 3
 
 
@@ -118,6 +119,7 @@ def lib():
         L.pf_engine_state_grids.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
         L.pf_engine_layout.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i32)]
         L.pf_engine_place_grids.argtypes = [vp, ctypes.POINTER(vp), i32, ctypes.POINTER(i32)]
+        L.pf_engine_place_grids5.argtypes = [vp, ctypes.POINTER(vp), i32, ctypes.POINTER(i32)]
         L.pf_engine_stream.restype = vp
         L.pf_engine_stream.argtypes = [vp, i32]
         L.pf_engine_sync.argtypes = [vp]
@@ -315,6 +317,14 @@ class HipEngine:
         idx = (ctypes.c_int32 * 4)()
         _check(lib().pf_engine_place_grids(self._h, arr, len(ptrs), idx))
         return idx[2] >= 0, list(idx)
+
+    def place_grids5(self, ptrs):
+        """The same with room for triples (pf_engine_place_grids5).  -> (steps per pass: 3 triples, 2 pairs, 0 single steps; idx[0:5]):
+        idx[2:4] = the grids the blocked kernel writes, idx[4] = the u^{n+1} grid of the triples (or -1)."""
+        arr = (ctypes.c_void_p * len(ptrs))(*[int(p) for p in ptrs])
+        idx = (ctypes.c_int32 * 5)()
+        _check(lib().pf_engine_place_grids5(self._h, arr, len(ptrs), idx))
+        return (3 if idx[4] >= 0 else (2 if idx[2] >= 0 else 0)), list(idx)
 
     def set_spares(self, ptr2, ptr3):
         """Two more caller-owned state grids: lets a slab engine step in temporally blocked pairs.  -> True if it will."""
