@@ -779,7 +779,13 @@ template <typename Real> struct Engine : EngineBase {
          const int np = tbx1 - tbx0;
          // ~16-plane chunks, even split (tools/tb2_probe.py); 13-point: ~24 (3.93 vs 4.07 ms per launch at 1024^3, 32-48 the same)
          // (k_tb3: 64 -- 3.28 ms per launch at 1024^3 against 3.57 with 32 and 3.63 with 16 in the plain tile order, tools/tb3_probe.py)
-         const int want_chunk = triple ? 64 : (fcc ? 24 : tb2_chunk);
+         // -- but a thin slab needs enough workgroups to fill the chip: at least ~1024 tiles, chunks of 16 planes or more (a rank of 8 at
+         // 1024^3: 125 box planes in 2 chunks of 63 were 408 workgroups on 256 CUs)
+         int want_chunk = fcc ? 24 : tb2_chunk;
+         if (triple) {
+            const int64_t tiles_yz = cdiv(tby1 - tby0, TR) * cdiv(tbz1 - tbz0, TC);
+            want_chunk = (int)std::min<int64_t>(64, std::max<int64_t>(16, np / std::max<int64_t>(cdiv(1024, std::max<int64_t>(tiles_yz, 1)), 1)));
+         }
          tb_chunk = (int)cdiv(np, std::max<int64_t>(cdiv(np, want_chunk), 1));
          tb_nxc = (int)cdiv(np, tb_chunk); tb_nyt = (int)cdiv(tby1 - tby0, TR); tb_nzt = (int)cdiv(tbz1 - tbz0, TC);
          const int64_t ntile = (int64_t)tb_nxc * tb_nyt * tb_nzt;

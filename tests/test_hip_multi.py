@@ -374,3 +374,33 @@ def test_a_hung_slab_thread_becomes_an_error_not_a_hang(tmp_path):
     r = subprocess.run([os.sys.executable, "-c", code], env={**os.environ, "PFFDTD_BARRIER_TIMEOUT_S": "2"}, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "ERROR after" in r.stdout and "hung" in r.stdout, (r.stdout, r.stderr[-1500:])
+
+
+# ---- round 5: slabs in TRIPLES across three split-phase steps ---------------------------------------------------------------
+@pytest.mark.parametrize("prec", ["single", "double"])
+@pytest.mark.parametrize("transport", [engine.PF_TRANSPORT_PEER, engine.PF_TRANSPORT_RCCL])
+def test_slabs_step_in_triples_across_three_split_phase_steps(prec, transport):
+    """A slab offered five grids whose wall regions fit steps THREE steps per pass (k_tb3 over its box, three edge planes per side on the
+    edge stream, wall regions for two steps and one single step for the third, ghost planes exchanged after every step): lossy walls of
+    two materials, receivers in the wall layers, in the box and next to the cuts, 2 and 3 slabs, step counts that leave one and two
+    single steps over -- the oracle's bits, every exchange checked; PF_MULTI_NO_TRIPLES keeps the round-4 pairs."""
+    nz = 276 if prec == "single" else 264
+    kw = dict(Nx=124, Ny=70, Nz=nz, Nt=41, wall=3, Nm=2, Mb=[11, 3], src=[61, 30, 100],
+              rcv=[[30, 25, 96], [70, 36, 110], [61, 4, 104], [62, 63, 101], [63, 30, 4], [60, 31, nz - 7], [41, 4, 4], [82, 63, nz - 7], [4, 30, 100], [117, 40, 120]])
+    sd = sim_data.SimData.from_sim(synth.shoebox(**kw), prec)
+    sd.scale_input()
+    oracle.run_sim(sd)
+    want = sd.u_out.copy()
+    assert np.abs(want).max() > 0 and np.abs(want[2:]).max() > 0
+    for devs, flags, spp in (([0, 0], 0, 3), ([0, 0, 0], 0, 3), ([0, 0], engine.PF_MULTI_NO_TRIPLES, 2)):
+        sd2 = sim_data.SimData.from_sim(synth.shoebox(**kw), prec)
+        sd2.scale_input()
+        m = engine.HipMulti(sd2, devs, multi_flags=engine.PF_MULTI_FORCE_PAIRS | flags, air_variant=40, transport=transport, verify_exchange=int(sd2.Nt), timing=1)
+        m.run(0, 20)
+        m.run(20, int(sd2.Nt) - 20)
+        info = m.info()
+        tms = [m.slab(g)["engine"].timing() for g in range(len(devs))]
+        m.close()
+        assert info["exchange_verified"] is True
+        assert all(t["tb_steps_per_pass"] == spp and t["tb2_launches"] > 0 and sum(t["wall_blocks"]) > 0 for t in tms), (devs, flags, [t["tb_steps_per_pass"] for t in tms])
+        assert np.array_equal(sd2.u_out, want), (devs, flags)

@@ -31,7 +31,7 @@ def _worker(rank, world, port, name, prec, q, along_z=False):
         paired = name == "box_pairs"
         sd = _big_sd(prec) if paired else cases.make_sd(name, prec)
         runner, loc, info = pdist.make_hip_runner(sd, rank, world, 0, along_z=along_z, **(dict(air_variant=40, pairs=True) if paired else {}))
-        assert runner.st.paired == paired and bool(getattr(info, "along_z", False)) == along_z
+        assert bool(runner.st.paired) == paired and bool(getattr(info, "along_z", False)) == along_z
         if along_z:
             assert runner.st.eng.layout()[2] is True and len(runner.st.grids[0]) == loc.Nz
         runner.run(0, sd.Nt)
