@@ -11,17 +11,25 @@ for ln in sys.stdin:
         if e: print("   N=%d rank %d (%d planes, pairs=%s): %.4f ms/step -> %.0f Gvox/s if every rank took that long; dominant kernel %s %.3f ms/launch; exchange %s" % (e["of"], e["rank"], e["planes"][1]-e["planes"][0], e["pairs"], e["ms_per_step"], d["value"], d["roofline"]["kernel"], d["roofline"]["kernel_ms_per_launch"], d["exchange"]["backend"]))
         else: print("   N=%d virtual slabs on one device: %.4f ms/step = %.1f Gvox/s; exchange %s verified=%s; pairs %s" % (d["n_gpus"], d["ms_per_step"], d["value"], d["exchange"]["backend"], d["exchange_verified"], [s["pairs"] for s in d["slabs"]]))'
 echo "## single domain (N=1), same build"
-python bench.py --steps 40 --warmup 6 --repeats 5 --no-rigid-run --no-cpu-baseline --no-selfcheck 2>/dev/null | python -c 'import json,sys
+python bench.py --steps 42 --warmup 6 --repeats 5 --no-rigid-run --no-cpu-baseline --no-selfcheck --no-pmc 2>/dev/null | python -c 'import json,sys
 for ln in sys.stdin:
     if ln.startswith("{"):
         d=json.loads(ln); print("   N=1: %.4f ms/step = %.1f Gvox/s (%s)" % (d["ms_per_step"], d["value"], d["roofline"].get("shell")))'
 for tr in rccl copy; do
   echo "## rank cost model, exchange by $tr"
   for spec in 0/2 1/2 0/4 1/4 0/8 3/8 7/8; do
-    python bench.py --emulate-slab $spec --emulate-transport $tr --steps 40 --warmup 6 --repeats 5 2>/dev/null | python -c "$P"
+    python bench.py --emulate-slab $spec --emulate-transport $tr --steps 42 --warmup 6 --repeats 5 --no-pmc 2>/dev/null | python -c "$P"
   done
 done
 echo "## whole chains as virtual slabs on ONE device (every slab's work on the one GPU: control flow + fixed costs, not scaling)"
 for n in 2 4 8; do
-  python bench.py --gpus $n --steps 30 --warmup 6 --repeats 3 --transport rccl 2>/dev/null | python -c "$P"
+  python bench.py --gpus $n --steps 30 --warmup 6 --repeats 3 --transport rccl --no-pmc 2>/dev/null | python -c "$P"
+done
+echo "## BASELINE configs[4]: 1536^3 13-point folded FCC fp64 -- single domain, then ranks of an 8-rank chain (exchange by copy)"
+python bench.py --fcc --size 1536 --precision double --steps 12 --warmup 4 --repeats 3 --no-rigid-run --no-cpu-baseline --no-selfcheck --no-pmc 2>/dev/null | python -c 'import json,sys
+for ln in sys.stdin:
+    if ln.startswith("{"):
+        d=json.loads(ln); print("   N=1: %.4f ms/step = %.1f Gvox/s (%s %.2f ms/launch)" % (d["ms_per_step"], d["value"], d["roofline"]["kernel"], d["roofline"]["kernel_ms_per_launch"]))'
+for spec in 0/8 3/8 7/8; do
+  python bench.py --fcc --size 1536 --precision double --emulate-slab $spec --emulate-transport copy --steps 12 --warmup 4 --repeats 3 --no-pmc 2>/dev/null | python -c "$P"
 done
