@@ -314,7 +314,8 @@ def run_chain(args, only=None):
     if only:
         transport = engine.PF_TRANSPORT_RCCL if args.emulate_transport == "rccl" else engine.PF_TRANSPORT_PEER
     m = engine.HipMulti(sd, devices, numerics=args.numerics, air_variant=args.variant, air_chunk=args.chunk, debug=args.debug,
-                        transport=transport, verify_exchange=0 if only else 2, only_slab=(only[0] + 1) if only else 0)  # (first contact: the first two exchanges of every chain are checksummed -- inside the warm-up unless W < 2)
+                        transport=transport, verify_exchange=0 if only else 2, only_slab=(only[0] + 1) if only else 0, wall_scale=args.wall_scale,
+                        multi_flags=0 if args.wall_scale > 0 else engine.PF_MULTI_MEASURE_WEIGHTS)  # (first contact: the first two exchanges of every chain are checksummed -- inside the warm-up unless W < 2)
     live = [only[0]] if only else list(range(N))
     slabs = [m.slab(g) for g in live]
     for g, sl in zip(live, slabs):
@@ -365,6 +366,8 @@ def run_chain(args, only=None):
     res["transport"] = info["transport_name"]  # "peer copies" | "rccl" | "host-staged" (the last resort: neither peer access nor a working RCCL)
     if info.get("transport_note"):
         res["transport_note"] = info["transport_note"]
+    res["partition"] = {"wall_scale": round(info["wall_scale"], 3), "measured_at_creation": info["wall_measured"],
+                        "planes": [s["x1"] - s["x0"] for s in slabs] if not only else None}
     res["exchange"] = {"backend": info["transport_name"], "ranks": N, "checked_steps": info["exchanges_checked"],
                        "nonzero_planes": info["exchange_nonzero"], "plane_bytes": info["plane_bytes"],
                        "what": "position-weighted bit-pattern checksums of the received ghost planes == the senders' planes, every slab"}
@@ -399,6 +402,8 @@ def main():
     ap.add_argument("--debug", type=lambda v: int(v, 0), default=0, help="pf_opts.debug (tuning switches)")
     ap.add_argument("--transport", default="auto", choices=["auto", "peer", "rccl", "host"],
                     help="N>1 from one process: how ghost planes travel (pf_opts.transport)")
+    ap.add_argument("--wall-scale", type=float, default=1.0, help="N>1 from one process: factor on the wall planes' weights of the cut "
+                    "(pf_opts.wall_scale); 1 = the compiled-in weights, 0 = measured on the scene when the chain is created (PF_MULTI_MEASURE_WEIGHTS)")
     ap.add_argument("--split-phase", action="store_true", help="N=1: drive the split-phase step like N>1 does")
     ap.add_argument("--emulate-slab", default="", help="debug: 'r/N' = run only slab r of an N-way split on this GPU, the exchange\n                    replaced by device copies of the same planes (per-rank cost model; physics is wrong)")
     ap.add_argument("--emulate-transport", default="copy", choices=["copy", "rccl"],

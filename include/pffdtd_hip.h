@@ -121,6 +121,9 @@ typedef struct pf_opts {
    int32_t test_faults;   /* tests only, pf_multi_create: fault injection for the first-contact paths of a multi-device box.  1: no peer
                              access between any two devices; 2: RCCL unusable; 4: the host thread of slab 1 stalls before the barrier
                              of its fourth step (the watchdog of the others must turn the hang into an error) */
+   double  wall_scale;    /* pf_multi_create / pf_run_sim_devices: > 0 = cut the chain with the wall planes' weights times this factor (a host that
+                             measured it once -- pf_slab_wall_scale -- and wants the same cut in every process); 0 = the compiled-in weights, or the
+                             library's own measurement under PF_MULTI_MEASURE_WEIGHTS */
 } pf_opts;
 
 #define PF_TRANSPORT_AUTO 0 /* peer copies where hipDeviceCanAccessPeer says yes for every neighbouring pair, else RCCL, else -- librccl
@@ -143,6 +146,11 @@ typedef struct pf_opts {
                                   exchanged (pf_engine_layout), what rooms whose large surfaces are normal to z gain 11-15 % from;
                                   chosen automatically for such rooms */
 #define PF_MULTI_CUT_X      32 /* never (the reference's arrangement, gpu_engine.h:516-662) */
+#define PF_MULTI_MEASURE_WEIGHTS 128 /* measure the wall planes' weights on the scene when the chain is created (pf_slab_wall_scale) instead of
+                                  cutting with the compiled-in ones (23 / 5 interior planes per full plane of lossy / rigid nodes).  Opt-in:
+                                  on MI355X the measurement reproduces the compiled-in figures where it is clean (factors 0.99-1.05,
+                                  profiles/r05_partition_weights.txt) and its own noise -- two engines of one geometry differ by 2-3 %
+                                  with the luck of their grid placement -- is larger than their error */
 #define PF_MULTI_NO_TRIPLES 64 /* slabs step in pairs at most (round 5: by default a slab whose wall regions fit steps THREE steps per
                                   pass across three split-phase steps, pf_engine_place_grids5) */
 
@@ -187,8 +195,16 @@ double      pf_run_sim(pf_simdata *sd);
  * peer copies on the edge stream while the interior planes run (replaces gpu_engine.h:516-662,739-823,993-1145).
  * base: options common to all slabs (numerics, air_variant, readout_chunk, debug, multi_flags); NULL = defaults. */
 double      pf_run_sim_devices(pf_simdata *sd, int32_t nslabs, const int32_t *devices, const pf_opts *base);
-/* The owned plane ranges such a run uses when cut along x: cuts[0..nslabs], slab g owns global planes [cuts[g], cuts[g+1]). */
+/* The owned plane ranges such a run uses when cut along x: cuts[0..nslabs], slab g owns global planes [cuts[g], cuts[g+1]).
+ * pf_slab_partition: with the compiled-in wall-plane weights; _w: those weights times wall_scale. */
 int         pf_slab_partition(const pf_simdata *sd, int32_t nslabs, int32_t even_split, int64_t *cuts);
+int         pf_slab_partition_w(const pf_simdata *sd, int32_t nslabs, int32_t even_split, double wall_scale, int64_t *cuts);
+/* Measures that factor for this scene on `device` (round 5): three short one-rank cost models -- an interior rank with Nx / nslabs planes,
+ * one with a few planes more, the first rank with its x wall -- give the cost of an interior plane and of the wall; the ratio to what
+ * the compiled-in weights predict is returned (<= 0: not measured -- scene too small, fewer than 63 steps --: use 1).  pf_multi_create
+ * does this by itself under PF_MULTI_MEASURE_WEIGHTS; hosts with one process per device measure on rank 0 and hand the factor to every
+ * rank (pf_opts.wall_scale). */
+double      pf_slab_wall_scale(pf_simdata *sd, int32_t nslabs, int32_t device, const pf_opts *base);
 
 /* ---- the same chain as an object (what pf_run_sim_devices does inside): lets a host warm up, time and inspect a
  * multi-device run -- bench.py --gpus N drives this from one plain process, as the reference drives all its GPUs from one
@@ -207,6 +223,8 @@ typedef struct pf_multi_info {
    double  last_run_seconds;   /* wall time of the last pf_multi_run */
    char    transport_name[64];
    char    transport_note[256]; /* why this transport: the fallbacks PF_TRANSPORT_AUTO took ("" = its first choice) */
+   double  wall_scale;         /* the factor on the wall planes' weights the chain was cut with (1: the compiled-in weights) */
+   int32_t wall_measured;      /* 1: that factor was measured at creation (pf_slab_wall_scale) */
 } pf_multi_info;
 int  pf_multi_create(pf_simdata *sd, int32_t nslabs, const int32_t *devices, const pf_opts *base, pf_multi **out);
 /* steps n0 .. n0+nsteps-1 on every slab; returns when all streams have drained and the receiver rows are in sd->u_out */

@@ -73,7 +73,11 @@ int fail(const char *fmt, const char *a = "") {
 // 1024^3 as 8 ranks with wall regions in the slabs: 132 interior planes 0.310 ms per step; 119 / 114 planes + an x wall, which stays
 // single steps, 0.337 / 0.329 -- an end rank is mostly fixed cost, 0.0014 ms per plane against 0.0024 inside)
 // along_z: the chain is cut along FILE Z instead (slab engines then store the grid with the x and z axes exchanged: Engine::swz)
-int partition(const pf_simdata *sd, int G, bool even, std::vector<int64_t> &cuts, bool along_z = false) {
+// wall_scale: the wall planes' weights (23 / 5 interior planes per full plane of lossy / rigid nodes, a fit at 1024^2 planes, Mb = 11, fp32) times
+// this factor -- 1: the constants as they are; pf_multi_create MEASURES the factor on the scene at hand (measure_wall_scale, round 5).
+// wall1 (optional): the per-plane wall cost at scale 1, in interior planes.
+int partition(const pf_simdata *sd, int G, bool even, std::vector<int64_t> &cuts, bool along_z = false, double wall_scale = 1.0,
+              std::vector<double> *wall1 = nullptr) {
    const int64_t Nx = along_z ? sd->Nz : sd->Nx; // planes along the cut axis
    if (G < 1 || G >= Nx) return fail(along_z ? "need 1 <= number of slabs < Nz: this scene's chain is cut along file z (the reference: ngpus < Nx, gpu_engine.h:682)"
                                              : "need 1 <= number of slabs < Nx (gpu_engine.h:682)");
@@ -97,9 +101,12 @@ int partition(const pf_simdata *sd, int G, bool even, std::vector<int64_t> &cuts
       mb_scale = s / (double)sd->Nbl / 11.0;
    }
    std::vector<double> cum(Nx + 1, 0.0);
+   if (wall1) wall1->assign(Nx, 0.0);
    for (int64_t x = 0; x < Nx; x++) {
       double c = (x == 0 || x == Nx - 1) ? 0.0 : 1.0; // the global ghost planes are not updated
-      c += (23.0 * mb_scale * nl[x] + 5.0 * (nb[x] - nl[x])) / (double)NzNy;
+      const double wc = (23.0 * mb_scale * nl[x] + 5.0 * (nb[x] - nl[x])) / (double)NzNy;
+      if (wall1) (*wall1)[x] = wc;
+      c += wall_scale * wc;
       cum[x + 1] = cum[x] + c;
    }
    for (int g = 1; g < G; g++) {
@@ -359,6 +366,8 @@ struct Shared {
    std::string transport_note;                                   // why this transport (fallbacks taken)
    double bar_timeout = 120.0;
    int faults = 0;                                               // pf_opts.test_faults
+   double wall_scale = 1.0;                                      // factor on the wall planes' weights the chain was cut with
+   bool wall_measured = false;                                   // ... measured at creation (pf_slab_wall_scale)
    // exchange self-check: the first `verify_n` exchanges after creation
    int64_t verify_n = 0;
    int64_t drop_step = -1; // test hook (pf_opts.test_drop_exchange): slab 1 misses the planes of that step; the self-check then always covers it
@@ -851,15 +860,90 @@ const char *transport_name(const Shared &S) {
 
 } // namespace
 
+namespace {
+// calibration chains (measure_wall_scale) are cut where the measurement wants them, not by partition()
+thread_local const std::vector<int64_t> *tl_force_cuts = nullptr;
+}
+
 extern "C" {
 
 int pf_slab_partition(const pf_simdata *sd, int32_t nslabs, int32_t even_split, int64_t *cuts) {
+   return pf_slab_partition_w(sd, nslabs, even_split, 1.0, cuts);
+}
+int pf_slab_partition_w(const pf_simdata *sd, int32_t nslabs, int32_t even_split, double wall_scale, int64_t *cuts) {
    if (!sd || !cuts) return fail("pf_slab_partition: null argument");
+   if (!(wall_scale > 0)) wall_scale = 1.0;
    std::vector<int64_t> c;
-   const int rc = partition(sd, nslabs, even_split != 0, c);
+   const int rc = partition(sd, nslabs, even_split != 0, c, false, wall_scale);
    if (rc) return rc;
    for (int g = 0; g <= nslabs; g++) cuts[g] = c[g];
    return PF_OK;
+}
+
+// How much does a wall plane at the end of THIS scene's chain cost, in interior planes, on THIS device and build?  Three one-rank
+// cost models (pf_opts.only_slab: a rank alone, its edge planes standing in for the neighbours'): an interior rank with p0 = Nx / G
+// planes, one with p0 + dp planes (-> the cost of an interior plane), and the first rank with p0 planes (-> what its x wall adds).
+// The ratio to what the compiled-in weights (23 / 5 interior planes per full plane of lossy / rigid nodes) predict for that wall is
+// the factor partition() scales them by.  <= 0: not measured (scene too small, too few steps, a chain cut along file z, or a
+// calibration run failed): the caller keeps factor 1.  Costs three short-lived slab engines (a few seconds at 1024^3 / 8).
+double pf_slab_wall_scale(pf_simdata *sd, int32_t nslabs, int32_t device, const pf_opts *base) {
+   if (!sd || nslabs < 2 || tl_force_cuts) return -1.0;
+   const int64_t Nx = sd->Nx, p0 = Nx / nslabs;
+   const int64_t ncal = 63; // steps each calibration chain takes: 9 to warm up, then 18 timed, three times (the fastest counts)
+   if (p0 < 24 || (sd->Npts / nslabs) < ((int64_t)1 << 24) || sd->Nt < ncal || 2 * p0 + 8 > Nx) return -1.0;
+   std::vector<int64_t> c0;
+   std::vector<double> wall1;
+   if (partition(sd, nslabs, false, c0, false, 1.0, &wall1) != PF_OK) return -1.0;
+   const int64_t dp = std::max<int64_t>(16, p0 / 2), cmid = std::max<int64_t>((Nx - p0 - dp) / 2, p0 + 1);
+   if (cmid + p0 + dp + 2 > Nx) return -1.0;
+   pf_opts o;
+   if (base) o = *base; else pf_opts_default(&o);
+   o.verify_exchange = 0; o.test_drop_exchange = 0; o.test_faults = 0; o.timing = 0;
+   o.transport = PF_TRANSPORT_PEER;
+   auto one = [&](const std::vector<int64_t> &cuts, int slab) -> double {
+      const int G = (int)cuts.size() - 1;
+      std::vector<int32_t> devs(G, device);
+      pf_opts oo = o;
+      oo.only_slab = slab + 1;
+      pf_multi *m = nullptr;
+      tl_force_cuts = &cuts;
+      const int rc = pf_multi_create(sd, G, devs.data(), &oo, &m);
+      tl_force_cuts = nullptr;
+      if (rc != PF_OK || !m) return -1.0;
+      double t = -1.0;
+      if (pf_multi_run(m, 0, 9) == PF_OK) {
+         for (int64_t n0 = 9; n0 + 18 <= ncal; n0 += 18) {
+            pf_multi_info info;
+            if (pf_multi_run(m, n0, 18) != PF_OK || pf_multi_get_info(m, &info) != PF_OK) { t = -1.0; break; }
+            t = t < 0 ? info.last_run_seconds / 18.0 : std::min(t, info.last_run_seconds / 18.0);
+         }
+      }
+      pf_multi_destroy(m);
+      return t;
+   };
+   // the calibration chains write their (meaningless) receiver rows into sd->u_out like any chain: keep what was there
+   std::vector<double> keep;
+   if (sd->u_out && sd->Nr > 0) keep.assign(sd->u_out, sd->u_out + (size_t)sd->Nr * sd->Nt);
+   struct Restore {
+      pf_simdata *sd; std::vector<double> &keep;
+      ~Restore() { if (!keep.empty()) memcpy(sd->u_out, keep.data(), sizeof(double) * keep.size()); }
+   } restore{sd, keep};
+   const double t1 = one({0, cmid, cmid + p0, Nx}, 1);
+   const double t2 = t1 > 0 ? one({0, cmid, cmid + p0 + dp, Nx}, 1) : -1.0;
+   const double te = t2 > 0 ? one({0, p0, Nx}, 0) : -1.0;
+   if (!(t1 > 0 && t2 > 0 && te > 0)) return -1.0;
+   double a = (t2 - t1) / (double)dp;                 // seconds per interior plane
+   if (!(a > 0.25 * t1 / (double)p0)) a = t1 / (double)p0; // (noise: at least a quarter of the average cost per plane; else the average itself)
+   const double w_planes = (te - t1) / a;             // what the first rank's wall adds, in interior planes
+   double model = 0;
+   for (int64_t x = 0; x < p0; x++) model += wall1[x] - wall1[cmid + x];
+   if (!(model > 0.5)) return -1.0;                   // (no wall to speak of at the end of the chain)
+   const double k = std::min(4.0, std::max(0.25, w_planes / model));
+   if (getenv("PFFDTD_VERBOSE"))
+      fprintf(stderr, "pffdtd_hip: wall weights measured on device %d: interior rank %ld planes %.4f ms, %ld planes %.4f ms, first rank %ld planes %.4f ms per step -> an interior "
+                      "plane %.5f ms, the x wall %.1f interior planes (compiled-in weights: %.1f) -> factor %.2f\n", device, (long)p0, t1 * 1e3, (long)(p0 + dp), t2 * 1e3,
+              (long)p0, te * 1e3, a * 1e3, w_planes, model, k);
+   return k;
 }
 
 int pf_multi_create(pf_simdata *sd, int32_t nslabs, const int32_t *devices, const pf_opts *base, pf_multi **out) {
@@ -911,7 +995,22 @@ int pf_multi_create(pf_simdata *sd, int32_t nslabs, const int32_t *devices, cons
       } else if (!(S.base.multi_flags & PF_MULTI_CUT_X) && !(S.base.debug & 0x2000) && can && (sd->Nz - 2) / G >= 16)
          S.along_z = pf__axis_exchange_pays(sd, nullptr) != 0;
    }
-   int rc = partition(sd, G, (S.base.multi_flags & PF_MULTI_EVEN_SPLIT) != 0, S.cuts, S.along_z);
+   int rc = PF_OK;
+   if (tl_force_cuts) { // (a calibration chain of pf_slab_wall_scale)
+      if ((int)tl_force_cuts->size() != G + 1) { delete m; return fail("internal: forced cuts do not fit the chain"); }
+      S.cuts = *tl_force_cuts;
+   } else {
+      // the wall planes' weights: the compiled-in figures times the caller's factor (pf_opts.wall_scale > 0), or times what three cost models
+      // of this scene on this device and build give (PF_MULTI_MEASURE_WEIGHTS)
+      const bool even = (S.base.multi_flags & PF_MULTI_EVEN_SPLIT) != 0;
+      S.wall_scale = 1.0;
+      if (S.base.wall_scale > 0) S.wall_scale = S.base.wall_scale;
+      else if (!even && !S.along_z && (S.base.multi_flags & PF_MULTI_MEASURE_WEIGHTS)) {
+         const double k = pf_slab_wall_scale(sd, G, devices[0], &S.base);
+         if (k > 0) { S.wall_scale = k; S.wall_measured = true; }
+      }
+      rc = partition(sd, G, even, S.cuts, S.along_z, S.wall_scale);
+   }
    S.slabs.resize(G);
    for (int g = 0; g < G && rc == PF_OK; g++) rc = cut_slab(sd, S.cuts, g, G, S.slabs[g], S.along_z);
    S.plane_bytes = S.along_z ? pf_grid_bytes(1, sd->Ny, sd->Nx, sd->real_bytes) : pf_grid_bytes(1, sd->Ny, sd->Nz, sd->real_bytes);
@@ -1012,6 +1111,8 @@ int pf_multi_get_info(pf_multi *m, pf_multi_info *info) {
    info->plane_bytes = (int64_t)S.plane_bytes;
    snprintf(info->transport_name, sizeof info->transport_name, "%s", transport_name(S));
    snprintf(info->transport_note, sizeof info->transport_note, "%s", S.transport_note.c_str());
+   info->wall_scale = S.wall_scale;
+   info->wall_measured = S.wall_measured ? 1 : 0;
    return PF_OK;
 }
 

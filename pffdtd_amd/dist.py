@@ -224,15 +224,35 @@ def scene_prefers_exchanged_axes(sd):
     return bool(fn(ctypes.byref(s), None))
 
 
-def make_hip_runner(sd, rank, world, device, group=None, balance=True, along_z=None, **engine_kw):
-    """along_z: cut the chain along FILE Z (slab engines store the x and z axes exchanged; what rooms gain 11-15 % from, DESIGN.md
+def measured_wall_scale(sd, rank, world, device, group=None, **engine_kw):
+    """The factor on the wall planes' weights for this scene (pf_slab_wall_scale), measured by rank 0 on its device and handed to
+    every rank, so that all cut the chain alike.  1.0 when the library declines (small scenes, fewer than 63 steps)."""
+    from . import engine
+    k = [1.0]
+    together = world > 1 and dist.is_available() and dist.is_initialized()
+    if rank == 0 or not together:  # (not together: a rank's cost model run alone, bench.py --emulate-via torch)
+        kw = {f: engine_kw[f] for f in ("numerics", "air_variant", "air_chunk", "debug") if f in engine_kw}
+        dev = device if isinstance(device, int) else (getattr(device, "index", None) or 0)
+        k = [engine.slab_wall_scale(sd, world, dev, **kw) or 1.0]
+    if together:
+        dist.broadcast_object_list(k, src=0, group=group)
+    return float(k[0])
+
+
+def make_hip_runner(sd, rank, world, device, group=None, balance=True, along_z=None, wall_scale=1.0, **engine_kw):
+    """wall_scale: factor on the wall planes' weights of the balanced cut; None = measured on the scene by rank 0 (measured_wall_scale;
+    opt-in like the C chain's PF_MULTI_MEASURE_WEIGHTS: the measurement's noise is larger than the compiled-in weights' error).
+    along_z: cut the chain along FILE Z (slab engines store the x and z axes exchanged; what rooms gain 11-15 % from, DESIGN.md
     5); None = the library's rule for the scene, like the C chain object (csrc/pf_multi.hip)."""
     import os
     if along_z is None:
         pairs_forced = engine_kw.get("pairs") or (engine_kw.get("air_variant", 0) & 255) in (40, 41)
         along_z = (world > 1 and not pairs_forced and not engine_kw.get("energy") and (sd.Nz - 2) // world >= 16
                    and not (int(engine_kw.get("debug", 0)) & 0x2000) and scene_prefers_exchanged_axes(sd))
-    loc, info = slab_mod.split(sd, world, rank, balance=balance, along_z=bool(along_z) and world > 1)
+    if wall_scale is None:
+        wall_scale = measured_wall_scale(sd, rank, world, device, group, **engine_kw) if (balance and world > 1 and not along_z) else 1.0
+    loc, info = slab_mod.split(sd, world, rank, balance=balance, along_z=bool(along_z) and world > 1, wall_scale=wall_scale)
+    info.wall_scale = wall_scale
     # temporally blocked step pairs in slab engines (four state grids per rank): measured on MI355X (1024^3, per-rank cost
     # model with an RCCL self-exchange, old / new on the same box) +3..14 % at 2 ranks, +5..10 % at 4, +7 % on the interior
     # slabs of 8 ranks (136 planes) and +0..2 % on its end slabs.  Default: on for slabs of at least 96 planes;

@@ -26,7 +26,7 @@ class PfOpts(ctypes.Structure):
                 ("ext_u1", ctypes.c_void_p), ("x_global0", ctypes.c_int32), ("debug", ctypes.c_int32),
                 ("energy", ctypes.c_int32), ("multi_flags", ctypes.c_int32), ("transport", ctypes.c_int32),
                 ("verify_exchange", ctypes.c_int32), ("only_slab", ctypes.c_int32), ("test_drop_exchange", ctypes.c_int32),
-                ("test_faults", ctypes.c_int32)]
+                ("test_faults", ctypes.c_int32), ("wall_scale", ctypes.c_double)]
 
 
 class PfTiming(ctypes.Structure):
@@ -43,7 +43,7 @@ class PfMultiInfo(ctypes.Structure):
                 ("exchange_verified", ctypes.c_int32), ("exchanges_checked", ctypes.c_int64),
                 ("exchange_nonzero", ctypes.c_int32), ("cut_along_z", ctypes.c_int32), ("plane_bytes", ctypes.c_int64),
                 ("last_run_seconds", ctypes.c_double), ("transport_name", ctypes.c_char * 64),
-                ("transport_note", ctypes.c_char * 256)]
+                ("transport_note", ctypes.c_char * 256), ("wall_scale", ctypes.c_double), ("wall_measured", ctypes.c_int32)]
 
 
 class PfError(RuntimeError):
@@ -54,12 +54,13 @@ EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_grid_bytes", "p
            "pf_run_sim", "pf_engine_create", "pf_engine_destroy", "pf_engine_run", "pf_engine_step_begin",
            "pf_engine_halo_ptrs", "pf_engine_step_end", "pf_engine_state_grids", "pf_engine_layout", "pf_engine_place_grids", "pf_engine_place_grids5", "pf_engine_set_spares", "pf_engine_stream", "pf_engine_sync",
            "pf_engine_flush_outputs", "pf_engine_get_grid", "pf_engine_set_grid", "pf_engine_timing", "pf_engine_set_timing",
-           "pf_engine_energy_cfg", "pf_engine_run_energy", "pf_run_sim_devices", "pf_slab_partition",
+           "pf_engine_energy_cfg", "pf_engine_run_energy", "pf_run_sim_devices", "pf_slab_partition", "pf_slab_partition_w", "pf_slab_wall_scale",
            "pf_multi_create", "pf_multi_run", "pf_multi_get_info", "pf_multi_get_slab", "pf_multi_destroy"]
 
 
 PF_MULTI_EVEN_SPLIT, PF_MULTI_ONE_THREAD, PF_MULTI_NO_PAIRS, PF_MULTI_FORCE_PAIRS, PF_MULTI_CUT_Z, PF_MULTI_CUT_X = 1, 2, 4, 8, 16, 32
 PF_MULTI_NO_TRIPLES = 64
+PF_MULTI_MEASURE_WEIGHTS = 128
 PF_TRANSPORT_AUTO, PF_TRANSPORT_PEER, PF_TRANSPORT_RCCL, PF_TRANSPORT_HOST = 0, 1, 2, 3
 
 
@@ -134,6 +135,9 @@ def lib():
         L.pf_run_sim_devices.restype = ctypes.c_double
         L.pf_run_sim_devices.argtypes = [ctypes.POINTER(PfSimData), i32, ctypes.POINTER(i32), ctypes.POINTER(PfOpts)]
         L.pf_slab_partition.argtypes = [ctypes.POINTER(PfSimData), i32, i32, ctypes.POINTER(i64)]
+        L.pf_slab_partition_w.argtypes = [ctypes.POINTER(PfSimData), i32, i32, ctypes.c_double, ctypes.POINTER(i64)]
+        L.pf_slab_wall_scale.argtypes = [ctypes.POINTER(PfSimData), i32, i32, ctypes.POINTER(PfOpts)]
+        L.pf_slab_wall_scale.restype = ctypes.c_double
         L.pf_engine_set_spares.argtypes = [vp, vp, vp]
         L.pf_multi_create.argtypes = [ctypes.POINTER(PfSimData), i32, ctypes.POINTER(i32), ctypes.POINTER(PfOpts), ctypes.POINTER(vp)]
         L.pf_multi_run.argtypes = [vp, i64, i64]
@@ -184,7 +188,7 @@ def _multi_opts(multi_flags, opts):
     o = PfOpts()
     lib().pf_opts_default(ctypes.byref(o))
     for k, v in opts.items():
-        setattr(o, k, int(v))
+        setattr(o, k, float(v) if k == "wall_scale" else int(v))
     o.multi_flags = int(multi_flags)
     return o
 
@@ -215,7 +219,8 @@ class HipMulti:
                 "rccl_self": bool(i.rccl_self), "exchanges_checked": i.exchanges_checked,
                 "exchange_verified": None if i.exchange_verified < 0 else bool(i.exchange_verified),
                 "exchange_nonzero": bool(i.exchange_nonzero), "cut_along_z": bool(i.cut_along_z), "plane_bytes": i.plane_bytes,
-                "last_run_seconds": i.last_run_seconds, "transport_note": i.transport_note.decode()}
+                "last_run_seconds": i.last_run_seconds, "transport_note": i.transport_note.decode(),
+                "wall_scale": i.wall_scale, "wall_measured": bool(i.wall_measured)}
 
     def slab(self, g):
         """-> dict(x0, x1, device, paired, engine): engine = a non-owning HipEngine view of slab g's engine (state_grids, timing)"""
@@ -249,12 +254,20 @@ class _EngineView:
     set_timing = lambda self, on: HipEngine.set_timing(self, on)  # noqa: E731
 
 
-def slab_partition(sd, nslabs, even=False):
-    """Owned plane ranges [(x0, x1)] of pf_run_sim_devices' slabs."""
+def slab_partition(sd, nslabs, even=False, wall_scale=1.0):
+    """Owned plane ranges [(x0, x1)] of pf_run_sim_devices' slabs (wall_scale: factor on the wall planes' weights)."""
     s = sd.as_struct()
     cuts = (ctypes.c_int64 * (nslabs + 1))()
-    _check(lib().pf_slab_partition(ctypes.byref(s), int(nslabs), int(bool(even)), cuts))
+    _check(lib().pf_slab_partition_w(ctypes.byref(s), int(nslabs), int(bool(even)), float(wall_scale), cuts))
     return [(int(cuts[g]), int(cuts[g + 1])) for g in range(nslabs)]
+
+
+def slab_wall_scale(sd, nslabs, device=0, **opts):
+    """pf_slab_wall_scale: the factor on the wall planes' weights measured for this scene on `device` (None: not measured)."""
+    s = sd.as_struct()
+    o = _multi_opts(0, opts)
+    k = float(lib().pf_slab_wall_scale(ctypes.byref(s), int(nslabs), int(device), ctypes.byref(o)))
+    return k if k > 0 else None
 
 
 class HipEngine:

@@ -159,7 +159,7 @@ def run_rank(a, world):
         runner, loc, info = pdist.make_hip_runner(sd, rank, world, local_rank, None, timing=True)
         if rank == 0:
             az = bool(getattr(info, "along_z", False))
-            print(f"--{world} GPUs, slabs of {[x1 - x0 for x0, x1 in pdist.slab_mod.partition_weighted(sd, world, az)]} planes"
+            print(f"--{world} GPUs, slabs of {[x1 - x0 for x0, x1 in pdist.slab_mod.partition_weighted(sd, world, az, getattr(info, 'wall_scale', 1.0))]} planes"
                   + (" cut along file z (engines store the x and z axes exchanged)" if az else " along x"))
         dist.barrier()
         torch.cuda.synchronize()

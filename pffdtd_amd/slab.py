@@ -28,10 +28,11 @@ LOSSY_PLANE_EQ = 23.0
 RIGID_PLANE_EQ = 5.0
 
 
-def partition_weighted(sd, G, along_z=False):
+def partition_weighted(sd, G, along_z=False, wall_scale=1.0):
     """Owned plane ranges balanced by estimated cost instead of plane count: the end slabs of a room carry whole
     wall planes of boundary nodes, which the reference's even split (gpu_engine.h:532-550) leaves unbalanced.
-    Deterministic (every rank computes the same cut).  along_z: ranges of FILE Z instead of x (rooms, see split)."""
+    Deterministic (every rank computes the same cut).  along_z: ranges of FILE Z instead of x (rooms, see split).
+    wall_scale: factor on the two wall-plane weights, as measured on the scene by the library (pf_slab_wall_scale; round 5)."""
     Nx = sd.Nz if along_z else sd.Nx
     if G < 1 or G >= Nx:
         raise ValueError(f"need 1 <= ngpus < Nx (got {G}, Nx={Nx})")
@@ -46,7 +47,7 @@ def partition_weighted(sd, G, along_z=False):
         mb_scale = float(np.mean(sd.Mb[sd.mat_bnl])) / 11.0
     cost = np.ones(Nx)
     cost[0] = cost[-1] = 0.0  # global ghost planes are not updated
-    cost += (LOSSY_PLANE_EQ * mb_scale * nl + RIGID_PLANE_EQ * (nb - nl)) / NzNy
+    cost += float(wall_scale) * ((LOSSY_PLANE_EQ * mb_scale * nl + RIGID_PLANE_EQ * (nb - nl)) / NzNy)
     cum = np.concatenate([[0.0], np.cumsum(cost)])
     cuts = [0]
     for g in range(1, G):
@@ -72,14 +73,14 @@ class SlabInfo:
         self.along_z = False                          # (split sets it: the plane numbers above are FILE Z then)
 
 
-def split(sd, G, rank, balance=False, along_z=False):
+def split(sd, G, rank, balance=False, along_z=False, wall_scale=1.0):
     """Local SimData of slab `rank` of `G` (a shallow variant of `sd` with re-based lists) and its SlabInfo.
     balance=False: the reference's even split; True: cost-balanced cut (partition_weighted).
     along_z: the chain is cut along FILE Z instead of x -- for rooms whose engines store the grid with the x and z axes
     exchanged (pf_engine_layout; csrc/pf_multi.hip does the same): the slab then holds the file's columns z in [xlo, xhi) of
     every row, its local file has Nz = xhi - xlo, and `info`'s plane numbers are z."""
     nplanes = sd.Nz if along_z else sd.Nx
-    parts = partition_weighted(sd, G, along_z) if balance else partition(nplanes, G)
+    parts = partition_weighted(sd, G, along_z, wall_scale) if balance else partition(nplanes, G)
     x0, x1 = parts[rank]
     info = SlabInfo(rank, G, x0, x1, nplanes)
     info.along_z = along_z

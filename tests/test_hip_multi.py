@@ -404,3 +404,40 @@ def test_slabs_step_in_triples_across_three_split_phase_steps(prec, transport):
         assert info["exchange_verified"] is True
         assert all(t["tb_steps_per_pass"] == spp and t["tb2_launches"] > 0 and sum(t["wall_blocks"]) > 0 for t in tms), (devs, flags, [t["tb_steps_per_pass"] for t in tms])
         assert np.array_equal(sd2.u_out, want), (devs, flags)
+
+
+# ---- round 5: the wall planes' weights of the balanced cut are measured when the chain is created ---------------------------
+def test_partition_weights_are_measured_at_creation_and_change_no_bits():
+    """PF_MULTI_MEASURE_WEIGHTS: pf_multi_create on a scene with at least 2^24 cells per slab and an interior rank (three slabs or more) times three one-rank cost models (an interior
+    rank, one with half as many planes again, the first rank with its wall) and scales the compiled-in wall-plane weights by what it finds
+    (pf_multi_info.wall_scale, wall_measured).  The calibration chains write receiver rows like any chain: what sd.u_out held must be
+    back afterwards.  Whatever the cut, the chain's receivers equal one domain's bit for bit; a caller-fixed factor skips the measurement,
+    and without the flag the compiled-in weights cut the chain."""
+    n, ny, nz, K, G = 480, 330, 322, 66, 3
+    rcv = [[n // 3 + 3, 8, 10], [n // 3 - 1, 5, 6], [n // 3 - 4, 14, 18], [n // 3 + 12, 4, 4], [n // 3, 20, 9]]  # (both sides of the cut, some in the wall layers)
+    sim = synth.shoebox(n, ny, nz, Nt=K, Nm=2, Mb=[11, 3], src=[n // 3 + 7, 12, 14], rcv=rcv)
+    sd = sim_data.SimData.from_sim(sim, "single", build_mask=False)
+    sd.scale_input()
+    e = engine.HipEngine(sd)
+    e.run(0, K)
+    e.flush_outputs()
+    e.close()
+    want = sd.u_out.copy()
+    assert np.abs(want).max() > 0 and all(np.abs(w).max() > 0 for w in want)
+    seen = {}
+    for key, flags, kw in (("measured", engine.PF_MULTI_MEASURE_WEIGHTS, {}), ("fixed", 0, {}), ("given", engine.PF_MULTI_MEASURE_WEIGHTS, dict(wall_scale=1.7))):
+        sd2 = sim_data.SimData.from_sim(sim, "single", build_mask=False)
+        sd2.scale_input()
+        sd2.u_out[:] = 7.25
+        m = engine.HipMulti(sd2, [0] * G, multi_flags=flags, verify_exchange=K, **kw)
+        assert np.all(sd2.u_out == 7.25), key
+        info = m.info()
+        m.run(0, K)
+        assert m.info()["exchange_verified"] is True
+        seen[key] = (info["wall_scale"], info["wall_measured"], [m.slab(g)["x1"] - m.slab(g)["x0"] for g in range(G)])
+        m.close()
+        assert np.array_equal(sd2.u_out, want), key
+    assert seen["measured"][1] is True and 0.25 <= seen["measured"][0] <= 4.0, seen
+    assert seen["fixed"][:2] == (1.0, False) and seen["given"][:2] == (1.7, False), seen
+    assert seen["measured"][2] == [x1 - x0 for x0, x1 in engine.slab_partition(sd, G, wall_scale=seen["measured"][0])], seen
+    print("wall weights:", seen)

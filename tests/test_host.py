@@ -203,5 +203,7 @@ def test_c_seam_slab_partition_matches_python(name):
     for G in (1, 2, 3, 5):
         assert engine.slab_partition(sd, G, even=True) == slab.partition(sd.Nx, G)
         assert engine.slab_partition(sd, G, even=False) == slab.partition_weighted(sd, G)
+        for k in (0.4, 2.5):  # (the factor the library measures at creation, round 5)
+            assert engine.slab_partition(sd, G, even=False, wall_scale=k) == slab.partition_weighted(sd, G, wall_scale=k)
     with pytest.raises(engine.PfError):
         engine.slab_partition(sd, sd.Nx)  # gpu_engine.h:682
