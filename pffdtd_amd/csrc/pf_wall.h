@@ -145,7 +145,10 @@ __device__ __forceinline__ Real fd_regs(Real p, Real u2, Real sf, int32_t k, con
 // axes: walls away from edges and corners, the bulk of the work.  The structure then arrives with the block (ds*) and the
 // per-lane node decoding, the node loop, the lane shuffles and the march-axis mirrors are compiled out.
 // NODES = false (FAST only): none of the block's pencils holds a boundary node (the plain-air part of a wide column strip).
-template <typename Real, int DP, int MODE, bool FAST, bool NODES, int MC, bool SG>
+// NS = 1: ONE step of the region (round 5: the third step of a triple) -- stage 1 alone, with the owned cells, the node value and the
+// branch state stored after it.  No halo is needed then (what stage 1 computes outside the owned cells is thrown away), so the state
+// may be updated in place (sv_in == sv_out) and the node values go from x2 to o1.
+template <typename Real, int DP, int MODE, bool FAST, bool NODES, int MC, bool SG, int NS = 2>
 __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const WallRegion &R, const int j, const int c, const Real a1, const Real a2,
                                           const WallLds<Real> *ldsp, const uint32_t dsx, const uint32_t dsz, const uint32_t dsw) {
    constexpr bool VEC = MODE == 2;
@@ -435,21 +438,23 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
    int32_t F1k = 0, Fqk = 0, F2k = 0;
 #pragma unroll
    for (int q = 0; q < 12; q++) { F1v[q] = F1g[q] = Fqv[q] = Fqg[q] = F2v[q] = F2g[q] = Real(0); }
-   uint4 Ep = make_uint4(0u, 0u, 0u, 0u), Ec = mask_ent(load_ent(ms - 1), ms - 1), En = mask_ent(load_ent(ms), ms), Eq;
-   load_pencil(wp.B, ms - 2, Bm);
-   load_pencil(wp.B, ms - 1, Bc);
-   load_pencil(wp.B, ms, Bn);
-   load_pencil(wp.A, ms - 1, Ac);
+   // first and last march step: two stages need u^{n+1} one plane before and after the owned ones
+   const int mf = NS == 1 ? ms : ms - 1, ml = NS == 1 ? me - 1 : me;
+   uint4 Ep = make_uint4(0u, 0u, 0u, 0u), Ec = mask_ent(load_ent(mf), mf), En = mask_ent(load_ent(mf + 1), mf + 1), Eq;
+   load_pencil(wp.B, mf - 1, Bm);
+   load_pencil(wp.B, mf, Bc);
+   load_pencil(wp.B, mf + 1, Bn);
+   load_pencil(wp.A, mf, Ac);
    mirror(Bm); mirror(Bc); mirror(Bn);
    fd_fetch(Ec, F1v, F1g, F1sf, F1u2, F1x1, F1k);
 #pragma unroll
    for (int k = 0; k < DP; k++) { Vm[k] = Real(0); Vc[k] = Real(0); Vn[k] = Real(0); W[k] = Real(0); }
-   // before the loop: what march step ms-1 needs next
-   Eq = load_ent(ms + 1);
-   load_pencil(wp.B, ms + 1, Bq);
-   load_pencil(wp.A, ms, Aq);
+   // before the loop: what march step mf needs next
+   Eq = load_ent(mf + 2);
+   load_pencil(wp.B, mf + 2, Bq);
+   load_pencil(wp.A, mf + 1, Aq);
    fd_fetch(En, Fqv, Fqg, Fqsf, Fqu2, Fqx1, Fqk);
-   for (int m = ms - 1; m <= me; m++) {
+   for (int m = mf; m <= ml; m++) {
       rkg = R.kg; rko0 = R.ko0; rko1 = R.ko1; rkb0 = R.kb0; rkb1 = R.kb1; rnbase = R.nbase; usx = dsx; usz = dsz; usw = dsw;
       asm volatile("" : "+s"(rkg), "+s"(rko0), "+s"(rko1), "+s"(rkb0), "+s"(rkb1), "+s"(rnbase), "+s"(usx), "+s"(usz), "+s"(usw));
       // stage 1: u^{n+1}(m)
@@ -461,7 +466,7 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
       // (opaque again: otherwise every per-cell predicate of stage 1 is kept for stage 2 -- in vector-register lanes, two
       // v_writelane per cell -- instead of being tested again with one scalar instruction)
       asm volatile("" : "+s"(rkg), "+s"(rko0), "+s"(rko1), "+s"(rnbase), "+s"(usx), "+s"(usz), "+s"(usw));
-      const bool do2 = m - 1 >= ms;
+      const bool do2 = NS == 2 && m - 1 >= ms;
       if (do2) {
          if (!mx && !FAST) {
             const bool sub_hi = m == NM - 1 && mg_hi, sub_lo = m - 2 == 0 && mg_lo;
@@ -487,6 +492,11 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
       if (own_m) store_pencil(wp.C, m, Vc);
       if (do2) store_pencil(wp.D, m - 1, W);
       if (st1) wp.o1[li1] = nv1;
+      if (NS == 1 && st1) { // one step: the state after stage 1 is the state
+#pragma unroll
+         for (int q = 0; q < 12; q++)
+            if (q < MC) { wp.sv_out[st_idx(q, li1)] = F1v[q]; wp.sg_out[st_idx(q, li1)] = F1g[q]; }
+      }
       if (st2) {
          wp.o2[li2] = nv2;
 #pragma unroll
@@ -500,9 +510,9 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
       F1sf = Fqsf; F1u2 = Fqu2; F1x1 = Fqx1; F1k = Fqk;
       Ep = Ec; Ec = En; En = mask_ent(Eq, m + 2);
       // ... and the loads of the one after the next
-      if (m + 1 <= me) {
+      if (m + 1 <= ml) {
          Eq = load_ent(m + 3);
-         if (m + 1 < me) {
+         if (m + 1 < ml) {
             load_pencil(wp.B, m + 3, Bq);
             load_pencil(wp.A, m + 2, Aq);
             fd_fetch(En, Fqv, Fqg, Fqsf, Fqu2, Fqx1, Fqk);
@@ -518,7 +528,7 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
 // bound every branch m sat in a block of its own -- compare, jump, reload of the array pointers, wait -- 12 times per fetch, per
 // evaluation and per store.  Slots between the scene's count and MC are loaded and stored back unchanged.
 // SG: the reference GPU engine's safeguarded arithmetic (pf_kernels.h: upd7 / upd_rigid / abc_loss<true>) instead of the C CPU engine's.
-template <typename Real, int DP, bool VEC, bool FAST, bool NODES = true, int MC = 12, bool SG = false>
+template <typename Real, int DP, bool VEC, bool FAST, bool NODES = true, int MC = 12, bool SG = false, int NS = 2>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FAST && !VEC) ? 2 : 1))) void k_wall2(WallParams<Real> wp, Real a1, Real a2) {
    static_assert(FAST || NODES, "generic blocks have everything");
    const uint4 bd = wp.blk[blockIdx.x];
@@ -530,9 +540,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FAST && !VE
       for (int i = threadIdx.x; i < wp.nmat; i += 64) { lds.beta[i] = wp.beta[i]; lds.M[i] = wp.Mb[i]; }
       __syncthreads();
    }
-   if constexpr (VEC) wall_body<Real, DP, 2, FAST, NODES, MC, SG>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
-   else if (R.mode == 1) wall_body<Real, DP, 1, FAST, NODES, MC, SG>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
-   else wall_body<Real, DP, 0, FAST, NODES, MC, SG>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
+   if constexpr (VEC) wall_body<Real, DP, 2, FAST, NODES, MC, SG, NS>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
+   else if (R.mode == 1) wall_body<Real, DP, 1, FAST, NODES, MC, SG, NS>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
+   else wall_body<Real, DP, 0, FAST, NODES, MC, SG, NS>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
 }
 
 } // namespace pf
