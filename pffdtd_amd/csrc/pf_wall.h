@@ -104,6 +104,16 @@ template <typename Real> struct WallLds {
    Real beta[PF_WALL_MAXMAT];
    int32_t M[PF_WALL_MAXMAT];
 };
+// Generic blocks: the frequency-dependent nodes beyond a pencil's first one go through memory (fd_core).  Where two walls meet, ONE
+// lane of a tile holds a pencil that lies inside the other wall's layer -- every cell a node -- and the wave used to run fd_core once
+// per pencil cell for that single lane (6 turns x 2 stages per march step: three quarters of a generic block's instructions).  The
+// jobs are parked here instead, [lane][pencil cell], and run TRANSPOSED after the node loop: lane L takes job slot t * 64 + L of the
+// flattened array, so the six jobs of one pencil run side by side in one pass.
+template <typename Real> struct WallJobs {
+   Real p[64 * 8];
+   int32_t li[64 * 8]; // position in the lossy arrays | owner << 30
+   uint32_t mask[64];  // pencil cells with a job, per lane
+};
 template <typename Real, int mmax>
 __device__ __forceinline__ Real fd_regs(Real p, Real u2, Real sf, int32_t k, const Real (&v1)[12], const Real (&g1)[12], Real (&v1o)[12], Real (&g1o)[12],
                                         const WallLds<Real> &L, Real lo2) {
@@ -150,7 +160,7 @@ __device__ __forceinline__ Real fd_regs(Real p, Real u2, Real sf, int32_t k, con
 // may be updated in place (sv_in == sv_out) and the node values go from x2 to o1.
 template <typename Real, int DP, int MODE, bool FAST, bool NODES, int MC, bool SG, int NS = 2>
 __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const WallRegion &R, const int j, const int c, const Real a1, const Real a2,
-                                          const WallLds<Real> *ldsp, const uint32_t dsx, const uint32_t dsz, const uint32_t dsw) {
+                                          const WallLds<Real> *ldsp, const uint32_t dsx, const uint32_t dsz, const uint32_t dsw, WallJobs<Real> *jobs = nullptr) {
    constexpr bool VEC = MODE == 2;
    typedef typename VecOf<Real>::type vec;
    constexpr int V = VecOf<Real>::V;
@@ -381,6 +391,8 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
          for (int k = 1; k < DP - 1; k++)
             if (__ballot((E.x >> k) & 1u) != 0ull) ub |= 1u << k;
          const int k0 = (int)(E.y >> 27);                          // pencil cell of the first frequency-dependent node
+         uint32_t jm = 0u;                                         // pencil cells of this lane whose branch ODEs are parked in `jobs`
+         constexpr bool BATCH = DP <= 8;                           // (8 job slots per lane)
          while (ub) {
             const int k = __ffs(ub) - 1;
             ub &= ub - 1u;
@@ -407,7 +419,13 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
             }
             // any further frequency-dependent node of the pencil: through memory, stored right here
             const bool fds = has && !prim && (inl ? lossy_inl : (rec & 64u) != 0u) && (STAGE == 1 || owner);
-            if (__ballot(fds) != 0ull) {
+            if (BATCH) {
+               if (fds) { // parked: the value after the rigid update, the node's place, who stores
+                  jobs->p[lane * 8 + k] = p;
+                  jobs->li[lane * 8 + k] = (int32_t)(rec >> 8) | (owner ? (1 << 30) : 0);
+                  jm |= 1u << k;
+               }
+            } else if (__ballot(fds) != 0ull) {
                if (fds) {
                   const int32_t li = (int32_t)(rec >> 8);
                   const Real u2 = STAGE == 1 ? wp.x2[li] : wp.x1[li];
@@ -418,6 +436,30 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
             }
 #pragma unroll
             for (int i = 1; i < DP - 1; i++) Out[i] = (has && k == i) ? p : Out[i];
+         }
+         if (BATCH && __ballot(jm != 0u) != 0ull) {
+            jobs->mask[lane] = jm;
+            __syncthreads(); // (one wave per block: orders the LDS traffic of its lanes)
+            for (int t = 0; t < 8; t++) {
+               const int slot = t * 64 + lane, src = slot >> 3, kk = slot & 7;
+               const bool valid = ((jobs->mask[src] >> kk) & 1u) != 0u;
+               if (__ballot(valid) != 0ull) {
+                  if (valid) {
+                     const int32_t w = jobs->li[slot], li = w & 0x3fffffff;
+                     const bool own = (w >> 30) != 0;
+                     const Real u2 = STAGE == 1 ? wp.x2[li] : wp.x1[li];
+                     const Real r = fd_core<Real>(jobs->p[slot], u2, li, STAGE == 1 ? wp.sv_in : wp.sv_out, STAGE == 1 ? wp.sg_in : wp.sg_out, wp.sv_out, wp.sg_out, own,
+                                                  wp.ssaf, wp.mat, wp.Mb, wp.mq, wp.beta, wp.lo2, wp.mmax);
+                     if (own) (STAGE == 1 ? wp.o1 : wp.o2)[li] = r;
+                     jobs->p[slot] = r;
+                  }
+               }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 1; i < DP - 1; i++)
+               if ((jm >> i) & 1u) Out[i] = jobs->p[lane * 8 + i];
+            __syncthreads(); // (before the next stage parks its jobs)
          }
       }
       // ghost cells of the new field: mirror along the pencil, then along the lanes
@@ -535,14 +577,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FAST && !VE
    const WallRegion R = wp.reg[bd.x & 7u];
    const int j = (int)((bd.x >> 3) & 0x1fffu), c = (int)(bd.x >> 16);
    __shared__ WallLds<Real> lds;
+   __shared__ typename std::conditional<FAST, int, WallJobs<Real>>::type jobs_mem; // (generic blocks only)
+   WallJobs<Real> *jobs = nullptr;
+   if constexpr (!FAST) {
+      jobs = &jobs_mem;
+      jobs->mask[threadIdx.x] = 0u;
+   }
    if (NODES) {
       for (int i = threadIdx.x; i < wp.nmat * 12; i += 64) lds.mq[i] = wp.mq[i];
       for (int i = threadIdx.x; i < wp.nmat; i += 64) { lds.beta[i] = wp.beta[i]; lds.M[i] = wp.Mb[i]; }
       __syncthreads();
    }
-   if constexpr (VEC) wall_body<Real, DP, 2, FAST, NODES, MC, SG, NS>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
-   else if (R.mode == 1) wall_body<Real, DP, 1, FAST, NODES, MC, SG, NS>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
-   else wall_body<Real, DP, 0, FAST, NODES, MC, SG, NS>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w);
+   if constexpr (VEC) wall_body<Real, DP, 2, FAST, NODES, MC, SG, NS>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w, jobs);
+   else if (R.mode == 1) wall_body<Real, DP, 1, FAST, NODES, MC, SG, NS>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w, jobs);
+   else wall_body<Real, DP, 0, FAST, NODES, MC, SG, NS>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w, jobs);
 }
 
 } // namespace pf
