@@ -303,17 +303,18 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
          for (int k = 1; k < DP - 1; k++) {
             const Real cc = Cur[k];
             const Real lm = lane_from_lower<true>(cc), lp = lane_from_upper<true>(cc);
-            Real p;
-            if (NODES && ((sx >> k) & 1u)) {
+            // the air update of EVERY cell, straight through; the few node cells (two or three of a pencil) replace theirs out of line:
+            // a taken branch per cell and stage -- 72 per march step of a 20-cell pencil -- was a fifth of a wave's time (one wave per SIMD:
+            // nothing hides the refill of the instruction buffer)
+            Real p = air(cc, Old[k], Cur[k + 1], Cur[k - 1], Nxt[k], Prv[k], lp, lm);
+            if (k == 1) {
+               const int nk = rnbase + k;
+               if (__builtin_expect((ng_lo && nk == 1) || (ng_hi && nk == NN - 2), 0)) p = abc_loss<SG>(p, Old[k], wp.l); // (cpu_engine.h:225-229)
+            }
+            if (NODES && __builtin_expect(((sx >> k) & 1u) != 0u, 0)) {
                const uint32_t jn = __popc(sx & ((1u << k) - 1u));
                p = rigid((usz >> (6 * jn)) & 63u, cc, Old[k], Cur[k + 1], Cur[k - 1], Nxt[k], Prv[k], lp, lm);
                if ((uint32_t)k == sk0) pfd = p;
-            } else {
-               p = air(cc, Old[k], Cur[k + 1], Cur[k - 1], Nxt[k], Prv[k], lp, lm);
-               if (k == 1) {
-                  const int nk = rnbase + k;
-                  if ((ng_lo && nk == 1) || (ng_hi && nk == NN - 2)) p = abc_loss<SG>(p, Old[k], wp.l); // (cpu_engine.h:225-229)
-               }
             }
             Out[k] = p;
          }
