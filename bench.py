@@ -171,7 +171,7 @@ def roofline_block(args, sd, tm, K, real_bytes, interior_planes, interior_per_pl
         rl["frac_of_blocked_compulsory"] = round(comp / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         wb = tm.get("wall_blocks", [0, 0])
         rl["shell"] = ("wall regions in pairs (k_wall2): %d blocks of alike pencils, %d generic" % (wb[0], wb[1])
-                       + ("; third step of a triple: one single step" if rl["steps_per_launch"] == 3 else "")) if sum(wb) else "single steps"
+                       + (("; third step of a triple: " + ("one single step by the list kernels" if ((getattr(args, "debug", 0) & 0x80000) or getattr(args, "gpus", 1) > 1 or getattr(args, "emulate_slab", "")) else "the regions' one-step form (k_wall2 NS = 1)")) if rl["steps_per_launch"] == 3 else "")) if sum(wb) else "single steps"
     return rl, bpv, kernel_ms, units
 
 
