@@ -199,7 +199,7 @@ def measure_traffic_live(args, inst):
             d = Path(td) / counter
             try:
                 r = subprocess.run([rp, "--pmc", counter, "--kernel-trace", "-d", str(d), "-o", "p", "--output-format", "csv", "--"] + child,
-                                   cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, capture_output=True, text=True, timeout=600)
+                                   cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, capture_output=True, text=True, timeout=120)  # (a pass takes ~5 s; a hung profiler must not hold the bench)
             except (OSError, subprocess.TimeoutExpired):
                 return None
             vals = []
