@@ -107,7 +107,8 @@ typedef struct pf_opts {
                              0x800000 replay the single-step loop from a hipGraph (six steps per graph; no faster on this stack);
                              0x100000 boundary pass in plain workgroup order; 0x200000 it fetches the neighbours inside
                              the wall too; 0x40000 13-point pairs by the round-4 kernel k_tb2_fcc_x (A/B measurements); 0x20000 never three
-                             steps per pass (pairs as in round 4) */
+                             steps per pass (pairs as in round 4); 0x80000 the third step of a single domain's triple by the list kernels (round-5 start)
+                             instead of the wall regions' one-step form */
    int32_t energy;        /* 1 = keep what the energy diagnostic needs (explicit Laplacian grid, unfused kernel
                              sequence); then use pf_engine_energy_cfg + pf_engine_run_energy */
    int32_t multi_flags;   /* pf_run_sim_devices / pf_multi_create only: PF_MULTI_* */

@@ -471,7 +471,7 @@ def test_three_steps_per_pass_give_the_oracles_bits(prec, numerics):
     assert (np.abs(ref_out[:-8]).max(axis=1) > 0).all()  # (all but the receiver in the far z wall layer: the random-field test covers that)
     base_out, base_g, _ = run(sim, 25, prec=prec, numerics=numerics)
     assert np.array_equal(base_out, ref_out)
-    for variant, chunk, dbg in ((40, 0, 0), (40, 7, 0), (40, 8, 0x4000000)):
+    for variant, chunk, dbg in ((40, 0, 0), (40, 7, 0), (40, 8, 0x4000000), (40, 0, 0x80000)):  # (0x80000: the third step by the list kernels instead of the regions' one-step form)
         out, g, tm = run(sim, variant, prec=prec, numerics=numerics, readout_chunk=chunk, debug=dbg)
         assert tm["tb_steps_per_pass"] == 3 and tm["tb2_launches"] > 0 and sum(tm["wall_blocks"]) > 0, (variant, chunk, tm)
         assert tm["tb2_dirty_tiles"] >= 2 and tm["steps"] == 100
