@@ -529,3 +529,20 @@ def test_three_steps_per_pass_with_geometry_inside_the_box(prec):
         assert np.array_equal(out, ref.u_out), chunk
         for a, b in zip(g, base_g):
             assert np.array_equal(a[1:-1, 1:-1, 1:-1], b[1:-1, 1:-1, 1:-1]), chunk
+
+
+def test_placement_search_grows_its_pool_when_no_assignment_is_fast(monkeypatch):
+    """Some pools of grids hold no fast assignment for the four streams of a blocked kernel (round 5: 3.40 ms per launch of k_tb3 where
+    2.95 is the rule): a search that ends above the known level -- 16 B per cell and launch at 5.5 TB/s -- allocates four more
+    candidates and searches on, three times at most.  PFFDTD_PLACE_FORCE_GROW walks that path on any box: more candidates timed, the same
+    bits (receivers against the oracle, triples still chosen)."""
+    sim = triple_scene(Nt=31)
+    ref = sim_data.SimData.from_sim(sim, "single")
+    ref.scale_input()
+    oracle.run_sim(ref)
+    out0, _, tm0 = run(sim, 40)
+    monkeypatch.setenv("PFFDTD_PLACE_FORCE_GROW", "1")
+    out1, _, tm1 = run(sim, 40)
+    assert tm0["tb_steps_per_pass"] == 3 and tm1["tb_steps_per_pass"] == 3
+    assert tm1["place_candidates"] > tm0["place_candidates"] > 0, (tm0["place_candidates"], tm1["place_candidates"])
+    assert np.array_equal(out0, ref.u_out) and np.array_equal(out1, ref.u_out)
