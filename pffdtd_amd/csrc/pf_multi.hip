@@ -900,6 +900,16 @@ double pf_slab_wall_scale(pf_simdata *sd, int32_t nslabs, int32_t device, const 
    if (base) o = *base; else pf_opts_default(&o);
    o.verify_exchange = 0; o.test_drop_exchange = 0; o.test_faults = 0; o.timing = 0;
    o.transport = PF_TRANSPORT_PEER;
+   // The forced cuts are x planes.  The real chain is cut along file z when the caller forces that or when pf_multi_create would
+   // choose it for G = nslabs (the same rule as there -- evaluated HERE, with the caller's G: a calibration chain of 2 or 3 slabs
+   // could decide otherwise): no x wall to weigh then.  The calibration chains themselves are pinned to x.
+   {
+      const int vb = o.air_variant & 255;
+      const bool can = !o.energy && vb != 40 && vb != 41 && !(o.multi_flags & PF_MULTI_FORCE_PAIRS) && nslabs < sd->Nz;
+      if (o.multi_flags & PF_MULTI_CUT_Z) return -1.0;
+      if (!(o.multi_flags & PF_MULTI_CUT_X) && !(o.debug & 0x2000) && can && (sd->Nz - 2) / nslabs >= 16 && pf__axis_exchange_pays(sd, nullptr) != 0) return -1.0;
+   }
+   o.multi_flags = (o.multi_flags | PF_MULTI_CUT_X) & ~(PF_MULTI_CUT_Z | PF_MULTI_MEASURE_WEIGHTS | PF_MULTI_EVEN_SPLIT);
    auto one = [&](const std::vector<int64_t> &cuts, int slab) -> double {
       const int G = (int)cuts.size() - 1;
       std::vector<int32_t> devs(G, device);
@@ -997,7 +1007,7 @@ int pf_multi_create(pf_simdata *sd, int32_t nslabs, const int32_t *devices, cons
    }
    int rc = PF_OK;
    if (tl_force_cuts) { // (a calibration chain of pf_slab_wall_scale)
-      if ((int)tl_force_cuts->size() != G + 1) { delete m; return fail("internal: forced cuts do not fit the chain"); }
+      if ((int)tl_force_cuts->size() != G + 1 || S.along_z) { delete m; return fail("internal: forced cuts do not fit the chain (they are x planes)"); }
       S.cuts = *tl_force_cuts;
    } else {
       // the wall planes' weights: the compiled-in figures times the caller's factor (pf_opts.wall_scale > 0), or times what three cost models
