@@ -173,6 +173,7 @@ typedef struct pf_timing {
    int64_t wall_blocks[2];  /* blocked pairs with the shell in pairs too (wall regions, pf_wall.h): blocks of the launches whose pencils
                                are all alike / generic blocks (edges, corners); 0, 0: the shell takes single steps */
    int64_t tb_steps_per_pass; /* steps one launch behind tb2_ms_total advances its cells by: 2 (pairs), 3 (k_tb3, pf_tb3.h), 0: none */
+   int64_t wall_bricks;     /* wall regions: bricks of the frame (edges and corners of the shell, stepped in LDS: pf_brick.h); 0: generic blocks */
 } pf_timing;
 
 typedef struct pf_engine pf_engine;

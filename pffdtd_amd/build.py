@@ -62,6 +62,8 @@ def build_hip(force=False, verbose=False):
     import hashlib
     for src in sorted(CSRC.glob("*.hip")):
         flags = [*HIP_FLAGS, *FILE_FLAGS.get(src.name, [])]
+        if os.environ.get("PFFDTD_DEV_F32") == "1" and src.name == "pf_engine.hip":  # development only: fp32 engine alone, half the compile time
+            flags.append("-DPF_DEV_F32_ONLY")
         # the flags are part of the object's name: a changed flag set (e.g. the -fno-slp-vectorize pf_tb2_fcc.hip needs for
         # bit-exactness) can never link a stale object
         tag = hashlib.sha1(" ".join(flags).encode()).hexdigest()[:8]

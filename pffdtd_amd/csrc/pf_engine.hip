@@ -23,6 +23,7 @@
 #include "pf_tb2.h"
 #include "pf_tb3.h"
 #include "pf_wall.h"
+#include "pf_brick.h"
 
 namespace {
 
@@ -228,6 +229,7 @@ template <typename Real> struct Engine : EngineBase {
    Real *home[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // the placed role cycle: state (0, 1) <-> targets (2, 3), 4 = the u^{n+1} grid
    static constexpr int tb3_wt = 8, tb3_r = 3, tb3_rows = tb3_wt * tb3_r - 4; // k_tb3<Real, 3, 8>: 20 core rows per tile
    int tbx0 = 0, tbx1 = 0, tby0 = 0, tby1 = 0, tbz0 = 0, tbz1 = 0; // box of cells k_tb2_reg produces
+   int tbzu0 = 0, tbzu1 = 0;                                        // ... its z range before it was moved to whole vectors / tiles (the frame's bricks end here)
    int szl = 0, szr = 0;                                  // 7-point column strips: columns [0, szl) and [szr, P)
    // planes per x chunk of k_tb2_reg: 12-20 are equally fast, 24 is 1 % and 48 is 6 % slower although longer chunks
    // re-read fewer prologue planes (1024^3, tools/tb2_probe.py)
@@ -275,6 +277,15 @@ template <typename Real> struct Engine : EngineBase {
    uint32_t *wl_rec = nullptr;                            // per node of a pencil: adjacency bits | lossy flag | lossy position
    int32_t *wl_rest = nullptr;                            // boundary nodes no wall region owns (inside the box): the list kernel's
    int64_t wl_nrest = 0;
+   // the frame (pf_brick.h): the edges and corners of the shell as bricks stepped in LDS -- instead of the regions' generic blocks
+   pf::Brick *wl_brk = nullptr;
+   uint32_t *wl_binfo = nullptr;                          // per cell of a brick's extended box: adjacency | node flags | ABC count
+   uint2 *wl_blos = nullptr;                              // per frequency-dependent node of a brick: cell | owned << 31, place in the lossy arrays
+   int32_t *wl_bown = nullptr;                            // the frequency-dependent nodes the bricks own (places in the lossy arrays)
+   Real *wl_bx1 = nullptr;                                // u^n of the bricks' nodes, snapshot before a pass (pf_brick.h: k_brick_snap)
+   int64_t wl_nbrk = 0, wl_nbown = 0, wl_nblos = 0;
+   int wl_chunk_want[2] = {0, 0};                         // march steps per block the x / y regions' and the column strips' launches aim for (init_walls)
+   size_t wl_brk_lds = 0;                                 // dynamic LDS of a brick launch (the largest brick)
    Real *vh1b = nullptr, *gh1b = nullptr;                 // the other half of the double-buffered branch state
    Real *bs_vout = nullptr, *bs_gout = nullptr;           // launch_boundary: where the new branch state goes (null: in place)
    // energy diagnostic (pf_energy.h)
@@ -294,7 +305,7 @@ template <typename Real> struct Engine : EngineBase {
       auto F = [](void *p) { if (p) hipFree(p); };
       for (Real *g : own_list) F(g); // state grids this engine allocated (u0/u1 unless external, the temporal-blocking spares)
       own_list.clear();
-      F(wl_pen); F(wl_rec); F(wl_rest); F(wl_blk); F(vh1b); F(gh1b); F(d_lossy); F(mask); F(zs_map); F(zs_adj); F(zs_li); F(zs_rest); F(zs_fd); F(tb_clean); F(tb_dirty); F(tb_sample); F(sh_tiles); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
+      F(wl_pen); F(wl_rec); F(wl_rest); F(wl_blk); F(wl_brk); F(wl_binfo); F(wl_blos); F(wl_bown); F(wl_bx1); F(vh1b); F(gh1b); F(d_lossy); F(mask); F(zs_map); F(zs_adj); F(zs_li); F(zs_rest); F(zs_fd); F(tb_clean); F(tb_dirty); F(tb_sample); F(sh_tiles); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
       F(d_beta); F(d_insig); F(d_mq); F(ub[0]); F(ub[1]); F(ub[2]); F(u2ba); F(vh1); F(gh1); F(ring);
       if (h_ring) hipHostFree(h_ring);
       for (auto &p : air_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -907,6 +918,7 @@ template <typename Real> struct Engine : EngineBase {
       tm.wall_blocks[0] = tm.wall_blocks[1] = 0;
       if (wl_on)
          for (const WlGroup &g : wl_grp) { tm.wall_blocks[0] += g.nblk[0] + g.nblk[2]; tm.wall_blocks[1] += g.nblk[1]; }
+      tm.wall_bricks = wl_on ? wl_nbrk : 0;
       if (t) *t = tm;
       if (reset) tm = pf_timing{};
       return PF_OK;
@@ -1007,10 +1019,12 @@ int pf_engine_create(const pf_simdata *sd, const pf_opts *opts, pf_engine **out)
       auto *e = new Engine<float>();
       rc = e->init(sd, &o);
       impl = e;
+#ifndef PF_DEV_F32_ONLY // (development builds, PFFDTD_DEV_F32=1 in pffdtd_amd/build.py: half the compile time; never shipped)
    } else if (sd->real_bytes == 8) {
       auto *e = new Engine<double>();
       rc = e->init(sd, &o);
       impl = e;
+#endif
    } else {
       return set_err(PF_ERR_ARG, "real_bytes must be 4 or 8 (got %d)", sd->real_bytes);
    }

@@ -114,9 +114,9 @@ template <typename Real> struct WallJobs {
    int32_t li[64 * 8]; // position in the lossy arrays | owner << 30
    uint32_t mask[64];  // pencil cells with a job, per lane
 };
-template <typename Real, int mmax>
+template <typename Real, int mmax, typename LDS = WallLds<Real>> // (LDS: anything with mq[], beta[], M[] -- pf_brick.h carves its own)
 __device__ __forceinline__ Real fd_regs(Real p, Real u2, Real sf, int32_t k, const Real (&v1)[12], const Real (&g1)[12], Real (&v1o)[12], Real (&g1o)[12],
-                                        const WallLds<Real> &L, Real lo2) {
+                                        const LDS &L, Real lo2) {
    // mmax = the largest branch count of the scene (uniform).  Branches m >= the node's own count M are computed and thrown away
    // (selects): a per-lane branch around every m put each LDS read of a coefficient and its wait into a block of its own --
    // two dozen dependent LDS round trips per node, with one wave per SIMD nothing to hide them.

@@ -213,7 +213,7 @@ def test_fcc_blocked_pairs_with_live_abc_and_odd_sizes():
 
 
 # ---- wall regions (pf_wall.h): the shell of a blocked pair in pairs too --------------------------------------------------
-WALL_MODES = [(0, "default"), (0x8000000, "all_generic"), (0x4000000, "one_stream"), (0x2000000, "split_strips"), (0x10000000, "single_step_shell")]
+WALL_MODES = [(0, "default"), (0x400000, "generic_blocks"), (0x8000000, "all_generic"), (0x4000000, "one_stream"), (0x2000000, "split_strips"), (0x10000000, "single_step_shell")]
 
 
 @pytest.mark.parametrize("prec", ["single", "double"])
@@ -238,8 +238,10 @@ def test_wall_regions_give_the_oracles_bits(prec, dbg, label):
             assert tm["wall_blocks"] == [0, 0]
         elif dbg == 0x8000000:
             assert tm["wall_blocks"][0] == 0 and tm["wall_blocks"][1] > 0
-        else:
-            assert tm["wall_blocks"][0] > 0 and tm["wall_blocks"][1] > 0, tm
+        elif dbg == 0x400000:  # the round-5 arrangement: edges and corners as generic blocks of k_wall2
+            assert tm["wall_blocks"][0] > 0 and tm["wall_blocks"][1] > 0 and tm["wall_bricks"] == 0, tm
+        else:  # the frame as bricks (pf_brick.h): what is left of the regions is alike
+            assert tm["wall_blocks"][0] > 0 and tm["wall_bricks"] > 0, tm
         assert np.array_equal(out, ref.u_out), (label, chunk)
         for a, b in zip(g, base_g):
             assert np.array_equal(a[1:-1, 1:-1, 1:-1], b[1:-1, 1:-1, 1:-1]), (label, chunk)
@@ -256,7 +258,7 @@ def test_wall_regions_from_random_fields(n, wall, expect, numerics):
     rng = np.random.default_rng(17)
     init = [(rng.standard_normal(n) * 1e-2).astype(np.float32) for _ in range(2)]
     fields = {}
-    for variant, dbg in ((25, 0), (40, 0), (40, 0x8000000)):
+    for variant, dbg in ((25, 0), (40, 0), (40, 0x400000), (40, 0x8000000)):  # (bricks; generic blocks for the frame; for everything)
         sd = sim_data.SimData.from_sim(sim, "single", build_mask=False)
         sd.scale_input()
         eng = engine.HipEngine(sd, air_variant=variant, timing=True, debug=dbg, numerics=numerics)
@@ -471,9 +473,11 @@ def test_three_steps_per_pass_give_the_oracles_bits(prec, numerics):
     assert (np.abs(ref_out[:-8]).max(axis=1) > 0).all()  # (all but the receiver in the far z wall layer: the random-field test covers that)
     base_out, base_g, _ = run(sim, 25, prec=prec, numerics=numerics)
     assert np.array_equal(base_out, ref_out)
-    for variant, chunk, dbg in ((40, 0, 0), (40, 7, 0), (40, 8, 0x4000000), (40, 0, 0x80000)):  # (0x80000: the third step by the list kernels instead of the regions' one-step form)
+    # (0x80000: the third step by the list kernels instead of the regions' one-step form; 0x400000: the frame as generic blocks of k_wall2 -- round 5 -- instead of bricks)
+    for variant, chunk, dbg in ((40, 0, 0), (40, 7, 0), (40, 8, 0x4000000), (40, 0, 0x80000), (40, 0, 0x400000)):
         out, g, tm = run(sim, variant, prec=prec, numerics=numerics, readout_chunk=chunk, debug=dbg)
         assert tm["tb_steps_per_pass"] == 3 and tm["tb2_launches"] > 0 and sum(tm["wall_blocks"]) > 0, (variant, chunk, tm)
+        assert (tm["wall_bricks"] > 0) == (dbg & 0x480000 == 0), (hex(dbg), tm)
         assert tm["tb2_dirty_tiles"] >= 2 and tm["steps"] == 100
         assert np.array_equal(out, ref_out), (variant, chunk, hex(dbg))
         assert np.array_equal(g[1][1:-1, 1:-1, 1:-1], ref_u1[1:-1, 1:-1, 1:-1]), (variant, chunk)
@@ -494,20 +498,22 @@ def test_three_steps_per_pass_from_random_fields(n, wall, triples):
     rng = np.random.default_rng(29)
     init = [(rng.standard_normal(n) * 1e-2).astype(np.float32) for _ in range(2)]
     fields = {}
-    for variant in (25, 40):
+    for variant, dbg in ((25, 0), (40, 0), (40, 0x400000)):  # (0x400000: the frame as generic blocks instead of bricks)
         sd = sim_data.SimData.from_sim(sim, "single", build_mask=False)
         sd.scale_input()
-        eng = engine.HipEngine(sd, air_variant=variant, timing=True)
+        eng = engine.HipEngine(sd, air_variant=variant, timing=True, debug=dbg)
         for k in (0, 1):
             eng.set_grid(k, init[k])
         eng.run(0, sd.Nt)
         tm = eng.timing()
-        fields[variant] = (sd.u_out.copy(), eng.get_grid(0).copy(), eng.get_grid(1).copy())
+        fields[(variant, dbg)] = (sd.u_out.copy(), eng.get_grid(0).copy(), eng.get_grid(1).copy())
         eng.close()
         if variant == 40:
             assert tm["tb_steps_per_pass"] == (3 if triples else 2) and tm["tb2_launches"] == 4, tm  # (3 triples + a pair; pairs come in twos: 2 x 2 + 3 single steps)
-    for a, b in zip(fields[40], fields[25]):
-        assert np.array_equal(a if a.ndim == 2 else a[1:-1, 1:-1, 1:-1], b if b.ndim == 2 else b[1:-1, 1:-1, 1:-1])
+            assert (tm["wall_bricks"] > 0) == (sum(tm["wall_blocks"]) > 0 and dbg == 0), tm
+    for key in ((40, 0), (40, 0x400000)):
+        for a, b in zip(fields[key], fields[(25, 0)]):
+            assert np.array_equal(a if a.ndim == 2 else a[1:-1, 1:-1, 1:-1], b if b.ndim == 2 else b[1:-1, 1:-1, 1:-1]), key
 
 
 @pytest.mark.parametrize("prec", ["single", "double"])
