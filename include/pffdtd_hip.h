@@ -108,7 +108,9 @@ typedef struct pf_opts {
                              0x100000 boundary pass in plain workgroup order; 0x200000 it fetches the neighbours inside
                              the wall too; 0x40000 13-point pairs by the round-4 kernel k_tb2_fcc_x (A/B measurements); 0x20000 never three
                              steps per pass (pairs as in round 4); 0x80000 the third step of a single domain's triple by the list kernels (round-5 start)
-                             instead of the wall regions' one-step form */
+                             instead of the wall regions' one-step form; 0x400000 the frame of the shell as generic blocks of k_wall2 (round 5) instead of
+                             bricks (pf_brick.h); 0x1000000 / 0x40000000 the x / y regions / the column strips of a triple take two steps + one instead
+                             of three in one pass */
    int32_t energy;        /* 1 = keep what the energy diagnostic needs (explicit Laplacian grid, unfused kernel
                              sequence); then use pf_engine_energy_cfg + pf_engine_run_energy */
    int32_t multi_flags;   /* pf_run_sim_devices / pf_multi_create only: PF_MULTI_* */
@@ -174,6 +176,8 @@ typedef struct pf_timing {
                                are all alike / generic blocks (edges, corners); 0, 0: the shell takes single steps */
    int64_t tb_steps_per_pass; /* steps one launch behind tb2_ms_total advances its cells by: 2 (pairs), 3 (k_tb3, pf_tb3.h), 0: none */
    int64_t wall_bricks;     /* wall regions: bricks of the frame (edges and corners of the shell, stepped in LDS: pf_brick.h); 0: generic blocks */
+   int64_t wall_three_steps;/* triples: which wall regions take all three steps in ONE pass (k_wall2<..., NS = 3>): bit 0 the x / y regions, bit 3 the
+                               column strips; 0: two steps + one */
 } pf_timing;
 
 typedef struct pf_engine pf_engine;

@@ -48,9 +48,8 @@ template <typename Real> struct BrickParams {
    const Brick *brk;
    const uint32_t *info;  // adjacency bits | 0x40 node | 0x80 frequency-dependent; air cells: ABC count Q << 8
    const uint2 *los;      // .x = cell of the extended box | owned << 31, .y = position in the lossy arrays
-   const Real *x2;        // node values u^{n-1} (lossy arrays' order): the u2b of step 1 (cpu_engine.h:290-301) -- nobody writes it during the pass
-   const Real *x1s;       // node values u^n of the bricks' nodes, per entry of `los`: the u2b of step 2.  A SNAPSHOT (k_brick_snap) taken before
-                          // the pass: the live buffer receives u^{n+2} from the nodes' owners while a brick still wants u^n of its halo nodes
+   const Real *x2, *x1;   // node values u^{n-1}, u^n (lossy arrays' order): the u2b of steps 1 and 2 (cpu_engine.h:290-301); nobody writes them
+                          // during the pass (single domains rotate FIVE node-value buffers: Engine::step_triple)
    const Real *sv_in, *sg_in;
    Real *sv_out, *sg_out;
    const Real *ssaf;
@@ -106,7 +105,7 @@ __global__ __launch_bounds__(BRICK_T) void k_brick(BrickParams<Real> bp, Real a1
          fsf[k] = bp.ssaf[fli[k]];
          fk[k] = bp.mat[fli[k]];
          fx2[k] = bp.x2[fli[k]];
-         fx1[k] = bp.x1s[bk.los_off + j];
+         fx1[k] = bp.x1[fli[k]];
       }
    }
    // u^{n-1}, u^n of the extended box
@@ -160,7 +159,7 @@ __global__ __launch_bounds__(BRICK_T) void k_brick(BrickParams<Real> bp, Real a1
             const Real u2 = s == 1 ? fx2[k] : (s == 2 ? fx1[k] : uo[cell]);
             const Real u = fd_regs<Real, MC>(un[cell], u2, fsf[k], fk[k], fv[k], fg[k], fv[k], fg[k], lds, bp.lo2);
             un[cell] = u;
-            if ((fc[k] >> 31) && bp.O[s - 1]) bp.O[s - 1][fli[k]] = u; // (a third step's values: Engine::launch_brick_values)
+            if (fc[k] >> 31) bp.O[s - 1][fli[k]] = u;
          }
       }
       __syncthreads();
@@ -185,19 +184,6 @@ __global__ __launch_bounds__(BRICK_T) void k_brick(BrickParams<Real> bp, Real a1
             if (m < MC) { bp.sv_out[st_idx(m, fli[k])] = fv[k][m]; bp.sg_out[st_idx(m, fli[k])] = fg[k][m]; }
       }
    }
-}
-
-// u^n of the bricks' frequency-dependent nodes (own and halo), per entry of the bricks' node lists, before a pass
-template <typename Real>
-static __global__ void k_brick_snap(const Real *__restrict__ x1, Real *__restrict__ x1s, const uint2 *__restrict__ los, int64_t n) {
-   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-   if (i < n) x1s[i] = x1[los[i].y];
-}
-// the node values of a brick's LAST step of three, copied out of the grid afterwards (Engine::launch_brick_values)
-template <typename Real>
-static __global__ void k_brick_values(const Real *__restrict__ G, Real *__restrict__ O, const int32_t *__restrict__ own, const int64_t *__restrict__ cell, int64_t n) {
-   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-   if (i < n) { const int32_t li = own[i]; O[li] = G[cell[li]]; }
 }
 
 } // namespace pf

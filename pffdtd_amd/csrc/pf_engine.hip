@@ -281,9 +281,9 @@ template <typename Real> struct Engine : EngineBase {
    pf::Brick *wl_brk = nullptr;
    uint32_t *wl_binfo = nullptr;                          // per cell of a brick's extended box: adjacency | node flags | ABC count
    uint2 *wl_blos = nullptr;                              // per frequency-dependent node of a brick: cell | owned << 31, place in the lossy arrays
-   int32_t *wl_bown = nullptr;                            // the frequency-dependent nodes the bricks own (places in the lossy arrays)
-   Real *wl_bx1 = nullptr;                                // u^n of the bricks' nodes, snapshot before a pass (pf_brick.h: k_brick_snap)
-   int64_t wl_nbrk = 0, wl_nbown = 0, wl_nblos = 0;
+   int64_t wl_nbrk = 0, wl_nbown_dbg = 0;
+   bool wl_ns3 = false, wl_ns3z = false, wl_no_ns3 = false;                // the x / y regions take three steps per pass (k_wall2<..., NS = 3>); ... found impossible for this scene
+   Real *ubx[2] = {nullptr, nullptr};                     // single domains with wall regions: two more node-value buffers beside ub[0..2]
    int wl_chunk_want[2] = {0, 0};                         // march steps per block the x / y regions' and the column strips' launches aim for (init_walls)
    size_t wl_brk_lds = 0;                                 // dynamic LDS of a brick launch (the largest brick)
    Real *vh1b = nullptr, *gh1b = nullptr;                 // the other half of the double-buffered branch state
@@ -305,7 +305,7 @@ template <typename Real> struct Engine : EngineBase {
       auto F = [](void *p) { if (p) hipFree(p); };
       for (Real *g : own_list) F(g); // state grids this engine allocated (u0/u1 unless external, the temporal-blocking spares)
       own_list.clear();
-      F(wl_pen); F(wl_rec); F(wl_rest); F(wl_blk); F(wl_brk); F(wl_binfo); F(wl_blos); F(wl_bown); F(wl_bx1); F(vh1b); F(gh1b); F(d_lossy); F(mask); F(zs_map); F(zs_adj); F(zs_li); F(zs_rest); F(zs_fd); F(tb_clean); F(tb_dirty); F(tb_sample); F(sh_tiles); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
+      F(wl_pen); F(wl_rec); F(wl_rest); F(wl_blk); F(wl_brk); F(wl_binfo); F(wl_blos); F(ubx[0]); F(ubx[1]); F(vh1b); F(gh1b); F(d_lossy); F(mask); F(zs_map); F(zs_adj); F(zs_li); F(zs_rest); F(zs_fd); F(tb_clean); F(tb_dirty); F(tb_sample); F(sh_tiles); F(Lu); F(vh_old); F(u2in); F(d_acc); F(d_DEF); F(d_bn); F(d_bnl); F(d_bna); F(d_in); F(d_out); F(d_adj); F(d_Q); F(d_mat); F(d_Mb); F(d_ssaf);
       F(d_beta); F(d_insig); F(d_mq); F(ub[0]); F(ub[1]); F(ub[2]); F(u2ba); F(vh1); F(gh1); F(ring);
       if (h_ring) hipHostFree(h_ring);
       for (auto &p : air_ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -919,6 +919,7 @@ template <typename Real> struct Engine : EngineBase {
       if (wl_on)
          for (const WlGroup &g : wl_grp) { tm.wall_blocks[0] += g.nblk[0] + g.nblk[2]; tm.wall_blocks[1] += g.nblk[1]; }
       tm.wall_bricks = wl_on ? wl_nbrk : 0;
+      tm.wall_three_steps = (wl_on && tb3) ? ((wl_ns3 ? 1 : 0) | (wl_ns3z ? 8 : 0)) : 0;
       if (t) *t = tm;
       if (reset) tm = pf_timing{};
       return PF_OK;

@@ -169,7 +169,9 @@ __device__ __forceinline__ Real upd_rigid(Real a2, Real sl2, uint32_t adj, Real 
    Real p = b1 * c - old;
 #pragma unroll
    for (int k = 0; k < NN; k++) {
-      const Real wk = a2 * (Real)((adj >> k) & 1u);
+      // a2 * (Real)bit (cpu_engine.h:247-252) as a select: a2 * 1 = a2 and a2 * 0 = +0 exactly (a2 > 0) -- one instruction instead of a
+      // conversion and a product, none at all where the adjacency word is wave-uniform (the alike blocks of pf_wall.h: a scalar select)
+      const Real wk = ((adj >> k) & 1u) ? a2 : Real(0);
       p = p + wk * nb[k];
    }
    return p;

@@ -52,9 +52,11 @@ struct WallRegion {
    int32_t l0, l1;      // lane-axis coordinates owned: [l0, l1)
    int32_t m0, m1;      // march coordinates owned: [m0, m1)
    int32_t mchunk, nlt; // march steps per block, lane tiles
-   int32_t nlp;         // pencils per march step in the pencil table (nlt * 60 + 4)
+   int32_t nlp;         // pencils per march step in the pencil table (nlt * lt + 2 * hl)
    uint32_t blk0;       // first block of the region in the launch
-   int64_t pen_off;     // the region's pencil table: entry (m - (m0-1)) * nlp + (lc - (l0-2))
+   int32_t hl, lt, hm;  // halo lanes per side of a tile (2; 3 where the region may take THREE steps per pass), owned lanes per tile (64 - 2 hl),
+                        // march planes the pencil table holds before m0 (1 / 2): it covers march steps m0 - hm .. m1 + hm - 1
+   int64_t pen_off;     // the region's pencil table: entry (m - (m0 - hm)) * nlp + (lc - (l0 - hl))
 };
 
 // pencil entry: .x bit k = pencil cell k is a boundary node; .y = index of its first record | pencil cell of its first
@@ -63,7 +65,7 @@ struct WallRegion {
 // record (all nodes of a pencil, in pencil order): adjacency bits | 0x40 frequency-dependent | position in the lossy arrays << 8
 template <typename Real> struct WallParams {
    const Real *A, *B;       // u^{n-1}, u^n
-   Real *C, *D;             // u^{n+1}, u^{n+2}
+   Real *C, *D, *E;         // u^{n+1}, u^{n+2}, u^{n+3} (NS = 3)
    int64_t plane;
    int32_t Nx, Ny, Nz, P, first, last;
    int32_t nreg;
@@ -75,7 +77,8 @@ template <typename Real> struct WallParams {
    const Real *sv_in, *sg_in;
    Real *sv_out, *sg_out;   // branch state vh1 / gh1 before and after the pair (64-node blocks, st_idx)
    const Real *x2, *x1;     // node values u^{n-1} (step 1) and u^n (step 2): the u2b of cpu_engine.h:290-301
-   Real *o1, *o2;           // node values u^{n+1}, u^{n+2} (o2 may be x1)
+   Real *o1, *o2, *o3;      // node values u^{n+1}, u^{n+2} (, u^{n+3}).  Single domains: buffers nobody reads during the pass (round 6:
+                            // five node-value buffers); slabs of a chain: o2 == x1 (an owner reads its node's u^n before it stores its u^{n+2})
    const Real *ssaf;
    const int8_t *mat, *Mb;
    const MatQuadT<Real> *mq;
@@ -155,6 +158,10 @@ __device__ __forceinline__ Real fd_regs(Real p, Real u2, Real sf, int32_t k, con
 // axes: walls away from edges and corners, the bulk of the work.  The structure then arrives with the block (ds*) and the
 // per-lane node decoding, the node loop, the lane shuffles and the march-axis mirrors are compiled out.
 // NODES = false (FAST only): none of the block's pencils holds a boundary node (the plain-air part of a wide column strip).
+// NS = 3 (round 6; alike blocks only): THREE steps in one pass -- stage 3 = u^{n+3}(m-2) from u^{n+2}(m-3 .. m-1) and u^{n+1}(m-2); one more
+// lane, march plane and pencil cell of halo on every side (region tables built with hl = 3, hm = 2), the branch state read and written ONCE
+// per triple instead of twice, u^{n+1} / u^{n+2} of the region never re-read.  A node's u2b is x2 at stage 1, x1 at stage 2, and its own
+// stage-1 value at stage 3.
 // NS = 1: ONE step of the region (round 5: the third step of a triple) -- stage 1 alone, with the owned cells, the node value and the
 // branch state stored after it.  No halo is needed then (what stage 1 computes outside the owned cells is thrown away), so the state
 // may be updated in place (sv_in == sv_out) and the node values go from x2 to o1.
@@ -174,14 +181,16 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
    const bool ng_lo = MODE == 0 ? (wp.first != 0) : true, ng_hi = MODE == 0 ? (wp.last != 0) : true;
    const int64_t sl = VEC ? (int64_t)wp.P : 1, sm = mx ? wp.plane : (int64_t)wp.P;
    const int64_t sn = VEC ? 1 : (MODE == 1 ? (int64_t)wp.P : wp.plane);
-   const int lc = R.l0 - 2 + WALL_LT * j + lane;                   // this lane's coordinate on the lane axis
+   static_assert(NS <= 2 || FAST, "three steps per pass: alike blocks only");
+   const int hl = R.hl, lt = R.lt;
+   const int lc = R.l0 - hl + lt * j + lane;                       // this lane's coordinate on the lane axis
    int lsrc = min(max(lc, 0), NL - 1);                             // where its u^n comes from: ghost cells mirror
    if (lsrc == 0) lsrc = 2;
    else if (lsrc == NL - 1) lsrc = NL - 3;
    const bool lg_lo = lc == 0, lg_hi = lc == NL - 1;
    const bool tile_lg = !FAST && __ballot(lg_lo || lg_hi) != 0ull;
-   const bool own_lane = lane >= 2 && lane <= 61 && lc < R.l1;
-   const bool eval_lane = lane >= 1 && lane <= 62 && lc <= R.l1;   // stage 1 is valid (and needed) here
+   const bool own_lane = lane >= hl && lane <= 63 - hl && lc < R.l1;
+   const bool eval_lane = lane >= 1 && lane <= 62 && lc <= R.l1 + (NS == 3 ? 1 : 0); // stage 1 is valid (and needed) here
    const int ms = R.m0 + c * R.mchunk, me = min(ms + R.mchunk, R.m1);
    if (ms >= me) return;
    const WallLds<Real> &lds = *ldsp;
@@ -225,14 +234,14 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
          b[k] = (k == rkg) ? src : b[k];
       }
    };
-   auto load_ent = [&](int m) __attribute__((always_inline)) { // march steps R.m0-1 .. R.m1 have entries
-      const uint4 *e = wp.pen + (R.pen_off + (int64_t)(min(m, R.m1) - (R.m0 - 1)) * R.nlp + (WALL_LT * j + lane));
+   auto load_ent = [&](int m) __attribute__((always_inline)) { // march steps R.m0 - hm .. R.m1 + hm - 1 have entries
+      const uint4 *e = wp.pen + (R.pen_off + (int64_t)(min(m, R.m1 + R.hm - 1) - (R.m0 - R.hm)) * R.nlp + (lt * j + lane));
       if (FAST && !NODES) return make_uint4(0u, 0u, 0u, 0u);
       if (FAST) return make_uint4(0u, 0u, 0u, e->w); // (only the place of the frequency-dependent node differs from lane to lane)
       return *e;
    };
    auto mask_ent = [&](uint4 e, int m) __attribute__((always_inline)) {
-      if (!eval_lane || m > R.m1) { e.x = 0u; e.w = 0u; }
+      if (!eval_lane || m > R.m1 + (NS == 3 ? 1 : 0)) { e.x = 0u; e.w = 0u; }
       return e;
    };
    auto store_pencil = [&](Real *G, int m, const Real(&v)[DP]) __attribute__((always_inline)) {
@@ -328,7 +337,7 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
          }
          if (NODES && sw5 != 0u) { // (cpu_engine.h:290-301, 363-405) the pencils' frequency-dependent node: state in registers
             const bool owner = own_m && own_lane && (int)sk0 >= rko0 && (int)sk0 < rko1;
-            if (eval_lane && (STAGE == 1 || owner)) {
+            if (eval_lane && (STAGE < NS || STAGE == 1 || owner)) { // (all but the last stage: the halo's nodes too, their state private)
                pfd = fd_regs<Real, MC>(pfd, Fu2, Fsf, Fk, Fv, Fg, Fvo, Fgo, lds, wp.lo2);
                st = owner;
                nval = pfd;
@@ -476,14 +485,16 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
    };
 
    Real Bm[DP], Bc[DP], Bn[DP], Bq[DP], Ac[DP], Aq[DP], Vm[DP], Vc[DP], Vn[DP], W[DP];
+   Real Xm[NS == 3 ? DP : 1], Xc[NS == 3 ? DP : 1], Y[NS == 3 ? DP : 1]; // NS = 3: u^{n+2}(m-3), u^{n+2}(m-2); stage 3's output
    Real F1v[12], F1g[12], Fqv[12], Fqg[12], F2v[12], F2g[12];
-   Real F1sf = 0, F1u2 = 0, F1x1 = 0, Fqsf = 0, Fqu2 = 0, Fqx1 = 0, F2sf = 0, F2u2 = 0;
-   int32_t F1k = 0, Fqk = 0, F2k = 0;
+   Real F3v[NS == 3 ? 12 : 1], F3g[NS == 3 ? 12 : 1];
+   Real F1sf = 0, F1u2 = 0, F1x1 = 0, Fqsf = 0, Fqu2 = 0, Fqx1 = 0, F2sf = 0, F2u2 = 0, F3sf = 0, F3u2 = 0, F2n1 = 0;
+   int32_t F1k = 0, Fqk = 0, F2k = 0, F3k = 0;
 #pragma unroll
-   for (int q = 0; q < 12; q++) { F1v[q] = F1g[q] = Fqv[q] = Fqg[q] = F2v[q] = F2g[q] = Real(0); }
-   // first and last march step: two stages need u^{n+1} one plane before and after the owned ones
-   const int mf = NS == 1 ? ms : ms - 1, ml = NS == 1 ? me - 1 : me;
-   uint4 Ep = make_uint4(0u, 0u, 0u, 0u), Ec = mask_ent(load_ent(mf), mf), En = mask_ent(load_ent(mf + 1), mf + 1), Eq;
+   for (int q = 0; q < 12; q++) { F1v[q] = F1g[q] = Fqv[q] = Fqg[q] = F2v[q] = F2g[q] = Real(0); if (NS == 3) F3v[q] = F3g[q] = Real(0); }
+   // first and last march step: NS stages need u^{n+1} NS - 1 planes before and after the owned ones (NS = 3: u^{n+2} one plane)
+   const int mf = NS == 1 ? ms : ms - (NS - 1), ml = NS == 1 ? me - 1 : me + (NS - 2);
+   uint4 Epp = make_uint4(0u, 0u, 0u, 0u), Ep = make_uint4(0u, 0u, 0u, 0u), Ec = mask_ent(load_ent(mf), mf), En = mask_ent(load_ent(mf + 1), mf + 1), Eq;
    load_pencil(wp.B, mf - 1, Bm);
    load_pencil(wp.B, mf, Bc);
    load_pencil(wp.B, mf + 1, Bn);
@@ -492,6 +503,10 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
    fd_fetch(Ec, F1v, F1g, F1sf, F1u2, F1x1, F1k);
 #pragma unroll
    for (int k = 0; k < DP; k++) { Vm[k] = Real(0); Vc[k] = Real(0); Vn[k] = Real(0); W[k] = Real(0); }
+   if constexpr (NS == 3) {
+#pragma unroll
+      for (int k = 0; k < DP; k++) { Xm[k] = Real(0); Xc[k] = Real(0); Y[k] = Real(0); }
+   }
    // before the loop: what march step mf needs next
    Eq = load_ent(mf + 2);
    load_pencil(wp.B, mf + 2, Bq);
@@ -502,14 +517,15 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
       asm volatile("" : "+s"(rkg), "+s"(rko0), "+s"(rko1), "+s"(rkb0), "+s"(rkb1), "+s"(rnbase), "+s"(usx), "+s"(usz), "+s"(usw));
       // stage 1: u^{n+1}(m)
       const bool own_m = m >= ms && m < me;
-      Real nv1 = Real(0), nv2 = Real(0);
-      bool st1 = false, st2 = false;
+      Real nv1 = Real(0), nv2 = Real(0), nv3 = Real(0);
+      bool st1 = false, st2 = false, st3 = false;
       update(std::integral_constant<int, 1>(), m, Bm, Bc, Bn, Ac, Ec, Vn, own_m, F1v, F1g, F1v, F1g, F1sf, F1u2, F1k, nv1, st1);
       // stage 2: u^{n+2}(m-1) from u^{n+1}(m-2 .. m); a ghost plane of the march axis is the plane two further in
       // (opaque again: otherwise every per-cell predicate of stage 1 is kept for stage 2 -- in vector-register lanes, two
       // v_writelane per cell -- instead of being tested again with one scalar instruction)
       asm volatile("" : "+s"(rkg), "+s"(rko0), "+s"(rko1), "+s"(rnbase), "+s"(usx), "+s"(usz), "+s"(usw));
-      const bool do2 = NS == 2 && m - 1 >= ms;
+      const bool do2 = NS >= 2 && m - 1 >= ms - (NS - 2);
+      const bool own_m2 = m - 1 >= ms && m - 1 < me;
       if (do2) {
          if (!mx && !FAST) {
             const bool sub_hi = m == NM - 1 && mg_hi, sub_lo = m - 2 == 0 && mg_lo;
@@ -517,9 +533,15 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
 #pragma unroll
             for (int k = 0; k < DP; k++) { Pv[k] = sub_lo ? Vn[k] : Vm[k]; Nv[k] = sub_hi ? Vm[k] : Vn[k]; }
             update(std::integral_constant<int, 2>(), m - 1, Pv, Vc, Nv, Bm, Ep, W, true, F2v, F2g, F2v, F2g, F2sf, F2u2, F2k, nv2, st2);
-         } else update(std::integral_constant<int, 2>(), m - 1, Vm, Vc, Vn, Bm, Ep, W, true, F2v, F2g, F2v, F2g, F2sf, F2u2, F2k, nv2, st2);
+         } else update(std::integral_constant<int, 2>(), m - 1, Vm, Vc, Vn, Bm, Ep, W, own_m2, F2v, F2g, F2v, F2g, F2sf, F2u2, F2k, nv2, st2);
       }
-      const int32_t li1 = (int32_t)(Ec.w >> 8), li2 = (int32_t)(Ep.w >> 8);
+      // stage 3 (NS = 3): u^{n+3}(m-2) from u^{n+2}(m-3 .. m-1) -- the last of them stage 2's output just now --, old value u^{n+1}(m-2)
+      const bool do3 = NS == 3 && m - 2 >= ms;
+      if constexpr (NS == 3) {
+         asm volatile("" : "+s"(rkg), "+s"(rko0), "+s"(rko1), "+s"(rnbase), "+s"(usx), "+s"(usz), "+s"(usw));
+         if (do3) update(std::integral_constant<int, 3>(), m - 2, Xm, Xc, W, Vm, Epp, Y, true, F3v, F3g, F3v, F3g, F3sf, F3u2, F3k, nv3, st3);
+      }
+      const int32_t li1 = (int32_t)(Ec.w >> 8), li2 = (int32_t)(Ep.w >> 8), li3 = (int32_t)(Epp.w >> 8);
       // Rotate.  What was loaded a march step ago is touched HERE, before anything is stored: gfx9 counts loads and stores in one
       // in-order counter, so a wait for those loads placed after this step's stores would wait for the stores as well (and
       // without the touch the copies below are mere renamings: the first real use, and the wait, would be in the next step).
@@ -533,7 +555,8 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
       mirror(Bn);
       // the stores of this march step ...
       if (own_m) store_pencil(wp.C, m, Vc);
-      if (do2) store_pencil(wp.D, m - 1, W);
+      if (do2 && own_m2) store_pencil(wp.D, m - 1, W);
+      if constexpr (NS == 3) { if (do3) store_pencil(wp.E, m - 2, Y); }
       if (st1) wp.o1[li1] = nv1;
       if (NS == 1 && st1) { // one step: the state after stage 1 is the state
 #pragma unroll
@@ -542,16 +565,34 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
       }
       if (st2) {
          wp.o2[li2] = nv2;
+         if (NS == 2) {
 #pragma unroll
-         for (int q = 0; q < 12; q++)
-            if (q < MC) { wp.sv_out[st_idx(q, li2)] = F2v[q]; wp.sg_out[st_idx(q, li2)] = F2g[q]; }
+            for (int q = 0; q < 12; q++)
+               if (q < MC) { wp.sv_out[st_idx(q, li2)] = F2v[q]; wp.sg_out[st_idx(q, li2)] = F2g[q]; }
+         }
+      }
+      if constexpr (NS == 3) {
+         if (st3) {
+            wp.o3[li3] = nv3;
+#pragma unroll
+            for (int q = 0; q < 12; q++)
+               if (q < MC) { wp.sv_out[st_idx(q, li3)] = F3v[q]; wp.sg_out[st_idx(q, li3)] = F3g[q]; }
+         }
       }
       asm volatile("" : : : "memory");
+      if constexpr (NS == 3) {
+#pragma unroll
+         for (int k = 0; k < DP; k++) { Xm[k] = Xc[k]; Xc[k] = W[k]; }
+#pragma unroll
+         for (int q = 0; q < 12; q++) { F3v[q] = F2v[q]; F3g[q] = F2g[q]; }
+         F3sf = F2sf; F3k = F2k; F3u2 = F2n1; // (stage 3's u2b: the node's own u^{n+1}, from its stage 1 two march steps ago)
+         F2n1 = nv1;
+      }
 #pragma unroll
       for (int q = 0; q < 12; q++) { F2v[q] = F1v[q]; F2g[q] = F1g[q]; F1v[q] = Fqv[q]; F1g[q] = Fqg[q]; }
       F2sf = F1sf; F2u2 = F1x1; F2k = F1k;
       F1sf = Fqsf; F1u2 = Fqu2; F1x1 = Fqx1; F1k = Fqk;
-      Ep = Ec; Ec = En; En = mask_ent(Eq, m + 2);
+      Epp = Ep; Ep = Ec; Ec = En; En = mask_ent(Eq, m + 2);
       // ... and the loads of the one after the next
       if (m + 1 <= ml) {
          Eq = load_ent(m + 3);
@@ -572,7 +613,7 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
 // evaluation and per store.  Slots between the scene's count and MC are loaded and stored back unchanged.
 // SG: the reference GPU engine's safeguarded arithmetic (pf_kernels.h: upd7 / upd_rigid / abc_loss<true>) instead of the C CPU engine's.
 template <typename Real, int DP, bool VEC, bool FAST, bool NODES = true, int MC = 12, bool SG = false, int NS = 2>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FAST && !VEC) ? 2 : 1))) void k_wall2(WallParams<Real> wp, Real a1, Real a2) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FAST && !VEC && NS != 3 && sizeof(Real) == 4) ? 2 : 1))) void k_wall2(WallParams<Real> wp, Real a1, Real a2) {
    static_assert(FAST || NODES, "generic blocks have everything");
    const uint4 bd = wp.blk[blockIdx.x];
    const WallRegion R = wp.reg[bd.x & 7u];

@@ -35,7 +35,7 @@ class PfTiming(ctypes.Structure):
                 ("tb2_ms_total", ctypes.c_double), ("tb2_launches", ctypes.c_int64), ("tb2_cells", ctypes.c_int64),
                 ("tune_ms", ctypes.c_double * 3), ("air_path", ctypes.c_int64), ("tb2_lw", ctypes.c_int64),
                 ("tb2_dirty_tiles", ctypes.c_int64), ("place_candidates", ctypes.c_int64), ("place_ms", ctypes.c_double * 3),
-                ("wall_blocks", ctypes.c_int64 * 2), ("tb_steps_per_pass", ctypes.c_int64), ("wall_bricks", ctypes.c_int64)]
+                ("wall_blocks", ctypes.c_int64 * 2), ("tb_steps_per_pass", ctypes.c_int64), ("wall_bricks", ctypes.c_int64), ("wall_three_steps", ctypes.c_int64)]
 
 
 class PfMultiInfo(ctypes.Structure):
@@ -388,7 +388,7 @@ class HipEngine:
                 "steps": t.steps, "tb2_ms_total": t.tb2_ms_total, "tb2_launches": t.tb2_launches, "tb2_cells": t.tb2_cells,
                 "tune_ms": list(t.tune_ms), "air_path": t.air_path, "tb2_lw": t.tb2_lw, "tb2_dirty_tiles": t.tb2_dirty_tiles,
                 "place_candidates": t.place_candidates, "place_ms": list(t.place_ms), "wall_blocks": list(t.wall_blocks),
-                "tb_steps_per_pass": t.tb_steps_per_pass, "wall_bricks": t.wall_bricks}
+                "tb_steps_per_pass": t.tb_steps_per_pass, "wall_bricks": t.wall_bricks, "wall_three_steps": t.wall_three_steps}
 
     def set_timing(self, on):
         _check(lib().pf_engine_set_timing(self._h, int(bool(on))))
