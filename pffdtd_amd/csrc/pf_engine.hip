@@ -662,7 +662,10 @@ template <typename Real> struct Engine : EngineBase {
       if (getenv("PFFDTD_VERBOSE") && atoi(getenv("PFFDTD_VERBOSE")) > 0)
          fprintf(stderr, "pffdtd_hip: engine on device %d, %ldx%ldx%ld %s %s, interior path: %s%s, numerics: %s, %d-lane row segments\n", op.device, (long)Nx, (long)Ny, (long)Nz,
                  fcc ? "13-point" : "7-point", sizeof(Real) == 4 ? "fp32" : "fp64",
-                 tb3 ? "three steps per pass (k_tb3), shell as wall regions + one single step" : tb2 ? "temporally blocked pairs" : (lean ? "lean fused kernel" : (vg ? "barrier-free kernel, virtual ghosts" : (abck ? "barrier-free kernel, in-kernel ABC" : "unfused reference sequence"))),
+                 tb3 ? ((wl_ns3 && wl_ns3z) ? "three steps per pass (k_tb3), the shell too: three-step wall regions + bricks" :
+                        wl_ns3 ? "three steps per pass (k_tb3), shell: three-step x / y regions + bricks, column strips two steps + one" :
+                        wl_nbrk ? "three steps per pass (k_tb3), shell: wall regions two steps + one, frame as bricks" :
+                                  "three steps per pass (k_tb3), shell as wall regions + one single step") : tb2 ? "temporally blocked pairs" : (lean ? "lean fused kernel" : (vg ? "barrier-free kernel, virtual ghosts" : (abck ? "barrier-free kernel, in-kernel ABC" : "unfused reference sequence"))),
                  tb2_geom && !tb2 ? " (pairs when the caller hands over four grids)" : (swz ? " (stored with the file's x and z axes exchanged)" : ""), sg ? "GPU-safeguarded" : "CPU-exact", tb2 ? tb_lw : (lean ? 64 : pick_lw()));
       HIPCHK(hipDeviceSynchronize());
       return PF_OK;
