@@ -196,8 +196,18 @@ def roofline_block(args, sd, tm, K, real_bytes, interior_planes, interior_per_pl
         rl["blocked_compulsory_GB_per_launch"] = round(comp / 1e9, 3)
         rl["frac_of_blocked_compulsory"] = round(comp / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         wb = tm.get("wall_blocks", [0, 0])
-        rl["shell"] = ("wall regions in pairs (k_wall2): %d blocks of alike pencils, %d generic" % (wb[0], wb[1])
-                       + (("; third step of a triple: " + ("one single step by the list kernels" if ((getattr(args, "debug", 0) & 0x80000) or getattr(args, "gpus", 1) > 1 or getattr(args, "emulate_slab", "")) else "the regions' one-step form (k_wall2 NS = 1)")) if rl["steps_per_launch"] == 3 else "")) if sum(wb) else "single steps"
+        nbr, w3 = int(tm.get("wall_bricks", 0)), int(tm.get("wall_three_steps", 0))
+        if not sum(wb):
+            rl["shell"] = "single steps"
+        else:
+            frame = (f"{nbr} bricks stepped in LDS (k_brick)" if nbr else f"{wb[1]} generic blocks of k_wall2")
+            if rl["steps_per_launch"] == 3:
+                how = ("all three steps in ONE pass before the box kernel (k_wall2 NS = 3: x / y regions and column strips)" if w3 == 9 else
+                       "x / y regions three steps in one pass (k_wall2 NS = 3), column strips two steps + one" if w3 == 1 else
+                       "two steps as wall regions + " + ("one single step by the list kernels" if ((getattr(args, "debug", 0) & 0x80000) or getattr(args, "gpus", 1) > 1 or getattr(args, "emulate_slab", "")) else "the regions' one-step form (k_wall2 NS = 1)"))
+            else:
+                how = "both steps of a pair in one pass (k_wall2 NS = 2)"
+            rl["shell"] = f"wall regions (k_wall2): {wb[0]} blocks of alike pencils, {how}; frame (edges, corners): {frame}"
     return rl, bpv, kernel_ms, units
 
 
