@@ -261,10 +261,16 @@ def bounded_headline(rl):
     """A kernel that advances its cells by more than one step per launch beats SURVEY 8d's per-update byte figure by design, so
     that figure over the peak is no fraction of a hardware limit (round-5 verdict).  For such kernels `achieved` / `frac` are the
     HBM bytes the launch really moved (PMC) over its duration; the 8d figure stays beside them as *_algorithmic_8d."""
-    if rl.get("steps_per_launch", 1) > 1 and rl.get("measured_traffic_frac") is not None:
+    if rl.get("steps_per_launch", 1) > 1 and "frac_algorithmic_8d" not in rl:
         rl["achieved_algorithmic_8d"], rl["frac_algorithmic_8d"] = rl["achieved"], rl["frac"]
-        rl["achieved"], rl["frac"] = rl["measured_traffic_GBs"], rl["measured_traffic_frac"]
-        rl["frac_is"] = "PMC bytes per launch / launch time / peak (steps_per_launch > 1: the 8d figure is under frac_algorithmic_8d)"
+        if rl.get("measured_traffic_frac") is not None:
+            rl["achieved"], rl["frac"] = rl["measured_traffic_GBs"], rl["measured_traffic_frac"]
+            rl["frac_is"] = "PMC bytes per launch / launch time / peak (steps_per_launch > 1: the 8d figure is under frac_algorithmic_8d)"
+        else:  # no counter pass of this instantiation (--no-pmc, rocprofv3 unusable): the bytes such a launch MUST move, a lower bound of the above
+            rl["frac"] = rl["frac_of_blocked_compulsory"]
+            rl["achieved"] = round(rl["frac"] * HBM_PEAK_GBS, 1)
+            rl["frac_is"] = ("compulsory bytes of a multi-step launch (4 grid passes) / launch time / peak -- no PMC traffic of this instantiation in "
+                             "this run; the 8d figure is under frac_algorithmic_8d")
 
 
 def add_traffic(rl, res, sd, kernel_ms, units, bpv, live=None):
@@ -297,6 +303,7 @@ def add_traffic(rl, res, sd, kernel_ms, units, bpv, live=None):
         if tfile.exists():
             break
     else:
+        bounded_headline(rl)
         return
     try:
         ks = json.load(open(tfile))["kernels"]
@@ -318,6 +325,7 @@ def add_traffic(rl, res, sd, kernel_ms, units, bpv, live=None):
             rl["traffic_note"] = "committed profile is of another kernel instantiation / workload: not quoted"
     except (OSError, KeyError, ValueError):
         pass
+    bounded_headline(rl)
 
 
 def base_result(args, sd, world, K, W, R, regions, el, real_bytes, lossy, parallelism):
@@ -420,6 +428,7 @@ def run_chain(args, only=None):
     (_, ly, lz), _, _ = slabs[g0]["engine"].layout()  # stored rows x columns of a plane (exchanged axes: Ny x Nx)
     rl, bpv, kernel_ms, units = roofline_block(args, sd, tms[g0], K, real_bytes, slabs[g0]["x1"] - slabs[g0]["x0"], (ly - 2) * (lz - 2))
     rl["slab"] = g0
+    bounded_headline(rl)
     res["roofline"] = rl
     res["exchange_verified"] = None if only else info["exchange_verified"]
     res["transport"] = info["transport_name"]  # "peer copies" | "rccl" | "host-staged" (the last resort: neither peer access nor a working RCCL)

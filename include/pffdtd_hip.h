@@ -98,19 +98,8 @@ typedef struct pf_opts {
    void   *ext_u1;        /*   pf_grid_bytes() bytes, zero-filled by the caller; NULL = engine allocates */
    int32_t x_global0;     /* global ix of this grid's plane 0 (slabs): only its parity matters, for the FCC
                              checkerboard form (fcc_flag 1) whose existing nodes have even ix+iy+iz */
-   int32_t debug;         /* test switches, 0 in production: 0x100 / 0x200 / 0x400 force 32- / 16- / 64-lane row segments; 0x4000 single
-                             steps only (no blocked pairs); 0x8000 no creation-time measurement (static rules choose the kernel);
-                             0x20000000 the boundary-list kernel visits every node (none left to the column-strip kernel); 0x1000 /
-                             0x2000 store the grid with the file's x and z axes exchanged / never (default: decided per scene);
-                             0x10000000 blocked pairs keep the single-step shell (no wall regions); 0x8000000 wall regions: every block
-                             generic; 0x4000000 all their launches on one stream; 0x2000000 wide column strips cut in two;
-                             0x800000 replay the single-step loop from a hipGraph (six steps per graph; no faster on this stack);
-                             0x100000 boundary pass in plain workgroup order; 0x200000 it fetches the neighbours inside
-                             the wall too; 0x40000 13-point pairs by the round-4 kernel k_tb2_fcc_x (A/B measurements); 0x20000 never three
-                             steps per pass (pairs as in round 4); 0x80000 the third step of a single domain's triple by the list kernels (round-5 start)
-                             instead of the wall regions' one-step form; 0x400000 the frame of the shell as generic blocks of k_wall2 (round 5) instead of
-                             bricks (pf_brick.h); 0x1000000 / 0x40000000 the x / y regions / the column strips of a triple take two steps + one instead
-                             of three in one pass */
+   int32_t debug;         /* development / test switches, 0 in production: a mask of the PF_DBG_* bits of pffdtd_amd/csrc/pf_debug.h
+                             (each forces one of the engine's alternative arrangements so that tests and A/B measurements can reach it) */
    int32_t energy;        /* 1 = keep what the energy diagnostic needs (explicit Laplacian grid, unfused kernel
                              sequence); then use pf_engine_energy_cfg + pf_engine_run_energy */
    int32_t multi_flags;   /* pf_run_sim_devices / pf_multi_create only: PF_MULTI_* */

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "pffdtd_hip.h"
+#include "pf_debug.h"
 #include "pf_kernels.h"
 #include "pf_air_fused.h"
 #include "pf_energy.h"

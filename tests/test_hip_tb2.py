@@ -520,6 +520,39 @@ def test_three_steps_per_pass_from_random_fields(n, wall, triples):
             assert np.array_equal(a if a.ndim == 2 else a[1:-1, 1:-1, 1:-1], b if b.ndim == 2 else b[1:-1, 1:-1, 1:-1]), key
 
 
+@pytest.mark.parametrize("off,bricks", [(2, True), (1, False)], ids=["two_cells_inside", "one_cell_inside"])
+def test_the_frames_bricks_need_the_source_two_cells_inside_the_box(off, bricks):
+    """A brick recomputes THREE steps of its halo from u^{n-1}, u^n (pf_brick.h), so a source -- added between the steps -- must stay two
+    cells inside the box; one cell inside, the frame goes back to the generic blocks of k_wall2 (two steps + one).  Either way the
+    oracle's receivers and field."""
+    n = (48, 100, 280)
+    sim0 = triple_scene(Nt=40, n=n)
+    sd0 = sim_data.SimData.from_sim(sim0, "single", build_mask=False)
+    sd0.scale_input()
+    eng = engine.HipEngine(sd0, air_variant=40, timing=True)
+    tm0 = eng.timing()
+    eng.close()
+    assert tm0["wall_bricks"] > 0
+    # the triples' box starts three cells beyond the deepest wall layer (wall = 3: layers at index 2 and 3, box from 6, Engine::init_tb2_impl);
+    # a source `off` cells inside it on x
+    x0 = 3 + 3
+    src = [x0 + off, n[1] // 2, n[2] // 2]
+    sim = synth.shoebox(*n, Nt=40, Nm=2, Mb=[11, 3], src=src, rcv=[[x0 + off + 1, n[1] // 2 + 2, n[2] // 2 - 1], [5, 30, 141], [20, 50, 139]], wall=3)
+    ref = sim_data.SimData.from_sim(sim, "single")
+    ref.scale_input()
+    e = oracle.Engine(ref)
+    for k in range(ref.Nt):
+        e.step(k)
+    ref_u1 = e.grid(1).copy()
+    e.close()
+    assert np.abs(ref.u_out).max() > 0
+    out, g, tm = run(sim, 40)
+    assert tm["tb2_launches"] > 0 and sum(tm["wall_blocks"]) > 0, tm
+    assert (tm["wall_bricks"] > 0) == bricks and (tm["wall_three_steps"] == 9) == bricks, tm
+    assert np.array_equal(out, ref.u_out)
+    assert np.array_equal(g[1][1:-1, 1:-1, 1:-1], ref_u1[1:-1, 1:-1, 1:-1])
+
+
 @pytest.mark.parametrize("prec", ["single", "double"])
 def test_three_steps_per_pass_with_geometry_inside_the_box(prec):
     """a block standing in the room: its surface nodes live INSIDE the box of k_tb3 -- their tiles (grown by two cells) take three

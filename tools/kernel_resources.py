@@ -15,7 +15,7 @@ out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = None
 rows = {}
 for line in out.splitlines():
-    m = re.search(r"remark: (?:Function Name: (\S+)|\s*(\w[\w ]*): (\d+))", line)
+    m = re.search(r"remark: (?:Function Name: (\S+)|\s*(\w[\w \[\]/]*): (\d+))", line)
     if not m:
         continue
     if m.group(1):
