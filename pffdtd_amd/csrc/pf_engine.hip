@@ -285,6 +285,7 @@ template <typename Real> struct Engine : EngineBase {
    int64_t wl_nbrk = 0, wl_nbown_dbg = 0;
    bool wl_ns3 = false, wl_ns3z = false, wl_no_ns3 = false;                // the x / y regions take three steps per pass (k_wall2<..., NS = 3>); ... found impossible for this scene
    Real *ubx[2] = {nullptr, nullptr};                     // single domains with wall regions: two more node-value buffers beside ub[0..2]
+   int wl_geo[4] = {0, 0, 0, 0};                          // per launch group: the box margin all its regions' pencils share (standard geometry, pf_wall.h GD), else 0
    int wl_chunk_want[2] = {0, 0};                         // march steps per block the x / y regions' and the column strips' launches aim for (init_walls)
    size_t wl_brk_lds = 0;                                 // dynamic LDS of a brick launch (the largest brick)
    Real *vh1b = nullptr, *gh1b = nullptr;                 // the other half of the double-buffered branch state

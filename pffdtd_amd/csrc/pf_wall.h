@@ -165,7 +165,12 @@ __device__ __forceinline__ Real fd_regs(Real p, Real u2, Real sf, int32_t k, con
 // NS = 1: ONE step of the region (round 5: the third step of a triple) -- stage 1 alone, with the owned cells, the node value and the
 // branch state stored after it.  No halo is needed then (what stage 1 computes outside the owned cells is thrown away), so the state
 // may be updated in place (sv_in == sv_out) and the node values go from x2 to o1.
-template <typename Real, int DP, int MODE, bool FAST, bool NODES, int MC, bool SG, int NS = 2>
+// GD > 0 (round 6; alike blocks of three-step launches): the pencil's geometry is the STANDARD one of a box whose margin on the pencil axis is GD
+// cells -- low side (HI = false): ghost cell 0, owned cells 1 .. GD-1, pencil from coordinate 0; high side: ghost cell DP-1, owned cells
+// DP-GD .. DP-2, pencil from N - DP -- and a compile-time constant: the ghost mirror, the owned range of every store, the ABC cell and the load
+// clamps cost no scalar compares and selects per cell and stage any more (x / y regions: -12 % vector, -29 % scalar instructions per march
+// step).  The host launches these bodies only when every region of the launch has that geometry (Engine::launch_walls_x), else GD = 0.
+template <typename Real, int DP, int MODE, bool FAST, bool NODES, int MC, bool SG, int NS = 2, int GD = 0, bool HI = false>
 __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const WallRegion &R, const int j, const int c, const Real a1, const Real a2,
                                           const WallLds<Real> *ldsp, const uint32_t dsx, const uint32_t dsz, const uint32_t dsw, WallJobs<Real> *jobs = nullptr) {
    constexpr bool VEC = MODE == 2;
@@ -197,7 +202,10 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
    // Wave-uniform values the loop body branches on.  They are made opaque once per march step (below): left alone, the compiler
    // hoists every uniform predicate derived from them out of the march loop, runs out of scalar registers and spills them into
    // vector-register lanes -- 300-500 v_readlane / v_writelane per step, a fifth of the vector instructions.
-   int rkg = R.kg, rko0 = R.ko0, rko1 = R.ko1, rkb0 = R.kb0, rkb1 = R.kb1, rnbase = R.nbase;
+   constexpr bool CG = GD > 0; // constant pencil geometry
+   static_assert(!CG || (FAST && NS == 3 && GD + 3 <= DP), "constant pencil geometry: alike blocks of three-step launches");
+   int rkg = CG ? (HI ? DP - 1 : 0) : R.kg, rko0 = CG ? (HI ? DP - GD : 1) : R.ko0, rko1 = CG ? (HI ? DP - 1 : GD) : R.ko1;
+   int rkb0 = CG ? (HI ? DP - GD - 3 : 0) : R.kb0, rkb1 = CG ? (HI ? DP : GD + 3) : R.kb1, rnbase = CG ? (HI ? NN - DP : 0) : R.nbase;
    uint32_t usx = dsx, usz = dsz, usw = dsw;
    auto msrc = [&](int m) __attribute__((always_inline)) {
       m = min(max(m, 0), NM - 1);
@@ -318,7 +326,8 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
             Real p = air(cc, Old[k], Cur[k + 1], Cur[k - 1], Nxt[k], Prv[k], lp, lm);
             if (k == 1) {
                const int nk = rnbase + k;
-               if (__builtin_expect((ng_lo && nk == 1) || (ng_hi && nk == NN - 2), 0)) p = abc_loss<SG>(p, Old[k], wp.l); // (cpu_engine.h:225-229)
+               const bool abc1 = CG ? (!HI && ng_lo) : ((ng_lo && nk == 1) || (ng_hi && nk == NN - 2));
+               if (__builtin_expect(abc1, 0)) p = abc_loss<SG>(p, Old[k], wp.l); // (cpu_engine.h:225-229)
             }
             if (NODES && __builtin_expect(((sx >> k) & 1u) != 0u, 0)) {
                const uint32_t jn = __popc(sx & ((1u << k) - 1u));
@@ -327,7 +336,9 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
             }
             Out[k] = p;
          }
-         {
+         if constexpr (CG) { // (high side: the ABC cell is pencil cell DP - 2, beside the ghost cell; low side: cell 1, above)
+            if (HI && ng_hi && !(NODES && ((sx >> (DP - 2)) & 1u))) Out[DP - 2] = abc_loss<SG>(Out[DP - 2], Old[DP - 2], wp.l);
+         } else {
             const int kh = NN - 2 - rnbase;
             if (ng_hi && kh >= 2 && kh <= DP - 2 && !(NODES && ((sx >> kh) & 1u))) {
                const Real t = abc_loss<SG>(wall_sel<Real, DP>(Out, kh), wall_sel<Real, DP>(Old, kh), wp.l);
@@ -513,8 +524,12 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
    load_pencil(wp.A, mf + 1, Aq);
    fd_fetch(En, Fqv, Fqg, Fqsf, Fqu2, Fqx1, Fqk);
    for (int m = mf; m <= ml; m++) {
-      rkg = R.kg; rko0 = R.ko0; rko1 = R.ko1; rkb0 = R.kb0; rkb1 = R.kb1; rnbase = R.nbase; usx = dsx; usz = dsz; usw = dsw;
-      asm volatile("" : "+s"(rkg), "+s"(rko0), "+s"(rko1), "+s"(rkb0), "+s"(rkb1), "+s"(rnbase), "+s"(usx), "+s"(usz), "+s"(usw));
+      usx = dsx; usz = dsz; usw = dsw;
+      if constexpr (CG) asm volatile("" : "+s"(usx), "+s"(usz), "+s"(usw));
+      else {
+         rkg = R.kg; rko0 = R.ko0; rko1 = R.ko1; rkb0 = R.kb0; rkb1 = R.kb1; rnbase = R.nbase;
+         asm volatile("" : "+s"(rkg), "+s"(rko0), "+s"(rko1), "+s"(rkb0), "+s"(rkb1), "+s"(rnbase), "+s"(usx), "+s"(usz), "+s"(usw));
+      }
       // stage 1: u^{n+1}(m)
       const bool own_m = m >= ms && m < me;
       Real nv1 = Real(0), nv2 = Real(0), nv3 = Real(0);
@@ -523,7 +538,8 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
       // stage 2: u^{n+2}(m-1) from u^{n+1}(m-2 .. m); a ghost plane of the march axis is the plane two further in
       // (opaque again: otherwise every per-cell predicate of stage 1 is kept for stage 2 -- in vector-register lanes, two
       // v_writelane per cell -- instead of being tested again with one scalar instruction)
-      asm volatile("" : "+s"(rkg), "+s"(rko0), "+s"(rko1), "+s"(rnbase), "+s"(usx), "+s"(usz), "+s"(usw));
+      if constexpr (CG) asm volatile("" : "+s"(usx), "+s"(usz), "+s"(usw));
+      else asm volatile("" : "+s"(rkg), "+s"(rko0), "+s"(rko1), "+s"(rnbase), "+s"(usx), "+s"(usz), "+s"(usw));
       const bool do2 = NS >= 2 && m - 1 >= ms - (NS - 2);
       const bool own_m2 = m - 1 >= ms && m - 1 < me;
       if (do2) {
@@ -538,7 +554,8 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
       // stage 3 (NS = 3): u^{n+3}(m-2) from u^{n+2}(m-3 .. m-1) -- the last of them stage 2's output just now --, old value u^{n+1}(m-2)
       const bool do3 = NS == 3 && m - 2 >= ms;
       if constexpr (NS == 3) {
-         asm volatile("" : "+s"(rkg), "+s"(rko0), "+s"(rko1), "+s"(rnbase), "+s"(usx), "+s"(usz), "+s"(usw));
+         if constexpr (CG) asm volatile("" : "+s"(usx), "+s"(usz), "+s"(usw));
+         else asm volatile("" : "+s"(rkg), "+s"(rko0), "+s"(rko1), "+s"(rnbase), "+s"(usx), "+s"(usz), "+s"(usw));
          if (do3) update(std::integral_constant<int, 3>(), m - 2, Xm, Xc, W, Vm, Epp, Y, true, F3v, F3g, F3v, F3g, F3sf, F3u2, F3k, nv3, st3);
       }
       const int32_t li1 = (int32_t)(Ec.w >> 8), li2 = (int32_t)(Ep.w >> 8), li3 = (int32_t)(Epp.w >> 8);
@@ -612,7 +629,7 @@ __device__ __forceinline__ void wall_body(const WallParams<Real> &wp, const Wall
 // bound every branch m sat in a block of its own -- compare, jump, reload of the array pointers, wait -- 12 times per fetch, per
 // evaluation and per store.  Slots between the scene's count and MC are loaded and stored back unchanged.
 // SG: the reference GPU engine's safeguarded arithmetic (pf_kernels.h: upd7 / upd_rigid / abc_loss<true>) instead of the C CPU engine's.
-template <typename Real, int DP, bool VEC, bool FAST, bool NODES = true, int MC = 12, bool SG = false, int NS = 2>
+template <typename Real, int DP, bool VEC, bool FAST, bool NODES = true, int MC = 12, bool SG = false, int NS = 2, int GD = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FAST && !VEC && NS != 3 && sizeof(Real) == 4) ? 2 : 1))) void k_wall2(WallParams<Real> wp, Real a1, Real a2) {
    static_assert(FAST || NODES, "generic blocks have everything");
    const uint4 bd = wp.blk[blockIdx.x];
@@ -630,7 +647,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FAST && !VE
       for (int i = threadIdx.x; i < wp.nmat; i += 64) { lds.beta[i] = wp.beta[i]; lds.M[i] = wp.Mb[i]; }
       __syncthreads();
    }
-   if constexpr (VEC) wall_body<Real, DP, 2, FAST, NODES, MC, SG, NS>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w, jobs);
+   if constexpr (GD > 0) { // constant pencil geometry: a low-side and a high-side body
+      const bool hi = R.kg != 0;
+      if constexpr (VEC) { if (hi) wall_body<Real, DP, 2, FAST, NODES, MC, SG, NS, GD, true>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w, jobs);
+                           else wall_body<Real, DP, 2, FAST, NODES, MC, SG, NS, GD, false>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w, jobs); }
+      else if (R.mode == 1) { if (hi) wall_body<Real, DP, 1, FAST, NODES, MC, SG, NS, GD, true>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w, jobs);
+                              else wall_body<Real, DP, 1, FAST, NODES, MC, SG, NS, GD, false>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w, jobs); }
+      else { if (hi) wall_body<Real, DP, 0, FAST, NODES, MC, SG, NS, GD, true>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w, jobs);
+             else wall_body<Real, DP, 0, FAST, NODES, MC, SG, NS, GD, false>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w, jobs); }
+   } else if constexpr (VEC) wall_body<Real, DP, 2, FAST, NODES, MC, SG, NS>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w, jobs);
    else if (R.mode == 1) wall_body<Real, DP, 1, FAST, NODES, MC, SG, NS>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w, jobs);
    else wall_body<Real, DP, 0, FAST, NODES, MC, SG, NS>(wp, R, j, c, a1, a2, &lds, bd.y, bd.z, bd.w, jobs);
 }

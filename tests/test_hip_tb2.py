@@ -475,7 +475,7 @@ def test_three_steps_per_pass_give_the_oracles_bits(prec, numerics):
     assert np.array_equal(base_out, ref_out)
     # (0x80000: the third step by the list kernels instead of the regions' one-step form; 0x400000: the frame as generic blocks of k_wall2 -- round 5 -- instead of bricks)
     # 0x1000000 / 0x40000000: the x / y regions / the column strips two steps + one instead of three in one pass (k_wall2<..., NS = 3>)
-    for variant, chunk, dbg in ((40, 0, 0), (40, 7, 0), (40, 8, 0x4000000), (40, 0, 0x80000), (40, 0, 0x400000), (40, 5, 0x1000000), (40, 0, 0x40000000)):
+    for variant, chunk, dbg in ((40, 0, 0), (40, 7, 0), (40, 8, 0x4000000), (40, 0, 0x80000), (40, 0, 0x400000), (40, 5, 0x1000000), (40, 0, 0x40000000), (40, 0, 0x800)):  # (0x800: the three-step bodies with run-time pencil geometry)
         out, g, tm = run(sim, variant, prec=prec, numerics=numerics, readout_chunk=chunk, debug=dbg)
         assert tm["tb_steps_per_pass"] == 3 and tm["tb2_launches"] > 0 and sum(tm["wall_blocks"]) > 0, (variant, chunk, tm)
         assert (tm["wall_bricks"] > 0) == (dbg & 0x480000 == 0), (hex(dbg), tm)
@@ -502,7 +502,7 @@ def test_three_steps_per_pass_from_random_fields(n, wall, triples):
     rng = np.random.default_rng(29)
     init = [(rng.standard_normal(n) * 1e-2).astype(np.float32) for _ in range(2)]
     fields = {}
-    for variant, dbg in ((25, 0), (40, 0), (40, 0x400000), (40, 0x1000000)):  # (0x400000: the frame as generic blocks instead of bricks; 0x1000000: regions two steps + one)
+    for variant, dbg in ((25, 0), (40, 0), (40, 0x400000), (40, 0x1000000), (40, 0x800)):  # (0x400000: the frame as generic blocks instead of bricks; 0x1000000: regions two steps + one; 0x800: run-time pencil geometry)
         sd = sim_data.SimData.from_sim(sim, "single", build_mask=False)
         sd.scale_input()
         eng = engine.HipEngine(sd, air_variant=variant, timing=True, debug=dbg)
@@ -515,7 +515,7 @@ def test_three_steps_per_pass_from_random_fields(n, wall, triples):
         if variant == 40:
             assert tm["tb_steps_per_pass"] == (3 if triples else 2) and tm["tb2_launches"] == 4, tm  # (3 triples + a pair; pairs come in twos: 2 x 2 + 3 single steps)
             assert (tm["wall_bricks"] > 0) == (sum(tm["wall_blocks"]) > 0 and dbg & 0x400000 == 0), tm
-    for key in ((40, 0), (40, 0x400000), (40, 0x1000000)):
+    for key in ((40, 0), (40, 0x400000), (40, 0x1000000), (40, 0x800)):
         for a, b in zip(fields[key], fields[(25, 0)]):
             assert np.array_equal(a if a.ndim == 2 else a[1:-1, 1:-1, 1:-1], b if b.ndim == 2 else b[1:-1, 1:-1, 1:-1]), key
 
