@@ -8,10 +8,12 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 CSRC = ROOT / "pffdtd_amd" / "csrc"
 pat = sys.argv[1] if len(sys.argv) > 1 else ""
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-       "-Wno-unused-value", "-I", str(ROOT / "include"), "-I", str(CSRC), str(CSRC / "pf_engine.hip"), "-o",
-       "/tmp/pf_res.so", "-Rpass-analysis=kernel-resource-usage"]
-out = subprocess.run(cmd, capture_output=True, text=True).stderr
+out = ""
+for unit in ("pf_engine.hip", "pf_engine_f64.hip"):  # (the fp32 and the fp64 instantiation of the engine)
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-ffp-contract=off",
+           "-Wno-unused-value", "-I", str(ROOT / "include"), "-I", str(CSRC), str(CSRC / unit), "-o",
+           "/tmp/pf_res.o", "-Rpass-analysis=kernel-resource-usage"]
+    out += subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = None
 rows = {}
 for line in out.splitlines():
