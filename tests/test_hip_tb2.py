@@ -520,6 +520,27 @@ def test_three_steps_per_pass_from_random_fields(n, wall, triples):
             assert np.array_equal(a if a.ndim == 2 else a[1:-1, 1:-1, 1:-1], b if b.ndim == 2 else b[1:-1, 1:-1, 1:-1]), key
 
 
+def test_three_step_regions_fall_back_where_pencils_are_not_alike():
+    """Every 13th frequency-dependent node rigid: hardly a block of the wall regions has pencils that all look alike, so the regions cannot
+    take three steps in one pass (a generic block has no third stage) -- the engine rebuilds its tables for two steps + one
+    (Engine::init_walls calls itself), keeps the frame's bricks, and gives the oracle's bits."""
+    n = (48, 100, 280)
+    src = [n[0] // 2, n[1] // 2, n[2] // 2]
+    sim = synth.shoebox(*n, Nt=31, Nm=2, Mb=[11, 3], src=src, rcv=[[src[0] + 2, src[1] - 1, src[2] + 3], [4, 47, 142], [24, 93, 144]], wall=3, rigid_every=13)
+    ref = sim_data.SimData.from_sim(sim, "single")
+    ref.scale_input()
+    e = oracle.Engine(ref)
+    for k in range(ref.Nt):
+        e.step(k)
+    ref_u1 = e.grid(1).copy()
+    e.close()
+    assert np.abs(ref.u_out).max() > 0
+    out, g, tm = run(sim, 40)
+    assert tm["tb_steps_per_pass"] == 3 and tm["wall_blocks"][1] > 0 and tm["wall_bricks"] > 0 and tm["wall_three_steps"] == 0, tm
+    assert np.array_equal(out, ref.u_out)
+    assert np.array_equal(g[1][1:-1, 1:-1, 1:-1], ref_u1[1:-1, 1:-1, 1:-1])
+
+
 @pytest.mark.parametrize("off,bricks", [(2, True), (1, False)], ids=["two_cells_inside", "one_cell_inside"])
 def test_the_frames_bricks_need_the_source_two_cells_inside_the_box(off, bricks):
     """A brick recomputes THREE steps of its halo from u^{n-1}, u^n (pf_brick.h), so a source -- added between the steps -- must stay two
