@@ -422,7 +422,7 @@ def run_chain(args, only=None):
         parallelism = (f"COST MODEL of rank {only[0]} of a z-slab x{N} chain on one device: slab {only[0]} alone exists (pf_opts.only_slab) and "
                        f"exchanges its own edge planes with itself by {info['transport_name']}; value = what an {N}-rank chain of such ranks would do")
         res = base_result(args, sd, N, K, W, R, regions, el, real_bytes, lossy, parallelism)
-        res["emulated_slab"] = {"rank": only[0], "of": N, "planes": [slabs[0]["x0"], slabs[0]["x1"]], "pairs": slabs[0]["paired"],
+        res["emulated_slab"] = {"rank": only[0], "of": N, "planes": [slabs[0]["x0"], slabs[0]["x1"]], "pairs": slabs[0]["paired"], "steps_per_pass": slabs[0]["steps_per_pass"],
                                 "ms_per_step": round(el / K * 1e3, 4), "ideal_ms_per_step_note": "single-domain ms/step / N"}
     g0 = max(range(len(slabs)), key=lambda g: slabs[g]["x1"] - slabs[g]["x0"])
     (_, ly, lz), _, _ = slabs[g0]["engine"].layout()  # stored rows x columns of a plane (exchanged axes: Ny x Nx)
@@ -439,7 +439,7 @@ def run_chain(args, only=None):
     res["exchange"] = {"backend": info["transport_name"], "ranks": N, "checked_steps": info["exchanges_checked"],
                        "nonzero_planes": info["exchange_nonzero"], "plane_bytes": info["plane_bytes"],
                        "what": "position-weighted bit-pattern checksums of the received ghost planes == the senders' planes, every slab"}
-    res["slabs"] = [{"device": sl["device"], "planes": [sl["x0"], sl["x1"]], "pairs": sl["paired"],
+    res["slabs"] = [{"device": sl["device"], "planes": [sl["x0"], sl["x1"]], "pairs": sl["paired"], "steps_per_pass": sl["steps_per_pass"],
                      "air_ms_per_step": round(t["air_ms_total"] / K, 4), "wall_region_blocks": sum(t.get("wall_blocks", [0, 0]))}
                     for sl, t in zip(slabs, tms)]
     res["virtual_slabs"] = virt

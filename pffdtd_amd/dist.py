@@ -63,7 +63,8 @@ class HipSlabStepper:
         # then cycles through all four); engines that cannot use them say so and the grids are dropped again.
         # The pair kernel's speed depends on where its four grids lie relative to each other (grid placement):
         # the engine is offered a pool of up to eight and keeps the four it is fastest on.
-        self.paired = False
+        self.paired = False       # strictly a boolean: does the slab step in blocked pairs or triples?
+        self.steps_per_pass = 0   # 0 single steps, 2 pairs, 3 triples
         if info.G > 1 and pairs:
             pool = list(self.grids)
             try:
@@ -74,11 +75,13 @@ class HipSlabStepper:
             except torch.OutOfMemoryError:  # no room for more: what fits
                 torch.cuda.empty_cache()
             if len(pool) >= 5:  # (five or more: the engine may step in triples, pf_engine_place_grids5)
-                self.paired, idx = self.eng.place_grids5([g.data_ptr() for g in pool])
+                self.steps_per_pass, idx = self.eng.place_grids5([g.data_ptr() for g in pool])
                 self.grids = [pool[i] for i in idx if i >= 0]
             elif len(pool) >= 4:
-                self.paired, idx = self.eng.place_grids([g.data_ptr() for g in pool])
+                two, idx = self.eng.place_grids([g.data_ptr() for g in pool])
+                self.steps_per_pass = 2 if two else 0
                 self.grids = [pool[i] for i in idx if i >= 0]
+            self.paired = self.steps_per_pass > 0
             del pool
             torch.cuda.empty_cache()
         self._by_ptr = {g.data_ptr(): g for g in self.grids}

@@ -223,10 +223,12 @@ class HipMulti:
                 "wall_scale": i.wall_scale, "wall_measured": bool(i.wall_measured)}
 
     def slab(self, g):
-        """-> dict(x0, x1, device, paired, engine): engine = a non-owning HipEngine view of slab g's engine (state_grids, timing)"""
+        """-> dict(x0, x1, device, paired, steps_per_pass, engine): engine = a non-owning HipEngine view of slab g's engine (state_grids, timing)"""
         x0, x1, dev, pr, eh = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_void_p()
         _check(lib().pf_multi_get_slab(self._h, int(g), ctypes.byref(x0), ctypes.byref(x1), ctypes.byref(dev), ctypes.byref(pr), ctypes.byref(eh)))
-        return {"x0": x0.value, "x1": x1.value, "device": dev.value, "paired": bool(pr.value), "engine": _EngineView(eh, self.sd.real_bytes)}
+        # (the C chain reports 0 = single steps, 1 = pairs, 3 = triples: here `paired` is strictly a boolean, `steps_per_pass` 0 / 2 / 3)
+        spp = {0: 0, 1: 2, 3: 3}.get(int(pr.value), 2)
+        return {"x0": x0.value, "x1": x1.value, "device": dev.value, "paired": spp > 0, "steps_per_pass": spp, "engine": _EngineView(eh, self.sd.real_bytes)}
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
