@@ -29,6 +29,10 @@
 //     of each other, of the box kernel and of the launch order.  For that the branch state is double-buffered (read
 //     sv_in / sg_in, write sv_out / sg_out; the engine swaps after the pair) and the node values of the two steps go to
 //     buffers nobody reads during the pair (o1, o2; x2 = u^{n-1} of the nodes is only read).
+//   * round 6: blocks whose pencils are not alike -- the frame of the shell: edges, corners -- are no longer this kernel's in single
+//     domains (pf_brick.h steps them in LDS); what remains is alike and may take THREE steps per pass (NS = 3, below: three lanes /
+//     march planes / pencil cells of halo instead of two), with the pencil's geometry compiled in where it is the standard one
+//     (GD, HI).  The generic path stays for slabs of a chain, rooms that are no plain box and the tests.
 //
 // Arithmetic: upd7 / upd_rigid / abc_loss of pf_kernels.h and the branch ODEs in fd_core's order, neighbours in FILE order
 // whatever the pencil's orientation -- bit-identical to the single-step kernels and to
@@ -40,7 +44,7 @@
 namespace pf {
 
 constexpr int WALL_MAXREG = 6;
-constexpr int WALL_LT = 60; // owned lanes per tile (lanes 2 .. 61)
+constexpr int WALL_LT = 60; // owned lanes per tile of the two-step tables (lanes 2 .. 61; three-step tables: 58, WallRegion::lt)
 #define PF_WALL_MAXMAT 64     // (= PF_MNM, fdtd_data.h:35)
 
 struct WallRegion {
