@@ -440,7 +440,8 @@ def run_chain(args, only=None):
                        "nonzero_planes": info["exchange_nonzero"], "plane_bytes": info["plane_bytes"],
                        "what": "position-weighted bit-pattern checksums of the received ghost planes == the senders' planes, every slab"}
     res["slabs"] = [{"device": sl["device"], "planes": [sl["x0"], sl["x1"]], "pairs": sl["paired"], "steps_per_pass": sl["steps_per_pass"],
-                     "air_ms_per_step": round(t["air_ms_total"] / K, 4), "wall_region_blocks": sum(t.get("wall_blocks", [0, 0]))}
+                     "air_ms_per_step": round(t["air_ms_total"] / K, 4), "wall_region_blocks": sum(t.get("wall_blocks", [0, 0])),
+                     "wall_bricks": int(t.get("wall_bricks", 0)), "wall_three_steps": int(t.get("wall_three_steps", 0))}
                     for sl, t in zip(slabs, tms)]
     res["virtual_slabs"] = virt
     m.close()

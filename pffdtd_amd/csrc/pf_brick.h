@@ -58,6 +58,8 @@ template <typename Real> struct BrickParams {
    const Real *beta;
    Real lo2, sl2, l;
    int32_t nmat, ns;
+   int32_t first, last;   // does this grid hold the ghost plane at x = 0 / x = Nx - 1?  (a slab of a chain: only the chain's ends do; plane 0 /
+                          // Nx - 1 of an inner cut is the neighbour's data, which a brick never needs: its bars keep three planes from the cuts)
 };
 
 template <typename Real> struct BrickLds { // (what fd_regs wants of WallLds, carved from the dynamic allocation: nmat materials, not 64)
@@ -123,8 +125,9 @@ __global__ __launch_bounds__(BRICK_T) void k_brick(BrickParams<Real> bp, Real a1
       int lo[3], hi[3];
 #pragma unroll
       for (int d = 0; d < 3; d++) {
-         lo[d] = bk.e0[d] > 1 ? s : 0;
-         hi[d] = bk.e0[d] + bk.en[d] < N[d] - 1 ? bk.en[d] - s : bk.en[d];
+         const bool glo = d > 0 || bp.first, ghi = d > 0 || bp.last; // is index 1 / N-2 of this axis the grid's own shell?
+         lo[d] = (bk.e0[d] > 1 || !glo) ? s : 0;
+         hi[d] = (bk.e0[d] + bk.en[d] < N[d] - 1 || !ghi) ? bk.en[d] - s : bk.en[d];
       }
       for (uint32_t idx = tid; idx < ncell; idx += BRICK_T) {
          const uint32_t iz = idx % ez, t = idx / ez, iy = t % ey, ix = t / ey;
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(BRICK_T) void k_brick(BrickParams<Real> bp, Real a1
          const uint32_t w = bp.info[bk.info_off + idx];
          const Real c = uc[idx], old = uo[idx];
          // ghost cells mirror the cell two further in (cpu_engine.h:145-172): at index 1 the -1 neighbour IS the +1 neighbour
-         const Real xp = uc[gx == bp.Nx - 2 ? idx - syx : idx + syx], xm = uc[gx == 1 ? idx + syx : idx - syx];
+         const Real xp = uc[(gx == bp.Nx - 2 && bp.last) ? idx - syx : idx + syx], xm = uc[(gx == 1 && bp.first) ? idx + syx : idx - syx];
          const Real yp = uc[gy == bp.Ny - 2 ? idx - ez : idx + ez], ym = uc[gy == 1 ? idx + ez : idx - ez];
          const Real zp = uc[gz == bp.Nz - 2 ? idx - 1 : idx + 1], zm = uc[gz == 1 ? idx + 1 : idx - 1];
          Real p;
