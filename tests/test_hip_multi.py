@@ -392,10 +392,12 @@ def test_slabs_step_in_triples_across_three_split_phase_steps(prec, transport):
     oracle.run_sim(sd)
     want = sd.u_out.copy()
     assert np.abs(want).max() > 0 and np.abs(want[2:]).max() > 0
-    for devs, flags, spp in (([0, 0], 0, 3), ([0, 0, 0], 0, 3), ([0, 0], engine.PF_MULTI_NO_TRIPLES, 2)):
+    # round 6: a slab in triples takes its shell's three steps in the FIRST split-phase step (three-step y / z regions + bricks for the four bars
+    # along x) unless a source sits within reach of them (two slabs: the source is at the cut) -- debug 0x400000: the round-5 shell
+    for devs, flags, spp, dbg in (([0, 0], 0, 3, 0), ([0, 0, 0], 0, 3, 0), ([0, 0, 0], 0, 3, 0x400000), ([0, 0], engine.PF_MULTI_NO_TRIPLES, 2, 0)):
         sd2 = sim_data.SimData.from_sim(synth.shoebox(**kw), prec)
         sd2.scale_input()
-        m = engine.HipMulti(sd2, devs, multi_flags=engine.PF_MULTI_FORCE_PAIRS | flags, air_variant=40, transport=transport, verify_exchange=int(sd2.Nt), timing=1)
+        m = engine.HipMulti(sd2, devs, multi_flags=engine.PF_MULTI_FORCE_PAIRS | flags, air_variant=40, transport=transport, verify_exchange=int(sd2.Nt), timing=1, debug=dbg)
         m.run(0, 20)
         m.run(20, int(sd2.Nt) - 20)
         info = m.info()
@@ -403,7 +405,10 @@ def test_slabs_step_in_triples_across_three_split_phase_steps(prec, transport):
         m.close()
         assert info["exchange_verified"] is True
         assert all(t["tb_steps_per_pass"] == spp and t["tb2_launches"] > 0 and sum(t["wall_blocks"]) > 0 for t in tms), (devs, flags, [t["tb_steps_per_pass"] for t in tms])
-        assert np.array_equal(sd2.u_out, want), (devs, flags)
+        if len(devs) == 3 and spp == 3:  # (fp64: two steps + one; three-step tables are fp32)
+            want3 = prec == "single" and dbg == 0
+            assert all((t["wall_three_steps"] == 9 and t["wall_bricks"] > 0) == want3 for t in tms), (hex(dbg), [(t["wall_three_steps"], t["wall_bricks"]) for t in tms])
+        assert np.array_equal(sd2.u_out, want), (devs, flags, hex(dbg))
 
 
 # ---- round 5: the wall planes' weights of the balanced cut are measured when the chain is created ---------------------------
