@@ -109,11 +109,28 @@ int partition(const pf_simdata *sd, int G, bool even, std::vector<int64_t> &cuts
       c += wall_scale * wc;
       cum[x + 1] = cum[x] + c;
    }
+   // Round 6: a cut keeps CUT_CLEAR planes from every source.  A slab in triples takes its shell's three steps in one pass, recomputing three
+   // planes of halo beside its box -- which starts four planes from a cut -- from u^{n-1}, u^n alone: a source there (it is added between the
+   // steps) would send the slab back to the two-steps-plus-one shell.  The headline scene's source sits at Nx / 2, exactly where an even
+   // number of ranks cuts.
+   constexpr int64_t CUT_CLEAR = 8;
+   std::vector<int64_t> src_planes;
+   for (int64_t i = 0; i < sd->Ns; i++) src_planes.push_back(plane_of(sd->in_ixyz[i]));
+   auto clear_of_sources = [&](int64_t x) {
+      for (int64_t p : src_planes) if (x > p - CUT_CLEAR && x <= p + CUT_CLEAR) return false; // (planes x-1 | x are the cut's two sides)
+      return true;
+   };
    for (int g = 1; g < G; g++) {
       const double target = cum[Nx] * (double)g / (double)G;
       int64_t x = (int64_t)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
-      x = std::max(x, cuts[g - 1] + 2);            // every slab updates at least one plane
-      x = std::min(x, Nx - 2 * (int64_t)(G - g));
+      const int64_t lo = cuts[g - 1] + 2, hi = Nx - 2 * (int64_t)(G - g);
+      x = std::max(x, lo);            // every slab updates at least one plane
+      x = std::min(x, hi);
+      if (!clear_of_sources(x)) // the nearest plane that is clear, if the slab thicknesses allow one
+         for (int64_t d = 1; d <= 2 * CUT_CLEAR + 2; d++) {
+            if (x - d >= lo && clear_of_sources(x - d)) { x -= d; break; }
+            if (x + d <= hi && clear_of_sources(x + d)) { x += d; break; }
+         }
       cuts[g] = x;
    }
    return PF_OK;

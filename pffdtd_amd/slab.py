@@ -26,6 +26,7 @@ def partition(Nx, G):
 # csrc/pf_multi.hip: partition)
 LOSSY_PLANE_EQ = 23.0
 RIGID_PLANE_EQ = 5.0
+CUT_CLEAR = 8  # planes a cut keeps from every source (csrc/pf_multi.hip: partition)
 
 
 def partition_weighted(sd, G, along_z=False, wall_scale=1.0):
@@ -49,12 +50,28 @@ def partition_weighted(sd, G, along_z=False, wall_scale=1.0):
     cost[0] = cost[-1] = 0.0  # global ghost planes are not updated
     cost += float(wall_scale) * ((LOSSY_PLANE_EQ * mb_scale * nl + RIGID_PLANE_EQ * (nb - nl)) / NzNy)
     cum = np.concatenate([[0.0], np.cumsum(cost)])
+    # a cut keeps CUT_CLEAR planes from every source (csrc/pf_multi.hip: partition -- a slab in triples recomputes three planes of halo beside
+    # its box, four planes from a cut, without the sources that are added between the steps)
+    src_planes = [int(p) for p in plane_of(np.asarray(sd.in_ixyz))]
+
+    def clear_of_sources(x):
+        return all(not (p - CUT_CLEAR < x <= p + CUT_CLEAR) for p in src_planes)
+
     cuts = [0]
     for g in range(1, G):
         target = cum[-1] * g / G
         x = int(np.searchsorted(cum, target))
-        x = max(x, cuts[-1] + 2)           # every slab updates at least one plane
-        x = min(x, Nx - 2 * (G - g))
+        lo, hi = cuts[-1] + 2, Nx - 2 * (G - g)
+        x = max(x, lo)           # every slab updates at least one plane
+        x = min(x, hi)
+        if not clear_of_sources(x):
+            for d in range(1, 2 * CUT_CLEAR + 3):
+                if x - d >= lo and clear_of_sources(x - d):
+                    x -= d
+                    break
+                if x + d <= hi and clear_of_sources(x + d):
+                    x += d
+                    break
         cuts.append(x)
     cuts.append(Nx)
     return [(cuts[g], cuts[g + 1]) for g in range(G)]
