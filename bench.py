@@ -196,7 +196,7 @@ def roofline_block(args, sd, tm, K, real_bytes, interior_planes, interior_per_pl
         rl["blocked_compulsory_GB_per_launch"] = round(comp / 1e9, 3)
         rl["frac_of_blocked_compulsory"] = round(comp / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         wb = tm.get("wall_blocks", [0, 0])
-        nbr, w3 = int(tm.get("wall_bricks", 0)), int(tm.get("wall_three_steps", 0))
+        nbr, w3 = int(tm.get("wall_bricks", 0)), int(tm.get("wall_three_steps", 0)) & 0xf  # (bits 4, 5: an end slab's x wall)
         if not sum(wb):
             rl["shell"] = "single steps"
         else:

@@ -166,7 +166,8 @@ typedef struct pf_timing {
    int64_t tb_steps_per_pass; /* steps one launch behind tb2_ms_total advances its cells by: 2 (pairs), 3 (k_tb3, pf_tb3.h), 0: none */
    int64_t wall_bricks;     /* wall regions: bricks of the frame (edges and corners of the shell, stepped in LDS: pf_brick.h); 0: generic blocks */
    int64_t wall_three_steps;/* triples: which wall regions take all three steps in ONE pass (k_wall2<..., NS = 3>): bit 0 the x / y regions, bit 3 the
-                               column strips; 0: two steps + one */
+                               column strips; 0: two steps + one.  Slabs of a chain: bits 4 / 5 -- the slab's low / high x side is the grid's own wall
+                               and a region's and the bricks' too (no single steps of its planes) */
 } pf_timing;
 
 typedef struct pf_engine pf_engine;
