@@ -468,7 +468,7 @@ def main():
     ap.add_argument("--numerics", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc child passes (then: the committed profile's figure)")
-    ap.add_argument("--debug", type=lambda v: int(v, 0), default=0, help="pf_opts.debug (tuning switches)")
+    ap.add_argument("--debug", type=lambda v: int(v, 0), default=0, help="internal PF_DBG_* switches (csrc/pf_debug.h), through the library's internal hook")
     ap.add_argument("--transport", default="auto", choices=["auto", "peer", "rccl", "host"],
                     help="N>1 from one process: how ghost planes travel (pf_opts.transport)")
     ap.add_argument("--wall-scale", type=float, default=1.0, help="N>1 from one process: factor on the wall planes' weights of the cut "

@@ -98,8 +98,7 @@ typedef struct pf_opts {
    void   *ext_u1;        /*   pf_grid_bytes() bytes, zero-filled by the caller; NULL = engine allocates */
    int32_t x_global0;     /* global ix of this grid's plane 0 (slabs): only its parity matters, for the FCC
                              checkerboard form (fcc_flag 1) whose existing nodes have even ix+iy+iz */
-   int32_t debug;         /* development / test switches, 0 in production: a mask of the PF_DBG_* bits of pffdtd_amd/csrc/pf_debug.h
-                             (each forces one of the engine's alternative arrangements so that tests and A/B measurements can reach it) */
+   int32_t layout;        /* PF_LAYOUT_*: how the engine stores the grid (pf_engine_layout reports it) */
    int32_t energy;        /* 1 = keep what the energy diagnostic needs (explicit Laplacian grid, unfused kernel
                              sequence); then use pf_engine_energy_cfg + pf_engine_run_energy */
    int32_t multi_flags;   /* pf_run_sim_devices / pf_multi_create only: PF_MULTI_* */
@@ -108,15 +107,15 @@ typedef struct pf_opts {
    int32_t only_slab;     /* pf_multi_create only: 1 + g = cost model of ONE rank -- the chain is cut as usual but slab g alone is
                              instantiated and receives its own edge planes as ghost planes, through the chosen transport (the
                              physics is wrong, the work and the launches are a rank's); 0 = the whole chain */
-   int32_t test_drop_exchange; /* tests only, pf_multi_create: 1 + n = slab 1 misses the ghost planes of step n (the exchange self-check, which
-                             then always covers that step, must notice) */
-   int32_t test_faults;   /* tests only, pf_multi_create: fault injection for the first-contact paths of a multi-device box.  1: no peer
-                             access between any two devices; 2: RCCL unusable; 4: the host thread of slab 1 stalls before the barrier
-                             of its fourth step (the watchdog of the others must turn the hang into an error) */
    double  wall_scale;    /* pf_multi_create / pf_run_sim_devices: > 0 = cut the chain with the wall planes' weights times this factor (a host that
                              measured it once -- pf_slab_wall_scale -- and wants the same cut in every process); 0 = the compiled-in weights, or the
                              library's own measurement under PF_MULTI_MEASURE_WEIGHTS */
 } pf_opts;
+
+#define PF_LAYOUT_AUTO      0 /* decided per scene: rooms whose large surfaces are normal to file z are stored with the file's x and z axes
+                               exchanged (single domains: +11-15 % on the two reference rooms; chains: PF_MULTI_CUT_Z) */
+#define PF_LAYOUT_EXCHANGED 1 /* always exchanged (a slab of a chain cut along file z: pffdtd_amd/dist.py; no energy diagnostic) */
+#define PF_LAYOUT_FILE      2 /* never: the file's own order (x slowest, z unit stride) */
 
 #define PF_TRANSPORT_AUTO 0 /* peer copies where hipDeviceCanAccessPeer says yes for every neighbouring pair, else RCCL, else -- librccl
                                missing, its communicators failing or not returning within PFFDTD_RCCL_INIT_TIMEOUT_S (60) seconds --
@@ -189,12 +188,15 @@ double      pf_run_sim(pf_simdata *sd);
 /* The same on an explicit chain: slab g on device devices[g]; an id may repeat ("virtual slabs": the whole multi-device
  * code path on one GPU).  One host thread per slab, split-phase steps, ghost planes pulled from the neighbours with
  * peer copies on the edge stream while the interior planes run (replaces gpu_engine.h:516-662,739-823,993-1145).
- * base: options common to all slabs (numerics, air_variant, readout_chunk, debug, multi_flags); NULL = defaults. */
+ * base: options common to all slabs (numerics, air_variant, readout_chunk, multi_flags, transport, ...); NULL = defaults. */
 double      pf_run_sim_devices(pf_simdata *sd, int32_t nslabs, const int32_t *devices, const pf_opts *base);
 /* The owned plane ranges such a run uses when cut along x: cuts[0..nslabs], slab g owns global planes [cuts[g], cuts[g+1]).
  * pf_slab_partition: with the compiled-in wall-plane weights; _w: those weights times wall_scale. */
 int         pf_slab_partition(const pf_simdata *sd, int32_t nslabs, int32_t even_split, int64_t *cuts);
 int         pf_slab_partition_w(const pf_simdata *sd, int32_t nslabs, int32_t even_split, double wall_scale, int64_t *cuts);
+/* ... and the cut along FILE Z (along_z = 1: what a chain of slabs stored with exchanged axes uses, PF_MULTI_CUT_Z) -- the ONE implementation of
+ * the cut: pffdtd_amd/slab.py (one process per GPU under torch.distributed) calls this too.  No device needed. */
+int         pf_slab_partition_axis(const pf_simdata *sd, int32_t nslabs, int32_t even_split, double wall_scale, int32_t along_z, int64_t *cuts);
 /* Measures that factor for this scene on `device` (round 5): three short one-rank cost models -- an interior rank with Nx / nslabs planes,
  * one with a few planes more, the first rank with its x wall -- give the cost of an interior plane and of the wall; the ratio to what
  * the compiled-in weights predict is returned (<= 0: not measured -- scene too small, fewer than 63 steps --: use 1).  pf_multi_create
@@ -223,7 +225,12 @@ typedef struct pf_multi_info {
    int32_t wall_measured;      /* 1: that factor was measured at creation (pf_slab_wall_scale) */
 } pf_multi_info;
 int  pf_multi_create(pf_simdata *sd, int32_t nslabs, const int32_t *devices, const pf_opts *base, pf_multi **out);
-/* steps n0 .. n0+nsteps-1 on every slab; returns when all streams have drained and the receiver rows are in sd->u_out */
+/* steps n0 .. n0+nsteps-1 on every slab; returns when all streams have drained and the receiver rows are in sd->u_out.
+ * A slab whose host thread does not reach a step barrier within PFFDTD_BARRIER_TIMEOUT_S seconds (a stuck device, a collective that never
+ * completes) turns the call into PF_ERR_HIP, pf_last_error() = "slab chain hung ...".  After THAT error the object is beyond repair: the
+ * stuck thread may still be inside a driver / RCCL call and cannot be joined, so pf_multi_destroy only detaches the threads and frees
+ * nothing -- device grids, pinned buffers and communicators of every slab stay allocated until the process ends.  A host that catches
+ * the error should report it and EXIT; retrying in the same process can run out of device memory. */
 int  pf_multi_run(pf_multi *m, int64_t n0, int64_t nsteps);
 int  pf_multi_get_info(pf_multi *m, pf_multi_info *info);
 /* slab g: owned global planes [x0, x1), device, whether it steps in temporally blocked pairs (1) or triples (3), and its engine (for
@@ -283,7 +290,7 @@ int  pf_engine_flush_outputs(pf_engine *e);          /* ring -> sd->u_out */
  * pf_engine_set_grid: the field must be FINITE everywhere, the cells inside the walls included.  In the CPU-exact arithmetic the
  * boundary pass does not fetch a neighbour whose adjacency bit is clear (a cell inside the wall): the reference adds (a2 * 0) * u1
  * there, which is +-0 for a finite u1 and leaves the sum as it is (the sums of the time loop never hold -0), but NaN for an Inf
- * or NaN -- pf_opts.debug 0x200000 fetches every neighbour, the exact reference behaviour for such fields too. */
+ * or NaN -- the internal switch PF_DBG_BND_FETCH_ALL (csrc/pf_debug.h) fetches every neighbour, the exact reference behaviour for such fields too. */
 int  pf_engine_get_grid(pf_engine *e, int32_t which, void *host);
 int  pf_engine_set_grid(pf_engine *e, int32_t which, const void *host);
 int  pf_engine_timing(pf_engine *e, pf_timing *t, int32_t reset);

@@ -1,7 +1,24 @@
-// pf_debug.h -- the bits of pf_opts.debug (include/pffdtd_hip.h): development and test switches, 0 in production.  Each one forces an
-// alternative arrangement the engine also contains -- an older kernel family, a fallback, one stream instead of two -- so that the
-// tests can pin every path to the oracle and A/B measurements can be taken on one box.  Internal: not part of the drop-in boundary.
+// pf_debug.h -- development and test switches, 0 in production.  Each PF_DBG_* bit forces an alternative arrangement the engine also
+// contains -- an older kernel family, a fallback, one stream instead of two -- so that the tests can pin every path to the oracle and A/B
+// measurements can be taken on one box.  INTERNAL: none of this is part of the drop-in boundary.  Round 6: the switches left the public
+// pf_opts (include/pffdtd_hip.h); they reach the library through pf_internal_hooks below (exported, declared only here; pffdtd_amd/engine.py
+// calls it for its `debug=` / `test_*=` keyword arguments) or the environment variable PFFDTD_DEBUG (a number, OR-ed in).
 #pragma once
+#include "pffdtd_hip.h"
+// the options as the engines and the chain see them: the public ones + the switches
+struct pf_opts_x : pf_opts {
+   int32_t debug;              // a mask of PF_DBG_* bits
+   int32_t test_drop_exchange; // pf_multi_create: 1 + n = slab 1 misses the ghost planes of step n (the exchange self-check, which then always
+                               // covers that step, must notice)
+   int32_t test_faults;        // pf_multi_create: fault injection for the first-contact paths of a multi-device box.  1: no peer access between
+                               // any two devices; 2: RCCL unusable; 4: the host thread of slab 1 stalls before the barrier of its fourth step
+                               // (the watchdog of the others must turn the hang into an error)
+};
+// The switches of the NEXT pf_engine_create / pf_multi_create / pf_run_sim_devices / pf_slab_wall_scale call of the calling thread (that call
+// clears them again).
+extern "C" void pf_internal_hooks(int32_t debug, int32_t test_drop_exchange, int32_t test_faults);
+pf_opts_x pf__take_hooks(const pf_opts *o); // *o (NULL: the defaults) + the calling thread's pending switches + PFFDTD_DEBUG
+int pf__engine_create_x(const pf_simdata *sd, const pf_opts_x *o, pf_engine **out);
 enum : int {
    PF_DBG_LW32 = 0x100,               // 32-lane row segments (0x200: 16-lane, 0x400: 64-lane) instead of the measured choice
    PF_DBG_LW16 = 0x200,

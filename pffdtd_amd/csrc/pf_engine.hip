@@ -51,7 +51,7 @@ extern "C" int pf__axis_exchange_pays(const pf_simdata *sd, int64_t *counts) {
 struct pf_engine {
    pfeng::EngineBase *impl;
 };
-pfeng::EngineBase *pf__new_engine_f64(const pf_simdata *sd, const pf_opts *o, int *rc); // pf_engine_f64.hip
+pfeng::EngineBase *pf__new_engine_f64(const pf_simdata *sd, const pf_opts_x *o, int *rc); // pf_engine_f64.hip
 
 extern "C" {
 
@@ -80,11 +80,35 @@ void pf_opts_default(pf_opts *o) {
    o->slab_last = 1;
 }
 
+// development / test switches (pf_debug.h): pending for the next create call of this thread
+static thread_local int32_t t_hooks[3] = {0, 0, 0};
+void pf_internal_hooks(int32_t debug, int32_t test_drop_exchange, int32_t test_faults) {
+   t_hooks[0] = debug; t_hooks[1] = test_drop_exchange; t_hooks[2] = test_faults;
+}
+
 int pf_engine_create(const pf_simdata *sd, const pf_opts *opts, pf_engine **out) {
-   if (!sd || !out) return set_err(PF_ERR_ARG, "null argument");
+   const pf_opts_x o = pf__take_hooks(opts);
+   return pf__engine_create_x(sd, &o, out);
+}
+
+} // extern "C"
+
+pf_opts_x pf__take_hooks(const pf_opts *opts) {
+   pf_opts_x x{};
+   if (opts) static_cast<pf_opts &>(x) = *opts; else pf_opts_default(&x);
+   x.debug = t_hooks[0]; x.test_drop_exchange = t_hooks[1]; x.test_faults = t_hooks[2];
+   t_hooks[0] = t_hooks[1] = t_hooks[2] = 0;
+   if (const char *e = getenv("PFFDTD_DEBUG")) x.debug |= (int32_t)strtol(e, nullptr, 0);
+   return x;
+}
+
+int pf__engine_create_x(const pf_simdata *sd, const pf_opts_x *opts, pf_engine **out) {
+   if (!sd || !out || !opts) return set_err(PF_ERR_ARG, "null argument");
    *out = nullptr;
-   pf_opts o;
-   if (opts) o = *opts; else pf_opts_default(&o);
+   pf_opts_x o = *opts;
+   if (o.layout == PF_LAYOUT_EXCHANGED) o.debug |= PF_DBG_SWZ_ON; // (the engine's own switches: the same two bits the tests force)
+   else if (o.layout == PF_LAYOUT_FILE) o.debug |= PF_DBG_SWZ_OFF;
+   else if (o.layout != PF_LAYOUT_AUTO) return set_err(PF_ERR_ARG, "pf_opts.layout must be PF_LAYOUT_AUTO, _EXCHANGED or _FILE");
    pfeng::EngineBase *impl = nullptr;
    int rc;
    if (sd->real_bytes == 4) {
@@ -102,6 +126,8 @@ int pf_engine_create(const pf_simdata *sd, const pf_opts *opts, pf_engine **out)
    *out = new pf_engine{impl};
    return PF_OK;
 }
+
+extern "C" {
 
 void pf_engine_destroy(pf_engine *e) {
    if (!e) return;

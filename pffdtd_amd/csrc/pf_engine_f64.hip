@@ -2,7 +2,7 @@
 // the fp32 one (pf_engine.hip, which also holds the C ABI).
 #include "pf_engine_class.inc"
 
-pfeng::EngineBase *pf__new_engine_f64(const pf_simdata *sd, const pf_opts *o, int *rc) {
+pfeng::EngineBase *pf__new_engine_f64(const pf_simdata *sd, const pf_opts_x *o, int *rc) {
    auto *e = new Engine<double>();
    *rc = e->init(sd, o);
    return e;

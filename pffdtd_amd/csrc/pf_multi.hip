@@ -42,6 +42,7 @@
 #include <vector>
 
 #include "pffdtd_hip.h"
+#include "pf_debug.h" // pf_opts_x: the public options + the development / test switches
 
 extern "C" void pf__set_error(const char *msg); // pf_engine.hip (feeds pf_last_error)
 extern "C" int pf__axis_exchange_pays(const pf_simdata *sd, int64_t *counts); // pf_engine.hip
@@ -120,18 +121,44 @@ int partition(const pf_simdata *sd, int G, bool even, std::vector<int64_t> &cuts
       for (int64_t p : src_planes) if (x > p - CUT_CLEAR && x <= p + CUT_CLEAR) return false; // (planes x-1 | x are the cut's two sides)
       return true;
    };
+   auto nudge = [&](int64_t x, int64_t lo, int64_t hi) { // the nearest plane that is clear of every source, if the slab thicknesses allow one
+      if (clear_of_sources(x)) return x;
+      for (int64_t d = 1; d <= 2 * CUT_CLEAR + 2; d++) {
+         if (x - d >= lo && clear_of_sources(x - d)) return x - d;
+         if (x + d <= hi && clear_of_sources(x + d)) return x + d;
+      }
+      return x;
+   };
+   std::vector<char> pinned(G + 1, 0);
+   bool any_pinned = false;
    for (int g = 1; g < G; g++) {
       const double target = cum[Nx] * (double)g / (double)G;
       int64_t x = (int64_t)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
       const int64_t lo = cuts[g - 1] + 2, hi = Nx - 2 * (int64_t)(G - g);
       x = std::max(x, lo);            // every slab updates at least one plane
       x = std::min(x, hi);
-      if (!clear_of_sources(x)) // the nearest plane that is clear, if the slab thicknesses allow one
-         for (int64_t d = 1; d <= 2 * CUT_CLEAR + 2; d++) {
-            if (x - d >= lo && clear_of_sources(x - d)) { x -= d; break; }
-            if (x + d <= hi && clear_of_sources(x + d)) { x += d; break; }
+      const int64_t xn = nudge(x, lo, hi);
+      if (xn != x) { pinned[g] = 1; any_pinned = true; }
+      cuts[g] = xn;
+   }
+   // A cut that a source pushed aside leaves its two neighbours up to CUT_CLEAR planes apart (1024^3 as 8 ranks, source at Nx / 2: 125 and
+   // 142 planes where 133 each was meant -- the thick one was the slowest rank of the chain): such a cut stays where it is and the ranks on
+   // either side of it share THEIR part of the cost equally among themselves (four ranks over 504 planes, four over 520).
+   if (any_pinned) {
+      int a = 0;
+      while (a < G) {
+         int b = a + 1;
+         while (b < G && !pinned[b]) b++;
+         const double c0 = cum[cuts[a]], c1 = cum[cuts[b]];
+         for (int g = a + 1; g < b; g++) {
+            const double target = c0 + (c1 - c0) * (double)(g - a) / (double)(b - a);
+            int64_t x = (int64_t)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+            const int64_t lo = cuts[g - 1] + 2, hi = cuts[b] - 2 * (int64_t)(b - g);
+            x = std::min(std::max(x, lo), hi);
+            cuts[g] = nudge(x, lo, hi);
          }
-      cuts[g] = x;
+         a = b;
+      }
    }
    return PF_OK;
 }
@@ -365,7 +392,7 @@ struct Shared {
    std::atomic<int> err{0};
    std::string err_msg;
    std::atomic_flag err_lock = ATOMIC_FLAG_INIT;
-   pf_opts base{};
+   pf_opts_x base{};
    int64_t Nt = 0;
    double t_loop = 0;
    // transport
@@ -382,12 +409,12 @@ struct Shared {
    std::vector<hipEvent_t> ev_d2h[2], ev_h2d[2];                 // [n&1][g]: my planes are in my buffer / my ghost planes have left the neighbours' buffers
    std::string transport_note;                                   // why this transport (fallbacks taken)
    double bar_timeout = 120.0;
-   int faults = 0;                                               // pf_opts.test_faults
+   int faults = 0;                                               // the test switch `test_faults` (csrc/pf_debug.h)
    double wall_scale = 1.0;                                      // factor on the wall planes' weights the chain was cut with
    bool wall_measured = false;                                   // ... measured at creation (pf_slab_wall_scale)
    // exchange self-check: the first `verify_n` exchanges after creation
    int64_t verify_n = 0;
-   int64_t drop_step = -1; // test hook (pf_opts.test_drop_exchange): slab 1 misses the planes of that step; the self-check then always covers it
+   int64_t drop_step = -1; // test hook (test switch `test_drop_exchange`): slab 1 misses the planes of that step; the self-check then always covers it
    std::vector<int64_t> steps_done;                              // [g]
    std::vector<uint64_t> sums;                                   // [g*4 + {send_lo, send_hi, recv_lo, recv_hi}]
    std::vector<std::vector<uint8_t>> hbuf;                       // [g] host staging for the checksums
@@ -438,13 +465,13 @@ void create_slab(Shared &S, int g) {
    const int d = S.dev[g];
    std::lock_guard<std::mutex> dev_lock(g_dev_mu[d & 63]);
    MCHK(g, hipSetDevice(d));
-   pf_opts o = S.base;
+   pf_opts_x o = S.base;
    o.device = d;
    o.slab_first = sl.first; o.slab_last = sl.last;
    o.x_global0 = (int32_t)sl.xlo;
    // (cut along file z: the engines store planes of file z, Ny rows of pitch(Nx) each -- debug 0x1000 -- and step singly)
    const size_t gb = S.along_z ? pf_grid_bytes(sl.sd.Nz, sl.sd.Ny, sl.sd.Nx, sl.sd.real_bytes) : pf_grid_bytes(sl.sd.Nx, sl.sd.Ny, sl.sd.Nz, sl.sd.real_bytes);
-   if (S.along_z) o.debug |= 0x1000;
+   if (S.along_z) o.layout = PF_LAYOUT_EXCHANGED;
    // temporally blocked pairs need all four grids in the caller's hands (pf_engine_set_spares); worth it for slabs of
    // >= 96 planes (measured)
    const int flags = S.base.multi_flags;
@@ -458,7 +485,7 @@ void create_slab(Shared &S, int g) {
    }
    MCHK(g, hipDeviceSynchronize());
    o.ext_u0 = S.grids[0][g]; o.ext_u1 = S.grids[1][g];
-   ECHK(g, pf_engine_create(&sl.sd, &o, &S.eng[g]));
+   ECHK(g, pf__engine_create_x(&sl.sd, &o, &S.eng[g]));
    if (want_pairs) {
       // a pool of up to eight grids: the engine keeps the four its pair kernel is fastest on (grid placement).
       // The pool is bounded by what the device has free, less a reserve (two grids or 1/16 of the device, whichever is
@@ -521,7 +548,7 @@ void create_slab(Shared &S, int g) {
 // EXPLICITLY requested transport that is not available is an error, never silently replaced.
 int init_rccl(Shared &S, bool all_same, std::string &why) {
    std::lock_guard<std::mutex> lk(g_rccl_mu);
-   if (S.faults & 2) { why = "RCCL switched off by pf_opts.test_faults"; return PF_ERR_ARG; }
+   if (S.faults & 2) { why = "RCCL switched off by the test switch `test_faults` (csrc/pf_debug.h)"; return PF_ERR_ARG; }
    if (!g_rccl.load(why)) return PF_ERR_ARG;
    S.comm.assign(S.G, nullptr);
    S.rank.assign(S.G, 0);
@@ -888,10 +915,13 @@ int pf_slab_partition(const pf_simdata *sd, int32_t nslabs, int32_t even_split, 
    return pf_slab_partition_w(sd, nslabs, even_split, 1.0, cuts);
 }
 int pf_slab_partition_w(const pf_simdata *sd, int32_t nslabs, int32_t even_split, double wall_scale, int64_t *cuts) {
+   return pf_slab_partition_axis(sd, nslabs, even_split, wall_scale, 0, cuts);
+}
+int pf_slab_partition_axis(const pf_simdata *sd, int32_t nslabs, int32_t even_split, double wall_scale, int32_t along_z, int64_t *cuts) {
    if (!sd || !cuts) return fail("pf_slab_partition: null argument");
    if (!(wall_scale > 0)) wall_scale = 1.0;
    std::vector<int64_t> c;
-   const int rc = partition(sd, nslabs, even_split != 0, c, false, wall_scale);
+   const int rc = partition(sd, nslabs, even_split != 0, c, along_z != 0, wall_scale);
    if (rc) return rc;
    for (int g = 0; g <= nslabs; g++) cuts[g] = c[g];
    return PF_OK;
@@ -903,7 +933,8 @@ int pf_slab_partition_w(const pf_simdata *sd, int32_t nslabs, int32_t even_split
 // The ratio to what the compiled-in weights (23 / 5 interior planes per full plane of lossy / rigid nodes) predict for that wall is
 // the factor partition() scales them by.  <= 0: not measured (scene too small, too few steps, a chain cut along file z, or a
 // calibration run failed): the caller keeps factor 1.  Costs three short-lived slab engines (a few seconds at 1024^3 / 8).
-double pf_slab_wall_scale(pf_simdata *sd, int32_t nslabs, int32_t device, const pf_opts *base) {
+static int multi_create_x(pf_simdata *sd, int32_t nslabs, const int32_t *devices, const pf_opts_x *base, pf_multi **out);
+static double slab_wall_scale_x(pf_simdata *sd, int32_t nslabs, int32_t device, const pf_opts_x *base) {
    if (!sd || nslabs < 2 || tl_force_cuts) return -1.0;
    const int64_t Nx = sd->Nx, p0 = Nx / nslabs;
    const int64_t ncal = 63; // steps each calibration chain takes: 9 to warm up, then 18 timed, three times (the fastest counts)
@@ -913,8 +944,7 @@ double pf_slab_wall_scale(pf_simdata *sd, int32_t nslabs, int32_t device, const 
    if (partition(sd, nslabs, false, c0, false, 1.0, &wall1) != PF_OK) return -1.0;
    const int64_t dp = std::max<int64_t>(16, p0 / 2), cmid = std::max<int64_t>((Nx - p0 - dp) / 2, p0 + 1);
    if (cmid + p0 + dp + 2 > Nx) return -1.0;
-   pf_opts o;
-   if (base) o = *base; else pf_opts_default(&o);
+   pf_opts_x o = *base;
    o.verify_exchange = 0; o.test_drop_exchange = 0; o.test_faults = 0; o.timing = 0;
    o.transport = PF_TRANSPORT_PEER;
    // The forced cuts are x planes.  The real chain is cut along file z when the caller forces that or when pf_multi_create would
@@ -924,17 +954,17 @@ double pf_slab_wall_scale(pf_simdata *sd, int32_t nslabs, int32_t device, const 
       const int vb = o.air_variant & 255;
       const bool can = !o.energy && vb != 40 && vb != 41 && !(o.multi_flags & PF_MULTI_FORCE_PAIRS) && nslabs < sd->Nz;
       if (o.multi_flags & PF_MULTI_CUT_Z) return -1.0;
-      if (!(o.multi_flags & PF_MULTI_CUT_X) && !(o.debug & 0x2000) && can && (sd->Nz - 2) / nslabs >= 16 && pf__axis_exchange_pays(sd, nullptr) != 0) return -1.0;
+      if (!(o.multi_flags & PF_MULTI_CUT_X) && !(o.debug & 0x2000) && o.layout != PF_LAYOUT_FILE && can && (sd->Nz - 2) / nslabs >= 16 && pf__axis_exchange_pays(sd, nullptr) != 0) return -1.0;
    }
    o.multi_flags = (o.multi_flags | PF_MULTI_CUT_X) & ~(PF_MULTI_CUT_Z | PF_MULTI_MEASURE_WEIGHTS | PF_MULTI_EVEN_SPLIT);
    auto one = [&](const std::vector<int64_t> &cuts, int slab) -> double {
       const int G = (int)cuts.size() - 1;
       std::vector<int32_t> devs(G, device);
-      pf_opts oo = o;
+      pf_opts_x oo = o;
       oo.only_slab = slab + 1;
       pf_multi *m = nullptr;
       tl_force_cuts = &cuts;
-      const int rc = pf_multi_create(sd, G, devs.data(), &oo, &m);
+      const int rc = multi_create_x(sd, G, devs.data(), &oo, &m);
       tl_force_cuts = nullptr;
       if (rc != PF_OK || !m) return -1.0;
       double t = -1.0;
@@ -973,8 +1003,17 @@ double pf_slab_wall_scale(pf_simdata *sd, int32_t nslabs, int32_t device, const 
    return k;
 }
 
+double pf_slab_wall_scale(pf_simdata *sd, int32_t nslabs, int32_t device, const pf_opts *base) {
+   const pf_opts_x x = pf__take_hooks(base);
+   return slab_wall_scale_x(sd, nslabs, device, &x);
+}
+
 int pf_multi_create(pf_simdata *sd, int32_t nslabs, const int32_t *devices, const pf_opts *base, pf_multi **out) {
-   if (!sd || nslabs < 1 || !devices || !out) return fail("pf_multi_create: bad argument");
+   const pf_opts_x x = pf__take_hooks(base);
+   return multi_create_x(sd, nslabs, devices, &x, out);
+}
+static int multi_create_x(pf_simdata *sd, int32_t nslabs, const int32_t *devices, const pf_opts_x *base, pf_multi **out) {
+   if (!sd || nslabs < 1 || !devices || !out || !base) return fail("pf_multi_create: bad argument");
    *out = nullptr;
    int ndev = 0;
    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { pf__set_error("no HIP device visible"); return PF_ERR_NODEV; }
@@ -983,7 +1022,7 @@ int pf_multi_create(pf_simdata *sd, int32_t nslabs, const int32_t *devices, cons
    pf_multi *m = new pf_multi();
    Shared &S = m->S;
    m->sd = sd;
-   if (base) S.base = *base; else pf_opts_default(&S.base);
+   S.base = *base;
    const int G = nslabs;
    S.G = G; S.Nt = sd->Nt;
    S.dev.assign(devices, devices + G);
@@ -1001,10 +1040,10 @@ int pf_multi_create(pf_simdata *sd, int32_t nslabs, const int32_t *devices, cons
    S.bar_timeout = barrier_timeout();
    S.faults = S.base.test_faults;
    if (G == 1) { // plain single-domain engine
-      pf_opts o = S.base;
+      pf_opts_x o = S.base;
       o.device = devices[0]; o.slab_first = o.slab_last = 1;
       S.cuts = {0, sd->Nx};
-      const int rc = pf_engine_create(sd, &o, &S.eng[0]);
+      const int rc = pf__engine_create_x(sd, &o, &S.eng[0]);
       if (rc != PF_OK) { delete m; return rc; }
       m->created = true;
       *out = m;
@@ -1019,7 +1058,7 @@ int pf_multi_create(pf_simdata *sd, int32_t nslabs, const int32_t *devices, cons
       if (S.base.multi_flags & PF_MULTI_CUT_Z) {
          if (!can) { delete m; return fail("PF_MULTI_CUT_Z: single steps only, no energy diagnostic, fewer slabs than Nz"); }
          S.along_z = true;
-      } else if (!(S.base.multi_flags & PF_MULTI_CUT_X) && !(S.base.debug & 0x2000) && can && (sd->Nz - 2) / G >= 16)
+      } else if (!(S.base.multi_flags & PF_MULTI_CUT_X) && !(S.base.debug & 0x2000) && S.base.layout != PF_LAYOUT_FILE && can && (sd->Nz - 2) / G >= 16)
          S.along_z = pf__axis_exchange_pays(sd, nullptr) != 0;
    }
    int rc = PF_OK;
@@ -1033,7 +1072,7 @@ int pf_multi_create(pf_simdata *sd, int32_t nslabs, const int32_t *devices, cons
       S.wall_scale = 1.0;
       if (S.base.wall_scale > 0) S.wall_scale = S.base.wall_scale;
       else if (!even && !S.along_z && (S.base.multi_flags & PF_MULTI_MEASURE_WEIGHTS)) {
-         const double k = pf_slab_wall_scale(sd, G, devices[0], &S.base);
+         const double k = slab_wall_scale_x(sd, G, devices[0], &S.base);
          if (k > 0) { S.wall_scale = k; S.wall_measured = true; }
       }
       rc = partition(sd, G, even, S.cuts, S.along_z, S.wall_scale);
@@ -1172,7 +1211,7 @@ void pf_multi_destroy(pf_multi *m) {
 }
 
 // run_sim on a chain of slabs, slab g on device devices[g] (ids may repeat).  base: engine options common to all slabs
-// (numerics, air_variant, readout_chunk, debug, multi_flags, transport, verify_exchange); NULL = defaults.
+// (numerics, air_variant, readout_chunk, multi_flags, transport, verify_exchange); NULL = defaults.
 double pf_run_sim_devices(pf_simdata *sd, int32_t nslabs, const int32_t *devices, const pf_opts *base) {
    pf_multi *m = nullptr;
    if (pf_multi_create(sd, nslabs, devices, base, &m) != PF_OK) return -1.0;

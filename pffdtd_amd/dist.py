@@ -48,11 +48,11 @@ class HipSlabStepper:
             if [g.data_ptr() for g in self.grids] != list(self.eng.state_grids()):
                 raise RuntimeError("torch copied the engine's state grids instead of wrapping them")
         else:
-            # a slab of a chain cut along FILE Z: the engine stores planes of file z, Ny rows of pitch(Nx) each (debug 0x1000)
+            # a slab of a chain cut along FILE Z: the engine stores planes of file z, Ny rows of pitch(Nx) each (PF_LAYOUT_EXCHANGED)
             zcut = bool(getattr(info, "along_z", False))
             if zcut:
                 self.plane = loc.Ny * engine.grid_pitch(loc.Nx, loc.real_bytes)
-                engine_kw = dict(engine_kw, debug=int(engine_kw.get("debug", 0)) | 0x1000)
+                engine_kw = dict(engine_kw, layout=engine.PF_LAYOUT_EXCHANGED)
             self.nplanes = loc.Nz if zcut else loc.Nx
             with torch.cuda.device(self.device):
                 self.grids = [torch.zeros((self.nplanes, self.plane), dtype=self.tdtype, device=self.device) for _ in range(2)]
@@ -251,7 +251,7 @@ def make_hip_runner(sd, rank, world, device, group=None, balance=True, along_z=N
     if along_z is None:
         pairs_forced = engine_kw.get("pairs") or (engine_kw.get("air_variant", 0) & 255) in (40, 41)
         along_z = (world > 1 and not pairs_forced and not engine_kw.get("energy") and (sd.Nz - 2) // world >= 16
-                   and not (int(engine_kw.get("debug", 0)) & 0x2000) and scene_prefers_exchanged_axes(sd))
+                   and not (int(engine_kw.get("debug", 0)) & 0x2000) and engine_kw.get("layout", 0) != 2 and scene_prefers_exchanged_axes(sd))
     if wall_scale is None:
         wall_scale = measured_wall_scale(sd, rank, world, device, group, **engine_kw) if (balance and world > 1 and not along_z) else 1.0
     loc, info = slab_mod.split(sd, world, rank, balance=balance, along_z=bool(along_z) and world > 1, wall_scale=wall_scale)

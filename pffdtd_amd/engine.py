@@ -23,10 +23,18 @@ class PfOpts(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int32), ("numerics", ctypes.c_int32), ("slab_first", ctypes.c_int32),
                 ("slab_last", ctypes.c_int32), ("readout_chunk", ctypes.c_int32), ("air_variant", ctypes.c_int32),
                 ("air_chunk", ctypes.c_int32), ("timing", ctypes.c_int32), ("ext_u0", ctypes.c_void_p),
-                ("ext_u1", ctypes.c_void_p), ("x_global0", ctypes.c_int32), ("debug", ctypes.c_int32),
+                ("ext_u1", ctypes.c_void_p), ("x_global0", ctypes.c_int32), ("layout", ctypes.c_int32),
                 ("energy", ctypes.c_int32), ("multi_flags", ctypes.c_int32), ("transport", ctypes.c_int32),
-                ("verify_exchange", ctypes.c_int32), ("only_slab", ctypes.c_int32), ("test_drop_exchange", ctypes.c_int32),
-                ("test_faults", ctypes.c_int32), ("wall_scale", ctypes.c_double)]
+                ("verify_exchange", ctypes.c_int32), ("only_slab", ctypes.c_int32), ("wall_scale", ctypes.c_double)]
+
+
+# Development / test switches (csrc/pf_debug.h: the PF_DBG_* bits, the chain's fault injection).  Not fields of pf_opts: they reach the
+# library through its internal hook, for the NEXT create call of this thread.
+_HOOKS = ("debug", "test_drop_exchange", "test_faults")
+
+
+def _set_hooks(debug=0, test_drop_exchange=0, test_faults=0):
+    lib().pf_internal_hooks(int(debug), int(test_drop_exchange), int(test_faults))
 
 
 class PfTiming(ctypes.Structure):
@@ -54,14 +62,17 @@ EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_grid_bytes", "p
            "pf_run_sim", "pf_engine_create", "pf_engine_destroy", "pf_engine_run", "pf_engine_step_begin",
            "pf_engine_halo_ptrs", "pf_engine_step_end", "pf_engine_state_grids", "pf_engine_layout", "pf_engine_place_grids", "pf_engine_place_grids5", "pf_engine_set_spares", "pf_engine_stream", "pf_engine_sync",
            "pf_engine_flush_outputs", "pf_engine_get_grid", "pf_engine_set_grid", "pf_engine_timing", "pf_engine_set_timing",
-           "pf_engine_energy_cfg", "pf_engine_run_energy", "pf_run_sim_devices", "pf_slab_partition", "pf_slab_partition_w", "pf_slab_wall_scale",
+           "pf_engine_energy_cfg", "pf_engine_run_energy", "pf_run_sim_devices", "pf_slab_partition", "pf_slab_partition_w", "pf_slab_partition_axis", "pf_slab_wall_scale",
            "pf_multi_create", "pf_multi_run", "pf_multi_get_info", "pf_multi_get_slab", "pf_multi_destroy"]
 
+
+INTERNAL_EXPORTS = ["pf_internal_hooks"]  # csrc/pf_debug.h: exported, but no part of the drop-in boundary (not in include/)
 
 PF_MULTI_EVEN_SPLIT, PF_MULTI_ONE_THREAD, PF_MULTI_NO_PAIRS, PF_MULTI_FORCE_PAIRS, PF_MULTI_CUT_Z, PF_MULTI_CUT_X = 1, 2, 4, 8, 16, 32
 PF_MULTI_NO_TRIPLES = 64
 PF_MULTI_MEASURE_WEIGHTS = 128
 PF_TRANSPORT_AUTO, PF_TRANSPORT_PEER, PF_TRANSPORT_RCCL, PF_TRANSPORT_HOST = 0, 1, 2, 3
+PF_LAYOUT_AUTO, PF_LAYOUT_EXCHANGED, PF_LAYOUT_FILE = 0, 1, 2
 
 
 def _preload_torch_hip():
@@ -107,6 +118,8 @@ def lib():
         L.pf_grid_pitch.restype = i64
         L.pf_grid_pitch.argtypes = [i64, i32]
         L.pf_opts_default.argtypes = [ctypes.POINTER(PfOpts)]
+        L.pf_internal_hooks.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+        L.pf_internal_hooks.restype = None
         L.pf_run_sim.restype = ctypes.c_double
         L.pf_run_sim.argtypes = [ctypes.POINTER(PfSimData)]
         L.pf_engine_create.argtypes = [ctypes.POINTER(PfSimData), ctypes.POINTER(PfOpts), ctypes.POINTER(vp)]
@@ -136,6 +149,7 @@ def lib():
         L.pf_run_sim_devices.argtypes = [ctypes.POINTER(PfSimData), i32, ctypes.POINTER(i32), ctypes.POINTER(PfOpts)]
         L.pf_slab_partition.argtypes = [ctypes.POINTER(PfSimData), i32, i32, ctypes.POINTER(i64)]
         L.pf_slab_partition_w.argtypes = [ctypes.POINTER(PfSimData), i32, i32, ctypes.c_double, ctypes.POINTER(i64)]
+        L.pf_slab_partition_axis.argtypes = [ctypes.POINTER(PfSimData), i32, i32, ctypes.c_double, i32, ctypes.POINTER(i64)]
         L.pf_slab_wall_scale.argtypes = [ctypes.POINTER(PfSimData), i32, i32, ctypes.POINTER(PfOpts)]
         L.pf_slab_wall_scale.restype = ctypes.c_double
         L.pf_engine_set_spares.argtypes = [vp, vp, vp]
@@ -185,11 +199,15 @@ def run_sim_devices(sd, devices, multi_flags=0, **opts):
 
 
 def _multi_opts(multi_flags, opts):
+    """pf_opts from keyword arguments; `debug` / `test_*` go to the library's internal hook (pending for the create call that follows)."""
     o = PfOpts()
     lib().pf_opts_default(ctypes.byref(o))
+    hooks = {k: opts[k] for k in _HOOKS if k in opts}
     for k, v in opts.items():
-        setattr(o, k, float(v) if k == "wall_scale" else int(v))
+        if k not in _HOOKS:
+            setattr(o, k, float(v) if k == "wall_scale" else int(v))
     o.multi_flags = int(multi_flags)
+    _set_hooks(**hooks)
     return o
 
 
@@ -256,11 +274,12 @@ class _EngineView:
     set_timing = lambda self, on: HipEngine.set_timing(self, on)  # noqa: E731
 
 
-def slab_partition(sd, nslabs, even=False, wall_scale=1.0):
-    """Owned plane ranges [(x0, x1)] of pf_run_sim_devices' slabs (wall_scale: factor on the wall planes' weights)."""
+def slab_partition(sd, nslabs, even=False, wall_scale=1.0, along_z=False):
+    """Owned plane ranges [(x0, x1)] of pf_run_sim_devices' slabs (wall_scale: factor on the wall planes' weights; along_z: the cut
+    along FILE Z of rooms stored with exchanged axes).  Host code only: works without a device."""
     s = sd.as_struct()
     cuts = (ctypes.c_int64 * (nslabs + 1))()
-    _check(lib().pf_slab_partition_w(ctypes.byref(s), int(nslabs), int(bool(even)), float(wall_scale), cuts))
+    _check(lib().pf_slab_partition_axis(ctypes.byref(s), int(nslabs), int(bool(even)), float(wall_scale), int(bool(along_z)), cuts))
     return [(int(cuts[g]), int(cuts[g + 1])) for g in range(nslabs)]
 
 
@@ -276,7 +295,7 @@ class HipEngine:
     """One engine instance = one grid (or one Z-slab) resident on one MI355X."""
 
     def __init__(self, sd, device=0, numerics=PF_NUM_CPU_EXACT, slab_first=True, slab_last=True, air_variant=0,
-                 air_chunk=0, timing=False, readout_chunk=0, ext_u0=None, ext_u1=None, debug=0, x_global0=0, energy=False):
+                 air_chunk=0, timing=False, readout_chunk=0, ext_u0=None, ext_u1=None, debug=0, x_global0=0, energy=False, layout=0):
         L = lib()
         self.sd = sd
         self._s = sd.as_struct()
@@ -286,12 +305,13 @@ class HipEngine:
         o.slab_first, o.slab_last = int(bool(slab_first)), int(bool(slab_last))
         o.air_variant, o.air_chunk, o.timing, o.readout_chunk = int(air_variant), int(air_chunk), int(bool(timing)), \
             int(readout_chunk)
-        o.debug = int(debug)
         o.x_global0 = int(x_global0)
+        o.layout = int(layout)
         o.energy = int(bool(energy))
         if ext_u0 is not None and ext_u1 is not None:
             o.ext_u0, o.ext_u1 = int(ext_u0), int(ext_u1)
         self._h = ctypes.c_void_p()
+        _set_hooks(debug=debug)
         _check(L.pf_engine_create(ctypes.byref(self._s), ctypes.byref(o), ctypes.byref(self._h)))
         self.dtype = np.float32 if sd.real_bytes == 4 else np.float64
 

@@ -1,80 +1,33 @@
 """Z-slab decomposition of a SimData along the slowest axis (file Nx), one slab per GPU.
 
 Re-thinks `split_data` + the per-GPU index localisation of the reference CUDA engine
-(c_cuda/gpu_engine.h:516-662, 739-823): same partition rule (Nx/G planes each, remainder to the first
-ranks, one ghost plane on every interior side), but the node lists are cut by plane with vectorised
-searches instead of per-GPU counting loops, and nothing here requires pre-sorted input (the engine
-sorts its lists itself).
+(c_cuda/gpu_engine.h:516-662, 739-823) for the one-process-per-GPU runs: the cut itself comes from the
+library (one implementation, `partition` below); here the node lists are cut by plane with vectorised
+searches instead of per-GPU counting loops, and nothing requires pre-sorted input (the engine sorts its
+lists itself).
 """
 import copy
 
 import numpy as np
 
 
-def partition(Nx, G):
-    """Owned plane ranges [x0, x1) per rank: Nx//G planes each, +1 for the first Nx%G ranks (gpu_engine.h:532-550)."""
-    if G < 1 or G >= Nx:
-        raise ValueError(f"need 1 <= ngpus < Nx (got {G}, Nx={Nx})")  # gpu_engine.h:682
-    base, rem = divmod(Nx, G)
-    sizes = [base + (1 if g < rem else 0) for g in range(G)]
-    x0 = np.concatenate([[0], np.cumsum(sizes)])
-    return [(int(x0[g]), int(x0[g + 1])) for g in range(G)]
-
-
-# measured on MI355X (1024^2 planes, round 4: slabs with wall regions): one full plane of lossy (Mb=11) boundary nodes costs about as much as 23 planes
-# of interior update, a full plane of rigid boundary nodes about 5 (profiles/r04_slab_cost_model.txt; the same figures as
-# csrc/pf_multi.hip: partition)
-LOSSY_PLANE_EQ = 23.0
-RIGID_PLANE_EQ = 5.0
-CUT_CLEAR = 8  # planes a cut keeps from every source (csrc/pf_multi.hip: partition)
+def partition(sd, G, balance=False, along_z=False, wall_scale=1.0):
+    """Owned plane ranges [(x0, x1)] per rank -- computed by the library (`pf_slab_partition_axis`, csrc/pf_multi.hip: partition; host code,
+    no device needed): ONE implementation of the cut for the C chain and for the processes under torch.distributed.
+    balance=False: the reference's rule, Nx//G planes each, +1 for the first Nx%G ranks (gpu_engine.h:532-550).  balance=True: equal
+    estimated cost -- the end slabs of a room carry whole wall planes of boundary nodes, which the even split leaves unbalanced --,
+    cuts kept clear of the sources.  Deterministic (every rank computes the same cut).  along_z: ranges of FILE Z instead of x (rooms,
+    see split).  wall_scale: factor on the two wall-plane weights, as measured on the scene by the library (pf_slab_wall_scale)."""
+    from . import engine
+    nplanes = sd.Nz if along_z else sd.Nx
+    if G < 1 or G >= nplanes:
+        raise ValueError(f"need 1 <= ngpus < Nx (got {G}, Nx={nplanes})")  # gpu_engine.h:682
+    return engine.slab_partition(sd, G, even=not balance, wall_scale=wall_scale, along_z=along_z)
 
 
 def partition_weighted(sd, G, along_z=False, wall_scale=1.0):
-    """Owned plane ranges balanced by estimated cost instead of plane count: the end slabs of a room carry whole
-    wall planes of boundary nodes, which the reference's even split (gpu_engine.h:532-550) leaves unbalanced.
-    Deterministic (every rank computes the same cut).  along_z: ranges of FILE Z instead of x (rooms, see split).
-    wall_scale: factor on the two wall-plane weights, as measured on the scene by the library (pf_slab_wall_scale; round 5)."""
-    Nx = sd.Nz if along_z else sd.Nx
-    if G < 1 or G >= Nx:
-        raise ValueError(f"need 1 <= ngpus < Nx (got {G}, Nx={Nx})")
-    if G == 1:
-        return [(0, Nx)]
-    NzNy = sd.Ny * (sd.Nx if along_z else sd.Nz)
-    plane_of = (lambda ii: ii % sd.Nz) if along_z else (lambda ii: ii // (sd.Ny * sd.Nz))
-    nb = np.bincount(plane_of(sd.bn_ixyz), minlength=Nx).astype(np.float64)
-    nl = np.bincount(plane_of(sd.bnl_ixyz), minlength=Nx).astype(np.float64) if sd.Nbl else np.zeros(Nx)
-    mb_scale = 1.0
-    if sd.Nbl:
-        mb_scale = float(np.mean(sd.Mb[sd.mat_bnl])) / 11.0
-    cost = np.ones(Nx)
-    cost[0] = cost[-1] = 0.0  # global ghost planes are not updated
-    cost += float(wall_scale) * ((LOSSY_PLANE_EQ * mb_scale * nl + RIGID_PLANE_EQ * (nb - nl)) / NzNy)
-    cum = np.concatenate([[0.0], np.cumsum(cost)])
-    # a cut keeps CUT_CLEAR planes from every source (csrc/pf_multi.hip: partition -- a slab in triples recomputes three planes of halo beside
-    # its box, four planes from a cut, without the sources that are added between the steps)
-    src_planes = [int(p) for p in plane_of(np.asarray(sd.in_ixyz))]
-
-    def clear_of_sources(x):
-        return all(not (p - CUT_CLEAR < x <= p + CUT_CLEAR) for p in src_planes)
-
-    cuts = [0]
-    for g in range(1, G):
-        target = cum[-1] * g / G
-        x = int(np.searchsorted(cum, target))
-        lo, hi = cuts[-1] + 2, Nx - 2 * (G - g)
-        x = max(x, lo)           # every slab updates at least one plane
-        x = min(x, hi)
-        if not clear_of_sources(x):
-            for d in range(1, 2 * CUT_CLEAR + 3):
-                if x - d >= lo and clear_of_sources(x - d):
-                    x -= d
-                    break
-                if x + d <= hi and clear_of_sources(x + d):
-                    x += d
-                    break
-        cuts.append(x)
-    cuts.append(Nx)
-    return [(cuts[g], cuts[g + 1]) for g in range(G)]
+    """The cost-balanced cut (partition(..., balance=True))."""
+    return partition(sd, G, True, along_z, wall_scale)
 
 
 class SlabInfo:
@@ -97,7 +50,7 @@ def split(sd, G, rank, balance=False, along_z=False, wall_scale=1.0):
     exchanged (pf_engine_layout; csrc/pf_multi.hip does the same): the slab then holds the file's columns z in [xlo, xhi) of
     every row, its local file has Nz = xhi - xlo, and `info`'s plane numbers are z."""
     nplanes = sd.Nz if along_z else sd.Nx
-    parts = partition_weighted(sd, G, along_z, wall_scale) if balance else partition(nplanes, G)
+    parts = partition(sd, G, balance, along_z, wall_scale)
     x0, x1 = parts[rank]
     info = SlabInfo(rank, G, x0, x1, nplanes)
     info.along_z = along_z

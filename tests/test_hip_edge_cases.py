@@ -116,12 +116,12 @@ def test_long_run_ring_wraps_and_stays_bit_exact():
 
 
 def test_graph_replay_of_the_step_loop():
-    """pf_opts.debug 0x800000: six steps per hipGraph with the step index / ring column in device counters (opt-in: no faster
+    """the internal switch PF_DBG_GRAPH (0x800000): six steps per hipGraph with the step index / ring column in device counters (opt-in: no faster
     than plain launches on this stack).  Unaligned step counts, several run() calls, a ring that wraps."""
     import cases
     import oracle
     from pffdtd_amd import engine
-    GRAPH = 0x800000  # pf_opts.debug: replay the step loop from a hipGraph
+    GRAPH = 0x800000  # PF_DBG_GRAPH: replay the step loop from a hipGraph
     for name, prec in (("cart_lossy", "single"), ("fcc2_lossy", "double"), ("cart_wall2", "single"), ("fcc1_outside", "single")):
         ref = cases.make_sd(name, prec)
         oracle.run_sim(ref)

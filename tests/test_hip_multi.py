@@ -226,7 +226,7 @@ def test_chain_with_wall_regions_agrees_with_one_domain_over_many_steps():
 
 
 def test_exchange_self_check_notices_a_missing_plane(tmp_path):
-    """pf_opts.test_drop_exchange = 1 + n makes slab 1 skip the pull of its ghost planes in step n: the run must fail, naming the
+    """test switch `test_drop_exchange` = 1 + n makes slab 1 skip the pull of its ghost planes in step n: the run must fail, naming the
     check -- also when the caller asked for no check at all (the fault injection switches it on)"""
     for ver in (70, 0):
         sd = cases.make_sd("cart_outside", "single")
@@ -341,7 +341,7 @@ def test_host_staged_transport_carries_slab_pairs():
 
 @pytest.mark.parametrize("faults,expect", [(1, engine.PF_TRANSPORT_RCCL), (3, engine.PF_TRANSPORT_HOST)], ids=["no_peer_access", "no_peer_access_no_rccl"])
 def test_automatic_transport_falls_back_edge_by_edge(faults, expect):
-    """pf_opts.test_faults forces every fallback edge of PF_TRANSPORT_AUTO on one device: without peer access the chain takes RCCL,
+    """the test switch `test_faults` (csrc/pf_debug.h) forces every fallback edge of PF_TRANSPORT_AUTO on one device: without peer access the chain takes RCCL,
     without RCCL as well the host-staged copies -- and says why (pf_multi_info.transport_note); the bits stay the oracle's.  An
     explicitly requested transport that is unavailable remains an error."""
     want = _ref("cart_outside", "single")
@@ -363,7 +363,7 @@ def test_automatic_transport_falls_back_edge_by_edge(faults, expect):
 
 
 def test_a_hung_slab_thread_becomes_an_error_not_a_hang(tmp_path):
-    """pf_opts.test_faults = 4: the host thread of slab 1 stalls before the barrier of its fourth step.  The watchdog of the other
+    """the test switch `test_faults` (csrc/pf_debug.h) = 4: the host thread of slab 1 stalls before the barrier of its fourth step.  The watchdog of the other
     slabs' barrier waits (PFFDTD_BARRIER_TIMEOUT_S) turns that into pf_last_error instead of a process that never returns.  In a
     process of its own: the chain object is abandoned with its stuck thread."""
     code = ("import sys, time; sys.path[:0] = [%r, %r]; import cases; from pffdtd_amd import engine; "

@@ -32,7 +32,7 @@ ap.add_argument("--fmax-scale", type=float, default=1.0, help="scale fmax (grid 
 ap.add_argument("--fmax", type=float, default=None, help="override fmax (Hz)")
 ap.add_argument("--ppw", type=float, default=None, help="override points per wavelength")
 ap.add_argument("--duration", type=float, default=None, help="override the simulated duration (s)")
-ap.add_argument("--debug", type=lambda v: int(v, 0), default=0, help="pf_opts.debug (tuning switches)")
+ap.add_argument("--debug", type=lambda v: int(v, 0), default=0, help="internal PF_DBG_* switches (csrc/pf_debug.h), through the library's internal hook")
 ap.add_argument("--variant", type=int, default=0, help="pf_opts.air_variant (0 = automatic, 40 = blocked pairs forced)")
 ap.add_argument("--chunk", type=int, default=0, help="pf_opts.air_chunk (planes marched per workgroup; 0 = automatic)")
 ap.add_argument("--energy", action="store_true", help="run all Nt steps with the energy diagnostic (double only)")
