@@ -23,6 +23,7 @@ enum : int {
    PF_DBG_LW32 = 0x100,               // 32-lane row segments (0x200: 16-lane, 0x400: 64-lane) instead of the measured choice
    PF_DBG_LW16 = 0x200,
    PF_DBG_LW64 = 0x400,
+   PF_DBG_SRC_TILES_SINGLE = 0x40,    // triples: the tiles within reach of a source (and a receiver's tile) step singly, the sources added by k_io (until round 6)
    PF_DBG_EDGE_SEPARATE = 0x80,       // slab triples: the edge planes of the two sides by separate launches (lean kernel, boundary kernel), as in round 5
    PF_DBG_RUNTIME_GEOMETRY = 0x800,   // three-step wall regions: the bodies with run-time pencil geometry, never the ones with it compiled in
    PF_DBG_SWZ_ON = 0x1000,            // store the grid with the file's x and z axes exchanged (0x2000: never; default: decided per scene)

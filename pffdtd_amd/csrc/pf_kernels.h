@@ -826,11 +826,12 @@ template <typename Real>
 static __global__ void k_io(const Real *__restrict__ u1, Real *__restrict__ u0, const int64_t *__restrict__ out_idx,
                      Real *__restrict__ ring, int64_t Nr, int64_t ring_col, int64_t ring_depth,
                      const int64_t *__restrict__ in_idx, const Real *__restrict__ in_sigs, int64_t Ns, int64_t Nt,
-                     int64_t n, const int64_t *__restrict__ ctr = nullptr) {
+                     int64_t n, const int64_t *__restrict__ ctr = nullptr, const Real *__restrict__ u1b = nullptr) {
    if (ctr) { n = ctr[0]; ring_col = ctr[1]; } // replayed from a hipGraph: step index and ring column live on the device
    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
    if (t < Nr) {
       ring[t * ring_depth + ring_col] = u1[out_idx[t]];
+      if (u1b) ring[t * ring_depth + ring_col + 1] = u1b[out_idx[t]]; // (the next step's readout in the same launch: Engine::step_triple)
    } else if (t == Nr) {
       for (int64_t s = 0; s < Ns; s++) u0[in_idx[s]] += in_sigs[s * Nt + n];
    }

@@ -23,6 +23,11 @@ struct Tb2Params {
    const uint8_t *mask;           // k_tb1_tile: the engine's skip-mask
    int32_t xsub;                  // k_tb1_tile: > 1: that many workgroups share a tile, each marching a piece of its x chunk
    void *E;                       // k_tb3 (pf_tb3.h): u^{n+3}; C = scratch for the u^{n+1} of flagged tiles, D = u^{n+2}
+   // k_tb3<..., SRC = true> (round 6): the sources, added in the kernel after every stage (cpu_engine.h:303-306: u0[in_ixyz] += in_sigs[n])
+   const int64_t *src_idx;        // cells (storage order), list order
+   const void *src_sig;           // Real [nsrc][src_Nt]
+   int64_t src_Nt, src_n;         // samples per source; the step stage 1 computes (stage s adds sample src_n + s - 1)
+   int32_t nsrc;
 };
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -27,8 +27,15 @@ constexpr uint32_t TB3_RIM = 0x80000000u; // tile-list flag: store u^{n+1} too
 // PROBE: the same code under another name, for the creation-time measurements (as k_tb2_reg's)
 // NS = 2: the same tiles, TWO steps -- stages 1 and 2 only, u^{n+1} stored into C by every tile, u^{n+2} into D: what steps the
 // last two steps of a run whose length is no multiple of three (Engine::run), with the triples' tile lists and wall regions.
-template <typename Real, int R, int WT, bool SG = false, bool PROBE = false, int NS = 3>
-__global__ __launch_bounds__(64 * WT) void k_tb3(Tb2Params tp, Real a1, Real a2) {
+// SRC (round 6; the kernel k_tb3_src below): the tiles within two cells of a SOURCE -- until then three single steps out of memory, the source added between
+// them by k_io: a serial tail of four dependent launches behind every triple -- run this form instead, a few workgroups beside the main
+// launch: after every stage the samples of the sources the stage has just computed are added in registers, in list order (duplicates
+// accumulate as in the reference's serial loop, cpu_engine.h:303-306), before the value is stored, published or used by the next stage.
+// Every tile whose computed region reaches a source within the two cells a later stage can still see runs it (Engine::init_tb2_impl marks them),
+// so all copies of a halo cell agree.  The main launch's code is untouched (if constexpr), and so is its name.
+constexpr int TB3_MAXSRC = 32; // sources k_tb3_src keeps per wave (Engine::init_tb2_impl: more than that, and k_io adds them as before)
+template <typename Real, int R, int WT, bool SG, int NS, bool SRC>
+__device__ __forceinline__ void tb3_body(const Tb2Params &tp, const Real a1, const Real a2) {
    typedef typename VecOf<Real>::type vec;
    // z halo: a stage loses one cell at each end of a row segment, so three stages need THREE halo cells per side: one 4-cell lane
    // in fp32, two 2-cell lanes in fp64 (k_tb2_reg: two stages, one lane either way)
@@ -85,6 +92,42 @@ __global__ __launch_bounds__(64 * WT) void k_tb3(Tb2Params tp, Real a1, Real a2)
 #pragma unroll
       for (int r = 0; r < R; r++) d[r] = *(const vec *)(pl + off[r]);
    };
+   // SRC: the sources whose row one of this wave's rows is, decoded ONCE (list order kept), in LDS: plane, row of the wave, column, place in
+   // the list.  (First version: every stage of every turn walked the whole list from memory, two 64-bit divisions per entry -- the few
+   // workgroups of this form took 1.04 ms where a workgroup of the main launch takes 0.19, and the main launch beside them 3 % longer.)
+   __shared__ int32_t sS[SRC ? WT : 1][SRC ? TB3_MAXSRC : 1][4];
+   __shared__ int32_t sNS[SRC ? WT : 1];
+   if constexpr (SRC) {
+      if (lane == 0) {
+         int c = 0;
+         for (int j = 0; j < tp.nsrc && c < TB3_MAXSRC; j++) {
+            const int64_t ii = tp.src_idx[j];
+            const int sx = (int)(ii / plane), rem = (int)(ii % plane), sy = rem / P, sz = rem % P;
+            const int rr = sy - yo;
+            if (rr < 0 || rr >= R) continue; // (rows are nominal here: a source sits inside the grid, a clamped row is outside it)
+            sS[w][c][0] = sx; sS[w][c][1] = rr; sS[w][c][2] = sz; sS[w][c][3] = j;
+            c++;
+         }
+         sNS[w] = c;
+      }
+      __syncthreads();
+   }
+   // ... and the sample `nn` of those that lie in plane xp added to the rows v[] this lane holds of that plane (nominal, unclamped columns
+   // only: a clamped lane is a copy of another cell and feeds nothing valid)
+   auto inject = [&](vec(&v)[R], int xp, int64_t nn) {
+      const int cnt = sNS[SRC ? w : 0];
+      for (int c = 0; c < cnt; c++) {
+         if (sS[SRC ? w : 0][c][0] != xp) continue;
+         const int rr = sS[SRC ? w : 0][c][1], dz = sS[SRC ? w : 0][c][2] - (ze0 + lane * V);
+         if (dz < 0 || dz >= V || zc != ze0 + lane * V) continue;
+         const Real sv = ((const Real *)tp.src_sig)[(int64_t)sS[SRC ? w : 0][c][3] * tp.src_Nt + nn];
+#pragma unroll
+         for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int i = 0; i < V; i++)
+               if (r == rr && i == dz) v[r][i] += sv;
+      }
+   };
    vec Bm[R], Bc[R + 2], Bn[R], Bf[R], Ac[R], Af[R];
    vec V1m[R], V1c[R + 2], V1n[R], V2m[R], V2c[R + 2], V2n[R];
    vec BhN = vec{}, BhF = vec{}; // edge waves: the outer halo row of the planes in Bn / Bf
@@ -112,6 +155,7 @@ __global__ __launch_bounds__(64 * WT) void k_tb3(Tb2Params tp, Real a1, Real a2)
       // stage 1: u^{n+1}(x1)
 #pragma unroll
       for (int r = 0; r < R; r++) V1n[r] = stencil(Bc[r + 1], Bn[r], Bm[r], Bc[r + 2], Bc[r], Ac[r]);
+      if constexpr (SRC) inject(V1n, x1, tp.src_n);
       // (tp.band & 2: slabs of a chain -- the planes beside the box step singly, the box's first and last plane leave their u^{n+1} too)
       const bool xedge = (tp.band & 2) && C != nullptr && (x1 == tp.x_begin || x1 == tp.x_end - 1);
       if ((NS == 2 || rim || xedge) && x1 >= xs && x1 < xe) { // a neighbour of a single-step tile (or the two-step form): its u^{n+1} is needed in memory
@@ -123,6 +167,7 @@ __global__ __launch_bounds__(64 * WT) void k_tb3(Tb2Params tp, Real a1, Real a2)
       // stage 2: u^{n+2}(x1-1); its old value is u^n(x1-1)
 #pragma unroll
       for (int r = 0; r < R; r++) V2n[r] = stencil(V1c[r + 1], V1n[r], V1m[r], V1c[r + 2], V1c[r], Bm[r]);
+      if constexpr (SRC) inject(V2n, x1 - 1, tp.src_n + 1);
       // the planes x1+3 of u^n and x1+2 of u^{n-1}, two turns ahead
       vec Bnew[R], Anew[R], Bhnew = vec{};
       const int xb = min(x1 + 3, xe + 2), xa = min(x1 + 2, xe + 1);
@@ -132,10 +177,20 @@ __global__ __launch_bounds__(64 * WT) void k_tb3(Tb2Params tp, Real a1, Real a2)
       // stage 3: u^{n+3}(x1-2); its old value is u^{n+1}(x1-2)
       if (NS == 3 && x1 - 2 >= xs && x1 - 2 < xe) {
          Real *pe = E + (int64_t)(x1 - 2) * plane;
+         if constexpr (SRC) {
+            vec o3[R];
 #pragma unroll
-         for (int r = 0; r < R; r++) {
-            const vec o = stencil(V2c[r + 1], V2n[r], V2m[r], V2c[r + 2], V2c[r], V1m[r]);
-            if (ok[r]) __builtin_nontemporal_store(o, (vec *)(pe + off[r]));
+            for (int r = 0; r < R; r++) o3[r] = stencil(V2c[r + 1], V2n[r], V2m[r], V2c[r + 2], V2c[r], V1m[r]);
+            inject(o3, x1 - 2, tp.src_n + 2);
+#pragma unroll
+            for (int r = 0; r < R; r++)
+               if (ok[r]) __builtin_nontemporal_store(o3[r], (vec *)(pe + off[r]));
+         } else {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+               const vec o = stencil(V2c[r + 1], V2n[r], V2m[r], V2c[r + 2], V2c[r], V1m[r]);
+               if (ok[r]) __builtin_nontemporal_store(o, (vec *)(pe + off[r]));
+            }
          }
       }
       if (x1 - 1 >= xs && x1 - 1 < xe) {
@@ -166,5 +221,11 @@ __global__ __launch_bounds__(64 * WT) void k_tb3(Tb2Params tp, Real a1, Real a2)
       BhN = BhF; BhF = Bhnew;
    }
 }
+
+template <typename Real, int R, int WT, bool SG = false, bool PROBE = false, int NS = 3>
+__global__ __launch_bounds__(64 * WT) void k_tb3(Tb2Params tp, Real a1, Real a2) { tb3_body<Real, R, WT, SG, NS, false>(tp, a1, a2); }
+// the tiles within two cells of a source (Engine::launch_tb3_src), beside the main launch
+template <typename Real, int R, int WT, bool SG = false, int NS = 3>
+__global__ __launch_bounds__(64 * WT) void k_tb3_src(Tb2Params tp, Real a1, Real a2) { tb3_body<Real, R, WT, SG, NS, true>(tp, a1, a2); }
 
 } // namespace pf

@@ -458,10 +458,12 @@ def triple_scene(Nt=40, n=(48, 100, 280), wall=3, **kw):
 @pytest.mark.parametrize("prec", ["single", "double"])
 @pytest.mark.parametrize("numerics", [engine.PF_NUM_CPU_EXACT, engine.PF_NUM_GPU_SAFEGUARDED], ids=["exact", "safeguarded"])
 def test_three_steps_per_pass_give_the_oracles_bits(prec, numerics):
-    """k_tb3 advances the box by three steps per pass (u^{n+1} never stored); the shell takes two steps as wall regions and one single
-    step, the source's and a receiver's tiles three single steps, reading the u^{n+1} their flagged neighbours left behind.  Receivers
-    in the box, in the shell and in the wall layers equal the oracle's; whole fields the single-step engine's.  Step counts that mix
-    triples, single steps and ring flushes."""
+    """k_tb3 advances the box by three steps per pass (u^{n+1} never stored); the shell takes its steps as wall regions and bricks (or two
+    steps + one).  Round 6: the tiles within two cells of the source run k_tb3<..., SRC> (the samples added in registers after every
+    stage), a receiver's tile merely stores its u^{n+1}: no tile steps singly; PF_DBG_SRC_TILES_SINGLE (0x40): as until then, the source's
+    and a receiver's tiles three single steps, reading the u^{n+1} their flagged neighbours left behind.  Receivers in the box, in the
+    shell and in the wall layers equal the oracle's; whole fields the single-step engine's.  Step counts that mix triples, single
+    steps and ring flushes."""
     sim = triple_scene(Nt=100, n=(48, 100, 280 if prec == "single" else 264))  # (column counts whose strips fit the wall regions' pencils)
     sd = sim_data.SimData.from_sim(sim, prec)
     sd.scale_input()
@@ -475,20 +477,62 @@ def test_three_steps_per_pass_give_the_oracles_bits(prec, numerics):
     assert np.array_equal(base_out, ref_out)
     # (0x80000: the third step by the list kernels instead of the regions' one-step form; 0x400000: the frame as generic blocks of k_wall2 -- round 5 -- instead of bricks)
     # 0x1000000 / 0x40000000: the x / y regions / the column strips two steps + one instead of three in one pass (k_wall2<..., NS = 3>)
-    for variant, chunk, dbg in ((40, 0, 0), (40, 7, 0), (40, 8, 0x4000000), (40, 0, 0x80000), (40, 0, 0x400000), (40, 5, 0x1000000), (40, 0, 0x40000000), (40, 0, 0x800)):  # (0x800: the three-step bodies with run-time pencil geometry)
+    for variant, chunk, dbg in ((40, 0, 0), (40, 7, 0), (40, 8, 0x4000000), (40, 0, 0x80000), (40, 0, 0x400000), (40, 5, 0x1000000), (40, 0, 0x40000000), (40, 0, 0x800), (40, 0, 0x40), (40, 7, 0x400040)):  # (0x800: the three-step bodies with run-time pencil geometry)
         out, g, tm = run(sim, variant, prec=prec, numerics=numerics, readout_chunk=chunk, debug=dbg)
         assert tm["tb_steps_per_pass"] == 3 and tm["tb2_launches"] > 0 and sum(tm["wall_blocks"]) > 0, (variant, chunk, tm)
         assert (tm["wall_bricks"] > 0) == (dbg & 0x480000 == 0), (hex(dbg), tm)
         # fp32: the whole shell in one pass with the box kernel (x / y regions: bit 0, column strips of 20-cell pencils: bit 3); fp64: two steps + one
         want3 = 0 if (prec == "double" or dbg & 0x1480000) else (1 if dbg & 0x40000000 else 9)
         assert tm["wall_three_steps"] == want3, (hex(dbg), tm)
-        assert tm["tb2_dirty_tiles"] >= 2 and tm["steps"] == 100
+        assert (tm["tb2_dirty_tiles"] >= 2 if dbg & 0x40 else tm["tb2_dirty_tiles"] == 0) and tm["steps"] == 100, (hex(dbg), tm)
         assert np.array_equal(out, ref_out), (variant, chunk, hex(dbg))
         assert np.array_equal(g[1][1:-1, 1:-1, 1:-1], ref_u1[1:-1, 1:-1, 1:-1]), (variant, chunk)
         for a, b in zip(g, base_g):
             assert np.array_equal(a[1:-1, 1:-1, 1:-1], b[1:-1, 1:-1, 1:-1]), (variant, chunk)
     out, _, tm = run(sim, 40, prec=prec, numerics=numerics, debug=0x20000)  # never triples: the round-4 pairs
     assert tm["tb_steps_per_pass"] == 2 and np.array_equal(out, ref_out)
+
+
+@pytest.mark.parametrize("prec", ["single", "double"])
+@pytest.mark.parametrize("sx,sy,sz", [(24, 24, 140), (24, 25, 140), (24, 26, 140), (24, 27, 140), (18, 50, 140), (19, 50, 140), (20, 50, 140),
+                                      (31, 44, 251), (32, 45, 254), (33, 46, 257), (24, 86, 20)])
+def test_sources_added_inside_k_tb3_at_tile_borders(sx, sy, sz, prec):
+    """The eight corner nodes of the source cell (p .. p + 1 on every axis) straddle the borders of k_tb3's tiles -- 20 rows, 248 (fp64:
+    120) core columns, x chunks of 13 planes -- in turn: every tile that computes one of those cells, in its core or in the two cells of
+    halo a later stage still sees, must add the same samples after the same stage.  One node listed twice (the reference's loop is
+    serial: both samples land, in list order).  Receivers beside the source and far from it equal the oracle's, whole fields too."""
+    n = (48, 100, 280 if prec == "single" else 264)
+    sz = min(sz, n[2] - 12)
+    rcv = [[sx + 2, sy - 1, sz + 3], [sx - 3, sy + 2, sz - 2], [4, 50, 100], [30, 90, 200]]
+    sim = synth.shoebox(*n, Nt=43, Nm=2, Mb=[11, 3], src=[sx, sy, sz], rcv=rcv, wall=3)
+
+    def make(mask=False):
+        sd = sim_data.SimData.from_sim(sim, prec, build_mask=mask)
+        k = 3  # one of the eight nodes a second time, with a signal of its own
+        sd.in_ixyz = np.ascontiguousarray(np.concatenate([sd.in_ixyz, sd.in_ixyz[k:k + 1]]))
+        sd.in_sigs = np.ascontiguousarray(np.concatenate([sd.in_sigs, 0.37 * np.roll(sd.in_sigs[k:k + 1], 5, axis=1)]))
+        sd.Ns += 1
+        sd.scale_input()
+        return sd
+
+    ref = make(True)
+    e = oracle.Engine(ref)
+    for k in range(ref.Nt):
+        e.step(k)
+    ref_u1 = e.grid(1).copy()
+    e.close()
+    assert np.abs(ref.u_out).max() > 0
+    for dbg in (0, 0x40):
+        sd = make()
+        eng = engine.HipEngine(sd, air_variant=40, timing=True, debug=dbg)
+        eng.run(0, sd.Nt)
+        tm = eng.timing()
+        g1 = eng.get_grid(1).copy()
+        eng.close()
+        assert tm["tb_steps_per_pass"] == 3 and tm["tb2_launches"] > 0, tm
+        assert (tm["tb2_dirty_tiles"] > 0) == bool(dbg), (hex(dbg), tm)
+        assert np.array_equal(sd.u_out, ref.u_out), hex(dbg)
+        assert np.array_equal(g1[1:-1, 1:-1, 1:-1], ref_u1[1:-1, 1:-1, 1:-1]), hex(dbg)
 
 
 @pytest.mark.parametrize("n,wall,triples", [((47, 101, 280), 3, True), ((50, 96, 280), 4, False), ((44, 90, 528), 3, True), ((47, 101, 283), 3, False)],
@@ -589,7 +633,7 @@ def test_three_steps_per_pass_with_geometry_inside_the_box(prec):
     _, base_g, _ = run(sim, 25, prec=prec)
     for chunk in (0, 5):
         out, g, tm = run(sim, 40, prec=prec, readout_chunk=chunk)
-        assert tm["tb_steps_per_pass"] == 3 and tm["tb2_launches"] > 0 and tm["tb2_dirty_tiles"] >= 3, tm
+        assert tm["tb_steps_per_pass"] == 3 and tm["tb2_launches"] > 0 and tm["tb2_dirty_tiles"] >= 2, tm  # (the block's tiles; the source's and the receivers' no longer step singly)
         assert np.array_equal(out, ref.u_out), chunk
         for a, b in zip(g, base_g):
             assert np.array_equal(a[1:-1, 1:-1, 1:-1], b[1:-1, 1:-1, 1:-1]), chunk

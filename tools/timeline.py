@@ -14,7 +14,7 @@ rows = []
 for f in glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_tb3" in r["Kernel_Name"] and anchor in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "k_tb3<" in r["Kernel_Name"] and anchor in r["Kernel_Name"]]
 if len(idx) < back + 1:
     sys.exit(f"only {len(idx)} anchor launches")
 i0, i1 = idx[-back - 1], idx[-back]
