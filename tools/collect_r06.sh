@@ -14,7 +14,7 @@ if [ "$WHAT" = all ] || [ "$WHAT" = n1 ]; then
   cp $O/bench_k20.json $R/gpurun_out/profiles_new/r06_bench_n1_driver_command.json
   # kernel timeline of one steady-state triple
   (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace -d $O/tr -o t --output-format csv -- python $R/bench.py --steps 24 --warmup 6 --repeats 2 --no-rigid-run --no-cpu-baseline --no-selfcheck --no-pmc > /dev/null 2>&1)
-  python tools/timeline.py $O/tr > $R/gpurun_out/profiles_new/r06_triple_timeline.txt 2>&1; rm -rf $O/tr
+  { echo "# a triple of a headline region (no per-launch events):"; python tools/timeline.py $O/tr "false, 3>" 12; echo "# a triple of the last region (per-launch HIP events on: the two readouts are separate launches there):"; python tools/timeline.py $O/tr "false, 3>" 3; } > $R/gpurun_out/profiles_new/r06_triple_timeline.txt 2>&1; rm -rf $O/tr
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = wall ]; then
   # issue counters of the shell's kernels (waves, cycles executing / waiting, instructions), each launch alone under --pmc
