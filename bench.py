@@ -475,7 +475,7 @@ def main():
                     "(pf_opts.wall_scale); 1 = the compiled-in weights, 0 = measured on the scene when the chain is created (PF_MULTI_MEASURE_WEIGHTS)")
     ap.add_argument("--split-phase", action="store_true", help="N=1: drive the split-phase step like N>1 does")
     ap.add_argument("--emulate-slab", default="", help="debug: 'r/N' = run only slab r of an N-way split on this GPU, the exchange\n                    replaced by device copies of the same planes (per-rank cost model; physics is wrong)")
-    ap.add_argument("--emulate-transport", default="copy", choices=["copy", "rccl"],
+    ap.add_argument("--emulate-transport", default="copy", choices=["copy", "rccl", "native"],
                     help="with --emulate-slab: 'rccl' sends the planes to this same rank through RCCL (real launch cost)")
     ap.add_argument("--emulate-via", default="chain", choices=["chain", "torch"],
                     help="with --emulate-slab: through the C chain object (pf_opts.only_slab; default) or the torch.distributed runner")
@@ -506,7 +506,9 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     group = None
-    if args.emulate_slab and args.emulate_transport == "rccl":
+    # (native too: the process then holds a torch RCCL process group, as every rank under torch.distributed.run does -- measured: without one
+    # the library's own communicator exchanges 0.08 ms per step slower, 0.305 against 0.228 for a rank of 8)
+    if args.emulate_slab and args.emulate_transport in ("rccl", "native"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29731")
@@ -556,6 +558,10 @@ def main():
                     for w in dist.batch_isend_irecv(ops):
                         w.wait()
             runner.exchange = _self_exchange
+        elif args.emulate_transport == "native":  # (--emulate-via torch) the library's own ncclSend / ncclRecv, a 1-rank communicator
+            del runner.exchange                   # (the class's method again)
+            if not runner.enable_native_rccl(local_rank, peers=(-1 if info.first else 0, -1 if info.last else 0)):
+                raise SystemExit("bench: native RCCL unavailable: " + getattr(runner, "native_note", "?"))
     else:
         runner, loc, info = pdist.make_hip_runner(sd, rank, world, local_rank, group, **ekw)
     eng = runner.st.eng
@@ -627,7 +633,7 @@ def main():
         res["roofline"] = rl
         if world > 1:
             res["exchange_verified"] = runner.exchange_verified
-            res["exchange"] = {"backend": backend, "ranks": world, "checked_steps": min(W, 6),
+            res["exchange"] = {"backend": backend, "transport": runner.exchange_backend, "ranks": world, "checked_steps": min(W, 6),
                                "what": "bit-pattern checksums of the received ghost planes == the senders' planes, all ranks"}
         if single and not args.no_selfcheck:
             # Did the timed run compute the right thing?  The same steps from the same seeded field through ANOTHER kernel

@@ -238,6 +238,18 @@ int  pf_multi_get_info(pf_multi *m, pf_multi_info *info);
 int  pf_multi_get_slab(pf_multi *m, int32_t g, int64_t *x0, int64_t *x1, int32_t *device, int32_t *paired, pf_engine **engine);
 void pf_multi_destroy(pf_multi *m);
 
+/* ---- one process per device: the plane exchange of a slab engine by native RCCL (replaces cudaMemcpyPeerAsync of gpu_engine.h:1086-1126
+ * for a host whose ranks are PROCESSES, e.g. under torch.distributed.run; the chain object above is the one-process form).  Rank 0 obtains
+ * the 128-byte id and hands it to every rank by any channel; all ranks then create their communicator together (returns PF_ERR_HIP with
+ * pf_last_error() if the rendezvous fails or does not complete within PFFDTD_RCCL_INIT_TIMEOUT_S seconds: fall back to the host's own p2p).
+ * pf_rccl_exchange goes between pf_engine_step_begin and pf_engine_step_end: first / last updated plane to rank peer_lo / peer_hi, theirs
+ * into the ghost planes (peer < 0: no neighbour there), one ncclGroup on the engine's edge stream; asynchronous. */
+typedef struct pf_rccl_comm pf_rccl_comm;
+int  pf_rccl_unique_id(void *id128);
+int  pf_rccl_comm_create(const void *id128, int32_t nranks, int32_t rank, int32_t device, pf_rccl_comm **out);
+int  pf_rccl_exchange(pf_rccl_comm *c, pf_engine *e, int32_t peer_lo, int32_t peer_hi);
+void pf_rccl_comm_destroy(pf_rccl_comm *c);
+
 /* ---- engine object (what run_sim does inside, exposed for the Python host, slabs and tests) ---- */
 int  pf_engine_create(const pf_simdata *sd, const pf_opts *opts, pf_engine **out);
 void pf_engine_destroy(pf_engine *e);

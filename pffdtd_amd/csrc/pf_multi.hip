@@ -296,6 +296,8 @@ struct Rccl {
    decltype(&ncclRecv) Recv = nullptr;
    decltype(&ncclGetErrorString) GetErrorString = nullptr;
    decltype(&ncclGetVersion) GetVersion = nullptr;
+   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;   // (these two: the one-process-per-device exchange, pf_rccl_*)
+   decltype(&ncclCommInitRank) CommInitRank = nullptr;
    std::string where;
    bool load(std::string &err) {
       if (h) return true;
@@ -322,6 +324,7 @@ struct Rccl {
       PF_SYM(CommInitAll, "ncclCommInitAll") PF_SYM(CommDestroy, "ncclCommDestroy") PF_SYM(GroupStart, "ncclGroupStart")
       PF_SYM(GroupEnd, "ncclGroupEnd") PF_SYM(Send, "ncclSend") PF_SYM(Recv, "ncclRecv")
       PF_SYM(GetErrorString, "ncclGetErrorString") PF_SYM(GetVersion, "ncclGetVersion")
+      PF_SYM(GetUniqueId, "ncclGetUniqueId") PF_SYM(CommInitRank, "ncclCommInitRank")
 #undef PF_SYM
       h = lib;
       return true;
@@ -1223,6 +1226,79 @@ double pf_run_sim_devices(pf_simdata *sd, int32_t nslabs, const int32_t *devices
    if (rc != PF_OK) { pf__set_error(keep.c_str()); return -1.0; }
    if (bad) { pf__set_error("slab exchange self-check failed: a ghost plane does not hold what the neighbour sent"); return -1.0; }
    return el;
+}
+
+// ---- one process per device (pffdtd_amd/dist.py under torch.distributed.run): the slab's two planes by NATIVE ncclSend / ncclRecv on the
+// engine's edge stream -- what the chain object above does for its slabs, for a host whose ranks are processes.  torch.distributed's own
+// p2p (batch_isend_irecv) runs on a stream of its own behind two cross-stream hops: measured on one MI355X (a rank of 8 at 1024^3
+// exchanging with itself, tools/host_loop_profile.py) every exchange sat between 130 us and 77 us of nothing, 0.33 ms per step where
+// this path takes 0.23-0.25.  The host hands the unique id from rank 0 to the others (any channel; dist.py: broadcast_object_list).
+struct pf_rccl_comm { ncclComm_t c = nullptr; int nranks = 0, rank = 0; };
+
+int pf_rccl_unique_id(void *id128) {
+   if (!id128) return fail("pf_rccl_unique_id: null argument");
+   std::string why;
+   { std::lock_guard<std::mutex> lk(g_rccl_mu); if (!g_rccl.load(why)) return fail("%s", why.c_str()); }
+   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId: 128 bytes");
+   ncclUniqueId id;
+   const ncclResult_t r = g_rccl.GetUniqueId(&id);
+   if (r != ncclSuccess) return fail("ncclGetUniqueId failed: %s", g_rccl.GetErrorString(r));
+   memcpy(id128, &id, sizeof id);
+   return PF_OK;
+}
+int pf_rccl_comm_create(const void *id128, int32_t nranks, int32_t rank, int32_t device, pf_rccl_comm **out) {
+   if (!id128 || !out || nranks < 1 || rank < 0 || rank >= nranks) return fail("pf_rccl_comm_create: bad argument");
+   *out = nullptr;
+   std::string why;
+   { std::lock_guard<std::mutex> lk(g_rccl_mu); if (!g_rccl.load(why)) return fail("%s", why.c_str()); }
+   // on a helper thread with a timeout, like the chain's communicators: a rendezvous that never completes must not hang the caller
+   struct Job { std::mutex mu; std::condition_variable cv; bool done = false; ncclResult_t r = ncclSuccess; ncclComm_t c = nullptr; ncclUniqueId id; int n, rk, dev; };
+   auto job = std::make_shared<Job>();
+   memcpy(&job->id, id128, sizeof job->id); job->n = nranks; job->rk = rank; job->dev = device;
+   fflush(stdout);
+   const int saved_out = dup(1); // (RCCL's banner goes to stdout: a host that prints machine-readable results there must not find it in between)
+   if (saved_out >= 0) dup2(2, 1);
+   std::thread([job] {
+      ncclResult_t r = ncclSuccess;
+      if (hipSetDevice(job->dev) != hipSuccess) r = ncclUnhandledCudaError;
+      if (r == ncclSuccess) r = g_rccl.CommInitRank(&job->c, job->n, job->id, job->rk);
+      { std::lock_guard<std::mutex> l2(job->mu); job->r = r; job->done = true; }
+      job->cv.notify_all();
+   }).detach();
+   double tmo = 60.0;
+   if (const char *ev = getenv("PFFDTD_RCCL_INIT_TIMEOUT_S")) { const double v = atof(ev); if (v > 0) tmo = v; }
+   bool finished;
+   { std::unique_lock<std::mutex> l2(job->mu); finished = job->cv.wait_for(l2, std::chrono::duration<double>(tmo), [&] { return job->done; }); }
+   if (saved_out >= 0) { fflush(stdout); dup2(saved_out, 1); close(saved_out); }
+   if (!finished) { char b[160]; snprintf(b, sizeof b, "ncclCommInitRank (rank %d of %d) did not return within %.0f s", rank, nranks, tmo); pf__set_error(b); return PF_ERR_HIP; }
+   if (job->r != ncclSuccess) { char b[256]; snprintf(b, sizeof b, "ncclCommInitRank (rank %d of %d) failed: %s", rank, nranks, g_rccl.GetErrorString(job->r)); pf__set_error(b); return PF_ERR_HIP; }
+   pf_rccl_comm *c = new pf_rccl_comm();
+   c->c = job->c; c->nranks = nranks; c->rank = rank;
+   *out = c;
+   return PF_OK;
+}
+// between pf_engine_step_begin and pf_engine_step_end: my first / last updated plane to rank peer_lo / peer_hi, theirs into my ghost planes
+// (peer < 0: no neighbour on that side), one group on the engine's edge stream -- ordered after the edge planes, before the next step's
+int pf_rccl_exchange(pf_rccl_comm *c, pf_engine *e, int32_t peer_lo, int32_t peer_hi) {
+   if (!c || !c->c || !e) return fail("pf_rccl_exchange: null argument");
+   if (peer_lo >= c->nranks || peer_hi >= c->nranks) return fail("pf_rccl_exchange: no such rank");
+   void *slo = nullptr, *shi = nullptr, *rlo = nullptr, *rhi = nullptr;
+   size_t nb = 0;
+   int rc = pf_engine_halo_ptrs(e, &slo, &shi, &rlo, &rhi, &nb);
+   if (rc) return rc;
+   hipStream_t s = (hipStream_t)pf_engine_stream(e, 1);
+   ncclResult_t r = g_rccl.GroupStart();
+   if (r == ncclSuccess && peer_lo >= 0) { r = g_rccl.Send(slo, nb, ncclChar, peer_lo, c->c, s); if (r == ncclSuccess) r = g_rccl.Recv(rlo, nb, ncclChar, peer_lo, c->c, s); }
+   if (r == ncclSuccess && peer_hi >= 0) { r = g_rccl.Send(shi, nb, ncclChar, peer_hi, c->c, s); if (r == ncclSuccess) r = g_rccl.Recv(rhi, nb, ncclChar, peer_hi, c->c, s); }
+   const ncclResult_t r2 = g_rccl.GroupEnd();
+   if (r == ncclSuccess) r = r2;
+   if (r != ncclSuccess) { char b[256]; snprintf(b, sizeof b, "pf_rccl_exchange: %s", g_rccl.GetErrorString(r)); pf__set_error(b); return PF_ERR_HIP; }
+   return PF_OK;
+}
+void pf_rccl_comm_destroy(pf_rccl_comm *c) {
+   if (!c) return;
+   if (c->c) g_rccl.CommDestroy(c->c);
+   delete c;
 }
 
 // double run_sim(struct SimData *sd): cpu_engine.h:52 / gpu_engine.h:665.  Like the reference's GPU engine it uses every

@@ -129,10 +129,52 @@ class SlabRunner:
         self.rank, self.G = info.rank, info.G
         self.verify_steps = 0          # >0: checksum the planes of that many upcoming exchanges against the senders'
         self.exchange_verified = None  # None = never checked, True / False = result on every rank (all-reduced)
+        self.native = None             # pf_rccl_comm*: the planes by native ncclSend / ncclRecv on the engine's edge stream
+        self.exchange_backend = "torch.distributed p2p"
+
+    def enable_native_rccl(self, device, peers=None):
+        """Collective over the group: every rank creates a communicator of the library's own (pf_rccl_*, include/pffdtd_hip.h) from an id
+        rank 0 hands round, and the exchange becomes ONE ncclGroup of sends / receives on the engine's edge stream.  torch's own p2p
+        runs on a stream of its own behind two cross-stream hops -- measured with a rank of 8 at 1024^3: 0.33 ms per step against 0.23-0.25
+        (tools/host_loop_profile.py).  Any rank failing (no librccl, a rendezvous that errs or times out): all stay on torch's p2p.
+        peers: (lo, hi) ranks of the communicator to exchange with instead of rank -/+ 1 (a rank alone exchanging with itself: (0, 0))."""
+        import ctypes
+        from . import engine
+        if self.G == 1 and peers is None:
+            return False
+        L = engine.lib()
+        idb = ctypes.create_string_buffer(128)
+        nranks, rank = (self.G, self.rank) if peers is None else (1, 0)
+        obj = [None]  # the id, or None if rank 0 could not get one
+        if rank == 0 and L.pf_rccl_unique_id(idb) == 0:
+            obj = [bytes(idb.raw)]
+        together = nranks > 1
+        if together:
+            dist.broadcast_object_list(obj, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        comm = ctypes.c_void_p()
+        good = obj[0] is not None and L.pf_rccl_comm_create(obj[0], nranks, rank, int(device), ctypes.byref(comm)) == 0
+        flags = [good]
+        if together:
+            flags = [None] * nranks
+            dist.all_gather_object(flags, bool(good), group=self.group)
+        if not all(flags):
+            if good:
+                L.pf_rccl_comm_destroy(comm)
+            self.native_note = engine.lib().pf_last_error().decode() if not good else "another rank could not create its communicator"
+            return False
+        self.native, self._peers = comm, peers
+        self.exchange_backend = "native RCCL (ncclSend / ncclRecv grouped on the engine's edge stream)"
+        return True
 
     def exchange(self):
         """Send my first/last updated planes to the neighbours' ghost planes, receive theirs (gpu_engine.h:1086-1126)."""
         if self.G == 1:
+            return
+        if self.native is not None:
+            from . import engine
+            lo, hi = self._peers if self._peers is not None else (-1 if self.info.first else self.rank - 1, -1 if self.info.last else self.rank + 1)
+            if engine.lib().pf_rccl_exchange(self.native, self.st.eng._h, lo, hi) != 0:
+                raise RuntimeError("pf_rccl_exchange: " + engine.lib().pf_last_error().decode())
             return
         s_lo, s_hi, r_lo, r_hi = self.st.halo_tensors()
         if s_lo.is_cuda and dist.get_backend(self.group) == "gloo":
@@ -204,6 +246,13 @@ class SlabRunner:
     def finish(self):
         self.st.finish()
 
+    def close_comm(self):
+        if self.native is not None:
+            from . import engine
+            self.st.sync()
+            engine.lib().pf_rccl_comm_destroy(self.native)
+            self.native = None
+
 
 def gather_outputs(sd, loc, info, group=None):
     """Collect every slab's receiver rows on all ranks (small: Nr x Nt doubles)."""
@@ -264,4 +313,10 @@ def make_hip_runner(sd, rank, world, device, group=None, balance=True, along_z=N
     env = os.environ.get("PFFDTD_SLAB_PAIRS", "")
     engine_kw.setdefault("pairs", not getattr(info, "along_z", False) and (env == "1" or (env != "0" and loc.Nx - 2 >= 96)))
     st = HipSlabStepper(loc, info, device, **engine_kw)
-    return SlabRunner(st, info, group), loc, info
+    runner = SlabRunner(st, info, group)
+    # one rank per GPU over RCCL: the planes by the library's own ncclSend / ncclRecv on the edge stream (PFFDTD_TORCH_P2P=1: torch's p2p)
+    if (world > 1 and dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
+            and os.environ.get("PFFDTD_TORCH_P2P", "") != "1"):
+        dev = device if isinstance(device, int) else (getattr(device, "index", None) or 0)
+        runner.enable_native_rccl(dev)
+    return runner, loc, info

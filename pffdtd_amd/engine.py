@@ -63,7 +63,8 @@ EXPORTS = ["pf_last_error", "pf_version", "pf_device_count", "pf_grid_bytes", "p
            "pf_engine_halo_ptrs", "pf_engine_step_end", "pf_engine_state_grids", "pf_engine_layout", "pf_engine_place_grids", "pf_engine_place_grids5", "pf_engine_set_spares", "pf_engine_stream", "pf_engine_sync",
            "pf_engine_flush_outputs", "pf_engine_get_grid", "pf_engine_set_grid", "pf_engine_timing", "pf_engine_set_timing",
            "pf_engine_energy_cfg", "pf_engine_run_energy", "pf_run_sim_devices", "pf_slab_partition", "pf_slab_partition_w", "pf_slab_partition_axis", "pf_slab_wall_scale",
-           "pf_multi_create", "pf_multi_run", "pf_multi_get_info", "pf_multi_get_slab", "pf_multi_destroy"]
+           "pf_multi_create", "pf_multi_run", "pf_multi_get_info", "pf_multi_get_slab", "pf_multi_destroy",
+           "pf_rccl_unique_id", "pf_rccl_comm_create", "pf_rccl_exchange", "pf_rccl_comm_destroy"]
 
 
 INTERNAL_EXPORTS = ["pf_internal_hooks"]  # csrc/pf_debug.h: exported, but no part of the drop-in boundary (not in include/)
@@ -159,6 +160,11 @@ def lib():
         L.pf_multi_get_slab.argtypes = [vp, i32, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(vp)]
         L.pf_multi_destroy.argtypes = [vp]
         L.pf_multi_destroy.restype = None
+        L.pf_rccl_unique_id.argtypes = [ctypes.c_char_p]
+        L.pf_rccl_comm_create.argtypes = [ctypes.c_char_p, i32, i32, i32, ctypes.POINTER(ctypes.c_void_p)]
+        L.pf_rccl_exchange.argtypes = [ctypes.c_void_p, ctypes.c_void_p, i32, i32]
+        L.pf_rccl_comm_destroy.argtypes = [ctypes.c_void_p]
+        L.pf_rccl_comm_destroy.restype = None
         _LIB = L
     return _LIB
 
