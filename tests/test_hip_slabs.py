@@ -71,6 +71,48 @@ def test_single_rank_runner_matches():
     assert np.array_equal(out, ref)
 
 
+@pytest.mark.parametrize("rank,G", [(1, 3), (0, 2), (2, 3)])
+def test_a_ranks_native_rccl_exchange_moves_the_planes_a_copy_would(rank, G):
+    """One process per GPU: SlabRunner.exchange through the library's own ncclSend / ncclRecv on the engine's edge stream (pf_rccl_*, a
+    1-rank communicator: the rank exchanges with itself) leaves the same bits in both state grids and the same receiver samples as plain
+    device copies of the same planes on the same stream -- interior and end ranks, the whole run (the physics of a rank fed its own edge
+    planes is wrong by design; the data movement and its ordering are what is compared)."""
+    def one(native):
+        sd = cases.make_sd("cart_lossy", "single")
+        runner, loc, info = pdist.make_hip_runner(sd, rank, G, 0)
+        st = runner.st
+        if native:
+            assert runner.enable_native_rccl(0, peers=(-1 if info.first else 0, -1 if info.last else 0)), getattr(runner, "native_note", "")
+            assert runner.native is not None and "native" in runner.exchange_backend
+        else:
+            def copies():
+                s_lo, s_hi, r_lo, r_hi = st.halo_tensors()
+                with st.comm_context():
+                    if not info.first:
+                        r_lo.copy_(s_lo, non_blocking=True)
+                    if not info.last:
+                        r_hi.copy_(s_hi, non_blocking=True)
+            runner.exchange = copies
+        rng = np.random.default_rng(7)  # a seeded field everywhere (a slab without the source would stay all zero)
+        for which in (0, 1):
+            g = st.eng.get_grid(which)
+            st.eng.set_grid(which, (rng.uniform(-1, 1, g.shape) * 1e-3).astype(g.dtype))
+        runner.run(0, sd.Nt)
+        runner.finish()
+        grids = [st.eng.get_grid(0).copy(), st.eng.get_grid(1).copy()]
+        out = loc.u_out.copy()
+        runner.close_comm()
+        st.close()
+        return grids, out
+
+    g0, o0 = one(False)
+    g1, o1 = one(True)
+    assert np.abs(g0[1]).max() > 0
+    assert np.array_equal(o0, o1)
+    for a, b in zip(g0, g1):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("torch_grids", [False, True])
 def test_single_domain_stepper_grids_are_the_engines(torch_grids, monkeypatch):
     """A single domain lets the engine allocate (and place) its state grids; `grids` are torch views of those allocations

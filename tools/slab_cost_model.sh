@@ -33,3 +33,7 @@ for ln in sys.stdin:
 for spec in 0/8 3/8 7/8; do
   python bench.py --fcc --size 1536 --precision double --emulate-slab $spec --emulate-transport copy --steps 12 --warmup 4 --repeats 3 --no-pmc 2>/dev/null | python -c "$P"
 done
+echo "## one process per GPU (pffdtd_amd/dist.py under torch.distributed.run): a rank of 8 alone, exchanging with itself -- device copies / torch.distributed p2p (batch_isend_irecv) / the library's own ncclSend + ncclRecv on the edge stream (pf_rccl_*, what dist.py uses under an RCCL process group)"
+for tr in copy rccl native; do
+  python bench.py --emulate-slab 3/8 --emulate-via torch --emulate-transport $tr --steps 42 --warmup 6 --repeats 5 --no-pmc 2>&1 >/dev/null | grep emulated | sed 's/^/   /'
+done
