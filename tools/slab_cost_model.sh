@@ -17,7 +17,7 @@ for ln in sys.stdin:
         d=json.loads(ln); print("   N=1: %.4f ms/step = %.1f Gvox/s (%s)" % (d["ms_per_step"], d["value"], d["roofline"].get("shell")))'
 for tr in rccl copy; do
   echo "## rank cost model, exchange by $tr"
-  for spec in 0/2 1/2 0/4 1/4 0/8 3/8 7/8; do
+  for spec in 0/2 1/2 0/4 1/4 2/4 0/8 3/8 4/8 7/8; do  # (2/4, 4/8: the ranks that hold the source)
     python bench.py --emulate-slab $spec --emulate-transport $tr --steps 42 --warmup 6 --repeats 5 --no-pmc 2>/dev/null | python -c "$P"
   done
 done
