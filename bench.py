@@ -700,6 +700,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
+        runner.close_comm()  # (the library's own communicator, if the exchange ran on one)
         dist.destroy_process_group()
 
 

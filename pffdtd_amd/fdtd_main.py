@@ -170,6 +170,7 @@ def run_rank(a, world):
         el = time.perf_counter() - t0
         tm = runner.st.eng.timing()
         pdist.gather_outputs(sd, loc, info)
+        runner.close_comm()
         runner.st.close()
         if rank == 0:
             _summary(sd, tm, el)  # air / boundary split: rank 0's slab; the total: the whole job
