@@ -112,9 +112,17 @@ __device__ __forceinline__ void tb3_body(const Tb2Params &tp, const Real a1, con
       }
       __syncthreads();
    }
+   // (the planes this wave's sources lie in, in scalar registers: every other turn's inject is two compares -- walking the list in LDS
+   // three times a turn made these few workgroups 0.51 ms long where a workgroup of the main launch takes 0.19)
+   int src_lo = 1 << 30, src_hi = -1;
+   if constexpr (SRC) {
+      for (int c = 0; c < sNS[w]; c++) { src_lo = min(src_lo, sS[w][c][0]); src_hi = max(src_hi, sS[w][c][0]); }
+      src_lo = __builtin_amdgcn_readfirstlane(src_lo); src_hi = __builtin_amdgcn_readfirstlane(src_hi);
+   }
    // ... and the sample `nn` of those that lie in plane xp added to the rows v[] this lane holds of that plane (nominal, unclamped columns
    // only: a clamped lane is a copy of another cell and feeds nothing valid)
    auto inject = [&](vec(&v)[R], int xp, int64_t nn) {
+      if (xp < src_lo || xp > src_hi) return;
       const int cnt = sNS[SRC ? w : 0];
       for (int c = 0; c < cnt; c++) {
          if (sS[SRC ? w : 0][c][0] != xp) continue;
