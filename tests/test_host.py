@@ -32,6 +32,17 @@ def test_library_exports_every_declared_symbol():
     assert len(engine.PfOpts._fields_) <= 20
 
 
+def test_native_rccl_entry_points_refuse_bad_arguments_without_touching_a_device():
+    """pf_rccl_* (one process per device): argument errors come back as PF_ERR_ARG with a message, before librccl or a device is needed."""
+    L = engine.lib()
+    comm = ctypes.c_void_p()
+    assert L.pf_rccl_unique_id(None) == 1 and b"null" in L.pf_last_error()
+    assert L.pf_rccl_comm_create(None, 2, 0, 0, ctypes.byref(comm)) == 1 and not comm.value
+    assert L.pf_rccl_comm_create(b"\0" * 128, 2, 2, 0, ctypes.byref(comm)) == 1 and not comm.value  # rank outside [0, nranks)
+    assert L.pf_rccl_exchange(None, None, -1, -1) == 1
+    L.pf_rccl_comm_destroy(None)  # (a null communicator: nothing to do)
+
+
 def test_struct_layout_matches_header():
     """ctypes mirror of pf_simdata: same size as the C struct (checked through a tiny compiled probe)."""
     import subprocess
