@@ -394,7 +394,9 @@ def test_slabs_step_in_triples_across_three_split_phase_steps(prec, transport):
     assert np.abs(want).max() > 0 and np.abs(want[2:]).max() > 0
     # round 6: a slab in triples takes its shell's three steps in the FIRST split-phase step (three-step y / z regions + bricks for the four bars
     # along x) unless a source sits within reach of them (two slabs: the source is at the cut) -- debug 0x400000: the round-5 shell
-    for devs, flags, spp, dbg in (([0, 0], 0, 3, 0), ([0, 0, 0], 0, 3, 0), ([0, 0, 0], 0, 3, 0x400000), ([0, 0], engine.PF_MULTI_NO_TRIPLES, 2, 0)):
+    # 0x40 (PF_DBG_SRC_TILES_SINGLE): the source's and the receivers' tiles step singly, the sources by k_io, as until late in round 6
+    # (default: the sources inside k_tb3_src, launched first on the regions' second stream; a receiver's tile stores its u^{n+1})
+    for devs, flags, spp, dbg in (([0, 0], 0, 3, 0), ([0, 0, 0], 0, 3, 0), ([0, 0, 0], 0, 3, 0x400000), ([0, 0, 0], 0, 3, 0x40), ([0, 0], engine.PF_MULTI_NO_TRIPLES, 2, 0)):
         sd2 = sim_data.SimData.from_sim(synth.shoebox(**kw), prec)
         sd2.scale_input()
         m = engine.HipMulti(sd2, devs, multi_flags=engine.PF_MULTI_FORCE_PAIRS | flags, air_variant=40, transport=transport, verify_exchange=int(sd2.Nt), timing=1, debug=dbg)
@@ -406,7 +408,9 @@ def test_slabs_step_in_triples_across_three_split_phase_steps(prec, transport):
         assert info["exchange_verified"] is True
         assert all(t["tb_steps_per_pass"] == spp and t["tb2_launches"] > 0 and sum(t["wall_blocks"]) > 0 for t in tms), (devs, flags, [t["tb_steps_per_pass"] for t in tms])
         if len(devs) == 3 and spp == 3:  # (fp64: two steps + one; three-step tables are fp32)
-            want3 = prec == "single" and dbg == 0
+            want3 = prec == "single" and dbg in (0, 0x40)
+            # the slab that holds the source: no tile steps singly unless asked to
+            assert (max(t["tb2_dirty_tiles"] for t in tms) > 0) == (dbg == 0x40), (hex(dbg), [t["tb2_dirty_tiles"] for t in tms])
             # (bits 0x10 / 0x20: an end slab's own x wall is a region's and the bricks' too -- no single steps of its planes)
             assert all((t["wall_three_steps"] == (9 | (0x10 if g == 0 else 0) | (0x20 if g == 2 else 0)) and t["wall_bricks"] > 0) == want3 for g, t in enumerate(tms)), \
                 (hex(dbg), [(t["wall_three_steps"], t["wall_bricks"]) for t in tms])
